@@ -1,0 +1,227 @@
+/*
+ * probnmn_hip.h -- C ABI of libprobnmn_hip.so, the MI355X (gfx950) kernels behind the
+ * probnmn.models / probnmn.modules class surface.
+ *
+ * The reference (kdexd/probnmn-clevr) has no FFI of its own: its hot path is torch ops called
+ * from Python.  Each entry point below therefore cites the reference torch call
+ * site(s) it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer into caller-owned, contiguous fp32 / int64 / int32 memory;
+ *     the library allocates nothing and keeps no state -> re-entrant per device;
+ *   - activations are NHWC ("channels last"): a feature map is [H*W][C] floats; conv weights are
+ *     [Cout][KH*KW][Cin] (what torch calls channels_last for a [Cout,Cin,KH,KW] tensor);
+ *   - work is described by arrays of fixed-size "item" records living in device memory, so one
+ *     launch executes the same op for many (example, module) pairs with different weights --
+ *     this is how the per-example dynamic program composition of nmn.py:197-238 is batched;
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), never synchronise;
+ *   - return 0 on success, a negative PNMN_E* for argument errors, a positive hipError_t
+ *     otherwise.
+ * No torch types appear anywhere in this interface.
+ */
+#ifndef PROBNMN_HIP_H
+#define PROBNMN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNMN_EINVAL (-1)   /* bad argument                                   */
+#define PNMN_ESHAPE (-2)   /* shape not supported by the gfx950 kernels      */
+
+#define PNMN_CHANNELS 128  /* module_channels the LDS tiling is built for    */
+
+/* ---------------------------------------------------------------------------------------------
+ * Grouped convolution, forward and data-gradient.
+ * Replaces: F.relu(conv3x3(feats * attn.repeat(...)))   nmn_modules.py:83-85,120-122,161-166
+ *           stem convs                                   nmn.py:67-72,183
+ *           ComparisonModule.projection on cat(in1,in2)  nmn_modules.py:241
+ *           classifier conv1x1                           nmn.py:76
+ *           and, with transposed weights + `gate`, the autograd dgrad of all of them.
+ * One item = one example's feature map through one convolution:
+ *   x[p][c]   = in[p*in_stride + c]            (chunk k of 128 input channels at in + 128k,
+ *                                               or taken from in2 for k>=1 when in2 != NULL)
+ *   x        *= mask[p]                        if mask  (single-channel attention, broadcast)
+ *   x         = gate[p*in_stride+c] > 0 ? x:0  if gate  (ReLU backward fused into the load)
+ *   out[p*out_stride + n] = act(bias[n] + sum_{tap,c} x[shift(p,tap,dil)][c] * W[n][tap][c])
+ *   (added to the previous contents of out when flags & PNMN_CONV_ACCUMULATE)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_conv_item {
+    const float* in;
+    const float* in2;
+    const float* mask;
+    const float* gate;
+    const float* weight;   /* [cout_total][ntaps][cin_chunks*128] */
+    const float* bias;     /* [cout_total] or NULL                */
+    float*       out;
+    int32_t      dilation;
+    int32_t      flags;    /* PNMN_CONV_ACCUMULATE: out += result (plain read-modify-write) */
+} pnmn_conv_item;          /* 64 bytes */
+#define PNMN_CONV_ACCUMULATE 1
+
+int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks,
+                   int ntaps /* 9 or 1 */, int in_stride, int out_stride,
+                   int cout_blocks /* cout_total / 128 */, int relu, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Grouped convolution weight-gradient (autograd wgrad of the convs above).
+ *   dW[n][tap][c] += sum_items sum_p dy[p][n] * (gate[p][n] > 0) * x[shift(p,tap,dil)][c]
+ * A job = a run of items sharing one weight; the kernel accumulates a job's items in registers
+ * and adds the result into dw with fp32 atomics (dw must be zeroed by the caller beforehand).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_wgrad_item {
+    const float* x;        /* [HW][x_stride]  forward input of the conv               */
+    const float* x2;       /* second source for input-channel blocks >= 1, or NULL    */
+    const float* xmask;    /* [HW] attention multiplied onto x in the forward, or NULL */
+    const float* dy;       /* [HW][dy_stride] gradient wrt the conv output            */
+    const float* gate;     /* [HW][dy_stride] forward output (ReLU gate), or NULL     */
+    int32_t      dilation;
+    int32_t      reserved;
+} pnmn_wgrad_item;         /* 48 bytes */
+
+typedef struct pnmn_wgrad_job {
+    float*  dw;            /* [cout_total][ntaps][cin_total] accumulated into        */
+    float*  dbias;         /* [cout_total] accumulated into, or NULL                 */
+    int32_t item_begin;
+    int32_t item_end;
+} pnmn_wgrad_job;          /* 24 bytes */
+
+int pnmn_conv_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int H,
+                    int W, int ntaps, int cin_blocks, int cout_blocks, int x_stride,
+                    int dy_stride, void* stream);
+
+/* [Cout][taps][Cin] -> [Cin][taps reversed][Cout] for a list of weights (dgrad operand). */
+typedef struct pnmn_wtrans_item {
+    const float* src;
+    float*       dst;
+    int32_t      cout, cin, ntaps, reserved;
+} pnmn_wtrans_item;        /* 32 bytes */
+int pnmn_transpose_weights(const pnmn_wtrans_item* items, int n_items, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * conv1x1(128 -> 1) + sigmoid                       nmn_modules.py:86,167
+ *   out[p] = sigmoid(b + sum_c in[p][c] * w[c])
+ * backward: dz = dout*out*(1-out); din[p][c] = dz[p]*w[c]; dw[c] += sum_p dz[p]*in[p][c];
+ *           db += sum_p dz[p]      (dw/db via fp32 atomics; din written, not accumulated)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_dot1_item {
+    const float* in;    /* [HW][128]                 */
+    const float* w;     /* [128]                     */
+    const float* b;     /* [1]                       */
+    float*       out;   /* [HW]    fwd: written; bwd: read */
+    const float* dout;  /* [HW]    bwd only          */
+    float*       din;   /* [HW][128] bwd only        */
+    float*       dw;    /* [128]   bwd only          */
+    float*       db;    /* [1]     bwd only          */
+} pnmn_dot1_item;       /* 64 bytes */
+int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream);
+int pnmn_dot1_sigmoid_bwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SameModule                                         nmn_modules.py:200-208
+ *   j = argmax_p attn[p] (first maximum, as max_pool2d); v[c] = feats[j][c]
+ *   out[p] = sigmoid(b + sum_c w[c]*feats[p][c]*v[c] + w[128]*attn[p])
+ * backward accumulates dfeats (+=), writes dattn, accumulates dw[129]/db with atomics.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_same_item {
+    const float* feats;  /* [HW][128] */
+    const float* attn;   /* [HW]      */
+    const float* w;      /* [129]     */
+    const float* b;      /* [1]       */
+    float*       out;    /* [HW]      */
+    const float* dout;   /* bwd */
+    float*       dfeats; /* bwd, += */
+    float*       dattn;  /* bwd, written */
+    float*       dw;     /* bwd, atomics */
+    float*       db;     /* bwd, atomics */
+} pnmn_same_item;        /* 80 bytes */
+int pnmn_same_fwd(const pnmn_same_item* items, int n_items, int HW, void* stream);
+int pnmn_same_bwd(const pnmn_same_item* items, int n_items, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * And / Or: elementwise min / max with 1 <-> C channel broadcast    nmn_modules.py:25-27,43-45
+ * backward routes the gradient to the selected operand (ties: half each, as torch.minimum),
+ * summing over channels for a broadcast operand; da / db are accumulated (+=).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_minmax_item {
+    const float* a;
+    const float* b;
+    float*       out;     /* fwd: written */
+    const float* dout;    /* bwd */
+    float*       da;      /* bwd, += (may be NULL) */
+    float*       db;      /* bwd, += (may be NULL) */
+    int32_t      a_channels, b_channels;   /* 1 or C */
+    int32_t      is_max, reserved;
+} pnmn_minmax_item;       /* 64 bytes */
+int pnmn_minmax_fwd(const pnmn_minmax_item* items, int n_items, int HW, int C, void* stream);
+int pnmn_minmax_bwd(const pnmn_minmax_item* items, int n_items, int HW, int C, void* stream);
+
+/* Backward of `feats * attn.repeat(1,C,1,1)` (nmn_modules.py:83,120,161):
+ *   dattn[p] = sum_c dx[p][c]*feats[p][c]  (written);  dfeats[p][c] += dx[p][c]*attn[p]
+ * attn == NULL means the all-ones attention `scene` produces: dfeats += dx, no dattn. */
+typedef struct pnmn_maskbwd_item {
+    const float* dx;
+    const float* feats;
+    const float* attn;
+    float*       dfeats;
+    float*       dattn;
+} pnmn_maskbwd_item;      /* 40 bytes */
+int pnmn_mask_bwd(const pnmn_maskbwd_item* items, int n_items, int HW, void* stream);
+
+/* dst[p][c] += src[p][c] for a list of [HW][128] maps (fan-in of value gradients). */
+typedef struct pnmn_axpy_item {
+    const float* src;
+    float*       dst;
+    int64_t      n;
+} pnmn_axpy_item;         /* 24 bytes */
+int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout changes at the boundary: the reference hands NCHW features (datasets.py:137-142).
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
+int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * classifier.1-3: ReLU (already applied by the conv) + MaxPool2d(2,2) + Flatten   nmn.py:77-79
+ *   in  [n][H*W][C] NHWC  ->  out [n][C*(H/2)*(W/2)] in the reference's NCHW-flatten order
+ * backward scatters dout to the arg-max position (first maximum in window scan order, as torch)
+ * and applies the ReLU gate of the conv output.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_maxpool2_flatten_fwd(const float* in, float* out, int n, int H, int W, int C, void* stream);
+int pnmn_maxpool2_flatten_bwd(const float* in, const float* dout, float* din, int n, int H, int W,
+                              int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Answer loss                                                          nmn.py:245-269
+ *   logprobs = log_softmax(logits[b]); pred[b] = argmax (first); loss[b] = -logprobs[answer[b]]
+ *   (answers == NULL: loss[b] = -max logprob); invalid rows: pred = unknown_index, loss = 3.33
+ *   dlogits[b] = (softmax - onehot) * scale for valid rows, 0 for invalid rows.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t* valid,
+                     int64_t* predictions, float* loss, float* dlogits, int n, int num_answers,
+                     int unknown_index, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused gradient clamp + Adam (trainers: clamp_(-5,5) then optimizer.step()).
+ * module_training_trainer.py:94-96, joint_training_trainer.py:182-188, _trainer.py:103-108,193
+ * torch.optim.Adam semantics (no amsgrad): g = clamp(g) + wd*p; m,v EMA; bias correction with
+ * `step`; p -= lr * mhat / (sqrt(vhat) + eps).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pnmn_adam_item {
+    float*       param;
+    const float* grad;
+    float*       exp_avg;
+    float*       exp_avg_sq;
+    int64_t      n;
+} pnmn_adam_item;         /* 40 bytes */
+int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, double clamp, int step, void* stream);
+
+/* Library / device self-description (no GPU needed for version). */
+int pnmn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROBNMN_HIP_H */

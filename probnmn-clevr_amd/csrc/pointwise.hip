@@ -1,0 +1,694 @@
+// Bandwidth-bound kernels of the NMN path for gfx950: the single-channel heads (conv1x1->1 +
+// sigmoid, SameModule), And/Or compose, attention-mask backward, layout changes, the
+// classifier's max-pool/flatten, the answer loss and the fused clamp+Adam update.
+//
+// Conventions: feature maps are NHWC [HW][128]; a "half-wave" (32 lanes x float4 = one 512-byte
+// pixel row) is the unit that walks pixels, so every global access is a full coalesced row and
+// channel reductions are five __shfl_xor steps inside the half-wave.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/probnmn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int C = PNMN_CHANNELS;  // 128
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+// ------------------------------------------------------------------------------------------------
+// conv1x1 (128 -> 1) + sigmoid
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dot1_sigmoid_fwd_kernel(const pnmn_dot1_item* __restrict__ items,
+                                                               int HW) {
+    const pnmn_dot1_item it = items[blockIdx.x];
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;  // half-wave id 0..7
+    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
+    const float b = it.b[0];
+    for (int p = hw; p < HW; p += 8) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(it.in + (size_t)p * C + 4 * h);
+        const float s = half_wave_sum(dot4(x, w));
+        if (h == 0) it.out[p] = sigmoidf(s + b);
+    }
+}
+
+__global__ __launch_bounds__(256) void dot1_sigmoid_bwd_kernel(const pnmn_dot1_item* __restrict__ items,
+                                                               int HW) {
+    __shared__ float red[8][C + 1];
+    const pnmn_dot1_item it = items[blockIdx.x];
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
+    f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db = 0.f;
+    for (int p = hw; p < HW; p += 8) {
+        const float o = it.out[p];
+        const float dz = it.dout[p] * o * (1.f - o);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(it.in + (size_t)p * C + 4 * h);
+        dw += x * dz;
+        db += dz;
+        *reinterpret_cast<f32x4*>(it.din + (size_t)p * C + 4 * h) = w * dz;
+    }
+    red[hw][4 * h + 0] = dw.x;
+    red[hw][4 * h + 1] = dw.y;
+    red[hw][4 * h + 2] = dw.z;
+    red[hw][4 * h + 3] = dw.w;
+    if (h == 0) red[hw][C] = db;
+    __syncthreads();
+    if (threadIdx.x <= C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+        if (threadIdx.x < C)
+            unsafeAtomicAdd(it.dw + threadIdx.x, s);
+        else
+            unsafeAtomicAdd(it.db, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SameModule
+// ------------------------------------------------------------------------------------------------
+__device__ int block_first_argmax(const float* __restrict__ attn, int HW, float* sval, int* sidx) {
+    // first maximum in scan order (what max_pool2d(return_indices=True) reports)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        const float v = attn[p];
+        if (v > best || (v != v && best == best)) {
+            best = v;
+            bi = p;
+        }
+    }
+    sval[threadIdx.x] = best;
+    sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = sval[threadIdx.x + s];
+            const int oi = sidx[threadIdx.x + s];
+            const float mv = sval[threadIdx.x];
+            const int mi = sidx[threadIdx.x];
+            if (ov > mv || (ov == mv && oi < mi)) {
+                sval[threadIdx.x] = ov;
+                sidx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int r = sidx[0];
+    __syncthreads();
+    return r == 0x7fffffff ? 0 : r;
+}
+
+__global__ __launch_bounds__(256) void same_fwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
+    __shared__ float sval[256];
+    __shared__ int sidx[256];
+    const pnmn_same_item it = items[blockIdx.x];
+    const int j = block_first_argmax(it.attn, HW, sval, sidx);
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(it.feats + (size_t)j * C + 4 * h);
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(it.w + 4 * h) * v;
+    const float wa = it.w[C];
+    const float b = it.b[0];
+    for (int p = hw; p < HW; p += 8) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(it.feats + (size_t)p * C + 4 * h);
+        const float s = half_wave_sum(dot4(x, wv));
+        if (h == 0) it.out[p] = sigmoidf(s + wa * it.attn[p] + b);
+    }
+}
+
+__global__ __launch_bounds__(256) void same_bwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
+    __shared__ float sval[256];
+    __shared__ int sidx[256];
+    __shared__ float red[8][2 * C + 2];
+    const pnmn_same_item it = items[blockIdx.x];
+    const int j = block_first_argmax(it.attn, HW, sval, sidx);
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(it.feats + (size_t)j * C + 4 * h);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
+    const f32x4 wv = w * v;
+    const float wa = it.w[C];
+    f32x4 sfx = f32x4{0.f, 0.f, 0.f, 0.f};  // sum_p dz[p] * feats[p][c]
+    float dwa = 0.f, db = 0.f;
+    for (int p = hw; p < HW; p += 8) {
+        const float o = it.out[p];
+        const float dz = it.dout[p] * o * (1.f - o);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(it.feats + (size_t)p * C + 4 * h);
+        sfx += x * dz;
+        if (h == 0) {
+            dwa += dz * it.attn[p];
+            db += dz;
+            unsafeAtomicAdd(it.dattn + p, dz * wa);
+        }
+        const f32x4 df = wv * dz;  // through x = feats * v, wrt feats[p]
+        float* d = it.dfeats + (size_t)p * C + 4 * h;
+        unsafeAtomicAdd(d + 0, df.x);
+        unsafeAtomicAdd(d + 1, df.y);
+        unsafeAtomicAdd(d + 2, df.z);
+        unsafeAtomicAdd(d + 3, df.w);
+    }
+    red[hw][4 * h + 0] = sfx.x;
+    red[hw][4 * h + 1] = sfx.y;
+    red[hw][4 * h + 2] = sfx.z;
+    red[hw][4 * h + 3] = sfx.w;
+    if (h == 0) {
+        red[hw][2 * C] = dwa;
+        red[hw][2 * C + 1] = db;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][c];
+        const float vc = it.feats[(size_t)j * C + c];
+        const float wc = it.w[c];
+        unsafeAtomicAdd(it.dw + c, s * vc);                       // d/dw[c]
+        unsafeAtomicAdd(it.dfeats + (size_t)j * C + c, s * wc);   // through v = feats[j]
+    } else if (threadIdx.x == C || threadIdx.x == C + 1) {
+        const int k2 = 2 * C + (threadIdx.x - C);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][k2];
+        unsafeAtomicAdd(threadIdx.x == C ? it.dw + C : it.db, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// And / Or
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void minmax_fwd_kernel(const pnmn_minmax_item* __restrict__ items,
+                                                         int HW, int Cn) {
+    const pnmn_minmax_item it = items[blockIdx.x];
+    const int oc = it.a_channels > it.b_channels ? it.a_channels : it.b_channels;
+    const int n = HW * oc;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int p = i / oc;
+        const int c = i - p * oc;
+        const float a = it.a[it.a_channels == 1 ? p : p * Cn + c];
+        const float b = it.b[it.b_channels == 1 ? p : p * Cn + c];
+        // torch.min/max propagate NaN; fminf/fmaxf would not
+        float r;
+        if (a != a || b != b)
+            r = NAN;
+        else
+            r = it.is_max ? (a > b ? a : b) : (a < b ? a : b);
+        it.out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_bwd_kernel(const pnmn_minmax_item* __restrict__ items,
+                                                         int HW, int Cn) {
+    const pnmn_minmax_item it = items[blockIdx.x];
+    const int oc = it.a_channels > it.b_channels ? it.a_channels : it.b_channels;
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;
+    if (oc == 1) {
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            const float a = it.a[p], b = it.b[p], g = it.dout[p];
+            const bool a_wins = it.is_max ? (a > b) : (a < b);
+            const float ga = (a == b) ? 0.5f * g : (a_wins ? g : 0.f);
+            const float gb = (a == b) ? 0.5f * g : (a_wins ? 0.f : g);
+            if (it.da) unsafeAtomicAdd(it.da + p, ga);
+            if (it.db) unsafeAtomicAdd(it.db + p, gb);
+        }
+        return;
+    }
+    // oc == Cn == 128: half-wave per pixel, 4 channels per lane
+    for (int p = hw; p < HW; p += 8) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(it.dout + (size_t)p * Cn + 4 * h);
+        f32x4 a, b;
+        if (it.a_channels == 1) {
+            const float s = it.a[p];
+            a = f32x4{s, s, s, s};
+        } else {
+            a = *reinterpret_cast<const f32x4*>(it.a + (size_t)p * Cn + 4 * h);
+        }
+        if (it.b_channels == 1) {
+            const float s = it.b[p];
+            b = f32x4{s, s, s, s};
+        } else {
+            b = *reinterpret_cast<const f32x4*>(it.b + (size_t)p * Cn + 4 * h);
+        }
+        f32x4 ga, gb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool a_wins = it.is_max ? (a[k] > b[k]) : (a[k] < b[k]);
+            ga[k] = (a[k] == b[k]) ? 0.5f * g[k] : (a_wins ? g[k] : 0.f);
+            gb[k] = (a[k] == b[k]) ? 0.5f * g[k] : (a_wins ? 0.f : g[k]);
+        }
+        if (it.da) {
+            if (it.a_channels == 1) {
+                const float s = half_wave_sum(ga.x + ga.y + ga.z + ga.w);
+                if (h == 0) unsafeAtomicAdd(it.da + p, s);
+            } else {
+                float* d = it.da + (size_t)p * Cn + 4 * h;
+                unsafeAtomicAdd(d + 0, ga.x);
+                unsafeAtomicAdd(d + 1, ga.y);
+                unsafeAtomicAdd(d + 2, ga.z);
+                unsafeAtomicAdd(d + 3, ga.w);
+            }
+        }
+        if (it.db) {
+            if (it.b_channels == 1) {
+                const float s = half_wave_sum(gb.x + gb.y + gb.z + gb.w);
+                if (h == 0) unsafeAtomicAdd(it.db + p, s);
+            } else {
+                float* d = it.db + (size_t)p * Cn + 4 * h;
+                unsafeAtomicAdd(d + 0, gb.x);
+                unsafeAtomicAdd(d + 1, gb.y);
+                unsafeAtomicAdd(d + 2, gb.z);
+                unsafeAtomicAdd(d + 3, gb.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of feats * attn (broadcast)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_bwd_kernel(const pnmn_maskbwd_item* __restrict__ items, int HW) {
+    const pnmn_maskbwd_item it = items[blockIdx.x];
+    const int h = threadIdx.x & 31;
+    const int hw = threadIdx.x >> 5;
+    for (int p = hw; p < HW; p += 8) {
+        const f32x4 dx = *reinterpret_cast<const f32x4*>(it.dx + (size_t)p * C + 4 * h);
+        float m = 1.f;
+        if (it.attn) {
+            m = it.attn[p];
+            const f32x4 f = *reinterpret_cast<const f32x4*>(it.feats + (size_t)p * C + 4 * h);
+            const float s = half_wave_sum(dot4(dx, f));
+            if (h == 0) unsafeAtomicAdd(it.dattn + p, s);
+        }
+        float* d = it.dfeats + (size_t)p * C + 4 * h;
+        unsafeAtomicAdd(d + 0, dx.x * m);
+        unsafeAtomicAdd(d + 1, dx.y * m);
+        unsafeAtomicAdd(d + 2, dx.z * m);
+        unsafeAtomicAdd(d + 3, dx.w * m);
+    }
+}
+
+__global__ __launch_bounds__(256) void accumulate_kernel(const pnmn_axpy_item* __restrict__ items) {
+    const pnmn_axpy_item it = items[blockIdx.x];
+    const int64_t n4 = it.n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        f32x4 d = reinterpret_cast<f32x4*>(it.dst)[i];
+        d += reinterpret_cast<const f32x4*>(it.src)[i];
+        reinterpret_cast<f32x4*>(it.dst)[i] = d;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < it.n; i += blockDim.x) it.dst[i] += it.src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight transposition for dgrad: [Cout][T][Cin] -> [Cin][T-1-t][Cout]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const pnmn_wtrans_item* __restrict__ items) {
+    __shared__ float tile[32][33];
+    const pnmn_wtrans_item it = items[blockIdx.z];
+    const int tiles_ci = (it.cin + 31) / 32;
+    const int tiles_co = (it.cout + 31) / 32;
+    const int per_tap = tiles_ci * tiles_co;
+    // blockIdx.x enumerates (tap, co tile, ci tile); items may have fewer tiles than the grid
+    if ((int)blockIdx.x >= per_tap * it.ntaps) return;
+    const int tap = blockIdx.x / per_tap;
+    const int rem = blockIdx.x % per_tap;
+    const int co0 = (rem / tiles_ci) * 32;
+    const int ci0 = (rem % tiles_ci) * 32;
+    const int tx = threadIdx.x & 31;
+    const int ty = threadIdx.x >> 5;  // 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < it.cout && ci < it.cin)
+            tile[r][tx] = it.src[((size_t)co * it.ntaps + tap) * it.cin + ci];
+    }
+    __syncthreads();
+    const int rt = it.ntaps - 1 - tap;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (co < it.cout && ci < it.cin)
+            it.dst[((size_t)ci * it.ntaps + rt) * it.cout + co] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW <-> NHWC
+// ------------------------------------------------------------------------------------------------
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                     int Cn, int HW) {
+    extern __shared__ float tile[];  // [64][HW+1]
+    const int n = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int ld = HW + 1;
+    const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
+    if (TO_NHWC) {
+        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
+            const int c = i / HW, p = i - c * HW;
+            tile[c * ld + p] = src[((size_t)n * Cn + c0 + c) * HW + p];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
+            const int p = i / cw, c = i - p * cw;
+            dst[((size_t)n * HW + p) * Cn + c0 + c] = tile[c * ld + p];
+        }
+    } else {
+        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
+            const int p = i / cw, c = i - p * cw;
+            tile[c * ld + p] = src[((size_t)n * HW + p) * Cn + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
+            const int c = i / HW, p = i - c * HW;
+            dst[((size_t)n * Cn + c0 + c) * HW + p] = tile[c * ld + p];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) + Flatten over a ReLU'd NHWC map, output in NCHW-flatten order
+// ------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                      float* __restrict__ out, int H, int W, int Cn) {
+    extern __shared__ float tile[];  // [HW][65]
+    const int n = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int HW = H * W;
+    const int PH = H / 2, PW = W / 2, PS = PH * PW;
+    const float* src = in + (size_t)n * HW * Cn;
+    for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
+        const int p = i >> 6, c = i & 63;
+        tile[p * 65 + c] = src[(size_t)p * Cn + c0 + c];
+    }
+    __syncthreads();
+    if (!BWD) {
+        float* o = out + (size_t)n * Cn * PS + (size_t)c0 * PS;
+        for (int i = threadIdx.x; i < 64 * PS; i += blockDim.x) {
+            const int c = i / PS, s = i - c * PS;
+            const int y = (s / PW) * 2, x = (s % PW) * 2;
+            const float a = tile[(y * W + x) * 65 + c];
+            const float b = tile[(y * W + x + 1) * 65 + c];
+            const float d = tile[((y + 1) * W + x) * 65 + c];
+            const float e = tile[((y + 1) * W + x + 1) * 65 + c];
+            o[i] = fmaxf(fmaxf(a, b), fmaxf(d, e));
+        }
+    } else {
+        // pass 1: pooled gradient -> argmax position, written back into the tile (in place)
+        const float* g = dout + (size_t)n * Cn * PS + (size_t)c0 * PS;
+        for (int i = threadIdx.x; i < 64 * PS; i += blockDim.x) {
+            const int c = i / PS, s = i - c * PS;
+            const int y = (s / PW) * 2, x = (s % PW) * 2;
+            const int q[4] = {y * W + x, y * W + x + 1, (y + 1) * W + x, (y + 1) * W + x + 1};
+            float best = tile[q[0] * 65 + c];
+            int bi = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float v = tile[q[k] * 65 + c];
+                if (v > best) {
+                    best = v;
+                    bi = k;
+                }
+            }
+            const float gv = best > 0.f ? g[i] : 0.f;  // ReLU gate of the conv output
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[q[k] * 65 + c] = (k == bi) ? gv : 0.f;
+        }
+        __syncthreads();
+        // rows/cols beyond the pooled area (odd H or W) receive no gradient
+        float* d = out + (size_t)n * HW * Cn;
+        for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
+            const int p = i >> 6, c = i & 63;
+            const int y = p / W, x = p - y * W;
+            const bool covered = (y < PH * 2) && (x < PW * 2);
+            d[(size_t)p * Cn + c0 + c] = covered ? tile[p * 65 + c] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// answer loss
+// ------------------------------------------------------------------------------------------------
+__global__ void answer_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ answers,
+                                   const int32_t* __restrict__ valid, int64_t* __restrict__ predictions,
+                                   float* __restrict__ loss, float* __restrict__ dlogits, int n, int A,
+                                   int unknown_index, float scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const float* z = logits + (size_t)b * A;
+    float mx = z[0];
+    int am = 0;
+    for (int k = 1; k < A; ++k)
+        if (z[k] > mx) {
+            mx = z[k];
+            am = k;
+        }
+    float se = 0.f;
+    for (int k = 0; k < A; ++k) se += expf(z[k] - mx);
+    const float lse = mx + logf(se);
+    const bool ok = valid == nullptr || valid[b] != 0;
+    if (predictions) predictions[b] = ok ? (int64_t)am : (int64_t)unknown_index;
+    float l;
+    if (answers)
+        l = lse - z[answers[b]];
+    else
+        l = lse - mx;
+    loss[b] = ok ? l : 3.33f;
+    if (dlogits) {
+        for (int k = 0; k < A; ++k) {
+            float gk = 0.f;
+            if (ok && answers) gk = (expf(z[k] - lse) - (k == (int)answers[b] ? 1.f : 0.f)) * scale;
+            dlogits[(size_t)b * A + k] = gk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// clamp + Adam
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clamp_adam_kernel(const pnmn_adam_item* __restrict__ items, float lr,
+                                                         float beta1, float beta2, float eps, float wd,
+                                                         float clampv, float bc1, float bc2_sqrt) {
+    const pnmn_adam_item it = items[blockIdx.y];
+    const int64_t n4 = it.n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = reinterpret_cast<f32x4*>(it.param)[i];
+        f32x4 g = reinterpret_cast<const f32x4*>(it.grad)[i];
+        f32x4 m = reinterpret_cast<f32x4*>(it.exp_avg)[i];
+        f32x4 v = reinterpret_cast<f32x4*>(it.exp_avg_sq)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gk = g[k];
+            if (clampv > 0.f) gk = fminf(fmaxf(gk, -clampv), clampv);
+            gk += wd * p[k];
+            m[k] = m[k] + (gk - m[k]) * (1.f - beta1);  // lerp, as torch
+            v[k] = v[k] * beta2 + (1.f - beta2) * gk * gk;
+            const float denom = sqrtf(v[k]) / bc2_sqrt + eps;
+            p[k] = p[k] - step_size * (m[k] / denom);
+        }
+        reinterpret_cast<f32x4*>(it.param)[i] = p;
+        reinterpret_cast<f32x4*>(it.exp_avg)[i] = m;
+        reinterpret_cast<f32x4*>(it.exp_avg_sq)[i] = v;
+    }
+    // tail
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < it.n; i += stride) {
+        float gk = it.grad[i];
+        if (clampv > 0.f) gk = fminf(fmaxf(gk, -clampv), clampv);
+        gk += wd * it.param[i];
+        const float m = it.exp_avg[i] + (gk - it.exp_avg[i]) * (1.f - beta1);
+        const float v = it.exp_avg_sq[i] * beta2 + (1.f - beta2) * gk * gk;
+        it.exp_avg[i] = m;
+        it.exp_avg_sq[i] = v;
+        it.param[i] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+    }
+}
+
+inline int last_error() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+#define STREAM(s) static_cast<hipStream_t>(s)
+
+extern "C" {
+
+int pnmn_abi_version(void) { return 1; }
+
+int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(dot1_sigmoid_fwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_dot1_sigmoid_bwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(dot1_sigmoid_bwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_same_fwd(const pnmn_same_item* items, int n_items, int HW, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(same_fwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_same_bwd(const pnmn_same_item* items, int n_items, int HW, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(same_bwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_minmax_fwd(const pnmn_minmax_item* items, int n_items, int HW, int Cn, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0 || Cn != C) return PNMN_EINVAL;
+    hipLaunchKernelGGL(minmax_fwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW, Cn);
+    return last_error();
+}
+
+int pnmn_minmax_bwd(const pnmn_minmax_item* items, int n_items, int HW, int Cn, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0 || Cn != C) return PNMN_EINVAL;
+    hipLaunchKernelGGL(minmax_bwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW, Cn);
+    return last_error();
+}
+
+int pnmn_mask_bwd(const pnmn_maskbwd_item* items, int n_items, int HW, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || HW <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(mask_bwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items) return PNMN_EINVAL;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items);
+    return last_error();
+}
+
+int pnmn_transpose_weights(const pnmn_wtrans_item* items, int n_items, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items) return PNMN_EINVAL;
+    // grid.x covers the largest supported weight: 9 taps x (1024/32) x (1024/32) tiles would be
+    // wasteful; the caller's weights are at most [1024][1][128] / [128][9][128] / [128][1][256].
+    const int max_tiles = 9 * 4 * 4 > 32 * 8 ? 9 * 4 * 4 : 32 * 8;
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3(max_tiles, 1, n_items), dim3(256), 0,
+                       STREAM(stream), items);
+    return last_error();
+}
+
+int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
+    if (n <= 0) return 0;
+    if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
+    const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+    if (lds > 160 * 1024) return PNMN_ESHAPE;
+    static bool cfg = false;
+    if (!cfg) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(layout_kernel<true>, dim3((Cn + 63) / 64, n), dim3(256), lds, STREAM(stream), src,
+                       dst, Cn, HW);
+    return last_error();
+}
+
+int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
+    if (n <= 0) return 0;
+    if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
+    const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+    if (lds > 160 * 1024) return PNMN_ESHAPE;
+    static bool cfg = false;
+    if (!cfg) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(layout_kernel<false>, dim3((Cn + 63) / 64, n), dim3(256), lds, STREAM(stream), src,
+                       dst, Cn, HW);
+    return last_error();
+}
+
+int pnmn_maxpool2_flatten_fwd(const float* in, float* out, int n, int H, int W, int Cn, void* stream) {
+    if (n <= 0) return 0;
+    if (!in || !out || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
+    const size_t lds = (size_t)H * W * 65 * sizeof(float);
+    if (lds > 160 * 1024) return PNMN_ESHAPE;
+    static bool cfg = false;
+    if (!cfg) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(maxpool_kernel<false>, dim3(Cn / 64, n), dim3(256), lds, STREAM(stream), in,
+                       (const float*)nullptr, out, H, W, Cn);
+    return last_error();
+}
+
+int pnmn_maxpool2_flatten_bwd(const float* in, const float* dout, float* din, int n, int H, int W, int Cn,
+                              void* stream) {
+    if (n <= 0) return 0;
+    if (!in || !dout || !din || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
+    const size_t lds = (size_t)H * W * 65 * sizeof(float);
+    if (lds > 160 * 1024) return PNMN_ESHAPE;
+    static bool cfg = false;
+    if (!cfg) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(maxpool_kernel<true>, dim3(Cn / 64, n), dim3(256), lds, STREAM(stream), in, dout, din,
+                       H, W, Cn);
+    return last_error();
+}
+
+int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t* valid, int64_t* predictions,
+                     float* loss, float* dlogits, int n, int num_answers, int unknown_index, float scale,
+                     void* stream) {
+    if (n <= 0) return 0;
+    if (!logits || !loss || num_answers <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(answer_loss_kernel, dim3((n + 63) / 64), dim3(64), 0, STREAM(stream), logits, answers,
+                       valid, predictions, loss, dlogits, n, num_answers, unknown_index, scale);
+    return last_error();
+}
+
+int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, double clamp, int step, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || step < 1) return PNMN_EINVAL;
+    // bias corrections in double, as torch.optim.Adam computes them on the host
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3(2048, n_items), dim3(256), 0, STREAM(stream), items, (float)lr,
+                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)clamp, (float)bc1,
+                       (float)sqrt(bc2));
+    return last_error();
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""ctypes binding of ``libprobnmn_hip.so`` (include/probnmn_hip.h).
+
+The library is the product: if it is missing, or a call fails, this module raises -- there is no
+CPU or eager-PyTorch fallback anywhere in the package.  ``torch`` is imported first on purpose:
+the library links ``libamdhip64.so.7`` and must bind to the HIP runtime torch already loaded, so
+that torch's stream handles and device pointers are valid inside it.
+"""
+import ctypes
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch  # noqa: F401  (must precede the dlopen below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libprobnmn_hip.so")
+
+CHANNELS = 128
+CONV_ACCUMULATE = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol the header
+# declares is exported.
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_D = ctypes.c_double
+_F = ctypes.c_float
+SIGNATURES: Dict[str, tuple] = {
+    "pnmn_abi_version": (),
+    "pnmn_conv_nhwc": (_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P),
+    "pnmn_conv_wgrad": (_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P),
+    "pnmn_transpose_weights": (_P, _I, _P),
+    "pnmn_dot1_sigmoid_fwd": (_P, _I, _I, _P),
+    "pnmn_dot1_sigmoid_bwd": (_P, _I, _I, _P),
+    "pnmn_same_fwd": (_P, _I, _I, _P),
+    "pnmn_same_bwd": (_P, _I, _I, _P),
+    "pnmn_minmax_fwd": (_P, _I, _I, _I, _P),
+    "pnmn_minmax_bwd": (_P, _I, _I, _I, _P),
+    "pnmn_mask_bwd": (_P, _I, _I, _P),
+    "pnmn_accumulate": (_P, _I, _P),
+    "pnmn_nchw_to_nhwc": (_P, _P, _I, _I, _I, _P),
+    "pnmn_nhwc_to_nchw": (_P, _P, _I, _I, _I, _P),
+    "pnmn_maxpool2_flatten_fwd": (_P, _P, _I, _I, _I, _I, _P),
+    "pnmn_maxpool2_flatten_bwd": (_P, _P, _P, _I, _I, _I, _I, _P),
+    "pnmn_answer_loss": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P),
+    "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
+}
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "libprobnmn_hip.so not found at %s -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950); there is no "
+                "fallback path" % LIB_PATH
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = ctypes.c_int
+            fn.argtypes = list(argtypes)
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        kind = "argument/shape error" if code < 0 else "hipError_t"
+        raise HipLibraryError("%s failed: %s %d" % (what, kind, code))
+
+
+# ---- item record layouts (must match include/probnmn_hip.h byte for byte) -------------------------
+_u64 = np.uint64
+_i32 = np.int32
+CONV_ITEM = np.dtype(
+    [("in", _u64), ("in2", _u64), ("mask", _u64), ("gate", _u64), ("weight", _u64), ("bias", _u64),
+     ("out", _u64), ("dilation", _i32), ("flags", _i32)]
+)
+WGRAD_ITEM = np.dtype(
+    [("x", _u64), ("x2", _u64), ("xmask", _u64), ("dy", _u64), ("gate", _u64), ("dilation", _i32),
+     ("reserved", _i32)]
+)
+WGRAD_JOB = np.dtype([("dw", _u64), ("dbias", _u64), ("item_begin", _i32), ("item_end", _i32)])
+WTRANS_ITEM = np.dtype(
+    [("src", _u64), ("dst", _u64), ("cout", _i32), ("cin", _i32), ("ntaps", _i32), ("reserved", _i32)]
+)
+DOT1_ITEM = np.dtype(
+    [("in", _u64), ("w", _u64), ("b", _u64), ("out", _u64), ("dout", _u64), ("din", _u64),
+     ("dw", _u64), ("db", _u64)]
+)
+SAME_ITEM = np.dtype(
+    [("feats", _u64), ("attn", _u64), ("w", _u64), ("b", _u64), ("out", _u64), ("dout", _u64),
+     ("dfeats", _u64), ("dattn", _u64), ("dw", _u64), ("db", _u64)]
+)
+MINMAX_ITEM = np.dtype(
+    [("a", _u64), ("b", _u64), ("out", _u64), ("dout", _u64), ("da", _u64), ("db", _u64),
+     ("a_channels", _i32), ("b_channels", _i32), ("is_max", _i32), ("reserved", _i32)]
+)
+MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats", _u64), ("dattn", _u64)])
+AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
+ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
+
+ITEM_SIZES = {
+    "pnmn_conv_item": (CONV_ITEM, 64),
+    "pnmn_wgrad_item": (WGRAD_ITEM, 48),
+    "pnmn_wgrad_job": (WGRAD_JOB, 24),
+    "pnmn_wtrans_item": (WTRANS_ITEM, 32),
+    "pnmn_dot1_item": (DOT1_ITEM, 64),
+    "pnmn_same_item": (SAME_ITEM, 80),
+    "pnmn_minmax_item": (MINMAX_ITEM, 64),
+    "pnmn_maskbwd_item": (MASKBWD_ITEM, 40),
+    "pnmn_axpy_item": (AXPY_ITEM, 24),
+    "pnmn_adam_item": (ADAM_ITEM, 40),
+}
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def to_device(records: np.ndarray, device: torch.device) -> torch.Tensor:
+    """Copy a numpy record array into device memory (asynchronously, via a pinned staging buffer).
+    The returned uint8 tensor owns the device copy; keep it alive until the kernels that read it
+    have been enqueued (stream order then protects it through the caching allocator)."""
+    raw = torch.from_numpy(records.view(np.uint8).reshape(-1))
+    if device.type != "cuda":
+        raise HipLibraryError("probnmn HIP kernels need a cuda (ROCm) device, got %s" % device)
+    return raw.pin_memory().to(device, non_blocking=True)
