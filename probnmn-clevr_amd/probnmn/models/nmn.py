@@ -1,0 +1,161 @@
+"""``NeuralModuleNetwork`` -- class surface of the reference's ``probnmn.models.nmn`` (reference:
+probnmn/models/nmn.py:23-296) executed by the gfx950 engine.
+
+Same constructor / ``from_config`` arguments, same submodule and ``state_dict`` names (``stem.0``,
+``stem.2``, ``classifier.{0,4,6}``, one child per program token), same ``forward`` signature and
+return dict.  What differs is how ``forward`` gets there: programs are compiled statically
+(validity included -- the reference's bare ``except`` is not reproduced, kernel errors surface),
+all module calls of the batch run as grouped kernels, and stem / classifier conv / max-pool are
+part of the same explicit forward+backward schedule (``probnmn.runtime.engine``).
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from probnmn.modules.nmn_modules import (
+    AndModule,
+    AttentionModule,
+    ComparisonModule,
+    Flatten,
+    OrModule,
+    QueryModule,
+    RelateModule,
+    SameModule,
+)
+from probnmn.runtime import program_compiler as pc
+from probnmn.utils.metrics import Average, BooleanAccuracy
+
+INVALID_PROGRAM_LOSS = 3.33  # ~ ln(28), the reference's constant (nmn.py:260,269)
+
+
+class _Trunk(torch.autograd.Function):
+    """stem -> module programs -> classifier conv + max-pool, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, features, engine, compiled, *params):
+        need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
+        pooled, state = engine.run_forward(features, compiled, need_backward)
+        ctx.engine, ctx.state = engine, state
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        if ctx.state is None:
+            raise RuntimeError("backward through a forward that was run without gradient tracking")
+        grads = ctx.engine.run_backward(ctx.state, dpooled)
+        return (None, None, None, *grads)
+
+
+class NeuralModuleNetwork(nn.Module):
+    def __init__(
+        self,
+        vocabulary,
+        image_feature_size: Tuple[int, int, int] = (1024, 14, 14),
+        module_channels: int = 128,
+        class_projection_channels: int = 1024,
+        classifier_linear_size: int = 1024,
+    ):
+        super().__init__()
+        self.vocabulary = vocabulary
+        channels, height, width = image_feature_size
+        # "@@UNKNOWN@@" is never produced by the classifier (reference nmn.py:60-63)
+        num_answers = len(vocabulary.get_index_to_token_vocabulary(namespace="answers")) - 1
+
+        self.stem = nn.Sequential(
+            nn.Conv2d(channels, module_channels, kernel_size=3, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(module_channels, module_channels, kernel_size=3, padding=1),
+            nn.ReLU(),
+        )
+        self.classifier = nn.Sequential(
+            nn.Conv2d(module_channels, class_projection_channels, kernel_size=1),
+            nn.ReLU(),
+            nn.MaxPool2d(kernel_size=2, stride=2),
+            Flatten(),
+            nn.Linear(class_projection_channels * height * width // 4, classifier_linear_size),
+            nn.ReLU(),
+            nn.Linear(classifier_linear_size, num_answers),
+        )
+
+        # one child module per program token, named by the token (reference nmn.py:86-115)
+        self._function_modules: Dict[str, Optional[nn.Module]] = {}
+        factories = {pc.AND: AndModule, pc.OR: OrModule}
+        sized = {pc.CMP: ComparisonModule, pc.QUERY: QueryModule, pc.REL: RelateModule,
+                 pc.SAME: SameModule, pc.ATT: AttentionModule}
+        for token in vocabulary.get_token_to_index_vocabulary("programs"):
+            kind = pc.classify_token(token)
+            if kind == pc.SKIP:
+                continue
+            if kind == pc.SCENE:
+                module = None
+            elif kind in factories:
+                module = factories[kind]()
+            else:
+                module = sized[kind](module_channels)
+            self._function_modules[token] = module
+            self.add_module(token, module)
+
+        self._unknown_answer = vocabulary.get_token_index("@@UNKNOWN@@", namespace="answers")
+        self._answer_accuracy = BooleanAccuracy()
+        self._average_invalid_programs = Average()
+
+        from probnmn.runtime.engine import NMNEngine
+
+        self._engine = NMNEngine(self, tuple(image_feature_size), module_channels, class_projection_channels)
+
+    @classmethod
+    def from_config(cls, config):
+        from probnmn.vocabulary import Vocabulary
+
+        _C = config
+        return cls(
+            vocabulary=Vocabulary.from_files(_C.DATA.VOCABULARY),
+            image_feature_size=tuple(_C.NMN.IMAGE_FEATURE_SIZE),
+            module_channels=_C.NMN.MODULE_CHANNELS,
+            class_projection_channels=_C.NMN.CLASS_PROJECTION_CHANNELS,
+            classifier_linear_size=_C.NMN.CLASSIFIER_LINEAR_SIZE,
+        )
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None):
+        engine = self._engine
+        arena = engine.ensure_arena()
+        # the programs decide the launch schedule, so they are needed on the host (the reference
+        # also reads them back, once per example: nmn.py:203)
+        compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
+        valid = torch.tensor([p.valid for p in compiled], device=features.device)
+
+        params = [arena.param(n) for n in arena.names]
+        pooled = _Trunk.apply(features, engine, compiled, *params)
+        hidden = F.relu(self.classifier[4](pooled))
+        answer_logits = self.classifier[6](hidden)
+
+        answer_logprobs = F.log_softmax(answer_logits, dim=-1)
+        best_logprobs, answer_predictions = torch.max(answer_logprobs, dim=1)
+        answer_predictions = torch.where(
+            valid, answer_predictions, torch.full_like(answer_predictions, self._unknown_answer))
+
+        if answers is not None:
+            loss = F.cross_entropy(answer_logits, answers, reduction="none")
+            self._answer_accuracy(answer_predictions, answers)
+            self._average_invalid_programs((~valid).sum())
+        else:
+            loss = -best_logprobs
+        # invalid programs: constant loss, no gradient (reference nmn.py:260,269)
+        loss = torch.where(valid, loss, torch.full_like(loss, INVALID_PROGRAM_LOSS))
+
+        output_dict = {"predictions": answer_predictions, "loss": loss}
+        if self.training:
+            output_dict["metrics"] = self.get_metrics(reset=True)
+        return output_dict
+
+    def get_metrics(self, reset: bool = True) -> Dict[str, float]:
+        return {
+            "answer_accuracy": self._answer_accuracy.get_metric(reset=reset),
+            "average_invalid": self._average_invalid_programs.get_metric(reset=reset),
+        }

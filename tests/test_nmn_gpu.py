@@ -1,0 +1,144 @@
+"""NeuralModuleNetwork on the MI355X against the CPU oracle at the reference's full dimensions
+(1024x14x14 features, 128 module channels): same weights, same programs, same answers.
+Tolerance: fp32 accumulation order only (relative 1e-3 on gradients that sum ~1e5 products)."""
+import numpy as np
+import pytest
+import torch
+
+from fixtures import VALIDITY_CASES, encode_programs
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=0, cases=VALIDITY_CASES):
+    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(seed)
+    net = NeuralModuleNetwork(vocab)
+    programs = encode_programs(cases, vocab.get_token_to_index_vocabulary("programs"))
+    B = programs.size(0)
+    g = torch.Generator().manual_seed(seed + 1)
+    features = torch.relu(torch.randn(B, 1024, 14, 14, generator=g))
+    answers = torch.randint(0, 28, (B,), generator=g)
+    return vocab, net, programs, features, answers
+
+
+def _oracle(vocab, sd, programs, features, answers):
+    from oracle import nmn_oracle
+
+    sd = {k: v.detach().clone().contiguous().requires_grad_(True) for k, v in sd.items()}
+    out = nmn_oracle.nmn_forward(sd, vocab.get_index_to_token_vocabulary("programs"), features, programs, answers)
+    if answers is not None:
+        out["loss"].mean().backward()
+    return out, sd
+
+
+def _grad_errors(net, ref_sd):
+    """max |g_hip - g_oracle| / max |g_oracle| per parameter."""
+    errs = {}
+    for name, p in net.named_parameters():
+        g_ref = ref_sd[name].grad
+        g_ref = torch.zeros_like(ref_sd[name]) if g_ref is None else g_ref
+        got = torch.zeros_like(g_ref) if p.grad is None else p.grad.detach().cpu()
+        scale = float(g_ref.abs().max())
+        if scale == 0.0:
+            assert float(got.abs().max()) == 0.0, name  # unused module: exactly no gradient
+            continue
+        errs[name] = float((got - g_ref).abs().max()) / scale
+    return errs
+
+
+def test_forward_backward_matches_oracle_full_batch():
+    """All 36 golden programs (valid and invalid) in one batch: identical predictions, losses to
+    1e-4, gradients to 2e-2 of each tensor's max (see the per-program test for why not tighter)."""
+    vocab, net, programs, features, answers = _setup()
+    cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ref, ref_sd = _oracle(vocab, cpu_sd, programs, features, answers)
+
+    dev = torch.device("cuda:0")
+    net.to(dev).train()
+    out = net(features.to(dev), programs.to(dev), answers.to(dev))
+    out["loss"].mean().backward()
+    torch.cuda.synchronize()
+
+    assert torch.equal(out["predictions"].cpu(), ref["predictions"])
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    n_invalid = int((ref["valid"] == 0).sum())
+    assert n_invalid > 0
+    assert out["metrics"]["average_invalid"] == n_invalid
+    errs = _grad_errors(net, ref_sd)
+    assert len(errs) > 60
+    worst = max(errs, key=errs.get)
+    print("worst relative gradient error", worst, errs[worst])
+    assert errs[worst] < 2e-2, (worst, errs[worst])
+
+    # state_dict keys and logical shapes are the reference's
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(cpu_sd[k].shape), k
+        torch.testing.assert_close(v.cpu(), cpu_sd[k])
+
+
+def test_gradients_per_program_tight():
+    """Each valid golden program on its own (batch of 2, fresh features).
+
+    The network is piecewise linear with hard gates (ReLU, 2x2 max-pool arg-max, min/max): when a
+    pre-activation lands within fp32 round-off of a gate, the GPU (MFMA accumulation order) and the
+    CPU oracle can take different sides, and that one element's gradient is routed differently --
+    a property of fp32, not of the kernels (the kernel-level tests in test_hip_kernels.py, which
+    share saved activations with autograd, match to 1e-4 everywhere).  It hits a few programs per
+    thousand gates, so the bar is: the typical program matches on EVERY parameter to 5e-5 of the
+    tensor's max, at least 3 in 4 programs match to 2e-4, and no program is off by more than a
+    single flipped gate can explain (5e-2)."""
+    from probnmn.models.nmn import NeuralModuleNetwork  # noqa: F401
+
+    vocab, net, _, _, _ = _setup()
+    cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    stoi = vocab.get_token_to_index_vocabulary("programs")
+    dev = torch.device("cuda:0")
+    net.to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    worst_per_case = []
+    for case in VALIDITY_CASES:
+        programs = encode_programs([case, case], stoi)
+        features = torch.relu(torch.randn(2, 1024, 14, 14, generator=g))
+        answers = torch.randint(0, 28, (2,), generator=g)
+        ref, ref_sd = _oracle(vocab, cpu_sd, programs, features, answers)
+        if int(ref["valid"][0]) == 0:
+            continue
+        net.zero_grad(set_to_none=True)
+        out = net(features.to(dev), programs.to(dev), answers.to(dev))
+        out["loss"].mean().backward()
+        torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-5, atol=2e-6)
+        errs = _grad_errors(net, ref_sd)
+        worst_per_case.append(max(errs.values()))
+    w = np.sort(np.asarray(worst_per_case))
+    print("per-program worst gradient errors:", np.array2string(w, precision=1))
+    assert len(w) >= 20
+    assert np.median(w) < 5e-5
+    assert np.mean(w < 2e-4) >= 0.75
+    assert w.max() < 5e-2
+
+
+def test_eval_without_answers_and_repeat_is_deterministic():
+    vocab, net, programs, features, _ = _setup(seed=3, cases=VALIDITY_CASES[:12])
+    cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ref, _ = _oracle(vocab, cpu_sd, programs, features, None)
+    dev = torch.device("cuda:0")
+    net.to(dev).eval()
+    with torch.no_grad():
+        out1 = net(features.to(dev), programs.to(dev))
+        out2 = net(features.to(dev), programs.to(dev))
+    assert "metrics" not in out1
+    assert torch.equal(out1["predictions"].cpu(), ref["predictions"])
+    torch.testing.assert_close(out1["loss"].cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(out1["loss"], out2["loss"])  # forward has no atomics: bitwise repeatable
+
+
+def test_cpu_tensors_fail_loudly():
+    from probnmn import _hip
+
+    vocab, net, programs, features, answers = _setup(cases=VALIDITY_CASES[:2])
+    with pytest.raises(_hip.HipLibraryError):
+        net(features, programs, answers)
