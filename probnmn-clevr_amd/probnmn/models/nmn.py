@@ -100,6 +100,9 @@ class NeuralModuleNetwork(nn.Module):
         self._unknown_answer = vocabulary.get_token_index("@@UNKNOWN@@", namespace="answers")
         self._answer_accuracy = BooleanAccuracy()
         self._average_invalid_programs = Average()
+        # reference behaviour: every training forward returns batch metrics as Python floats, which
+        # costs a device->host sync per step; trainers that log less often switch this off
+        self.report_batch_metrics = True
 
         from probnmn.runtime.engine import NMNEngine
 
@@ -142,15 +145,16 @@ class NeuralModuleNetwork(nn.Module):
 
         if answers is not None:
             loss = F.cross_entropy(answer_logits, answers, reduction="none")
-            self._answer_accuracy(answer_predictions, answers)
-            self._average_invalid_programs((~valid).sum())
+            if self.report_batch_metrics or not self.training:
+                self._answer_accuracy(answer_predictions, answers)
+                self._average_invalid_programs(sum(1 for p in compiled if not p.valid))
         else:
             loss = -best_logprobs
         # invalid programs: constant loss, no gradient (reference nmn.py:260,269)
         loss = torch.where(valid, loss, torch.full_like(loss, INVALID_PROGRAM_LOSS))
 
         output_dict = {"predictions": answer_predictions, "loss": loss}
-        if self.training:
+        if self.training and self.report_batch_metrics:
             output_dict["metrics"] = self.get_metrics(reset=True)
         return output_dict
 

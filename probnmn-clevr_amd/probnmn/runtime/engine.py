@@ -90,6 +90,33 @@ class NMNEngine:
         self.compiler = pc.ProgramCompiler(
             net.vocabulary.get_index_to_token_vocabulary("programs"), module_channels)
         self.last_plan: Optional[StepPlan] = None
+        # when a list, every conv / wgrad launch is bracketed by events on the launch stream and
+        # (kernel, algorithmic flops, start, end) is appended -- used by bench.py's roofline pass
+        self.event_log: Optional[list] = None
+
+    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
+        log = self.event_log
+        if log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _hip.check(_hip.lib().pnmn_conv_nhwc(ptr, n, self.H, self.W, cin_chunks, ntaps, in_stride, out_stride,
+                                             cout_blocks, relu, st), what)
+        if log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1))
+
+    def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, st, what):
+        log = self.event_log
+        if log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _hip.check(_hip.lib().pnmn_conv_wgrad(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
+                                              x_stride, dy_stride, st), what)
+        if log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1))
 
     # ---- parameters ---------------------------------------------------------------------------
     def trunk_named_parameters(self):
@@ -284,8 +311,8 @@ class NMNEngine:
         H, W = self.H, self.W
         chk = _hip.check
         chk(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
-        chk(lib.pnmn_conv_nhwc(pack.ptr("stem1"), B, H, W, self.cin // C, 9, self.cin, C, 1, 1, st), "stem conv1")
-        chk(lib.pnmn_conv_nhwc(pack.ptr("stem2"), B, H, W, 1, 9, C, C, 1, 1, st), "stem conv2")
+        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
+        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
 
         final = ws["final"][: B * HW * C].view(B, HW * C)
         feat = ws["feat"][: B * HW * C].view(B, HW * C)
@@ -299,7 +326,7 @@ class NMNEngine:
 
         self._run_forward_launches(plan, pack, st)
 
-        chk(lib.pnmn_conv_nhwc(pack.ptr("cls"), B, H, W, 1, 1, C, self.cproj, self.cproj // C, 1, st), "classifier conv")
+        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
         chk(lib.pnmn_maxpool2_flatten_fwd(ws["cls"].data_ptr(), pooled.data_ptr(), B, H, W, self.cproj, st), "maxpool")
 
@@ -315,9 +342,9 @@ class NMNEngine:
         for l in plan.forward:
             n = l.end - l.begin
             if l.kind == "conv":
-                chk(lib.pnmn_conv_nhwc(pack.ptr("conv", l.begin), n, H, W, 1, 9, C, C, 1, 1, st), "module conv")
+                self._conv(pack.ptr("conv", l.begin), n, 1, 9, C, C, 1, 1, st, "module conv")
             elif l.kind == "proj":
-                chk(lib.pnmn_conv_nhwc(pack.ptr("proj", l.begin), n, H, W, 2, 1, C, C, 1, 1, st), "projection")
+                self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection")
             elif l.kind == "dot":
                 chk(lib.pnmn_dot1_sigmoid_fwd(pack.ptr("dot", l.begin), n, HW, st), "dot1")
             elif l.kind == "same":
@@ -352,10 +379,9 @@ class NMNEngine:
         chk(lib.pnmn_maxpool2_flatten_bwd(ws["cls"].data_ptr(), dpooled.data_ptr(), ws["gcls"].data_ptr(), B, H, W,
                                           self.cproj, st), "maxpool bwd")
         nj = len(state.fixed["cls_wg_jobs"])
-        chk(lib.pnmn_conv_wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, H, W, 1, 1, self.cproj // C, C,
-                                self.cproj, st), "classifier wgrad")
-        chk(lib.pnmn_conv_nhwc(pack.ptr("cls_dgrad"), B, H, W, self.cproj // C, 1, self.cproj, C, 1, 0, st),
-            "classifier dgrad")
+        self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, st,
+                    "classifier wgrad")
+        self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
         if plan.feat_result_examples.size:
             idx = torch.from_numpy(plan.feat_result_examples).to(dev)
             gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
@@ -373,9 +399,9 @@ class NMNEngine:
                 elif l.kind == "minmax_bwd":
                     chk(lib.pnmn_minmax_bwd(pack.ptr("minmax", l.begin), n, HW, C, st), "minmax bwd")
                 elif l.kind == "dgrad":
-                    chk(lib.pnmn_conv_nhwc(pack.ptr("dgrad", l.begin), n, H, W, 1, 9, C, C, 1, 0, st), "module dgrad")
+                    self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad")
                 elif l.kind == "pdgrad":
-                    chk(lib.pnmn_conv_nhwc(pack.ptr("pdgrad", l.begin), n, H, W, 1, 1, C, C, 1, 0, st), "projection dgrad")
+                    self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad")
                 elif l.kind == "maskbwd":
                     chk(lib.pnmn_mask_bwd(pack.ptr("maskbwd", l.begin), n, HW, st), "mask bwd")
                 else:
@@ -384,18 +410,20 @@ class NMNEngine:
         # all module-conv weight gradients in one grouped launch each
         nj = len(plan.wgrad_jobs["wg3"])
         if nj:
-            chk(lib.pnmn_conv_wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs"), nj, H, W, 9, 1, 1, C, C, st), "module wgrad")
+            self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs"), nj, len(plan.records["wg3"]), 9, 1, 1, C, C, st,
+                        "module wgrad")
         nj = len(plan.wgrad_jobs["wgp"])
         if nj:
-            chk(lib.pnmn_conv_wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, H, W, 1, 2, 1, C, C, st), "projection wgrad")
+            self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, st,
+                        "projection wgrad")
 
         # stem
-        chk(lib.pnmn_conv_nhwc(pack.ptr("stem2_dgrad"), B, H, W, 1, 9, C, C, 1, 0, st), "stem conv2 dgrad")
+        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad")
         nj = len(state.fixed["stem2_wg_jobs"])
-        chk(lib.pnmn_conv_wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, H, W, 9, 1, 1, C, C, st), "stem conv2 wgrad")
+        self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, st, "stem conv2 wgrad")
         nj = len(state.fixed["stem1_wg_jobs"])
-        chk(lib.pnmn_conv_wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, H, W, 9, self.cin // C, 1, self.cin,
-                                C, st), "stem conv1 wgrad")
+        self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, st,
+                    "stem conv1 wgrad")
 
         if self.direct_grads:
             a.attach_grads()

@@ -1,0 +1,39 @@
+"""One module-training iteration on one GPU (reference: probnmn/trainers/_trainer.py:135-151 and
+module_training_trainer.py:88-98): zero_grad -> NMN forward on the given programs -> mean loss ->
+backward -> clamp to [-5, 5] -> Adam.  Programs come from the batch (ground-truth or pre-sampled)
+or, when a frozen ``program_generator`` is supplied, are sampled from it as the reference does."""
+from typing import Any, Dict, Optional
+
+import torch
+
+from probnmn import parallel
+from probnmn.optim import ClampAdam
+
+
+class ModuleTrainingStep:
+    def __init__(self, nmn, lr: float = 1e-4, weight_decay: float = 0.0, program_generator=None,
+                 report_metrics: bool = False):
+        self.nmn = nmn
+        self.program_generator = program_generator
+        self.report_metrics = report_metrics
+        arena = nmn.engine.ensure_arena()
+        nmn.engine.direct_grads = True  # gradients stay in the arena; the optimizer reads them there
+        self.optimizer = ClampAdam(nmn.parameters(), arenas=[arena], lr=lr, weight_decay=weight_decay, clamp=5.0)
+        self.iteration = 0
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        self.optimizer.zero_grad()
+        if self.program_generator is not None:
+            with torch.no_grad():
+                programs = self.program_generator(batch["question"], decoding_strategy="sampling")["predictions"]
+        else:
+            programs = batch["program"]
+        self.nmn.train()
+        self.nmn.report_batch_metrics = self.report_metrics
+        out = self.nmn(batch["image"], programs, batch["answer"])
+        loss = out["loss"].mean()
+        loss.backward()
+        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose)
+        self.optimizer.step()
+        self.iteration += 1
+        return {"loss": loss.detach(), "metrics": out.get("metrics")}

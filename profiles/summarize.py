@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""rocprofv3 (ROCm 7.2 writes a rocpd sqlite database) -> the per-kernel table `--stats` would show.
+
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o NAME -- python bench.py ...
+    python profiles/summarize.py gpurun_out/prof/NAME_results.db > profiles/rNN_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
+    suffix = tab.replace("rocpd_kernel_dispatch", "")
+    q = f"""select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start),
+                   max(s.arch_vgpr_count), max(s.accum_vgpr_count), max(s.sgpr_count), max(d.group_segment_size)
+            from rocpd_kernel_dispatch{suffix} d join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
+            group by s.kernel_name order by 3 desc"""
+    rows = list(cur.execute(q))
+    total = sum(r[2] for r in rows)
+    print("# kernel-trace summary of %s" % path)
+    print("# total kernel time %.3f ms over %d dispatches" % (total / 1e6, sum(r[1] for r in rows)))
+    print("%-72s %8s %12s %11s %10s %10s %6s %5s %5s %5s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct", "vgpr", "agpr", "sgpr", "lds"))
+    for r in rows:
+        name = r[0].replace(".kd", "")
+        print("%-72s %8d %12.3f %11.1f %10.1f %10.1f %6.2f %5d %5d %5d %7d" % (
+            name[:72], r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
