@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void same_bwd_kernel(const pnmn_same_item* __r
         if (h == 0) {
             dwa += dz * it.attn[p];
             db += dz;
-            unsafeAtomicAdd(it.dattn + p, dz * wa);
+            if (it.dattn) unsafeAtomicAdd(it.dattn + p, dz * wa);
         }
         const f32x4 df = wv * dz;  // through x = feats * v, wrt feats[p]
         float* d = it.dfeats + (size_t)p * C + 4 * h;
@@ -608,9 +608,9 @@ int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int Cn, int HW, void*
     if (lds > 160 * 1024) return PNMN_ESHAPE;
     static bool cfg = false;
     if (!cfg) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         cfg = true;
     }
@@ -626,7 +626,7 @@ int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int Cn, int HW, void*
     if (lds > 160 * 1024) return PNMN_ESHAPE;
     static bool cfg = false;
     if (!cfg) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         cfg = true;
     }
@@ -642,7 +642,7 @@ int pnmn_maxpool2_flatten_fwd(const float* in, float* out, int n, int H, int W, 
     if (lds > 160 * 1024) return PNMN_ESHAPE;
     static bool cfg = false;
     if (!cfg) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         cfg = true;
     }
@@ -659,7 +659,7 @@ int pnmn_maxpool2_flatten_bwd(const float* in, const float* dout, float* din, in
     if (lds > 160 * 1024) return PNMN_ESHAPE;
     static bool cfg = false;
     if (!cfg) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         cfg = true;
     }

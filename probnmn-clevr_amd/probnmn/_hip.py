@@ -126,11 +126,65 @@ def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _PinnedRing:
+    """Reusable page-locked staging buffers for small host->device copies.
+
+    ``Tensor.pin_memory()`` costs a hipHostMalloc (milliseconds) per call; a training step uploads
+    its work lists every iteration, so staging memory is allocated once and recycled.  A slot is
+    reused only after the copy that last read it has completed (event), which lets the host run
+    several steps ahead of the GPU without overwriting bytes that are still to be copied."""
+
+    def __init__(self, slots: int = 6):
+        self._bufs = [None] * slots
+        self._events = [None] * slots
+        self._next = 0
+
+    def stage(self, raw: np.ndarray, device: torch.device) -> torch.Tensor:
+        i = self._next
+        self._next = (i + 1) % len(self._bufs)
+        ev = self._events[i]
+        if ev is not None:
+            ev.synchronize()
+        n = raw.size
+        buf = self._bufs[i]
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n * 2, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._bufs[i] = buf
+        buf.numpy()[:n] = raw
+        out = buf[:n].to(device, non_blocking=True)
+        if ev is None:
+            ev = torch.cuda.Event()
+            self._events[i] = ev
+        ev.record(torch.cuda.current_stream(device))
+        return out
+
+
+_rings: Dict[int, _PinnedRing] = {}
+
+
+def _ring(device: torch.device) -> _PinnedRing:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    r = _rings.get(idx)
+    if r is None:
+        r = _rings[idx] = _PinnedRing()
+    return r
+
+
 def to_device(records: np.ndarray, device: torch.device) -> torch.Tensor:
-    """Copy a numpy record array into device memory (asynchronously, via a pinned staging buffer).
-    The returned uint8 tensor owns the device copy; keep it alive until the kernels that read it
-    have been enqueued (stream order then protects it through the caching allocator)."""
-    raw = torch.from_numpy(records.view(np.uint8).reshape(-1))
+    """Copy a numpy (record) array into device memory asynchronously through the pinned ring.
+    Returns a uint8 tensor owning the device copy; stream order protects it until the kernels that
+    read it have run."""
     if device.type != "cuda":
         raise HipLibraryError("probnmn HIP kernels need a cuda (ROCm) device, got %s" % device)
-    return raw.pin_memory().to(device, non_blocking=True)
+    raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+    return _ring(device).stage(raw, device)
+
+
+def small_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """A short Python list -> device tensor WITHOUT synchronising the stream (``torch.tensor(...,
+    device=cuda)`` copies from pageable memory and waits for all queued work first)."""
+    host = torch.tensor(values, dtype=dtype)
+    if host.numel() == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    raw = host.view(torch.uint8).numpy() if dtype != torch.bool else host.numpy().view(np.uint8)
+    return to_device(raw, device).view(dtype)

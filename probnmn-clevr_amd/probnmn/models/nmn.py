@@ -130,8 +130,11 @@ class NeuralModuleNetwork(nn.Module):
         arena = engine.ensure_arena()
         # the programs decide the launch schedule, so they are needed on the host (the reference
         # also reads them back, once per example: nmn.py:203)
+        # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
         compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
-        valid = torch.tensor([p.valid for p in compiled], device=features.device)
+        from probnmn import _hip
+
+        valid = _hip.small_to_device([p.valid for p in compiled], torch.bool, features.device)
 
         params = [arena.param(n) for n in arena.names]
         pooled = _Trunk.apply(features, engine, compiled, *params)

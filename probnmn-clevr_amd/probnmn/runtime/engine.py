@@ -318,10 +318,10 @@ class NMNEngine:
         feat = ws["feat"][: B * HW * C].view(B, HW * C)
         valid = [p.valid for p in compiled]
         if not all(valid):
-            inv = torch.tensor([i for i, v in enumerate(valid) if not v], device=dev)
+            inv = _hip.small_to_device([i for i, v in enumerate(valid) if not v], torch.long, dev)
             final.index_fill_(0, inv, 0.0)  # reference: zeros_like(feat_input) for invalid programs
         if plan.feat_result_examples.size:
-            idx = torch.from_numpy(plan.feat_result_examples).to(dev)
+            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             final.index_copy_(0, idx, feat.index_select(0, idx))
 
         self._run_forward_launches(plan, pack, st)
@@ -383,7 +383,7 @@ class NMNEngine:
                     "classifier wgrad")
         self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
         if plan.feat_result_examples.size:
-            idx = torch.from_numpy(plan.feat_result_examples).to(dev)
+            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
             gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
             gfeat.index_add_(0, idx, gfinal.index_select(0, idx))

@@ -75,6 +75,7 @@ class ProgramCompiler:
         for idx, tok in index_to_token.items():
             self.kinds[idx] = classify_token(tok)
         self._cache: Dict[Tuple[int, ...], CompiledProgram] = {}
+        self._bytes_cache: Dict[bytes, CompiledProgram] = {}
 
     def compile(self, tokens: Sequence[int]) -> CompiledProgram:
         key = tuple(int(t) for t in tokens)
@@ -85,8 +86,20 @@ class ProgramCompiler:
         return hit
 
     def compile_batch(self, programs) -> List[CompiledProgram]:
-        """``programs``: (B, T) integer array-like (numpy / list), already on the host."""
-        return [self.compile(row) for row in programs]
+        """``programs``: (B, T) integer array (numpy), already on the host."""
+        import numpy as np
+
+        arr = np.ascontiguousarray(programs, dtype=np.int64)
+        out = []
+        cache = self._bytes_cache
+        for row in arr:
+            key = row.tobytes()
+            hit = cache.get(key)
+            if hit is None:
+                hit = self.compile(row.tolist())
+                cache[key] = hit
+            out.append(hit)
+        return out
 
     # ---------------------------------------------------------------------------------
     def _compile(self, tokens: Tuple[int, ...]) -> CompiledProgram:

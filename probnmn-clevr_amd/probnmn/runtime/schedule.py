@@ -7,18 +7,21 @@ Same, And/Or), each primitive gets the dependency level at which its inputs are 
 primitives of one (level, kind) become ONE grouped kernel launch whose work list says, per item,
 which example's buffers and which token's weights to use.
 
-Host cost matters (the GPU step is milliseconds), so nothing here loops over examples:
-programs are grouped by *structure* (their calls' kinds and wiring, tokens ignored); a structure's
-primitive list is built once and cached (:class:`Template`), and the per-batch records are
-produced with numpy broadcasting over all examples that share the structure -- weights come from
-per-token offset tables, buffers from per-example base addresses.
+Host cost matters (a GPU step is a few milliseconds), so the per-batch work is a fixed number of
+numpy operations, independent of batch size and of how many different programs the batch holds:
+a program *structure* (its calls' kinds and wiring, tokens ignored) is expanded once into a dense
+integer table of primitives (:class:`Template`, cached in a bank); a batch gathers its examples'
+tables with one fancy index, and every address / weight pointer of every primitive is computed
+by whole-array arithmetic (per-kind base + per-example stride + in-block offset; weights through
+per-token offset tables).  Records are assembled as ``uint64`` matrices that are bit-identical to
+the C structs of include/probnmn_hip.h.
 
 Value placement: each example owns a contiguous block of the activation arena laid out by its
-template; the gradient arena mirrors it offset-for-offset, so ``grad(x) = x - act_base + grad_base``.
-The value a program returns is placed directly in the classifier's input row (``FINAL``).
+template; the gradient arena mirrors it offset-for-offset.  The value a program returns is
+placed directly in the classifier's input row (``FINAL``).
 """
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from dataclasses import dataclass
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 
@@ -28,8 +31,16 @@ HW_ALIGN = 64  # floats; keeps every slot 256-byte aligned
 
 # operand location kinds
 L_SLOT, L_FEAT, L_ONES, L_FINAL = 0, 1, 2, 3
+# primitive kinds
+K_CONV, K_PROJ, K_DOT, K_SAME, K_MINMAX = 0, 1, 2, 3, 4
+KIND_NAMES = ("conv", "proj", "dot", "same", "minmax")
 
 RELATE_DILATIONS = (1, 2, 4, 8, 1)  # reference nmn_modules.py:146-150
+
+# columns of a template's primitive table
+(C_KIND, C_LEVEL, C_CALL, C_WIDX, C_DIL, C_AK, C_AO, C_BK, C_BO, C_OK, C_OO, C_ACH, C_BCH, C_ISMAX,
+ C_MASKED, C_SCRATCH) = range(16)
+NCOLS = 16
 
 
 def _align(n: int) -> int:
@@ -37,32 +48,15 @@ def _align(n: int) -> int:
 
 
 @dataclass
-class _Prim:
-    kind: str  # "conv" | "proj" | "dot" | "same" | "minmax"
-    level: int
-    call: int  # index of the module call (selects the token -> weights)
-    widx: int = 0  # which weight of the module (0 = projection, 1..5 = conv1..conv5)
-    dil: int = 1
-    a: Tuple[int, int] = (L_ONES, 0)  # main input (conv/dot: feature map; same/minmax: a)
-    b: Tuple[int, int] = (L_ONES, 0)  # second input (proj: in2; conv: mask; same: attn; minmax: b)
-    out: Tuple[int, int] = (L_SLOT, 0)
-    a_ch: int = 0
-    b_ch: int = 0
-    is_max: int = 0
-    masked: bool = False  # conv whose input is FEAT * attention (needs mask backward)
-
-
-@dataclass
 class Template:
-    """Primitive list of one program structure; offsets are floats relative to the example's
-    arena block."""
+    """One program structure: ``table`` is [n_prims, NCOLS]; offsets are floats relative to the
+    example's arena block (values first, then one scratch map per masked conv)."""
 
+    table: np.ndarray
     n_calls: int
-    size: int  # arena floats per example
-    result: Tuple[int, int]  # location of the returned value (L_FINAL, 0) or (L_FEAT, 0)
-    prims: List[_Prim]
+    size: int  # arena floats per example (values + backward scratch)
+    result_is_feat: bool
     depth: int
-    n_masked: int = 0  # convs whose input is FEAT * attention (each needs one scratch map in backward)
 
 
 def structure_key(prog: pc.CompiledProgram) -> Tuple:
@@ -72,8 +66,8 @@ def structure_key(prog: pc.CompiledProgram) -> Tuple:
 def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template:
     big, small = _align(hw * channels), _align(hw)
     calls = prog.calls
-    # liveness: only calls that reach the result are executed (results are unaffected: a dead
-    # call's output feeds nothing; validity was already decided on the full program)
+    # liveness: only calls that reach the result are executed (a dead call's output feeds nothing;
+    # validity was already decided on the full program)
     needed = [False] * len(calls)
     stack = [prog.result]
     while stack:
@@ -92,7 +86,12 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
 
     loc: Dict[int, Tuple[int, int]] = {pc.FEAT: (L_FEAT, 0), pc.ONES: (L_ONES, 0)}
     lvl: Dict[int, int] = {pc.FEAT: 0, pc.ONES: 0}
-    prims: List[_Prim] = []
+    rows: List[List[int]] = []
+
+    def prim(kind, level, call, widx=0, dil=1, a=(L_ONES, 0), b=(L_ONES, 0), out=(L_SLOT, 0), a_ch=0,
+             b_ch=0, is_max=0, masked=0):
+        rows.append([kind, level, call, widx, dil, a[0], a[1], b[0], b[1], out[0], out[1], a_ch, b_ch,
+                     is_max, masked, -1])
 
     for ci, c in enumerate(calls):
         if not needed[ci]:
@@ -105,20 +104,18 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
             out = (L_SLOT, alloc(small))
         if c.kind in (pc.AND, pc.OR):
             level = max(lvl[c.a], lvl[c.b]) + 1
-            prims.append(
-                _Prim("minmax", level, ci, a=loc[c.a], b=loc[c.b], out=out, a_ch=c.a_channels,
-                      b_ch=c.b_channels, is_max=int(c.kind == pc.OR))
-            )
+            prim(K_MINMAX, level, ci, a=loc[c.a], b=loc[c.b], out=out, a_ch=c.a_channels, b_ch=c.b_channels,
+                 is_max=int(c.kind == pc.OR))
         elif c.kind == pc.SAME:
             level = lvl[c.a] + 1
-            prims.append(_Prim("same", level, ci, a=(L_FEAT, 0), b=loc[c.a], out=out))
+            prim(K_SAME, level, ci, a=(L_FEAT, 0), b=loc[c.a], out=out)
         elif c.kind == pc.CMP:
             level = max(lvl[c.a], lvl[c.b]) + 1
             t0 = (L_SLOT, alloc(big))
             t1 = (L_SLOT, alloc(big))
-            prims.append(_Prim("proj", level, ci, widx=0, a=loc[c.a], b=loc[c.b], out=t0))
-            prims.append(_Prim("conv", level + 1, ci, widx=1, a=t0, out=t1))
-            prims.append(_Prim("conv", level + 2, ci, widx=2, a=t1, out=out))
+            prim(K_PROJ, level, ci, widx=0, a=loc[c.a], b=loc[c.b], out=t0)
+            prim(K_CONV, level + 1, ci, widx=1, a=t0, out=t1)
+            prim(K_CONV, level + 2, ci, widx=2, a=t1, out=out)
             level += 2
         else:  # ATT / QUERY / REL
             nconv = 5 if c.kind == pc.REL else 2
@@ -129,21 +126,23 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
                 level += 1
                 last_is_out = (k == nconv - 1) and c.kind == pc.QUERY
                 dst = out if last_is_out else (L_SLOT, alloc(big))
-                p = _Prim("conv", level, ci, widx=k + 1, dil=dils[k], a=src, out=dst)
-                if k == 0:
-                    p.b = loc[c.a]  # attention mask (L_ONES -> no multiply)
-                    p.masked = True
-                prims.append(p)
+                if k == 0:  # input is FEAT * attention (L_ONES -> no multiply)
+                    prim(K_CONV, level, ci, widx=1, dil=dils[0], a=src, b=loc[c.a], out=dst, masked=1)
+                else:
+                    prim(K_CONV, level, ci, widx=k + 1, dil=dils[k], a=src, out=dst)
                 src = dst
             if c.kind != pc.QUERY:
                 level += 1
-                prims.append(_Prim("dot", level, ci, a=src, out=out))
+                prim(K_DOT, level, ci, a=src, out=out)
         loc[vid] = out
         lvl[vid] = level
 
-    result = loc[prog.result] if prog.result >= 2 else (L_FEAT, 0)
-    depth = max([p.level for p in prims], default=0)
-    return Template(len(calls), cursor, result, prims, depth, sum(1 for p in prims if p.masked))
+    for r in rows:  # backward scratch: gradient wrt (FEAT * attention) of each masked conv
+        if r[C_MASKED]:
+            r[C_SCRATCH] = alloc(big)
+    table = np.asarray(rows, dtype=np.int64).reshape(-1, NCOLS)
+    depth = int(table[:, C_LEVEL].max()) if len(rows) else 0
+    return Template(table, len(calls), cursor, prog.result < 2, depth)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -185,13 +184,22 @@ class Launch:
 
 @dataclass
 class StepPlan:
-    records: Dict[str, np.ndarray]  # kind -> record array (sorted by level)
+    records: Dict[str, np.ndarray]  # kind -> record array (sorted by level / by weight)
     forward: List[Launch]
     backward: List[List[Launch]]  # phases per level (reverse level order)
     wgrad_jobs: Dict[str, np.ndarray]
     arena_floats: int
     feat_result_examples: np.ndarray  # examples whose program returns FEAT itself
     n_prims: int
+
+
+def _cut(levels: np.ndarray) -> List[Tuple[int, int, int]]:
+    """(level, begin, end) runs of a sorted level array."""
+    if levels.size == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(levels)) + 1
+    bounds = np.concatenate(([0], cuts, [levels.size]))
+    return [(int(levels[b]), int(b), int(e)) for b, e in zip(bounds[:-1], bounds[1:])]
 
 
 class BatchScheduler:
@@ -202,280 +210,271 @@ class BatchScheduler:
         self.tables = tables
         self.dt = record_dtypes
         self.wgrad_chunk = wgrad_chunk
-        self._templates: Dict[Tuple, Template] = {}
+        self._ids: Dict[Tuple, int] = {}
+        self._templates: List[Template] = []
+        self._bank = None  # (tables [T, Pmax, NCOLS], nprims [T], sizes [T])
+
+    # ---- template bank -------------------------------------------------------------------------
+    def template_id(self, prog: pc.CompiledProgram) -> int:
+        tid = getattr(prog, "_template_id", None)
+        if tid is not None and getattr(prog, "_template_owner", None) is self:
+            return tid
+        key = structure_key(prog)
+        tid = self._ids.get(key)
+        if tid is None:
+            tid = len(self._templates)
+            self._templates.append(build_template(prog, self.hw, self.channels))
+            self._ids[key] = tid
+            self._bank = None
+        object.__setattr__(prog, "_template_id", tid)
+        object.__setattr__(prog, "_template_owner", self)
+        object.__setattr__(prog, "_tokens", np.asarray([c.token for c in prog.calls], dtype=np.int64))
+        return tid
+
+    def template(self, prog: pc.CompiledProgram) -> Template:
+        return self._templates[self.template_id(prog)]
+
+    def _get_bank(self):
+        if self._bank is None:
+            pmax = max([t.table.shape[0] for t in self._templates] + [1])
+            tables = np.zeros((len(self._templates), pmax, NCOLS), np.int64)
+            for i, t in enumerate(self._templates):
+                tables[i, : t.table.shape[0]] = t.table
+            nprims = np.asarray([t.table.shape[0] for t in self._templates], np.int64)
+            sizes = np.asarray([t.size for t in self._templates], np.int64)
+            isfeat = np.asarray([t.result_is_feat for t in self._templates], bool)
+            self._bank = (tables, nprims, sizes, isfeat)
+        return self._bank
 
     def arena_floats(self, programs: Sequence[pc.CompiledProgram]) -> int:
         """Activation-arena size (floats) the batch needs; the gradient arena mirrors it."""
-        big = _align(self.hw * self.channels)
-        total = 0
-        for prog in programs:
-            if prog.valid:
-                t = self.template(prog)
-                total += t.size + t.n_masked * big
-        return total
-
-    def template(self, prog: pc.CompiledProgram) -> Template:
-        key = structure_key(prog)
-        t = self._templates.get(key)
-        if t is None:
-            t = build_template(prog, self.hw, self.channels)
-            self._templates[key] = t
-        return t
+        return int(sum(self.template(p).size for p in programs if p.valid))
 
     # --------------------------------------------------------------------------------------------
     def plan(self, programs: Sequence[pc.CompiledProgram], buf: Buffers) -> StepPlan:
         hw, C = self.hw, self.channels
         map_bytes = hw * C * 4
         tb = self.tables
+        u64 = np.uint64
 
-        # group valid examples by structure
-        groups: Dict[Tuple, List[int]] = {}
-        for e, prog in enumerate(programs):
-            if prog.valid:
-                groups.setdefault(structure_key(prog), []).append(e)
+        ex_valid = [e for e, p in enumerate(programs) if p.valid]
+        tids = np.asarray([self.template_id(programs[e]) for e in ex_valid], dtype=np.int64)
+        tables, nprims, sizes, isfeat = self._get_bank()
+        E = np.asarray(ex_valid, dtype=np.int64)
+        nv = E.size
+        empty = {
+            "conv": np.zeros(0, self.dt["conv"]), "proj": np.zeros(0, self.dt["conv"]),
+            "dgrad": np.zeros(0, self.dt["conv"]), "pdgrad": np.zeros(0, self.dt["conv"]),
+            "dot": np.zeros(0, self.dt["dot"]), "same": np.zeros(0, self.dt["same"]),
+            "minmax": np.zeros(0, self.dt["minmax"]), "maskbwd": np.zeros(0, self.dt["maskbwd"]),
+            "wg3": np.zeros(0, self.dt["wgrad_item"]), "wgp": np.zeros(0, self.dt["wgrad_item"]),
+        }
+        empty_jobs = {"wg3": np.zeros(0, self.dt["wgrad_job"]), "wgp": np.zeros(0, self.dt["wgrad_job"])}
+        if nv == 0:
+            return StepPlan(empty, [], [], empty_jobs, 0, np.zeros(0, np.int64), 0)
 
-        parts: Dict[str, List[np.ndarray]] = {k: [] for k in
-                                              ("conv", "proj", "dot", "same", "minmax", "dgrad", "pdgrad",
-                                               "maskbwd", "wg3", "wgp")}
-        levels: Dict[str, List[np.ndarray]] = {k: [] for k in parts}
-        wkeys: Dict[str, List[np.ndarray]] = {"wg3": [], "wgp": []}
-        feat_result: List[int] = []
-        cursor = 0
-        n_prims = 0
+        # per-example arena block
+        blk = sizes[tids]
+        base = np.cumsum(blk) - blk  # floats
+        arena = int(blk.sum())
+        feat_result = E[isfeat[tids]]
 
-        for key, ex in groups.items():
-            prog0 = programs[ex[0]]
-            t = self.template(prog0)
-            E = np.asarray(ex, dtype=np.int64)
-            n = len(ex)
-            tokens = np.asarray([[c.token for c in programs[e].calls] for e in ex], dtype=np.int64).reshape(n, -1)
-            base = cursor + np.arange(n, dtype=np.int64) * t.size  # floats
-            cursor += n * t.size
-            if t.result[0] == L_FEAT:
-                feat_result.extend(ex)
-            n_prims += n * len(t.prims)
+        # tokens of every call, padded
+        cmax = max(1, max(programs[e]._tokens.size for e in ex_valid))
+        tokens = np.zeros((nv, cmax), np.int64)
+        for i, e in enumerate(ex_valid):
+            t = programs[e]._tokens
+            tokens[i, : t.size] = t
 
-            def addr(loc, grad=False):
-                kind, off = loc
-                if kind == L_SLOT:
-                    return (buf.gact if grad else buf.act) + (base + off) * 4
-                if kind == L_FEAT:
-                    return (buf.gfeat if grad else buf.feat) + E * map_bytes
-                if kind == L_FINAL:
-                    return (buf.gfinal if grad else buf.final) + E * map_bytes
-                return np.zeros(n, dtype=np.int64)  # L_ONES
+        # gather every example's primitive table and drop the padding
+        P = tables[tids]  # [nv, Pmax, NCOLS]
+        keep = np.arange(P.shape[1])[None, :] < nprims[tids][:, None]
+        rows = P[keep]  # [N, NCOLS]
+        xi = np.broadcast_to(np.arange(nv)[:, None], keep.shape)[keep]  # index into the valid list
+        N = rows.shape[0]
+        ex = E[xi]
+        tok = tokens[xi, rows[:, C_CALL]]
+        blockbase = base[xi]
 
-            def addr_or_ones(loc):
-                if loc[0] == L_ONES:
-                    return np.full(n, buf.ones, dtype=np.int64)
-                return addr(loc)
+        kind_base = np.asarray([buf.act, buf.feat, 0, buf.final], np.int64)
+        kind_gbase = np.asarray([buf.gact, buf.gfeat, 0, buf.gfinal], np.int64)
+        kind_stride = np.asarray([0, map_bytes, 0, map_bytes], np.int64)
 
-            for p in t.prims:
-                tok = tokens[:, p.call]
-                lv = np.full(n, p.level, dtype=np.int32)
-                if p.kind in ("conv", "proj"):
-                    name = "conv" if p.kind == "conv" else "proj"
-                    r = np.zeros(n, self.dt["conv"])
-                    r["in"] = addr(p.a)
-                    if p.kind == "proj":
-                        r["in2"] = addr(p.b)
-                    elif p.masked and p.b[0] != L_ONES:
-                        r["mask"] = addr(p.b)
-                    r["weight"] = buf.params + tb.w3[tok, p.widx] * 4
-                    r["bias"] = buf.params + tb.b3[tok, p.widx] * 4
-                    r["out"] = addr(p.out)
-                    r["dilation"] = p.dil
-                    parts[name].append(r)
-                    levels[name].append(lv)
-                    # ---- backward: dgrad ----
-                    if p.kind == "conv":
-                        d = np.zeros(n, self.dt["conv"])
-                        d["in"] = addr(p.out, grad=True)
-                        d["gate"] = addr(p.out)
-                        d["weight"] = buf.wt + tb.wt3[tok, p.widx] * 4
-                        d["dilation"] = p.dil
-                        if p.masked:
-                            # gradient wrt (FEAT * attn): private scratch map, assigned below
-                            d["out"] = 0
-                        else:
-                            d["out"] = addr(p.a, grad=True)
-                        parts["dgrad"].append(d)
-                        levels["dgrad"].append(lv)
-                        w = np.zeros(n, self.dt["wgrad_item"])
-                        w["x"] = addr(p.a)
-                        if p.masked and p.b[0] != L_ONES:
-                            w["xmask"] = addr(p.b)
-                        w["dy"] = addr(p.out, grad=True)
-                        w["gate"] = addr(p.out)
-                        w["dilation"] = p.dil
-                        parts["wg3"].append(w)
-                        levels["wg3"].append(lv)
-                        wkeys["wg3"].append(tok * 8 + p.widx)
-                    else:
-                        for half, operand in ((0, p.a), (1, p.b)):
-                            d = np.zeros(n, self.dt["conv"])
-                            d["in"] = addr(p.out, grad=True)
-                            d["gate"] = addr(p.out)
-                            d["weight"] = buf.wt + (tb.wt3[tok, 0] + half * C * C) * 4
-                            d["out"] = addr(operand, grad=True)
-                            d["flags"] = 1  # accumulate into the operand's gradient
-                            parts["pdgrad"].append(d)
-                            levels["pdgrad"].append(lv * 2 + half)  # the two halves never share a launch
-                        w = np.zeros(n, self.dt["wgrad_item"])
-                        w["x"] = addr(p.a)
-                        w["x2"] = addr(p.b)
-                        w["dy"] = addr(p.out, grad=True)
-                        w["gate"] = addr(p.out)
-                        parts["wgp"].append(w)
-                        levels["wgp"].append(lv)
-                        wkeys["wgp"].append(tok)
-                elif p.kind == "dot":
-                    r = np.zeros(n, self.dt["dot"])
-                    r["in"] = addr(p.a)
-                    r["w"] = buf.params + tb.dotw[tok] * 4
-                    r["b"] = buf.params + tb.dotb[tok] * 4
-                    r["out"] = addr(p.out)
-                    r["dout"] = addr(p.out, grad=True)
-                    r["din"] = addr(p.a, grad=True)
-                    r["dw"] = buf.grads + tb.dotw[tok] * 4
-                    r["db"] = buf.grads + tb.dotb[tok] * 4
-                    parts["dot"].append(r)
-                    levels["dot"].append(lv)
-                elif p.kind == "same":
-                    r = np.zeros(n, self.dt["same"])
-                    r["feats"] = addr(p.a)
-                    r["attn"] = addr_or_ones(p.b)
-                    r["w"] = buf.params + tb.dotw[tok] * 4
-                    r["b"] = buf.params + tb.dotb[tok] * 4
-                    r["out"] = addr(p.out)
-                    r["dout"] = addr(p.out, grad=True)
-                    r["dfeats"] = addr(p.a, grad=True)
-                    r["dattn"] = addr(p.b, grad=True)  # 0 for the all-ones attention
-                    r["dw"] = buf.grads + tb.dotw[tok] * 4
-                    r["db"] = buf.grads + tb.dotb[tok] * 4
-                    parts["same"].append(r)
-                    levels["same"].append(lv)
-                else:  # minmax
-                    r = np.zeros(n, self.dt["minmax"])
-                    r["a"] = addr_or_ones(p.a)
-                    r["b"] = addr_or_ones(p.b)
-                    r["out"] = addr(p.out)
-                    r["dout"] = addr(p.out, grad=True)
-                    r["da"] = addr(p.a, grad=True)
-                    r["db"] = addr(p.b, grad=True)
-                    r["a_channels"] = p.a_ch
-                    r["b_channels"] = p.b_ch
-                    r["is_max"] = p.is_max
-                    parts["minmax"].append(r)
-                    levels["minmax"].append(lv)
+        def addr(kcol, ocol, grad=False, ones=0):
+            k = rows[:, kcol]
+            a = (kind_gbase if grad else kind_base)[k] + kind_stride[k] * ex
+            a = a + (k == L_SLOT) * ((blockbase + rows[:, ocol]) * 4)
+            if ones:
+                a = np.where(k == L_ONES, ones, a)
+            return a
 
-        # masked convs: private dx scratch (one map per masked conv, after the example blocks)
+        a_f, a_g = addr(C_AK, C_AO), addr(C_AK, C_AO, grad=True)
+        b_f, b_g = addr(C_BK, C_BO), addr(C_BK, C_BO, grad=True)
+        o_f, o_g = addr(C_OK, C_OO), addr(C_OK, C_OO, grad=True)
+        level = rows[:, C_LEVEL]
+        kind = rows[:, C_KIND]
+        widx = rows[:, C_WIDX]
+        dil = rows[:, C_DIL]
+
         records: Dict[str, np.ndarray] = {}
-        order: Dict[str, np.ndarray] = {}
-        for k in parts:
-            if parts[k]:
-                rec = np.concatenate(parts[k])
-                lv = np.concatenate(levels[k])
-            else:
-                proto = {"conv": "conv", "proj": "conv", "dgrad": "conv", "pdgrad": "conv", "dot": "dot",
-                         "same": "same", "minmax": "minmax", "maskbwd": "maskbwd", "wg3": "wgrad_item",
-                         "wgp": "wgrad_item"}[k]
-                rec = np.zeros(0, self.dt[proto])
-                lv = np.zeros(0, np.int32)
-            records[k] = rec
-            order[k] = lv
+        launches: Dict[str, List[Tuple[int, int, int]]] = {}
 
-        # scratch maps + mask-backward records for masked convs
-        dg, dgl = records["dgrad"], order["dgrad"]
-        masked = np.nonzero(dg["out"] == 0)[0]
-        big = _align(hw * C)
-        if masked.size:
-            scratch = cursor + np.arange(masked.size, dtype=np.int64) * big
-            cursor += masked.size * big
-            dg["out"][masked] = buf.gact + scratch * 4
-            # the matching forward conv records are in the same order as the dgrad records
-            fw = records["conv"][masked]
-            mb = np.zeros(masked.size, self.dt["maskbwd"])
-            mb["dx"] = dg["out"][masked]
-            mb["feats"] = fw["in"]
-            mb["attn"] = fw["mask"]
-            mb["dfeats"] = fw["in"] - buf.feat + buf.gfeat
-            has_attn = fw["mask"] != 0
-            mb["dattn"][has_attn] = fw["mask"][has_attn] - buf.act + buf.gact
-            records["maskbwd"] = mb
-            order["maskbwd"] = dgl[masked]
-        # sort every kind by level and cut launches
-        launches: Dict[str, List[Launch]] = {}
-        for k, rec in records.items():
-            lv = order[k]
-            if k in ("wg3", "wgp"):
-                continue
+        def finish(name, mat, lv, dtype_key):
+            """sort by level, view as records, cut launches"""
             idx = np.argsort(lv, kind="stable")
-            records[k] = rec[idx]
-            lv = lv[idx]
-            cuts = np.flatnonzero(np.diff(lv)) + 1 if lv.size else np.zeros(0, np.int64)
-            bounds = np.concatenate(([0], cuts, [lv.size])).astype(np.int64)
-            launches[k] = [Launch(k, int(lv[b]), int(b), int(e)) for b, e in zip(bounds[:-1], bounds[1:]) if e > b]
+            records[name] = np.ascontiguousarray(mat[idx]).view(self.dt[dtype_key]).reshape(-1)
+            launches[name] = _cut(lv[idx])
+            return idx
 
-        depth = max([l.level for ls in launches.values() for l in ls if l.kind != "pdgrad"], default=0)
+        # ---- 3x3 convs ---------------------------------------------------------------------------
+        m = kind == K_CONV
+        n = int(m.sum())
+        if n:
+            t_, w_, lv = tok[m], widx[m], level[m]
+            masked = rows[m, C_MASKED] == 1
+            mask_ptr = np.where(masked, b_f[m], 0)  # 0 for the all-ones attention too
+            w_off, b_off, wt_off = tb.w3[t_, w_], tb.b3[t_, w_], tb.wt3[t_, w_]
+            scratch = buf.gact + (blockbase[m] + rows[m, C_SCRATCH]) * 4
+            fw = np.zeros((n, 8), u64)
+            fw[:, 0], fw[:, 2] = a_f[m], mask_ptr
+            fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
+            fw[:, 7] = dil[m]  # dilation in the low 32 bits, flags = 0
+            dg = np.zeros((n, 8), u64)
+            dg[:, 0], dg[:, 3], dg[:, 4] = o_g[m], o_f[m], buf.wt + wt_off * 4
+            dg[:, 6] = np.where(masked, scratch, a_g[m])
+            dg[:, 7] = dil[m]
+            wg = np.zeros((n, 6), u64)
+            wg[:, 0], wg[:, 2], wg[:, 3], wg[:, 4], wg[:, 5] = a_f[m], mask_ptr, o_g[m], o_f[m], dil[m]
+            idx = finish("conv", fw, lv, "conv")
+            finish("dgrad", dg, lv, "conv")
+            # mask backward for the masked convs (same level order as the dgrads)
+            mm = masked[idx]
+            if mm.any():
+                src = idx[mm]
+                mb = np.zeros((src.size, 5), u64)
+                mb[:, 0], mb[:, 1], mb[:, 2] = scratch[src], a_f[m][src], mask_ptr[src]
+                mb[:, 3] = a_g[m][src]
+                mb[:, 4] = np.where(mask_ptr[src] != 0, b_g[m][src], 0)
+                records["maskbwd"] = mb.view(self.dt["maskbwd"]).reshape(-1)
+                launches["maskbwd"] = _cut(lv[src])
+            wkey = t_ * 8 + w_
+            records["wg3"], jobs3 = self._wgrad_jobs(wg, wkey, buf.grads + w_off * 4, buf.grads + b_off * 4)
+        else:
+            jobs3 = empty_jobs["wg3"]
+
+        # ---- projections (ComparisonModule) ------------------------------------------------------
+        m = kind == K_PROJ
+        n = int(m.sum())
+        if n:
+            t_, lv = tok[m], level[m]
+            w_off, b_off, wt_off = tb.w3[t_, 0], tb.b3[t_, 0], tb.wt3[t_, 0]
+            fw = np.zeros((n, 8), u64)
+            fw[:, 0], fw[:, 1] = a_f[m], b_f[m]
+            fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
+            fw[:, 7] = 1
+            finish("proj", fw, lv, "conv")
+            # two dgrads (one per operand), accumulate flag set; the halves never share a launch
+            pd = np.zeros((2 * n, 8), u64)
+            pd[:, 0], pd[:, 3] = np.tile(o_g[m], 2), np.tile(o_f[m], 2)
+            pd[:n, 4], pd[n:, 4] = buf.wt + wt_off * 4, buf.wt + (wt_off + C * C) * 4
+            pd[:n, 6], pd[n:, 6] = a_g[m], b_g[m]
+            pd[:, 7] = 1 | (1 << 32)
+            finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + 1)), "conv")
+            wg = np.zeros((n, 6), u64)
+            wg[:, 0], wg[:, 1], wg[:, 3], wg[:, 4] = a_f[m], b_f[m], o_g[m], o_f[m]
+            records["wgp"], jobsp = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4)
+        else:
+            jobsp = empty_jobs["wgp"]
+
+        # ---- one-channel heads -----------------------------------------------------------------
+        m = kind == K_DOT
+        n = int(m.sum())
+        if n:
+            t_ = tok[m]
+            r = np.zeros((n, 8), u64)
+            r[:, 0], r[:, 1], r[:, 2] = a_f[m], buf.params + tb.dotw[t_] * 4, buf.params + tb.dotb[t_] * 4
+            r[:, 3], r[:, 4], r[:, 5] = o_f[m], o_g[m], a_g[m]
+            r[:, 6], r[:, 7] = buf.grads + tb.dotw[t_] * 4, buf.grads + tb.dotb[t_] * 4
+            finish("dot", r, level[m], "dot")
+
+        m = kind == K_SAME
+        n = int(m.sum())
+        if n:
+            t_ = tok[m]
+            bk = rows[m, C_BK]
+            r = np.zeros((n, 10), u64)
+            r[:, 0], r[:, 1] = a_f[m], np.where(bk == L_ONES, buf.ones, b_f[m])
+            r[:, 2], r[:, 3] = buf.params + tb.dotw[t_] * 4, buf.params + tb.dotb[t_] * 4
+            r[:, 4], r[:, 5], r[:, 6], r[:, 7] = o_f[m], o_g[m], a_g[m], b_g[m]  # dattn = 0 for all-ones
+            r[:, 8], r[:, 9] = buf.grads + tb.dotw[t_] * 4, buf.grads + tb.dotb[t_] * 4
+            finish("same", r, level[m], "same")
+
+        m = kind == K_MINMAX
+        n = int(m.sum())
+        if n:
+            ak, bk = rows[m, C_AK], rows[m, C_BK]
+            r = np.zeros((n, 8), u64)
+            r[:, 0] = np.where(ak == L_ONES, buf.ones, a_f[m])
+            r[:, 1] = np.where(bk == L_ONES, buf.ones, b_f[m])
+            r[:, 2], r[:, 3], r[:, 4], r[:, 5] = o_f[m], o_g[m], a_g[m], b_g[m]
+            r[:, 6] = rows[m, C_ACH] | (rows[m, C_BCH] << 32)
+            r[:, 7] = rows[m, C_ISMAX]
+            finish("minmax", r, level[m], "minmax")
+
+        for k, v in empty.items():
+            records.setdefault(k, v)
+
+        # ---- launch order ------------------------------------------------------------------------
+        depth = int(level.max()) if N else 0
+        at: Dict[int, Dict[str, Tuple[int, int]]] = {}
+        for k in ("conv", "proj", "dot", "same", "minmax", "dgrad", "maskbwd"):
+            for lv, b, e in launches.get(k, []):
+                at.setdefault(lv, {})[k] = (b, e)
+        pd_at: Dict[int, List[Tuple[int, int]]] = {}
+        for lv, b, e in launches.get("pdgrad", []):
+            pd_at.setdefault(lv // 2, []).append((b, e))
+
         fwd: List[Launch] = []
-        by_level: Dict[int, Dict[str, Launch]] = {}
-        for k in ("conv", "proj", "dot", "same", "minmax"):
-            for l in launches.get(k, []):
-                by_level.setdefault(l.level, {})[k] = l
-        for level in range(1, depth + 1):
-            for k in ("minmax", "same", "dot", "proj", "conv"):
-                if k in by_level.get(level, {}):
-                    fwd.append(by_level[level][k])
-
-        bwd_by_level: Dict[int, Dict[str, List[Launch]]] = {}
-        for k in ("dgrad", "maskbwd"):
-            for l in launches.get(k, []):
-                bwd_by_level.setdefault(l.level, {}).setdefault(k, []).append(l)
-        for l in launches.get("pdgrad", []):
-            bwd_by_level.setdefault(l.level // 2, {}).setdefault("pdgrad", []).append(l)
         bwd: List[List[Launch]] = []
-        for level in range(depth, 0, -1):
+        for lv in range(1, depth + 1):
+            here = at.get(lv, {})
+            for k in ("minmax", "same", "dot", "proj", "conv"):
+                if k in here:
+                    fwd.append(Launch(k, lv, *here[k]))
+        for lv in range(depth, 0, -1):
+            here = at.get(lv, {})
             phase: List[Launch] = []
-            lv_f = by_level.get(level, {})
-            lv_b = bwd_by_level.get(level, {})
-            for k in ("minmax", "same", "dot"):  # reuse the forward records (they carry bwd fields)
-                if k in lv_f:
-                    phase.append(Launch(k + "_bwd", level, lv_f[k].begin, lv_f[k].end))
-            phase.extend(lv_b.get("pdgrad", []))
-            phase.extend(lv_b.get("dgrad", []))
-            phase.extend(lv_b.get("maskbwd", []))
-            bwd.append(phase)
+            for k in ("minmax", "same", "dot"):  # the forward records carry the backward fields
+                if k in here:
+                    phase.append(Launch(k + "_bwd", lv, *here[k]))
+            for b, e in pd_at.get(lv, []):
+                phase.append(Launch("pdgrad", lv, b, e))
+            for k in ("dgrad", "maskbwd"):
+                if k in here:
+                    phase.append(Launch(k, lv, *here[k]))
+            if phase:
+                bwd.append(phase)
 
-        # weight-gradient jobs: items sorted by weight, cut into chunks
-        jobs: Dict[str, np.ndarray] = {}
-        for k, col in (("wg3", None), ("wgp", None)):
-            rec = records[k]
-            if rec.size == 0:
-                jobs[k] = np.zeros(0, self.dt["wgrad_job"])
-                continue
-            wk = np.concatenate(wkeys[k])
-            idx = np.argsort(wk, kind="stable")
-            records[k] = rec[idx]
-            wk = wk[idx]
-            starts = np.concatenate(([0], np.flatnonzero(np.diff(wk)) + 1))
-            ends = np.concatenate((starts[1:], [wk.size]))
-            jb, je, jw = [], [], []
-            for s, e in zip(starts, ends):
-                cs = np.arange(s, e, self.wgrad_chunk)
-                jb.append(cs)
-                je.append(np.minimum(cs + self.wgrad_chunk, e))
-                jw.append(np.full(cs.size, wk[s]))
-            jb, je, jw = np.concatenate(jb), np.concatenate(je), np.concatenate(jw)
-            j = np.zeros(jb.size, self.dt["wgrad_job"])
-            if k == "wg3":
-                tok, widx = jw // 8, jw % 8
-            else:
-                tok, widx = jw, np.zeros_like(jw)
-            j["dw"] = buf.grads + tb.w3[tok, widx] * 4
-            j["dbias"] = buf.grads + tb.b3[tok, widx] * 4
-            j["item_begin"] = jb
-            j["item_end"] = je
-            jobs[k] = j
+        return StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N)
 
-        return StepPlan(records, fwd, bwd, jobs, cursor, np.asarray(feat_result, dtype=np.int64), n_prims)
+    # --------------------------------------------------------------------------------------------
+    def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray):
+        """Sort weight-gradient items by weight and cut each weight's run into jobs of at most
+        ``wgrad_chunk`` items (one workgroup column per job)."""
+        idx = np.argsort(wkey, kind="stable")
+        items, wkey, dw, db = items[idx], wkey[idx], dw[idx], db[idx]
+        n = wkey.size
+        newgrp = np.empty(n, bool)
+        newgrp[0] = True
+        np.not_equal(wkey[1:], wkey[:-1], out=newgrp[1:])
+        gstart = np.flatnonzero(newgrp)
+        gid = np.cumsum(newgrp) - 1
+        pos = np.arange(n) - gstart[gid]
+        jstart = np.flatnonzero(pos % self.wgrad_chunk == 0)
+        gend = np.concatenate((gstart[1:], [n]))
+        jend = np.minimum(jstart + self.wgrad_chunk, gend[gid[jstart]])
+        jobs = np.zeros((jstart.size, 3), np.uint64)
+        jobs[:, 0], jobs[:, 1] = dw[jstart], db[jstart]
+        jobs[:, 2] = jstart.astype(np.uint64) | (jend.astype(np.uint64) << np.uint64(32))
+        rec = np.ascontiguousarray(items).view(self.dt["wgrad_item"]).reshape(-1)
+        return rec, jobs.view(self.dt["wgrad_job"]).reshape(-1)

@@ -1,0 +1,109 @@
+"""Host-side scheduler invariants (no GPU): every primitive's inputs are produced at a lower level,
+every buffer a launch writes is written by exactly one item of that launch, arena blocks do not
+overlap, and records are bit-compatible with the C structs."""
+import numpy as np
+
+from probnmn import _hip
+from probnmn.data.synthetic import synthetic_batch
+from probnmn.runtime import program_compiler as pc
+from probnmn.runtime.schedule import BatchScheduler, Buffers, WeightTables
+from probnmn.vocabulary import Vocabulary
+
+from fixtures import VALIDITY_CASES, encode_programs
+
+DT = {"conv": _hip.CONV_ITEM, "dot": _hip.DOT1_ITEM, "same": _hip.SAME_ITEM, "minmax": _hip.MINMAX_ITEM,
+      "maskbwd": _hip.MASKBWD_ITEM, "wgrad_item": _hip.WGRAD_ITEM, "wgrad_job": _hip.WGRAD_JOB}
+BUF = Buffers(params=1 << 40, grads=2 << 40, wt=3 << 40, act=4 << 40, gact=5 << 40, feat=6 << 40,
+              gfeat=7 << 40, final=8 << 40, gfinal=9 << 40, ones=10 << 40)
+HW, C = 196, 128
+
+
+def _scheduler():
+    v = Vocabulary.clevr()
+    comp = pc.ProgramCompiler(v.get_index_to_token_vocabulary("programs"))
+    V = 44
+    tb = WeightTables(np.arange(V * 6).reshape(V, 6) * 200000, np.arange(V * 6).reshape(V, 6) * 200000 + 150000,
+                      np.arange(V * 6).reshape(V, 6) * 200000, np.arange(V) * 1000 + 10 ** 8, np.arange(V) * 1000 + 10 ** 8 + 500)
+    return v, comp, BatchScheduler(HW, C, tb, DT)
+
+
+def _check_plan(plan, n_examples):
+    written_at = {}  # address -> forward level that produces it
+    for l in plan.forward:
+        rec = plan.records[l.kind][l.begin:l.end]
+        outs = rec["out"]
+        assert len(np.unique(outs)) == len(outs), "two items of one launch write the same buffer"
+        ins = [rec[f] for f in {"conv": ("in", "mask"), "proj": ("in", "in2"), "dot": ("in",),
+                                "same": ("feats", "attn"), "minmax": ("a", "b")}[l.kind]]
+        for arr in ins:
+            for a in arr:
+                a = int(a)
+                if a == 0 or a == BUF.ones or (BUF.feat <= a < BUF.feat + (1 << 39)):
+                    continue
+                assert a in written_at and written_at[a] < l.level, (l.kind, l.level, hex(a))
+        for o in outs:
+            written_at[int(o)] = l.level
+    # forward and backward cover the same primitives
+    nf = sum(l.end - l.begin for l in plan.forward)
+    assert nf == plan.n_prims
+    nb = sum(l.end - l.begin for ph in plan.backward for l in ph if l.kind in ("dgrad", "dot_bwd", "same_bwd", "minmax_bwd"))
+    nb += sum(l.end - l.begin for ph in plan.backward for l in ph if l.kind == "pdgrad") // 2
+    assert nb == plan.n_prims
+    # accumulate-mode launches never write one buffer twice
+    for ph in plan.backward:
+        for l in ph:
+            if l.kind in ("pdgrad", "dgrad"):
+                outs = plan.records[l.kind][l.begin:l.end]["out"]
+                assert len(np.unique(outs)) == len(outs)
+    # arena addresses stay inside the arena
+    for k in ("conv", "proj", "dot"):
+        o = plan.records[k]["out"].astype(np.int64)
+        inside = (o >= BUF.act) & (o < BUF.act + plan.arena_floats * 4)
+        final = (o >= BUF.final) & (o < BUF.final + n_examples * HW * C * 4)
+        assert np.all(inside | final)
+    # weight-gradient jobs partition the items, each job within one weight
+    for k, key in (("wg3", None), ("wgp", None)):
+        jobs, items = plan.wgrad_jobs[k], plan.records[k]
+        covered = np.zeros(len(items), int)
+        for j in jobs:
+            covered[j["item_begin"]:j["item_end"]] += 1
+            assert 0 < j["item_end"] - j["item_begin"] <= 8
+        assert np.all(covered == 1)
+
+
+def test_golden_programs_plan():
+    v, comp, s = _scheduler()
+    progs = encode_programs(VALIDITY_CASES, v.get_token_to_index_vocabulary("programs")).numpy()
+    compiled = comp.compile_batch(progs)
+    plan = s.plan(compiled, BUF)
+    assert plan.arena_floats == s.arena_floats(compiled)
+    _check_plan(plan, len(compiled))
+    # empty / placeholder-only programs return the stem output itself
+    assert set(plan.feat_result_examples.tolist()) == {0, 1}
+    # each case alone (ragged, single-structure batches; some have no primitives at all)
+    for case in VALIDITY_CASES:
+        one = comp.compile_batch(encode_programs([case, case], v.get_token_to_index_vocabulary("programs")).numpy())
+        _check_plan(s.plan(one, BUF), 2)
+
+
+def test_synthetic_batch_plan_and_counts():
+    v, comp, s = _scheduler()
+    batch = synthetic_batch(v, 256, seed=1000, with_image=False)
+    compiled = comp.compile_batch(batch["program"].numpy())
+    assert all(p.valid for p in compiled)
+    plan = s.plan(compiled, BUF)
+    _check_plan(plan, 256)
+    n3 = len(plan.records["conv"])
+    assert len(plan.records["dgrad"]) == n3 == len(plan.records["wg3"])
+    assert len(plan.records["pdgrad"]) == 2 * len(plan.records["proj"])
+    # 3x3 conv count per template: T1 6, T2 13, T3 18, T4 25, T5 12, T6 20, T7 6, T8 17
+    assert 256 * 6 <= n3 <= 256 * 25
+    depth = max(l.level for l in plan.forward)
+    assert depth <= 40
+
+
+def test_invalid_batch_is_empty_plan():
+    v, comp, s = _scheduler()
+    progs = encode_programs(["scene", "count"], v.get_token_to_index_vocabulary("programs")).numpy()
+    plan = s.plan(comp.compile_batch(progs), BUF)
+    assert plan.n_prims == 0 and plan.arena_floats == 0 and not plan.forward and not plan.backward
