@@ -233,7 +233,9 @@ class NMNEngine:
             return r
 
         def jobs(dw, db, yblocks):
-            chunk = max(1, B * yblocks // 512)  # aim at >= 512 workgroups per launch
+            # aim at >= 512 workgroups per launch, but never fewer than 4 items per job: every job
+            # ends with an atomic add of its whole slab into the shared weight gradient
+            chunk = min(16, max(4, B * yblocks // 512))
             starts = np.arange(0, B, chunk)
             j = np.zeros(starts.size, _hip.WGRAD_JOB)
             j["dw"], j["dbias"] = dw, db
@@ -252,11 +254,11 @@ class NMNEngine:
             "stem2_dgrad": conv(gs2 + e * m128, self.wt.data_ptr() + self.wt_stem2 * 4, None, gs1 + e * m128,
                                 gate=s2 + e * m128),
             "cls_wg": wg(fin + e * m128, gcls + e * mcls),
-            "cls_wg_jobs": jobs(go("classifier.0.weight"), go("classifier.0.bias"), self.cproj // C),
+            "cls_wg_jobs": jobs(go("classifier.0.weight"), go("classifier.0.bias"), 2 * self.cproj // C),
             "stem2_wg": wg(s1 + e * m128, gs2 + e * m128, gate=s2 + e * m128),
-            "stem2_wg_jobs": jobs(go("stem.2.weight"), go("stem.2.bias"), 3),
+            "stem2_wg_jobs": jobs(go("stem.2.weight"), go("stem.2.bias"), 2),
             "stem1_wg": wg(xin + e * mcin, gs1 + e * m128, gate=s1 + e * m128),
-            "stem1_wg_jobs": jobs(go("stem.0.weight"), go("stem.0.bias"), 3 * self.cin // C),
+            "stem1_wg_jobs": jobs(go("stem.0.weight"), go("stem.0.bias"), 2 * self.cin // C),
         }
         self._fixed_cache[key] = out
         return out
