@@ -1,0 +1,91 @@
+"""Data-parallel reducer with world_size 2 over gloo on CPU (no GPU): summing the two ranks'
+gradient arenas and scaling by 1/2 reproduces the single-process gradient of the mean loss over
+the concatenated batch; parameters broadcast from rank 0; scalar partial sums add up."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _FakeArena:
+    """Stands in for runtime.arena.ParamArena: the reducer only touches .flat and .grad."""
+
+    def __init__(self, n, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.flat = torch.randn(n, generator=g)
+        self.grad = torch.zeros(n)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "probnmn-clevr_amd"))
+    from probnmn import parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    # a tiny "model": y = x @ w.T + b, loss = per-example squared error, mean over the shard
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 5, generator=g)
+    Y = torch.randn(8, 3, generator=g)
+    arena = _FakeArena(15, seed=rank)  # different initial weights per rank on purpose
+    loose = torch.nn.Parameter(torch.randn(3, generator=torch.Generator().manual_seed(10 + rank)))
+    parallel.broadcast_parameters([arena], [loose])
+    w = arena.flat.view(3, 5).clone().requires_grad_(True)
+    shard = slice(rank * 4, rank * 4 + 4)
+    loss = ((X[shard] @ w.T + loose - Y[shard]) ** 2).sum(1).mean()
+    loss.backward()
+    arena.grad.copy_(w.grad.reshape(-1))
+    parallel.all_reduce_gradients([arena], [loose])
+    sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
+    if rank == 0:
+        torch.save({"w": arena.flat.clone(), "gw": arena.grad.clone(), "gb": loose.grad.clone(),
+                    "b": loose.detach().clone(), "sums": sums}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-process reference on the full batch with rank 0's (broadcast) parameters
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 5, generator=g)
+    Y = torch.randn(8, 3, generator=g)
+    w = got["w"].view(3, 5).clone().requires_grad_(True)
+    b = got["b"].clone().requires_grad_(True)
+    loss = ((X @ w.T + b - Y) ** 2).sum(1).mean()
+    loss.backward()
+    torch.testing.assert_close(got["gw"], w.grad.reshape(-1), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got["gb"], b.grad, rtol=1e-6, atol=1e-6)
+    assert got["sums"].tolist() == [3.0, 8.0]
+    # broadcast really took rank 0's values
+    torch.testing.assert_close(got["w"], _FakeArena(15, seed=0).flat)
+
+
+def test_single_process_is_a_noop():
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "probnmn-clevr_amd"))
+    from probnmn import parallel
+
+    a = _FakeArena(4, 0)
+    a.grad.fill_(2.0)
+    parallel.all_reduce_gradients([a])
+    assert parallel.world() == 1 and a.grad.tolist() == [2.0] * 4
