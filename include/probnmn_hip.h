@@ -218,6 +218,33 @@ typedef struct pnmn_adam_item {
 int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2,
                     double eps, double weight_decay, double clamp, int step, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LSTM cell gate math (torch nn.LSTM / nn.LSTMCell, gate order i,f,g,o), the point-wise half of
+ * every encoder step (allennlp PytorchSeq2SeqWrapper(nn.LSTM), seq2seq_base.py:145) and decoder
+ * step (SimpleSeq2Seq._decoder_cell, seq2seq_base.py:201):
+ *   gates[b][4H] = x W_ih^T + b_ih + h W_hh^T + b_hh  (computed by the caller's GEMMs)
+ *   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c');  act (optional) keeps the activated gates
+ * backward: given dh, dc_in (either may be NULL) -> dgates[b][4H] (wrt the pre-activations), dc_prev.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_lstm_cell_fwd(const float* gates, const float* c_prev, float* h, float* c, float* act,
+                       int B, int hidden, void* stream);
+int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, const float* dh,
+                       const float* dc_in, float* dgates, float* dc_prev, int B, int hidden,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One decoding step's token choice                                   seq2seq_base.py:203-220
+ *   greedy:   tokens[b] = argmax softmax(logits[b])            (first maximum)
+ *   sampling: weights = softmax(logits[b]) with pad/unk/start zeroed; tokens[b] ~ weights
+ *             (inverse CDF in index order; u from Philox4x32-10 keyed by `seed`, counter =
+ *             (row_offset + b, step) -- shard-invariant under data parallelism)
+ *   logprobs[b] = log_softmax(logits[b])[tokens[b]]            (unmodified distribution)
+ * V <= 512.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, int B, int V,
+                       int greedy, uint64_t seed, uint64_t row_offset, uint32_t step, int pad_index,
+                       int unk_index, int start_index, void* stream);
+
 /* Library / device self-description (no GPU needed for version). */
 int pnmn_abi_version(void);
 

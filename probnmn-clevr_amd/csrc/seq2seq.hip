@@ -1,0 +1,215 @@
+// Seq2seq point kernels for gfx950: the LSTM cell (gate non-linearities + state update, forward and
+// backward) and the per-step token sampler (softmax, forbidden-token masking, inverse-CDF draw from
+// a counter-based Philox stream or arg-max, log-prob gather).  The 256-wide GEMMs around them are
+// plain library GEMMs and stay with hipBLASLt.
+//
+// All are bandwidth/latency-bound: one thread per (row, hidden unit) reading the four gate
+// pre-activations (coalesced across units), one wave per sampled row with shuffle reductions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/probnmn_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
+
+// gates: [B][4*Hd] pre-activations in torch order (i, f, g, o)
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ gates,
+                                                            const float* __restrict__ c_prev, float* __restrict__ h,
+                                                            float* __restrict__ c, float* __restrict__ act, int B,
+                                                            int Hd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hd) return;
+    const int b = idx / Hd, u = idx - b * Hd;
+    const float* gr = gates + (size_t)b * 4 * Hd;
+    const float i = sigm(gr[u]);
+    const float f = sigm(gr[Hd + u]);
+    const float g = tanhf(gr[2 * Hd + u]);
+    const float o = sigm(gr[3 * Hd + u]);
+    const float cn = f * c_prev[idx] + i * g;
+    c[idx] = cn;
+    h[idx] = o * tanhf(cn);
+    if (act) {
+        float* ar = act + (size_t)b * 4 * Hd;
+        ar[u] = i;
+        ar[Hd + u] = f;
+        ar[2 * Hd + u] = g;
+        ar[3 * Hd + u] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ act,
+                                                            const float* __restrict__ c_prev,
+                                                            const float* __restrict__ c, const float* __restrict__ dh,
+                                                            const float* __restrict__ dc_in, float* __restrict__ dgates,
+                                                            float* __restrict__ dc_prev, int B, int Hd) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Hd) return;
+    const int b = idx / Hd, u = idx - b * Hd;
+    const float* ar = act + (size_t)b * 4 * Hd;
+    const float i = ar[u], f = ar[Hd + u], g = ar[2 * Hd + u], o = ar[3 * Hd + u];
+    const float tc = tanhf(c[idx]);
+    const float gh = dh ? dh[idx] : 0.f;
+    float dc = gh * o * (1.f - tc * tc);
+    if (dc_in) dc += dc_in[idx];
+    float* dg = dgates + (size_t)b * 4 * Hd;
+    dg[u] = dc * g * i * (1.f - i);
+    dg[Hd + u] = dc * c_prev[idx] * f * (1.f - f);
+    dg[2 * Hd + u] = dc * i * (1.f - g * g);
+    dg[3 * Hd + u] = gh * tc * o * (1.f - o);
+    dc_prev[idx] = dc * f;
+}
+
+// ---- Philox4x32-10 (Salmon et al. 2011), one draw per (seed, row, step) ------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    ctr[0] = hi1 ^ ctr[1] ^ k0;
+    ctr[1] = lo1;
+    ctr[2] = hi0 ^ ctr[3] ^ k1;
+    ctr[3] = lo0;
+}
+
+__device__ float philox_uniform(uint64_t seed, uint64_t row, uint32_t step) {
+    uint32_t ctr[4] = {(uint32_t)row, (uint32_t)(row >> 32), step, 0x9E3779B9u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(ctr, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return (float)(ctr[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per row; V up to 64*MAXV
+constexpr int MAXV = 8;
+__global__ __launch_bounds__(256) void sample_tokens_kernel(const float* __restrict__ logits, int64_t* __restrict__ tokens,
+                                                            float* __restrict__ logprobs, int B, int V, int greedy,
+                                                            uint64_t seed, uint64_t row_offset, uint32_t step,
+                                                            int pad, int unk, int start) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* z = logits + (size_t)row * V;
+    float v[MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < V ? z[j] : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) se += (lane + 64 * k < V) ? expf(v[k] - mx) : 0.f;
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    int choice;
+    if (greedy) {
+        // first index of the maximum
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int j = lane + 64 * k;
+            if (j < V && v[k] == mx && j < best) best = j;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(best, o);
+            best = other < best ? other : best;
+        }
+        choice = best;
+    } else {
+        // weights = softmax with the forbidden tokens zeroed (seq2seq_base.py:212-214); inverse CDF
+        float w[MAXV];
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int j = lane + 64 * k;
+            const bool ok = j < V && j != pad && j != unk && j != start;
+            w[k] = ok ? expf(v[k] - lse) : 0.f;
+            tot += w[k];
+        }
+        tot = wave_sum(tot);
+        const float target = philox_uniform(seed, row_offset + (uint64_t)row, step) * tot;
+        // token order = index order: chunk k holds indices [64k, 64k+64); scan chunk by chunk
+        float before = 0.f;
+        choice = -1;
+        int last_ok = -1;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            // inclusive prefix sum over lanes
+            float inc = w[k];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const bool hit = (w[k] > 0.f) && (before + inc > target);
+            const unsigned long long m = __ballot(hit);
+            if (choice < 0 && m) choice = 64 * k + (int)__ffsll((long long)m) - 1;
+            const unsigned long long pos = __ballot(w[k] > 0.f);
+            if (pos) last_ok = 64 * k + 63 - __clzll((long long)pos);
+            before += __shfl(inc, 63);
+        }
+        if (choice < 0) choice = last_ok;  // round-off at the very end of the CDF
+    }
+    if (lane == 0) {
+        tokens[row] = choice;
+        logprobs[row] = z[choice] - lse;  // from the UNMODIFIED log-softmax (seq2seq_base.py:204,220)
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnmn_lstm_cell_fwd(const float* gates, const float* c_prev, float* h, float* c, float* act, int B, int Hd,
+                       void* stream) {
+    if (B <= 0) return 0;
+    if (!gates || !c_prev || !h || !c || Hd <= 0) return PNMN_EINVAL;
+    const int n = B * Hd;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       gates, c_prev, h, c, act, B, Hd);
+    return (int)hipGetLastError();
+}
+
+int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, const float* dh, const float* dc_in,
+                       float* dgates, float* dc_prev, int B, int Hd, void* stream) {
+    if (B <= 0) return 0;
+    if (!act || !c_prev || !c || !dgates || !dc_prev || Hd <= 0) return PNMN_EINVAL;
+    const int n = B * Hd;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       act, c_prev, c, dh, dc_in, dgates, dc_prev, B, Hd);
+    return (int)hipGetLastError();
+}
+
+int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, int B, int V, int greedy,
+                       uint64_t seed, uint64_t row_offset, uint32_t step, int pad_index, int unk_index,
+                       int start_index, void* stream) {
+    if (B <= 0) return 0;
+    if (!logits || !tokens || !logprobs || V <= 0) return PNMN_EINVAL;
+    if (V > 64 * MAXV) return PNMN_ESHAPE;
+    hipLaunchKernelGGL(sample_tokens_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
+                       tokens, logprobs, B, V, greedy, seed, row_offset, step, pad_index, unk_index, start_index);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

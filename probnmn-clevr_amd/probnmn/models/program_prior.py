@@ -1,0 +1,62 @@
+"""``ProgramPrior``: LSTM language model over programs, p(z) (reference:
+probnmn/models/program_prior.py:15-155).  Input and output embeddings are tied.  ``forward`` gives
+the per-sequence cross entropy used as -log p(z) in the REINFORCE reward, plus per-position
+samples (unused by the trainers).  ``sample`` (reference :174-301) is outside the hot path."""
+from typing import Dict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from probnmn import _hip
+from probnmn.modules.seq2seq_base import (_Encoder, _TokenEmbedder, add_sentence_boundary_token_ids,
+                                          sequence_cross_entropy)
+from probnmn.utils.metrics import Average
+
+
+class ProgramPrior(nn.Module):
+    def __init__(self, vocabulary, input_size: int = 256, hidden_size: int = 128, num_layers: int = 2,
+                 dropout: float = 0.0):
+        super().__init__()
+        self.vocabulary = vocabulary
+        self._start_index = vocabulary.get_token_index("@start@", namespace="programs")
+        self._end_index = vocabulary.get_token_index("@end@", namespace="programs")
+        self._pad_index = vocabulary.get_token_index("@@PADDING@@", namespace="programs")
+        self._unk_index = vocabulary.get_token_index("@@UNKNOWN@@", namespace="programs")
+        vocab_size = vocabulary.get_vocab_size(namespace="programs")
+        self._embedder = _TokenEmbedder("programs", vocab_size, input_size, self._pad_index)
+        self._encoder = _Encoder(input_size, hidden_size, num_layers, dropout)
+        self._projection_layer = nn.Linear(hidden_size, input_size, bias=False)
+        self._output_layer = nn.Linear(input_size, vocab_size, bias=False)
+        self._output_layer.weight = self._embedder.embedding.weight  # tied
+        self._log2_perplexity = Average()
+
+    @classmethod
+    def from_config(cls, config):
+        from probnmn.vocabulary import Vocabulary
+
+        _C = config
+        return cls(vocabulary=Vocabulary.from_files(_C.DATA.VOCABULARY), input_size=_C.PROGRAM_PRIOR.INPUT_SIZE,
+                   hidden_size=_C.PROGRAM_PRIOR.HIDDEN_SIZE, num_layers=_C.PROGRAM_PRIOR.NUM_LAYERS,
+                   dropout=_C.PROGRAM_PRIOR.DROPOUT)
+
+    def forward(self, program_tokens: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if program_tokens.device.type != "cuda":
+            raise _hip.HipLibraryError("program prior input on %s: the HIP path needs a ROCm device" % program_tokens.device)
+        toks = add_sentence_boundary_token_ids(program_tokens, self._pad_index, self._start_index, self._end_index)
+        mask = toks != self._pad_index
+        encoded = self._encoder(self._embedder(toks), mask)
+        logits = self._output_layer(self._projection_layer(encoded))
+        with torch.no_grad():
+            probs = F.softmax(logits, dim=-1).clone()
+            probs[:, :, [self._start_index, self._pad_index, self._unk_index]] = 0
+            B, T, V = probs.shape
+            predictions = torch.multinomial(probs.view(B * T, V), 1).view(B, T)
+            predictions = predictions[:, :-1] * mask[:, 1:]
+        loss = sequence_cross_entropy(logits[:, :-1], toks[:, 1:], mask[:, 1:])
+        if not self.training:
+            self._log2_perplexity(loss.mean().item())
+        return {"predictions": predictions, "loss": loss}
+
+    def get_metrics(self, reset: bool = True) -> Dict[str, float]:
+        return {"perplexity": 2 ** self._log2_perplexity.get_metric(reset=reset)}

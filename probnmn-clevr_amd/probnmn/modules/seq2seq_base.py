@@ -1,0 +1,290 @@
+"""``Seq2SeqBase`` -- class surface of the reference's ``probnmn.modules.seq2seq_base`` (reference:
+probnmn/modules/seq2seq_base.py:19-375), without AllenNLP.
+
+The reference subclasses ``allennlp.models.encoder_decoders.SimpleSeq2Seq`` (AllenNLP 0.9.0, not
+part of this build); the pieces it inherits are restated here from the reference's call sites
+and SURVEY.md App. A: token embedder with a zero padding row, a 2-layer LSTM encoder over packed
+sequences, dot-product attention with AllenNLP's ``masked_softmax``, an ``LSTMCell`` decoder fed
+``cat(attended, embedded)``, a linear output projection.  Parameter names follow the reference's
+``state_dict`` so released checkpoints load.
+
+On the MI355X the per-step gate math of every LSTM step and the token choice are hand-written
+kernels (``pnmn_lstm_cell_{fwd,bwd}``, ``pnmn_sample_tokens``); the 256-wide GEMMs around them are
+plain library GEMMs (torch -> hipBLASLt).  Everything that the reference does with per-row Python
+loops and ``.cpu()`` round trips (sentence boundaries, trimming at ``@end@``) is vectorised on the
+device: a forward pass performs no host synchronisation.
+"""
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from probnmn import _hip
+from probnmn.utils.metrics import Average
+
+
+class _LSTMCellPointwise(torch.autograd.Function):
+    """(gate pre-activations [B,4H], c_prev [B,H]) -> (h, c) on the gfx950 kernel."""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        if gates.device.type != "cuda":
+            raise _hip.HipLibraryError("LSTM cell on %s: the HIP path needs a ROCm device (no CPU fallback)" % gates.device)
+        gates, c_prev = gates.contiguous(), c_prev.contiguous()
+        B, H4 = gates.shape
+        Hd = H4 // 4
+        h = torch.empty_like(c_prev)
+        c = torch.empty_like(c_prev)
+        act = torch.empty_like(gates)
+        _hip.check(_hip.lib().pnmn_lstm_cell_fwd(gates.data_ptr(), c_prev.data_ptr(), h.data_ptr(), c.data_ptr(),
+                                                 act.data_ptr(), B, Hd, _hip.stream_ptr(gates.device)), "lstm_cell_fwd")
+        ctx.save_for_backward(act, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        act, c_prev, c = ctx.saved_tensors
+        B, H4 = act.shape
+        dgates = torch.empty_like(act)
+        dc_prev = torch.empty_like(c)
+        dh_p = dh.contiguous().data_ptr() if dh is not None else None
+        dc_p = dc.contiguous().data_ptr() if dc is not None else None
+        _hip.check(_hip.lib().pnmn_lstm_cell_bwd(act.data_ptr(), c_prev.data_ptr(), c.data_ptr(), dh_p, dc_p,
+                                                 dgates.data_ptr(), dc_prev.data_ptr(), B, H4 // 4,
+                                                 _hip.stream_ptr(act.device)), "lstm_cell_bwd")
+        return dgates, dc_prev
+
+
+def lstm_cell_pointwise(gates, c_prev):
+    return _LSTMCellPointwise.apply(gates, c_prev)
+
+
+def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
+                  pad: int, unk: int, start: int):
+    """One decoding step's token choice on the device; returns (tokens int64 [B], logprob [B] no grad)."""
+    logits = logits.detach().contiguous()
+    B, V = logits.shape
+    tokens = torch.empty(B, dtype=torch.long, device=logits.device)
+    lp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    _hip.check(_hip.lib().pnmn_sample_tokens(logits.data_ptr(), tokens.data_ptr(), lp.data_ptr(), B, V, int(greedy),
+                                             seed, row_offset, step, pad, unk, start,
+                                             _hip.stream_ptr(logits.device)), "sample_tokens")
+    return tokens, lp
+
+
+def add_sentence_boundary_token_ids(tokens: torch.Tensor, pad: int, bos: int, eos: int) -> torch.Tensor:
+    """(B,T) right-padded -> (B,T+2): @start@ first, @end@ right after the last real token
+    (allennlp.nn.util.add_sentence_boundary_token_ids, vectorised)."""
+    B, T = tokens.shape
+    lengths = (tokens != pad).sum(1)
+    out = tokens.new_zeros(B, T + 2)
+    out[:, 1:-1] = tokens
+    out[:, 0] = bos
+    out.scatter_(1, (lengths + 1).unsqueeze(1), eos)
+    return out
+
+
+def masked_softmax(vector: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """allennlp.nn.util.masked_softmax (memory_efficient=False), including its 1e-13."""
+    result = F.softmax(vector * mask, dim=-1) * mask
+    return result / (result.sum(dim=-1, keepdim=True) + 1e-13)
+
+
+def sequence_cross_entropy(logits, targets, weights, eps: float = 1e-13):
+    """Per-sequence masked-mean cross entropy (allennlp sequence_cross_entropy_with_logits,
+    average=None)."""
+    weights = weights.float()
+    nll = -F.log_softmax(logits, dim=-1).gather(2, targets.unsqueeze(-1)).squeeze(-1) * weights
+    return nll.sum(1) / (weights.sum(1) + eps)
+
+
+def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
+    length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
+    input GEMM batched over time and the gate math on the HIP kernel."""
+    B, T, _ = x.shape
+    inp = x
+    for layer in range(lstm.num_layers):
+        w_ih = getattr(lstm, "weight_ih_l%d" % layer)
+        w_hh = getattr(lstm, "weight_hh_l%d" % layer)
+        bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
+        xp = F.linear(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
+        h = x.new_zeros(B, lstm.hidden_size)
+        c = x.new_zeros(B, lstm.hidden_size)
+        w_hh_t = w_hh.t()
+        outs = []
+        for t in range(T):
+            gates = torch.addmm(xp[:, t], h, w_hh_t)
+            h, c = lstm_cell_pointwise(gates, c)
+            outs.append(h)
+        inp = torch.stack(outs, 1)
+    return inp * mask.unsqueeze(-1).to(inp.dtype)
+
+
+class _TokenEmbedder(nn.Module):
+    """``BasicTextFieldEmbedder({"tokens": Embedding})`` as far as parameter naming goes."""
+
+    def __init__(self, key: str, num_embeddings: int, dim: int, padding_index: int):
+        super().__init__()
+        emb = nn.Embedding(num_embeddings, dim, padding_idx=padding_index)
+        nn.init.xavier_uniform_(emb.weight)  # AllenNLP Embedding init, then zero padding row
+        with torch.no_grad():
+            emb.weight[padding_index].fill_(0)
+        setattr(self, "token_embedder_" + key, emb)
+        self._key = "token_embedder_" + key
+
+    @property
+    def embedding(self) -> nn.Embedding:
+        return getattr(self, self._key)
+
+    def forward(self, tokens):
+        return self.embedding(tokens)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, dropout):
+        super().__init__()
+        self._module = nn.LSTM(input_size, hidden_size, num_layers, dropout=dropout, batch_first=True)
+
+    def forward(self, x, mask):
+        return masked_lstm(self._module, x, mask)
+
+
+class Seq2SeqBase(nn.Module):
+    def __init__(
+        self,
+        vocabulary,
+        source_namespace: str,
+        target_namespace: str,
+        input_size: int = 256,
+        hidden_size: int = 256,
+        num_layers: int = 2,
+        dropout: float = 0.0,
+        max_decoding_steps: int = 30,
+    ):
+        super().__init__()
+        self.vocabulary = vocabulary
+        # @@PADDING@@, @@UNKNOWN@@, @start@, @end@ have the same indices in all namespaces
+        self._pad_index = vocabulary.get_token_index("@@PADDING@@", namespace=source_namespace)
+        self._unk_index = vocabulary.get_token_index("@@UNKNOWN@@", namespace=source_namespace)
+        self._end_index = vocabulary.get_token_index("@end@", namespace=target_namespace)
+        self._start_index = vocabulary.get_token_index("@start@", namespace=target_namespace)
+        self._max_decoding_steps = max_decoding_steps
+        self._scheduled_sampling_ratio = 0.0
+        if dropout != 0.0:
+            raise NotImplementedError("dropout != 0 is not used by any reference config and not built")
+
+        v_src = vocabulary.get_vocab_size(namespace=source_namespace)
+        v_tgt = vocabulary.get_vocab_size(namespace=target_namespace)
+        self._source_embedder = _TokenEmbedder("tokens", v_src, input_size, self._pad_index)
+        self._encoder = _Encoder(input_size, hidden_size, num_layers, dropout)
+        # SimpleSeq2Seq: target embedding dim = source embedding dim; decoder dim = encoder dim
+        self._target_embedder = nn.Embedding(v_tgt, input_size)
+        nn.init.xavier_uniform_(self._target_embedder.weight)
+        self._decoder_cell = nn.LSTMCell(hidden_size + input_size, hidden_size)
+        self._output_projection_layer = nn.Linear(hidden_size, v_tgt)
+
+        self._log2_perplexity = Average()
+        self._sequence_accuracy = Average()
+        self._unigram_recall = Average()
+        # row offset of this rank's shard in the global batch (keeps the sample stream shard-invariant)
+        self.sample_row_offset = 0
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(
+        self,
+        source_tokens: torch.LongTensor,
+        target_tokens: Optional[torch.LongTensor] = None,
+        decoding_strategy: str = "sampling",
+    ) -> Dict[str, torch.Tensor]:
+        if decoding_strategy not in ("sampling", "greedy"):
+            raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
+        if source_tokens.device.type != "cuda":
+            raise _hip.HipLibraryError("seq2seq input on %s: the HIP path needs a ROCm device" % source_tokens.device)
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        src = add_sentence_boundary_token_ids(source_tokens, pad, bos, eos)[:, 1:]  # @start@ is not encoded
+        tgt = None
+        if target_tokens is not None:
+            tgt = add_sentence_boundary_token_ids(target_tokens, pad, bos, eos)
+
+        # _encode / _init_decoder_state
+        src_mask = src != pad
+        enc = self._encoder(self._source_embedder(src), src_mask)
+        B = src.size(0)
+        rows = torch.arange(B, device=src.device)
+        h = enc[rows, src_mask.sum(1) - 1]
+        c = torch.zeros_like(h)
+        fmask = src_mask.float()
+
+        steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
+        greedy = decoding_strategy == "greedy"
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        last = src.new_full((B,), bos)
+        w_ih_t = self._decoder_cell.weight_ih.t()
+        w_hh_t = self._decoder_cell.weight_hh.t()
+        bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
+        step_logits, step_logprobs, step_predictions = [], [], []
+        for t in range(steps):
+            inputs = tgt[:, t] if tgt is not None else last
+            e = self._target_embedder(inputs)
+            scores = torch.bmm(enc, h.unsqueeze(-1)).squeeze(-1)
+            weights = masked_softmax(scores, fmask)
+            attended = torch.bmm(weights.unsqueeze(1), enc).squeeze(1)
+            x = torch.cat((attended, e), -1)
+            gates = torch.addmm(torch.addmm(bias, x, w_ih_t), h, w_hh_t)
+            h, c = lstm_cell_pointwise(gates, c)
+            logits = self._output_projection_layer(h)
+            last, _ = choose_tokens(logits, greedy, seed, self.sample_row_offset, t, pad, self._unk_index, bos)
+            logprobs = F.log_softmax(logits, dim=-1)
+            step_predictions.append(last.unsqueeze(1))
+            step_logits.append(logits.unsqueeze(1))
+            step_logprobs.append(logprobs.gather(1, last.unsqueeze(1)))
+
+        raw = torch.cat(step_predictions, 1)
+        predictions = self._trim_predictions(raw)
+        logprobs = torch.cat(step_logprobs, 1)
+        pmask = (predictions != pad).float()
+        sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
+        output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
+        if tgt is not None:
+            logits = torch.cat(step_logits, 1)
+            tmask = tgt != pad
+            ce = sequence_cross_entropy(logits, tgt[:, 1:], tmask[:, 1:])
+            output_dict["loss"] = ce
+            if not self.training:
+                self._record_metrics(predictions, tgt[:, 1:], ce)
+        return output_dict
+
+    def _trim_predictions(self, predictions: torch.LongTensor) -> torch.LongTensor:
+        """Keep each row up to and including its first @end@; a row starting with @end@ becomes all
+        padding, a row without @end@ is kept whole (reference :278-293), without leaving the device."""
+        steps = predictions.size(1)
+        is_end = predictions == self._end_index
+        has_end = is_end.any(1, keepdim=True)
+        first = is_end.float().argmax(1, keepdim=True)  # first occurrence
+        pos = torch.arange(steps, device=predictions.device).unsqueeze(0)
+        keep = torch.where(has_end, (pos <= first) & (first > 0), torch.ones_like(is_end))
+        return predictions * keep
+
+    @torch.no_grad()
+    def _record_metrics(self, predictions, relevant_targets, ce) -> None:
+        n = relevant_targets.size(1)
+        pred = predictions[:, :n]
+        mask = relevant_targets != self._pad_index
+        correct = ((pred == relevant_targets) | ~mask).all(1).float().mean()
+        # unigram recall: fraction of gold tokens that appear anywhere in the prediction
+        hit = (relevant_targets.unsqueeze(2) == pred.unsqueeze(1)).any(2) & mask
+        recall = (hit.sum(1).float() / mask.sum(1).clamp(min=1).float()).mean()
+        self._log2_perplexity(ce.mean().item())
+        self._sequence_accuracy(correct.item())
+        self._unigram_recall(recall.item())
+
+    def get_metrics(self, reset: bool = True) -> Dict[str, float]:
+        if self.training:
+            return {}
+        return {
+            "perplexity": 2 ** self._log2_perplexity.get_metric(reset=reset),
+            "sequence_accuracy": self._sequence_accuracy.get_metric(reset=reset),
+            "word_error_rate": 1 - self._unigram_recall.get_metric(reset=reset),
+        }

@@ -1,0 +1,173 @@
+"""Seq2seq models on the MI355X against the CPU oracle (same weights, same tokens).  fp32
+tolerance: losses 1e-4, gradients 2e-3 of each tensor's max (BPTT over ~47 steps)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tokens(B, T, V, seed, min_len=2):
+    g = torch.Generator().manual_seed(seed)
+    out = torch.zeros(B, T, dtype=torch.long)
+    lens = torch.randint(min_len, T + 1, (B,), generator=g)
+    lens[0] = T  # one full-length row
+    for i in range(B):
+        out[i, : lens[i]] = torch.randint(4, V, (int(lens[i]),), generator=g)
+    return out
+
+
+def _models(seed=0):
+    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(seed)
+    return vocab, ProgramGenerator(vocab), QuestionReconstructor(vocab), ProgramPrior(vocab, hidden_size=256)
+
+
+def _cmp_grads(model, ref_sd, tag, tol=2e-3):
+    worst = 0.0
+    for name, p in model.named_parameters():
+        g_ref = ref_sd[name].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        scale = float(g_ref.abs().max()) + 1e-12
+        err = float((p.grad.cpu() - g_ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < tol, (tag, name, err)
+    return worst
+
+
+def test_lstm_cell_kernel_matches_torch():
+    from probnmn.modules.seq2seq_base import lstm_cell_pointwise
+
+    g = torch.Generator().manual_seed(0)
+    B, Hd = 37, 256
+    gates = (torch.randn(B, 4 * Hd, generator=g) * 2).requires_grad_(True)
+    c0 = torch.randn(B, Hd, generator=g).requires_grad_(True)
+    i, f, gg, o = gates.chunk(4, 1)
+    c_ref = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    dh, dc = torch.randn(B, Hd, generator=g), torch.randn(B, Hd, generator=g)
+    (h_ref * dh + c_ref * dc).sum().backward()
+    gd = gates.detach().to(DEV).requires_grad_(True)
+    cd = c0.detach().to(DEV).requires_grad_(True)
+    h, c = lstm_cell_pointwise(gd, cd)
+    (h * dh.to(DEV) + c * dc.to(DEV)).sum().backward()
+    torch.testing.assert_close(h.detach().cpu(), h_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(c.detach().cpu(), c_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gd.grad.cpu(), gates.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(cd.grad.cpu(), c0.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_sampler_kernel_distribution_and_greedy():
+    from probnmn.modules.seq2seq_base import choose_tokens
+
+    g = torch.Generator().manual_seed(1)
+    V = 100
+    base = torch.randn(V, generator=g) * 2
+    logits = base.unsqueeze(0).repeat(200000, 1).to(DEV)
+    tok, lp = choose_tokens(logits, False, seed=1234, row_offset=0, step=3, pad=0, unk=1, start=2)
+    tok, lp = tok.cpu(), lp.cpu()
+    assert not torch.isin(tok, torch.tensor([0, 1, 2])).any()
+    p = F.softmax(base, 0).clone()
+    p[:3] = 0
+    p = p / p.sum()
+    freq = torch.bincount(tok, minlength=V).float() / tok.numel()
+    # binomial std of a frequency ~ sqrt(p/N): allow 6 sigma + tiny absolute
+    assert torch.all((freq - p).abs() < 6 * torch.sqrt(p / tok.numel()) + 1e-5)
+    torch.testing.assert_close(lp, F.log_softmax(base, 0)[tok], rtol=1e-5, atol=1e-5)
+    # same (seed,row,step) -> same draw; different step -> different stream
+    tok2, _ = choose_tokens(logits, False, seed=1234, row_offset=0, step=3, pad=0, unk=1, start=2)
+    tok3, _ = choose_tokens(logits, False, seed=1234, row_offset=0, step=4, pad=0, unk=1, start=2)
+    assert torch.equal(tok2.cpu(), tok) and not torch.equal(tok3.cpu(), tok)
+    # shard invariance: rows [1000, 2000) with offset 0 == rows [0, 1000) with offset 1000
+    a, _ = choose_tokens(logits[:2000], False, 99, 0, 0, 0, 1, 2)
+    b, _ = choose_tokens(logits[:1000], False, 99, 1000, 0, 0, 1, 2)
+    assert torch.equal(a[1000:], b)
+    gt, glp = choose_tokens(torch.randn(64, 44, generator=g).to(DEV), True, 0, 0, 0, 0, 1, 2)
+    assert gt.shape == (64,)
+
+
+@pytest.mark.parametrize("which", ["pg", "qr"])
+def test_teacher_forced_and_sampled_match_oracle(which):
+    from oracle import seq2seq_oracle as so
+
+    vocab, pg, qr, _ = _models()
+    model = pg if which == "pg" else qr
+    vq, vp = vocab.get_vocab_size("questions"), vocab.get_vocab_size("programs")
+    B = 12
+    src = _tokens(B, 20 if which == "pg" else 12, vq if which == "pg" else vp, 5)
+    tgt = _tokens(B, 12 if which == "pg" else 20, vp if which == "pg" else vq, 6)
+    cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+
+    # 1. teacher forcing: CE loss and its gradients
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in cpu_sd.items()}
+    ref = so.seq2seq_forward(ref_sd, src, tgt, "greedy")
+    ref["loss"].mean().backward()
+    out = model(src.to(DEV), tgt.to(DEV), decoding_strategy="greedy")
+    out["loss"].mean().backward()
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(out["predictions"].cpu(), ref["predictions"])
+    print(which, "teacher-forced worst grad err", _cmp_grads(model, ref_sd, which + "/tf"))
+
+    # 2. sampling: replay the device's samples through the oracle
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(7)
+    out = model(src.to(DEV), None, decoding_strategy="sampling")
+    out["loss"].mean().backward()
+    pred = out["predictions"].cpu()
+    assert pred.shape == (B, model._max_decoding_steps)
+    assert not torch.isin(pred, torch.tensor([1, 2])).any()
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in cpu_sd.items()}
+    ref = so.seq2seq_forward(ref_sd, src, None, "sampling", max_decoding_steps=model._max_decoding_steps,
+                             forced_predictions=pred)
+    ref["loss"].mean().backward()
+    assert torch.equal(ref["predictions"], pred)
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    print(which, "sampled worst grad err", _cmp_grads(model, ref_sd, which + "/sample"))
+
+    # 3. free-running greedy in eval mode
+    model.eval()
+    with torch.no_grad():
+        out = model(src.to(DEV), None, decoding_strategy="greedy")
+    ref = so.seq2seq_forward(cpu_sd, src, None, "greedy", max_decoding_steps=model._max_decoding_steps)
+    same = (out["predictions"].cpu() == ref["predictions"]).all(1).float().mean()
+    assert same >= 0.9  # an arg-max near-tie may diverge a row; the rest must be identical
+    # 4. eval with targets records metrics
+    model(src.to(DEV), tgt.to(DEV), decoding_strategy="greedy")
+    m = model.get_metrics()
+    assert set(m) == {"perplexity", "sequence_accuracy", "word_error_rate"}
+
+
+def test_trim_predictions_matches_reference_rule():
+    from oracle import seq2seq_oracle as so
+
+    _, pg, _, _ = _models()
+    p = torch.tensor([[9, 8, 3, 7, 3], [3, 9, 9, 9, 9], [9, 9, 9, 9, 9], [9, 3, 3, 3, 3], [0, 0, 3, 0, 0]])
+    assert torch.equal(pg._trim_predictions(p.to(DEV)).cpu(), so.trim_predictions(p))
+
+
+def test_program_prior_loss_and_gradients():
+    from oracle import seq2seq_oracle as so
+
+    vocab, _, _, prior = _models()
+    progs = _tokens(10, 26, 44, 9)
+    cpu_sd = {k: v.detach().clone() for k, v in prior.state_dict().items() if k != "_output_layer.weight"}
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in cpu_sd.items()}
+    ref = so.program_prior_loss(ref_sd, progs)
+    ref.mean().backward()
+    prior.to(DEV).eval()
+    out = prior(progs.to(DEV))
+    out["loss"].mean().backward()
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    assert out["predictions"].shape == (10, 27)
+    for name, p in prior.named_parameters():
+        g_ref = ref_sd[name].grad
+        scale = float(g_ref.abs().max()) + 1e-12
+        assert float((p.grad.cpu() - g_ref).abs().max()) / scale < 2e-3, name
