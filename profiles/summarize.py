@@ -28,5 +28,27 @@ def main(path):
             name[:72], r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
 
 
+def pmc(path):
+    """Per-kernel sums of the PMC counters of a `rocprofv3 --kernel-trace --pmc X` run."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
+    suffix = tab.replace("rocpd_kernel_dispatch", "")
+    q = f"""select s.kernel_name, i.name, count(*), sum(e.value), avg(e.value)
+            from rocpd_pmc_event{suffix} e
+            join rocpd_kernel_dispatch{suffix} d on d.event_id = e.event_id
+            join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
+            join rocpd_info_pmc{suffix} i on i.id = e.pmc_id
+            group by s.kernel_name, i.name order by 4 desc"""
+    print("# PMC summary of %s (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide" % path)
+    print("# coalesced reads at half their bytes -- MI355X_MICROARCH.md, HBM section)")
+    print("%-72s %-12s %8s %14s %12s" % ("kernel", "counter", "calls", "sum", "avg/launch"))
+    for name, ctr, n, tot, avg in cur.execute(q):
+        print("%-72s %-12s %8d %14.1f %12.2f" % (name.replace(".kd", "")[:72], ctr, n, tot, avg))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--pmc":
+        pmc(sys.argv[2])
+    else:
+        main(sys.argv[1])
