@@ -86,12 +86,16 @@ def cpu_baseline(vocab, state_dict, sample, steps, seed):
 
 
 def kernel_rooflines(engine, trainer, batch, passes):
-    """Instrumented pass: events around every conv / wgrad launch on the launch stream."""
+    """Instrumented pass: events around every conv / wgrad launch on the launch stream.  The pass
+    runs with the weight-gradient overlap switched off (one stream), so that each kernel's duration
+    is its own and not that of two kernels sharing the chip."""
+    overlap, engine.overlap_wgrad = engine.overlap_wgrad, False
     engine.event_log = []
     for _ in range(passes):
         trainer.step(batch)
     torch.cuda.synchronize()
     log, engine.event_log = engine.event_log, None
+    engine.overlap_wgrad = overlap
     agg = {}
     for kern, what, flops, e0, e1 in log:
         a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "by": {}})
@@ -116,6 +120,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="run weight gradients on a second stream concurrently with the data-gradient chain")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +152,7 @@ def main():
         cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net.to(dev)
     trainer = ModuleTrainingStep(net, lr=1e-4, weight_decay=0.0, report_metrics=False)
+    net.engine.overlap_wgrad = args.overlap_wgrad
     parallel.broadcast_parameters(trainer.optimizer.arenas, trainer.optimizer.loose)
     # weak scaling: every rank gets its own batch of --batch questions
     batch = synthetic_batch(vocab, args.batch, seed=1000 + rank, device=dev)
@@ -161,10 +168,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    from probnmn import _hip
+    w0 = _hip.ring_wait_seconds()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step(batch)
-    host_elapsed = time.perf_counter() - t0  # time to ENQUEUE the steps (host scheduling + launches)
+    host_elapsed = time.perf_counter() - t0
+    host_blocked = _hip.ring_wait_seconds() - w0  # part of it spent waiting for the GPU to free a staging slot  # time to ENQUEUE the steps (host scheduling + launches)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -218,6 +228,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
             "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
+            "host_busy_ms_per_step": round((host_elapsed - host_blocked) / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -228,6 +239,7 @@ def main():
                             "template shapes, fwd+bwd+clamp+Adam" % args.batch,
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world,
+                "streams": 2 if args.overlap_wgrad else 1,
                 "module_primitives_per_step": plan.n_prims if plan else None,
             },
             "roofline": roof,

@@ -1,0 +1,251 @@
+// Body of the grouped NHWC convolution (see conv_nhwc.hip for the design notes), shared by the
+// one-launch-per-level kernel (conv_nhwc.hip) and the persistent dataflow kernel (dataflow.hip).
+//
+// conv_body<H, W, KSPLIT>: the calling workgroup (512 threads) computes output channels
+// [cout_block*128 + nsub*128/KSPLIT, ... + 128/KSPLIT) of one item; `lds` is (H*W+1)*128 floats.
+// All 512 threads must call it; it ends with the epilogue executed by the waves that own the
+// reduced accumulators and contains no barrier after the point where the other waves return.
+//
+// Optional fused epilogue (MaskBwd != nullptr; data-gradient of a conv whose forward input was
+// feats * attn): instead of storing dx, adds dx * attn into dfeats and sum_c dx*feats into dattn
+// (fp32 atomics; the same buffers are shared by every consumer of the example's stem output).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/probnmn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace pnmn {
+
+constexpr int CB = 128;  // channels per block (input chunk and output block)
+
+struct MaskBwd {
+    const float* feats;  // [HW][128] forward features (stem output)
+    const float* attn;   // [HW] or nullptr for the all-ones attention
+    float* dfeats;       // [HW][128], +=
+    float* dattn;        // [HW], += (ignored when attn == nullptr)
+};
+
+template <int H, int W, int KSPLIT>
+__device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, int cout_block, int cin_chunks,
+                                          int ntaps, int in_stride, int out_stride, int relu, float* lds,
+                                          const MaskBwd* mb) {
+    constexpr int HW = H * W;
+    constexpr int MT = (HW + 15) / 16;
+    constexpr int NT = 8 / KSPLIT;   // 16-channel output tiles per workgroup
+    constexpr int KB = 8 / KSPLIT;   // 16-channel input blocks per wave and tap
+    constexpr int NTHREADS = 512;
+
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int li = lane & 15;
+    const int g = lane >> 4;
+
+    const int nt = wave % NT;
+    const int ks = wave / NT;  // which slice of the input channels this wave contracts
+    const int n0 = cout_block * CB + (nsub * NT + nt) * 16;  // this wave's 16 out channels
+    const int cin_total = cin_chunks * CB;
+    const int dil = it.dilation;
+
+    // pixel handled by this lane in each m-tile (as the MFMA "column" index)
+    int py[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = mt * 16 + li;
+        py[mt] = (p < HW) ? p / W : -100000;
+        px[mt] = p % W;
+    }
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight row of this lane: output channel n0 + li, channels 4g.. of each 16-block
+    const float* wrow = it.weight + (size_t)(n0 + li) * ntaps * cin_total + 4 * g + ks * KB * 16;
+
+    if (tid < 32) reinterpret_cast<f32x4*>(lds + HW * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < cin_chunks; ++chunk) {
+        // ---- stage this 128-channel chunk of the input into LDS (fused prologue) ----
+        const float* src = (it.in2 != nullptr && chunk > 0) ? it.in2 : it.in + chunk * CB;
+        const float* gsrc = it.gate ? it.gate + chunk * CB : nullptr;
+        if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk
+        for (int idx = tid; idx < HW * 32; idx += NTHREADS) {
+            const int p = idx >> 5;
+            const int s = idx & 31;
+            f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * in_stride + s * 4);
+            if (it.mask) {
+                const float m = it.mask[p];
+                v *= m;
+            }
+            if (gsrc) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(gsrc + (size_t)p * in_stride + s * 4);
+                v.x = gt.x > 0.f ? v.x : 0.f;
+                v.y = gt.y > 0.f ? v.y : 0.f;
+                v.z = gt.z > 0.f ? v.z : 0.f;
+                v.w = gt.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(lds + p * CB + ((s ^ (p & 15)) << 2)) = v;
+        }
+        __syncthreads();
+
+        const float* wchunk = wrow + chunk * CB;
+
+        // LDS float offset of the (tap-shifted) pixel row of every m-tile, swizzle bits folded in:
+        // q*128 + ((g ^ (q&3)) << 2), low 2 bits carry (q>>2)&3
+        auto rowbases = [&](int tap, int (&rb)[MT]) {
+            int dy = 0, dx = 0;
+            if (ntaps == 9) {
+                dy = (tap / 3 - 1) * dil;
+                dx = (tap % 3 - 1) * dil;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int yy = py[mt] + dy;
+                const int xx = px[mt] + dx;
+                const bool ok = ((unsigned)yy < (unsigned)H) && ((unsigned)xx < (unsigned)W);
+                const int q = ok ? yy * W + xx : HW;
+                rb[mt] = q * CB + ((g ^ (q & 3)) << 2) + ((q >> 2) & 3);
+            }
+        };
+        // Software pipeline, half a step deep, on ONE set of fragment registers: a step (one tap, one
+        // 16-channel block) is computed in two halves of m-tiles; as soon as the MFMAs of a half
+        // have been issued, the same registers are re-loaded with that half's fragments of the NEXT
+        // step, which then have the other half's 24-28 MFMAs (~800 cycles) to arrive -- LDS and L2
+        // latency never sit between MFMAs, at no extra register cost.  Inside a half the MFMAs walk
+        // its 6-7 accumulators round-robin (no dependent-issue stall).
+        constexpr int MH = (MT + 1) / 2;
+        int rb[MT];
+        rowbases(0, rb);
+        f32x4 afrag[MT];
+        f32x4 bfrag[2];
+        auto load_half = [&](int lo, int hi, int kbg) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt >= lo && mt < hi)
+                    afrag[mt] = *reinterpret_cast<const f32x4*>(lds + (rb[mt] & ~3) + ((kbg ^ (rb[mt] & 3)) << 4));
+        };
+        auto mfma_half = [&](int lo, int hi, const f32x4 bw) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.x, afrag[mt].x, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.y, afrag[mt].y, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.z, afrag[mt].z, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.w, afrag[mt].w, acc[mt], 0, 0, 0);
+        };
+        load_half(0, MT, ks * KB);
+        bfrag[0] = *reinterpret_cast<const f32x4*>(wchunk);
+
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int tn = (tap + 1 < ntaps) ? tap + 1 : tap;  // (the last tap re-requests its own data)
+            const float* wtap = wchunk + (size_t)tap * cin_total;
+            const float* wtn = wchunk + (size_t)tn * cin_total;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const bool last = (kb + 1 == KB);
+                const int kbg_next = last ? ks * KB : ks * KB + kb + 1;
+                bfrag[1] = *reinterpret_cast<const f32x4*>(last ? wtn : wtap + (kb + 1) * 16);
+                const f32x4 bw = bfrag[0];
+                mfma_half(0, MH, bw);
+                __builtin_amdgcn_sched_barrier(0);
+                if (last) rowbases(tn, rb);  // rows of the next tap (every fragment of this tap is already in flight or in registers)
+                load_half(0, MH, kbg_next);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_half(MH, MT, bw);
+                __builtin_amdgcn_sched_barrier(0);
+                load_half(MH, MT, kbg_next);
+                __builtin_amdgcn_sched_barrier(0);
+                bfrag[0] = bfrag[1];
+            }
+        }
+    }
+
+    if (KSPLIT > 1) {
+        // sum the KSPLIT partial accumulators of each output tile through LDS (input image is dead)
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(lds);
+        if (ks > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) red[(((ks - 1) * NT + nt) * MT + mt) * 64 + lane] = acc[mt];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll 1
+            for (int k2 = 1; k2 < KSPLIT; ++k2) {
+                const f32x4* src = red + (((k2 - 1) * NT + nt) * MT) * 64 + lane;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] += src[mt * 64];
+            }
+        }
+    }
+    if (ks != 0) return;  // (no barrier follows inside this function)
+
+    // ---- epilogue: lane holds out channels n0+4g..+3 of pixel mt*16+li ----
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it.bias) bias4 = *reinterpret_cast<const f32x4*>(it.bias + n0 + 4 * g);
+    if (mb == nullptr) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = mt * 16 + li;
+            if (p < HW) {
+                f32x4 v = acc[mt] + bias4;
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                float* dstf = it.out + (size_t)p * out_stride + n0 + 4 * g;
+                if (it.flags & PNMN_CONV_ATOMIC) {
+                    unsafeAtomicAdd(dstf + 0, v.x);
+                    unsafeAtomicAdd(dstf + 1, v.y);
+                    unsafeAtomicAdd(dstf + 2, v.z);
+                    unsafeAtomicAdd(dstf + 3, v.w);
+                } else {
+                    f32x4* dst = reinterpret_cast<f32x4*>(dstf);
+                    if (it.flags & PNMN_CONV_ACCUMULATE) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    } else {
+        // fused backward of (feats * attn): this wave owns channels n0..n0+15 of every pixel
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = mt * 16 + li;
+            const bool ok = p < HW;
+            const f32x4 v = acc[mt];
+            float part = 0.f;
+            if (ok) {
+                float m = 1.f;
+                if (mb->attn) {
+                    m = mb->attn[p];
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(mb->feats + (size_t)p * CB + n0 + 4 * g);
+                    part = v.x * f.x + v.y * f.y + v.z * f.z + v.w * f.w;
+                }
+                float* d = mb->dfeats + (size_t)p * CB + n0 + 4 * g;
+                unsafeAtomicAdd(d + 0, v.x * m);
+                unsafeAtomicAdd(d + 1, v.y * m);
+                unsafeAtomicAdd(d + 2, v.z * m);
+                unsafeAtomicAdd(d + 3, v.w * m);
+            }
+            if (mb->attn) {
+                part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
+                part += __shfl_xor(part, 32);
+                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p, part);
+            }
+        }
+    }
+}
+
+}  // namespace pnmn

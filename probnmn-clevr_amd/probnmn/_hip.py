@@ -7,16 +7,19 @@ that torch's stream handles and device pointers are valid inside it.
 """
 import ctypes
 import os
+import time
 from typing import Dict, Optional
 
 import numpy as np
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libprobnmn_hip.so")
+LIB_PATH = os.environ.get("PNMN_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libprobnmn_hip.so")
 
 CHANNELS = 128
 CONV_ACCUMULATE = 1
+CONV_ATOMIC = 2
+CONV_MASKBWD = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -52,6 +55,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
+    "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
 
@@ -85,7 +89,8 @@ _u64 = np.uint64
 _i32 = np.int32
 CONV_ITEM = np.dtype(
     [("in", _u64), ("in2", _u64), ("mask", _u64), ("gate", _u64), ("weight", _u64), ("bias", _u64),
-     ("out", _u64), ("dilation", _i32), ("flags", _i32)]
+     ("out", _u64), ("dilation", _i32), ("flags", _i32), ("mb_feats", _u64), ("mb_attn", _u64),
+     ("mb_dfeats", _u64), ("mb_dattn", _u64)]
 )
 WGRAD_ITEM = np.dtype(
     [("x", _u64), ("x2", _u64), ("xmask", _u64), ("dy", _u64), ("gate", _u64), ("dilation", _i32),
@@ -111,8 +116,13 @@ MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
+TASK = np.dtype([("p", _u64, (12,)), ("type", _i32), ("sub", _i32), ("dilation", _i32), ("flags", _i32),
+                 ("dep", _i32, (3,)), ("need", _i32, (3,)), ("slot", _i32), ("pad", _i32, (5,))])
+T_CONV, T_DOT_FWD, T_DOT_BWD, T_SAME_FWD, T_SAME_BWD, T_MINMAX_FWD, T_MINMAX_BWD = range(7)
+
 ITEM_SIZES = {
-    "pnmn_conv_item": (CONV_ITEM, 64),
+    "pnmn_task": (TASK, 160),
+    "pnmn_conv_item": (CONV_ITEM, 96),
     "pnmn_wgrad_item": (WGRAD_ITEM, 48),
     "pnmn_wgrad_job": (WGRAD_JOB, 24),
     "pnmn_wtrans_item": (WTRANS_ITEM, 32),
@@ -141,13 +151,16 @@ class _PinnedRing:
         self._bufs = [None] * slots
         self._events = [None] * slots
         self._next = 0
+        self.wait_seconds = 0.0  # time the host spent blocked on the GPU (diagnostic)
 
     def stage(self, raw: np.ndarray, device: torch.device) -> torch.Tensor:
         i = self._next
         self._next = (i + 1) % len(self._bufs)
         ev = self._events[i]
-        if ev is not None:
-            ev.synchronize()
+        if ev is not None and not ev.query():
+            t0 = time.perf_counter()
+            ev.synchronize()  # the host is >= 2 steps ahead of the GPU: wait for the slot
+            self.wait_seconds += time.perf_counter() - t0
         n = raw.size
         buf = self._bufs[i]
         if buf is None or buf.numel() < n:
@@ -171,6 +184,11 @@ def _ring(device: torch.device) -> _PinnedRing:
     if r is None:
         r = _rings[idx] = _PinnedRing()
     return r
+
+
+def ring_wait_seconds() -> float:
+    """Total time the host has been blocked waiting for staging slots (i.e. for the GPU)."""
+    return sum(r.wait_seconds for r in _rings.values())
 
 
 def to_device(records: np.ndarray, device: torch.device) -> torch.Tensor:

@@ -12,6 +12,7 @@ forward levels in reverse; every weight gradient of the module convs is deferred
 grouped launch at the end, where all (example, conv) pairs that share a weight are accumulated by
 the same workgroups.
 """
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -32,6 +33,7 @@ _DT = {
     "maskbwd": _hip.MASKBWD_ITEM,
     "wgrad_item": _hip.WGRAD_ITEM,
     "wgrad_job": _hip.WGRAD_JOB,
+    "task": _hip.TASK,
 }
 
 
@@ -93,6 +95,19 @@ class NMNEngine:
         # when a list, every conv / wgrad launch is bracketed by events on the launch stream and
         # (kernel, algorithmic flops, start, end) is appended -- used by bench.py's roofline pass
         self.event_log: Optional[list] = None
+        # True: weight gradients run on a second stream, concurrently with the level-by-level
+        # data-gradient chain.  Measured on MI355X (B=256): no gain -- a wgrad workgroup holds its CU
+        # (151 KiB LDS) for ~400 us and delays the chain's critical path as much as it fills its gaps --
+        # so the default is one stream, which also keeps per-kernel profiles clean.
+        self.overlap_wgrad = False
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        # True: the module programs run in the persistent dataflow executor (one launch per pass)
+        # instead of one grouped launch per (level, kind)
+        self.dataflow = os.environ.get("PNMN_DATAFLOW", "0") == "1"
+        self.dataflow_ksplit = int(os.environ.get("PNMN_DATAFLOW_KSPLIT", "2"))
+        self.dataflow_workgroups = int(os.environ.get("PNMN_DATAFLOW_WGS", "256"))
+        self._df_state: Optional[torch.Tensor] = None  # int32: [queue head, error, completion counters...]
+        self._df_checks: list = []
 
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
         log = self.event_log
@@ -106,16 +121,18 @@ class NMNEngine:
             e1.record()
             log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1))
 
-    def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, st, what):
+    def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
+        """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
         log = self.event_log
+        st = stream.cuda_stream
         if log is not None:
             e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(stream)
         _hip.check(_hip.lib().pnmn_conv_wgrad(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
                                               x_stride, dy_stride, st), what)
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
+            e1.record(stream)
             log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1))
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -186,7 +203,8 @@ class NMNEngine:
         self._wt_records = _hip.to_device(rec, a.device)
         self._wt_count = len(wt_items)
         self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
-        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT)
+        import os
+        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT, wgrad_chunk=int(os.environ.get('PNMN_WG_CHUNK', '8')), wgrad_groups=int(os.environ.get('PNMN_WG_GROUPS', '1')))
 
     # ---- workspaces ---------------------------------------------------------------------------
     def _buf(self, name: str, numel: int) -> torch.Tensor:
@@ -296,6 +314,8 @@ class NMNEngine:
             act=act.data_ptr(), gact=gact.data_ptr(), feat=ws["feat"].data_ptr(),
             gfeat=ws["gfeat"].data_ptr(), final=ws["final"].data_ptr(), gfinal=ws["gfinal"].data_ptr(),
             ones=self.ones.data_ptr())
+        self.scheduler.dataflow = self.dataflow
+        self.scheduler.dataflow_ksplit = self.dataflow_ksplit
         plan = self.scheduler.plan(compiled, bufs)
         assert plan.arena_floats == floats, (plan.arena_floats, floats)
         self.last_plan = plan
@@ -308,6 +328,10 @@ class NMNEngine:
             pack.add(k, rec)
         for k, rec in plan.wgrad_jobs.items():
             pack.add(k + "_jobs", rec)
+        if plan.fwd_tasks is not None:
+            pack.add("fwd_tasks", plan.fwd_tasks)
+            if need_backward:
+                pack.add("bwd_tasks", plan.bwd_tasks)
         pack.upload(dev)
 
         H, W = self.H, self.W
@@ -326,7 +350,10 @@ class NMNEngine:
             idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             final.index_copy_(0, idx, feat.index_select(0, idx))
 
-        self._run_forward_launches(plan, pack, st)
+        if plan.fwd_tasks is not None:
+            self._run_dataflow(pack.ptr("fwd_tasks"), plan.fwd_tasks, plan.n_fwd_slots, dev, "module forward (dataflow)")
+        else:
+            self._run_forward_launches(plan, pack, st)
 
         self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
@@ -338,6 +365,53 @@ class NMNEngine:
             state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
             state.generation = self.generation
         return pooled, state
+
+    def _run_dataflow(self, tasks_ptr: int, tasks: np.ndarray, n_slots: int, dev, what: str) -> None:
+        """One persistent launch that executes a whole task list (see csrc/dataflow.hip)."""
+        self._check_dataflow_errors()
+        need = 2 + n_slots
+        if self._df_state is None or self._df_state.numel() < need or self._df_state.device != dev:
+            self._df_state = torch.empty(max(need, 1 << 16), dtype=torch.int32, device=dev)
+        state = self._df_state
+        state[:need].zero_()
+        stream = torch.cuda.current_stream(dev)
+        log = self.event_log
+        if log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        _hip.check(_hip.lib().pnmn_dataflow(tasks_ptr, len(tasks), state.data_ptr(), state.data_ptr() + 8, self.H, self.W,
+                                            self.dataflow_ksplit, self.dataflow_workgroups, stream.cuda_stream), what)
+        if log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(stream)
+            conv = tasks[tasks["type"] == _hip.T_CONV]
+            taps = np.where(conv["flags"] & 32, 1, 9) * np.where(conv["flags"] & 64, 2, 1)
+            flops = float((2.0 * self.HW * (C // self.dataflow_ksplit) * taps * C).sum())
+            log.append(("dataflow", what, flops, e0, e1))
+        # error word -> pinned host memory (async copy), read without blocking at a later launch
+        if not hasattr(self, "_df_host"):
+            self._df_host = torch.zeros(64, dtype=torch.int32).pin_memory()
+            self._df_host_next = 0
+        i = self._df_host_next
+        self._df_host_next = (i + 1) % 64
+        self._df_host[i:i + 1].copy_(state[1:2], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._df_checks.append((ev, i, what))
+
+    def _check_dataflow_errors(self, block: bool = False) -> None:
+        pending = []
+        for ev, i, what in self._df_checks:
+            if block:
+                ev.synchronize()
+            if block or ev.query():
+                code = int(self._df_host[i])
+                if code != 0:
+                    self._df_checks = []
+                    raise _hip.HipLibraryError("%s: task %d timed out waiting for its inputs" % (what, code - 1))
+            else:
+                pending.append((ev, i, what))
+        self._df_checks = pending[-32:]
 
     def _run_forward_launches(self, plan: StepPlan, pack: _Pack, st: int) -> None:
         lib, chk, H, W, HW = _hip.lib(), _hip.check, self.H, self.W, self.HW
@@ -377,11 +451,27 @@ class NMNEngine:
         ws["gfeat"][: B * HW * C].zero_()
         chk(lib.pnmn_transpose_weights(self._wt_records.data_ptr(), self._wt_count, st), "transpose weights")
 
+        main = torch.cuda.current_stream(dev)
+        if self.overlap_wgrad:
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+        else:
+            side = main
+
+        def fork():
+            """work queued on `side` from here on may read everything `main` has produced so far"""
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+
         # classifier conv
         chk(lib.pnmn_maxpool2_flatten_bwd(ws["cls"].data_ptr(), dpooled.data_ptr(), ws["gcls"].data_ptr(), B, H, W,
                                           self.cproj, st), "maxpool bwd")
+        fork()
         nj = len(state.fixed["cls_wg_jobs"])
-        self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, st,
+        self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
                     "classifier wgrad")
         self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
         if plan.feat_result_examples.size:
@@ -390,8 +480,12 @@ class NMNEngine:
             gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
             gfeat.index_add_(0, idx, gfinal.index_select(0, idx))
 
-        # module programs, levels in reverse
-        for phase in plan.backward:
+        # module programs, levels in reverse; each group of module-conv weight gradients is released
+        # to the side stream as soon as the data-gradient chain has passed its lowest level
+        groups = list(plan.wgrad_groups or [])
+        n_items3 = len(plan.records["wg3"])
+        n_jobs3 = max(1, len(plan.wgrad_jobs["wg3"]))
+        for phase in ([] if plan.bwd_tasks is not None else plan.backward):
             for l in phase:
                 n = l.end - l.begin
                 if l.kind == "dot_bwd":
@@ -408,24 +502,37 @@ class NMNEngine:
                     chk(lib.pnmn_mask_bwd(pack.ptr("maskbwd", l.begin), n, HW, st), "mask bwd")
                 else:
                     raise AssertionError(l.kind)
-
-        # all module-conv weight gradients in one grouped launch each
-        nj = len(plan.wgrad_jobs["wg3"])
-        if nj:
-            self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs"), nj, len(plan.records["wg3"]), 9, 1, 1, C, C, st,
-                        "module wgrad")
+            level = phase[0].level
+            ready = [g for g in groups if g[0] >= level]
+            if ready:
+                groups = [g for g in groups if g[0] < level]
+                fork()
+                for _, jb, je in ready:
+                    self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3,
+                                9, 1, 1, C, C, side, "module wgrad")
+        if plan.bwd_tasks is not None:
+            self._run_dataflow(pack.ptr("bwd_tasks"), plan.bwd_tasks, plan.n_bwd_slots, dev, "module backward (dataflow)")
+        fork()
+        for _, jb, je in groups:  # (all of them when the dataflow executor ran the data gradients)
+            self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3, 9, 1, 1,
+                        C, C, side, "module wgrad")
         nj = len(plan.wgrad_jobs["wgp"])
         if nj:
-            self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, st,
+            self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, side,
                         "projection wgrad")
 
-        # stem
-        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad")
+        # stem: gfeat is complete here
         nj = len(state.fixed["stem2_wg_jobs"])
-        self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, st, "stem conv2 wgrad")
+        self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, side, "stem conv2 wgrad")
+        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad")
+        fork()
         nj = len(state.fixed["stem1_wg_jobs"])
-        self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, st,
+        self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, side,
                     "stem conv1 wgrad")
+        if side is not main:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
 
         if self.direct_grads:
             a.attach_grads()

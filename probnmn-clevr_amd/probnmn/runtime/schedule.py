@@ -39,8 +39,9 @@ RELATE_DILATIONS = (1, 2, 4, 8, 1)  # reference nmn_modules.py:146-150
 
 # columns of a template's primitive table
 (C_KIND, C_LEVEL, C_CALL, C_WIDX, C_DIL, C_AK, C_AO, C_BK, C_BO, C_OK, C_OO, C_ACH, C_BCH, C_ISMAX,
- C_MASKED, C_SCRATCH) = range(16)
-NCOLS = 16
+ C_MASKED, C_SCRATCH, C_PA, C_PB, C_C0, C_C1, C_C2) = range(21)
+NCOLS = 21  # C_PA/C_PB: local index of the primitive producing input a/b (-1: stem output / ones);
+            # C_C0..2: local indices of the primitives consuming this primitive's output (-1: none)
 
 
 def _align(n: int) -> int:
@@ -57,6 +58,7 @@ class Template:
     size: int  # arena floats per example (values + backward scratch)
     result_is_feat: bool
     depth: int
+    dataflow_ok: bool = True  # False if some output has more than three consumers
 
 
 def structure_key(prog: pc.CompiledProgram) -> Tuple:
@@ -86,12 +88,14 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
 
     loc: Dict[int, Tuple[int, int]] = {pc.FEAT: (L_FEAT, 0), pc.ONES: (L_ONES, 0)}
     lvl: Dict[int, int] = {pc.FEAT: 0, pc.ONES: 0}
+    prod: Dict[int, int] = {pc.FEAT: -1, pc.ONES: -1}  # value id -> local index of its producing primitive
     rows: List[List[int]] = []
 
     def prim(kind, level, call, widx=0, dil=1, a=(L_ONES, 0), b=(L_ONES, 0), out=(L_SLOT, 0), a_ch=0,
-             b_ch=0, is_max=0, masked=0):
+             b_ch=0, is_max=0, masked=0, pa=-1, pb=-1):
         rows.append([kind, level, call, widx, dil, a[0], a[1], b[0], b[1], out[0], out[1], a_ch, b_ch,
-                     is_max, masked, -1])
+                     is_max, masked, -1, pa, pb, -1, -1, -1])
+        return len(rows) - 1
 
     for ci, c in enumerate(calls):
         if not needed[ci]:
@@ -104,45 +108,62 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
             out = (L_SLOT, alloc(small))
         if c.kind in (pc.AND, pc.OR):
             level = max(lvl[c.a], lvl[c.b]) + 1
-            prim(K_MINMAX, level, ci, a=loc[c.a], b=loc[c.b], out=out, a_ch=c.a_channels, b_ch=c.b_channels,
-                 is_max=int(c.kind == pc.OR))
+            last = prim(K_MINMAX, level, ci, a=loc[c.a], b=loc[c.b], out=out, a_ch=c.a_channels, b_ch=c.b_channels,
+                        is_max=int(c.kind == pc.OR), pa=prod[c.a], pb=prod[c.b])
         elif c.kind == pc.SAME:
             level = lvl[c.a] + 1
-            prim(K_SAME, level, ci, a=(L_FEAT, 0), b=loc[c.a], out=out)
+            last = prim(K_SAME, level, ci, a=(L_FEAT, 0), b=loc[c.a], out=out, pb=prod[c.a])
         elif c.kind == pc.CMP:
             level = max(lvl[c.a], lvl[c.b]) + 1
             t0 = (L_SLOT, alloc(big))
             t1 = (L_SLOT, alloc(big))
-            prim(K_PROJ, level, ci, widx=0, a=loc[c.a], b=loc[c.b], out=t0)
-            prim(K_CONV, level + 1, ci, widx=1, a=t0, out=t1)
-            prim(K_CONV, level + 2, ci, widx=2, a=t1, out=out)
+            j0 = prim(K_PROJ, level, ci, widx=0, a=loc[c.a], b=loc[c.b], out=t0, pa=prod[c.a], pb=prod[c.b])
+            j1 = prim(K_CONV, level + 1, ci, widx=1, a=t0, out=t1, pa=j0)
+            last = prim(K_CONV, level + 2, ci, widx=2, a=t1, out=out, pa=j1)
             level += 2
         else:  # ATT / QUERY / REL
             nconv = 5 if c.kind == pc.REL else 2
             dils = RELATE_DILATIONS if c.kind == pc.REL else (1, 1)
             level = lvl[c.a]
             src = (L_FEAT, 0)
+            last = -1
             for k in range(nconv):
                 level += 1
                 last_is_out = (k == nconv - 1) and c.kind == pc.QUERY
                 dst = out if last_is_out else (L_SLOT, alloc(big))
                 if k == 0:  # input is FEAT * attention (L_ONES -> no multiply)
-                    prim(K_CONV, level, ci, widx=1, dil=dils[0], a=src, b=loc[c.a], out=dst, masked=1)
+                    last = prim(K_CONV, level, ci, widx=1, dil=dils[0], a=src, b=loc[c.a], out=dst, masked=1,
+                                pb=prod[c.a])
                 else:
-                    prim(K_CONV, level, ci, widx=k + 1, dil=dils[k], a=src, out=dst)
+                    last = prim(K_CONV, level, ci, widx=k + 1, dil=dils[k], a=src, out=dst, pa=last)
                 src = dst
             if c.kind != pc.QUERY:
                 level += 1
-                prim(K_DOT, level, ci, a=src, out=out)
+                last = prim(K_DOT, level, ci, a=src, out=out, pa=last)
         loc[vid] = out
         lvl[vid] = level
+        prod[vid] = last
 
     for r in rows:  # backward scratch: gradient wrt (FEAT * attention) of each masked conv
         if r[C_MASKED]:
             r[C_SCRATCH] = alloc(big)
+    # consumers of every primitive's output (for the backward dependencies of the dataflow executor)
+    ok = True
+    for j, r in enumerate(rows):
+        for pcol in (C_PA, C_PB):
+            src_prim = r[pcol]
+            if src_prim >= 0:
+                for ccol in (C_C0, C_C1, C_C2):
+                    if rows[src_prim][ccol] < 0:
+                        rows[src_prim][ccol] = j
+                        break
+                    if rows[src_prim][ccol] == j:  # same consumer through both operands
+                        break
+                else:
+                    ok = False
     table = np.asarray(rows, dtype=np.int64).reshape(-1, NCOLS)
     depth = int(table[:, C_LEVEL].max()) if len(rows) else 0
-    return Template(table, len(calls), cursor, prog.result < 2, depth)
+    return Template(table, len(calls), cursor, prog.result < 2, depth, ok)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -191,6 +212,15 @@ class StepPlan:
     arena_floats: int
     feat_result_examples: np.ndarray  # examples whose program returns FEAT itself
     n_prims: int
+    # module-conv weight-gradient jobs grouped by forward level range, deepest first:
+    # (lowest level of the group, first job, one past the last job) -- a group may be launched as soon
+    # as the backward pass has finished the phase of its lowest level
+    wgrad_groups: List[Tuple[int, int, int]] = None
+    # dataflow executor (None when a structure in the batch is not supported by it)
+    fwd_tasks: np.ndarray = None
+    bwd_tasks: np.ndarray = None
+    n_fwd_slots: int = 0
+    n_bwd_slots: int = 0
 
 
 def _cut(levels: np.ndarray) -> List[Tuple[int, int, int]]:
@@ -204,12 +234,16 @@ def _cut(levels: np.ndarray) -> List[Tuple[int, int, int]]:
 
 class BatchScheduler:
     def __init__(self, hw: int, channels: int, tables: WeightTables, record_dtypes: Dict[str, np.dtype],
-                 wgrad_chunk: int = 8):
+                 wgrad_chunk: int = 8, wgrad_groups: int = 4):
         self.hw = hw
         self.channels = channels
         self.tables = tables
         self.dt = record_dtypes
         self.wgrad_chunk = wgrad_chunk
+        self.wgrad_groups = wgrad_groups
+        self.fuse_mask_bwd = True  # masked convs' data-gradients do the `feats * attn` backward in their epilogue
+        self.dataflow = False      # build task lists for the persistent dataflow executor
+        self.dataflow_ksplit = 2   # sub-tasks per convolution
         self._ids: Dict[Tuple, int] = {}
         self._templates: List[Template] = []
         self._bank = None  # (tables [T, Pmax, NCOLS], nprims [T], sizes [T])
@@ -271,7 +305,7 @@ class BatchScheduler:
         }
         empty_jobs = {"wg3": np.zeros(0, self.dt["wgrad_job"]), "wgp": np.zeros(0, self.dt["wgrad_job"])}
         if nv == 0:
-            return StepPlan(empty, [], [], empty_jobs, 0, np.zeros(0, np.int64), 0)
+            return StepPlan(empty, [], [], empty_jobs, 0, np.zeros(0, np.int64), 0, [])
 
         # per-example arena block
         blk = sizes[tids]
@@ -335,21 +369,30 @@ class BatchScheduler:
             mask_ptr = np.where(masked, b_f[m], 0)  # 0 for the all-ones attention too
             w_off, b_off, wt_off = tb.w3[t_, w_], tb.b3[t_, w_], tb.wt3[t_, w_]
             scratch = buf.gact + (blockbase[m] + rows[m, C_SCRATCH]) * 4
-            fw = np.zeros((n, 8), u64)
+            fw = np.zeros((n, 12), u64)
             fw[:, 0], fw[:, 2] = a_f[m], mask_ptr
             fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
             fw[:, 7] = dil[m]  # dilation in the low 32 bits, flags = 0
-            dg = np.zeros((n, 8), u64)
+            dg = np.zeros((n, 12), u64)
             dg[:, 0], dg[:, 3], dg[:, 4] = o_g[m], o_f[m], buf.wt + wt_off * 4
-            dg[:, 6] = np.where(masked, scratch, a_g[m])
-            dg[:, 7] = dil[m]
+            if self.fuse_mask_bwd:
+                # masked convs: the data-gradient kernel adds straight into dFEAT / d(attention)
+                dg[:, 6] = np.where(masked, 0, a_g[m])
+                dg[:, 7] = dil[m] + np.where(masked, 4 << 32, 0)
+                dg[:, 8] = np.where(masked, a_f[m], 0)
+                dg[:, 9] = mask_ptr
+                dg[:, 10] = np.where(masked, a_g[m], 0)
+                dg[:, 11] = np.where(masked & (mask_ptr != 0), b_g[m], 0)
+            else:
+                dg[:, 6] = np.where(masked, scratch, a_g[m])
+                dg[:, 7] = dil[m]
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 2], wg[:, 3], wg[:, 4], wg[:, 5] = a_f[m], mask_ptr, o_g[m], o_f[m], dil[m]
             idx = finish("conv", fw, lv, "conv")
             finish("dgrad", dg, lv, "conv")
             # mask backward for the masked convs (same level order as the dgrads)
             mm = masked[idx]
-            if mm.any():
+            if mm.any() and not self.fuse_mask_bwd:
                 src = idx[mm]
                 mb = np.zeros((src.size, 5), u64)
                 mb[:, 0], mb[:, 1], mb[:, 2] = scratch[src], a_f[m][src], mask_ptr[src]
@@ -358,9 +401,16 @@ class BatchScheduler:
                 records["maskbwd"] = mb.view(self.dt["maskbwd"]).reshape(-1)
                 launches["maskbwd"] = _cut(lv[src])
             wkey = t_ * 8 + w_
-            records["wg3"], jobs3 = self._wgrad_jobs(wg, wkey, buf.grads + w_off * 4, buf.grads + b_off * 4)
+            depth3 = int(lv.max())
+            grp = (depth3 - lv) * self.wgrad_groups // max(depth3, 1)  # 0 = deepest levels
+            records["wg3"], jobs3, jgrp = self._wgrad_jobs(wg, grp * 4096 + wkey, buf.grads + w_off * 4,
+                                                           buf.grads + b_off * 4, group=grp)
+            wgroups = []
+            for gid, jb, je in _cut(jgrp):
+                wgroups.append((int(lv[grp == gid].min()), jb, je))
         else:
             jobs3 = empty_jobs["wg3"]
+            wgroups = []
 
         # ---- projections (ComparisonModule) ------------------------------------------------------
         m = kind == K_PROJ
@@ -368,13 +418,13 @@ class BatchScheduler:
         if n:
             t_, lv = tok[m], level[m]
             w_off, b_off, wt_off = tb.w3[t_, 0], tb.b3[t_, 0], tb.wt3[t_, 0]
-            fw = np.zeros((n, 8), u64)
+            fw = np.zeros((n, 12), u64)
             fw[:, 0], fw[:, 1] = a_f[m], b_f[m]
             fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
             fw[:, 7] = 1
             finish("proj", fw, lv, "conv")
             # two dgrads (one per operand), accumulate flag set; the halves never share a launch
-            pd = np.zeros((2 * n, 8), u64)
+            pd = np.zeros((2 * n, 12), u64)
             pd[:, 0], pd[:, 3] = np.tile(o_g[m], 2), np.tile(o_f[m], 2)
             pd[:n, 4], pd[n:, 4] = buf.wt + wt_off * 4, buf.wt + (wt_off + C * C) * 4
             pd[:n, 6], pd[n:, 6] = a_g[m], b_g[m]
@@ -382,7 +432,7 @@ class BatchScheduler:
             finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + 1)), "conv")
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 1], wg[:, 3], wg[:, 4] = a_f[m], b_f[m], o_g[m], o_f[m]
-            records["wgp"], jobsp = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4)
+            records["wgp"], jobsp, _ = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4)
         else:
             jobsp = empty_jobs["wgp"]
 
@@ -455,14 +505,133 @@ class BatchScheduler:
             if phase:
                 bwd.append(phase)
 
-        return StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N)
+        plan = StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N, wgroups)
+        if self.dataflow and all(self._templates[t].dataflow_ok for t in np.unique(tids)):
+            self._dataflow_tasks(plan, rows, xi, nprims[tids], tok, a_f, a_g, b_f, b_g, o_f, o_g, buf)
+        return plan
 
     # --------------------------------------------------------------------------------------------
-    def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray):
-        """Sort weight-gradient items by weight and cut each weight's run into jobs of at most
-        ``wgrad_chunk`` items (one workgroup column per job)."""
+    def _dataflow_tasks(self, plan, rows, xi, nprims_per_example, tok, a_f, a_g, b_f, b_g, o_f, o_g, buf):
+        """Task lists (pnmn_task records) of the persistent executor: forward in level order, backward
+        in reverse level order; a dependency is the completion slot of the producing (forward) or
+        consuming (backward) primitive."""
+        T = self.dt["task"]
+        tb, C, s = self.tables, self.channels, self.dataflow_ksplit
+        N = rows.shape[0]
+        kind, level, widx, dil = rows[:, C_KIND], rows[:, C_LEVEL], rows[:, C_WIDX], rows[:, C_DIL]
+        is_conv, is_proj = kind == K_CONV, kind == K_PROJ
+        is_dot, is_same, is_mm = kind == K_DOT, kind == K_SAME, kind == K_MINMAX
+        convlike = is_conv | is_proj
+        masked = rows[:, C_MASKED] == 1
+        rowbase = (np.cumsum(nprims_per_example) - nprims_per_example)[xi]
+
+        # parameter pointers per row
+        wsel = np.where(convlike, widx, 0)
+        tsel = np.where(convlike, tok, 0)
+        w3 = buf.params + tb.w3[tsel, wsel] * 4
+        b3 = buf.params + tb.b3[tsel, wsel] * 4
+        wt3 = buf.wt + tb.wt3[tsel, wsel] * 4
+        hsel = np.where(is_dot | is_same, tok, 0)
+        hw_, hb_ = buf.params + tb.dotw[hsel] * 4, buf.params + tb.dotb[hsel] * 4
+        ghw, ghb = buf.grads + tb.dotw[hsel] * 4, buf.grads + tb.dotb[hsel] * 4
+        ones_a = np.where(rows[:, C_AK] == L_ONES, buf.ones, a_f)
+        ones_b = np.where(rows[:, C_BK] == L_ONES, buf.ones, b_f)
+        mask_ptr = np.where(masked, b_f, 0)
+        mm_flags = (rows[:, C_ACH] == C) * 1 + (rows[:, C_BCH] == C) * 2 + rows[:, C_ISMAX] * 4
+
+        def resolve(order, count, cols, need_of_row):
+            """order: rows in task order; returns (slot_of_row, dep[N,3], need[N,3]) in row space."""
+            slot_of_row = np.empty(N, np.int64)
+            slot_of_row[order] = np.arange(N)
+            deps = np.full((N, 3), -1, np.int64)
+            needs = np.zeros((N, 3), np.int64)
+            for k, col in enumerate(cols):
+                local = rows[:, col]
+                has = local >= 0
+                src = np.where(has, rowbase + local, 0)
+                deps[:, k] = np.where(has, slot_of_row[src], -1)
+                needs[:, k] = np.where(has, need_of_row[src], 0)
+            return slot_of_row, deps, needs
+
+        def expand(order, count):
+            """item rows -> task rows: (row index per task, sub index per task)"""
+            cnt = count[order]
+            rep = np.repeat(order, cnt)
+            start = np.cumsum(cnt) - cnt
+            sub = np.arange(rep.size) - np.repeat(start, cnt)
+            return rep, sub
+
+        # ---------------- forward ----------------
+        # list scheduling by ALAP level: a program shallower than the deepest one in the batch is
+        # delayed by the difference, so that long chains run ahead and every chain ends together --
+        # otherwise the last levels of the longest programs run on a nearly empty chip
+        ex_depth = np.zeros(int(xi.max()) + 1, np.int64)
+        np.maximum.at(ex_depth, xi, level)
+        alap = level + (int(level.max()) - ex_depth[xi])
+        order = np.argsort(alap, kind="stable")
+        count = np.where(convlike, s, 1)
+        slot, deps, needs = resolve(order, count, (C_PA, C_PB), count)
+        rep, sub = expand(order, count)
+        f = np.zeros(rep.size, T)
+        P = f["p"]
+        r = rep
+        kc, kp, kd, ks_, km = is_conv[r], is_proj[r], is_dot[r], is_same[r], is_mm[r]
+        cl = kc | kp
+        P[:, 0] = np.where(km, ones_a[r], a_f[r])
+        P[:, 1] = np.where(kp, b_f[r], np.where(kd, hw_[r], np.where(km | ks_, ones_b[r], 0)))
+        P[:, 2] = np.where(kc, mask_ptr[r], np.where(kd, hb_[r], np.where(ks_, hw_[r], np.where(km, o_f[r], 0))))
+        P[:, 3] = np.where(kd, o_f[r], np.where(ks_, hb_[r], 0))
+        P[:, 4] = np.where(cl, w3[r], np.where(ks_, o_f[r], 0))
+        P[:, 5] = np.where(cl, b3[r], 0)
+        P[:, 6] = np.where(cl, o_f[r], 0)
+        f["type"] = np.select([cl, kd, ks_, km], [0, 1, 3, 5])
+        f["sub"] = sub
+        f["dilation"] = dil[r]
+        f["flags"] = np.where(kc, 16, np.where(kp, 16 | 32 | 64, np.where(km, mm_flags[r], 0)))
+        f["dep"] = deps[r]
+        f["need"] = needs[r]
+        f["slot"] = slot[r]
+        plan.fwd_tasks, plan.n_fwd_slots = f, N
+
+        # ---------------- backward ----------------
+        order = np.argsort(-level, kind="stable")
+        count = np.where(is_conv, s, np.where(is_proj, 2 * s, 1))
+        slot, deps, needs = resolve(order, count, (C_C0, C_C1, C_C2), count)
+        rep, sub = expand(order, count)
+        b = np.zeros(rep.size, T)
+        P = b["p"]
+        r = rep
+        kc, kp, kd, ks_, km = is_conv[r], is_proj[r], is_dot[r], is_same[r], is_mm[r]
+        cl = kc | kp
+        mk = masked[r] & kc
+        second = kp & (sub >= s)  # projection: second operand's half of the transposed weight
+        P[:, 0] = np.where(cl, o_g[r], np.where(km, ones_a[r], a_f[r]))
+        P[:, 1] = np.where(kd, hw_[r], np.where(km | ks_, ones_b[r], 0))
+        P[:, 2] = np.where(kd, hb_[r], np.where(ks_, hw_[r], np.where(km, o_f[r], 0)))
+        P[:, 3] = np.where(cl | kd, o_f[r], np.where(ks_, hb_[r], np.where(km, o_g[r], 0)))
+        P[:, 4] = np.where(cl, wt3[r] + second * (C * C * 4), np.where(kd, o_g[r], np.where(ks_, o_f[r], np.where(km, a_g[r], 0))))
+        P[:, 5] = np.where(kd, a_g[r], np.where(ks_, o_g[r], np.where(km, b_g[r], 0)))
+        P[:, 6] = np.where(cl, np.where(second, b_g[r], a_g[r]), np.where(kd, ghw[r], np.where(ks_, a_g[r], 0)))
+        P[:, 6] = np.where(mk, 0, P[:, 6])
+        P[:, 7] = np.where(mk, a_f[r], np.where(kd, ghb[r], np.where(ks_, b_g[r], 0)))
+        P[:, 8] = np.where(mk, mask_ptr[r], np.where(ks_, ghw[r], 0))
+        P[:, 9] = np.where(mk, a_g[r], np.where(ks_, ghb[r], 0))
+        P[:, 10] = np.where(mk & (mask_ptr[r] != 0), b_g[r], 0)
+        b["type"] = np.select([cl, kd, ks_, km], [0, 2, 4, 6])
+        b["sub"] = np.where(second, sub - s, sub)
+        b["dilation"] = dil[r]
+        b["flags"] = np.where(mk, 128, np.where(kp, 32 | 1 | 2, np.where(km, mm_flags[r], 0)))
+        b["dep"] = deps[r]
+        b["need"] = needs[r]
+        b["slot"] = slot[r]
+        plan.bwd_tasks, plan.n_bwd_slots = b, N
+
+    def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray, group=None):
+        """Sort weight-gradient items by (group,) weight and cut each run into jobs of at most
+        ``wgrad_chunk`` items (one workgroup column per job).  Returns (items, jobs, group id per job)."""
         idx = np.argsort(wkey, kind="stable")
         items, wkey, dw, db = items[idx], wkey[idx], dw[idx], db[idx]
+        group = np.zeros(wkey.size, np.int64) if group is None else group[idx]
         n = wkey.size
         newgrp = np.empty(n, bool)
         newgrp[0] = True
@@ -477,4 +646,4 @@ class BatchScheduler:
         jobs[:, 0], jobs[:, 1] = dw[jstart], db[jstart]
         jobs[:, 2] = jstart.astype(np.uint64) | (jend.astype(np.uint64) << np.uint64(32))
         rec = np.ascontiguousarray(items).view(self.dt["wgrad_item"]).reshape(-1)
-        return rec, jobs.view(self.dt["wgrad_job"]).reshape(-1)
+        return rec, jobs.view(self.dt["wgrad_job"]).reshape(-1), group[jstart]
