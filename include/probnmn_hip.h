@@ -243,6 +243,21 @@ int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, co
                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Persistent LSTM layer over a whole padded sequence (hidden = 256): the recurrent half of
+ * nn.LSTM (PytorchSeq2SeqWrapper(nn.LSTM), seq2seq_base.py:145; program_prior.py:117).
+ *   forward : gates_t = xp[b][t] + h_{t-1} W_hh^T (xp = X W_ih^T + b_ih + b_hh, all steps, from the
+ *             caller's GEMM), zero initial state -> hs[b][t][H], cs[b][t][H], act[b][t][4H]
+ *   backward: dhs[b][t][H] (gradient wrt every h_t) -> dgates[b][t][4H] (= gradient wrt xp);
+ *             w_hh_t is W_hh transposed ([H][4H]); dW_hh = sum_t dgates_t^T h_{t-1} is the
+ *             caller's GEMM over the saved hs.
+ * One workgroup owns 16 batch rows for all T steps (h in LDS, c in registers, W_hh streamed).
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B,
+                      int T, int hidden, void* stream);
+int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const float* w_hh_t,
+                      float* dgates, int B, int T, int hidden, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * One decoding step's token choice                                   seq2seq_base.py:203-220
  *   greedy:   tokens[b] = argmax softmax(logits[b])            (first maximum)
  *   sampling: weights = softmax(logits[b]) with pad/unk/start zeroed; tokens[b] ~ weights

@@ -213,3 +213,216 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Persistent LSTM layer (the recurrent half of nn.LSTM over a whole padded sequence).
+//
+// The input projection of ALL time steps is one big GEMM done by the caller (xp = X W_ih^T + b_ih +
+// b_hh); what remains is inherently sequential: gates_t = xp_t + h_{t-1} W_hh^T, then the cell.
+// Launching that per step costs T x (GEMM + cell) tiny kernels; here ONE workgroup owns 16 batch rows
+// for all T steps: h lives in LDS (double buffered), c and the gate accumulators in registers, W_hh
+// (1 MiB for H = 256) is streamed from L2 every step straight into MFMA B operands.  Rows are
+// independent, so there is no inter-workgroup communication at all.
+//
+// Wave w (of 8) owns hidden units [32w, 32w+32) for all four gates: 8 accumulators of 16x16 whose
+// lane (li, g) / register r holds (batch row 4g+r, unit 32w + 16*ut + li) -- the i, f, g, o values of
+// one (row, unit) sit in the same lane and register of four accumulators, so the cell update is
+// lane-local.  v_mfma_f32_16x16x4_f32, K consumed in the permuted order used by the conv kernels
+// (lane group g takes k = 4g..4g+3 of each 16-block) so that A (h from LDS) and B (W_hh rows from
+// global) are single 16-byte loads.
+// =====================================================================================================
+namespace {
+
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+constexpr int LH = 256;        // hidden size the kernel is built for
+constexpr int LROWS = 16;      // batch rows per workgroup
+constexpr int LLD = LH + 4;    // LDS row stride (floats): 16-byte aligned, breaks the 1 KiB bank period
+
+__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ w_hh,
+                                                           float* __restrict__ hs, float* __restrict__ cs,
+                                                           float* __restrict__ act, int B, int T) {
+    __shared__ __attribute__((aligned(16))) float hl[2][LROWS][LLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * LROWS;
+    float creg[2][4];
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) creg[ut][r] = 0.f;
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        f32x4_ acc[4][2];
+        // start from the input projection
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 4 * g + r;
+                    const int n = gate * LH + 32 * wave + 16 * ut + li;
+                    acc[gate][ut][r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + n] : 0.f;
+                }
+        if (t > 0) {
+#pragma unroll 4
+            for (int kb = 0; kb < LH / 16; ++kb) {
+                const f32x4_ a = *reinterpret_cast<const f32x4_*>(&hl[cur][li][kb * 16 + 4 * g]);
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+                    for (int ut = 0; ut < 2; ++ut) {
+                        const int n = gate * LH + 32 * wave + 16 * ut + li;
+                        const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh + (size_t)n * LH + kb * 16 + 4 * g);
+                        acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[gate][ut], 0, 0, 0);
+                        acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[gate][ut], 0, 0, 0);
+                        acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[gate][ut], 0, 0, 0);
+                        acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[gate][ut], 0, 0, 0);
+                    }
+            }
+        }
+        // cell update, lane-local
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * g + r;
+                const int row = row0 + rl;
+                const int u = 32 * wave + 16 * ut + li;
+                const float ig = sigm(acc[0][ut][r]);
+                const float fg = sigm(acc[1][ut][r]);
+                const float gg = tanhf(acc[2][ut][r]);
+                const float og = sigm(acc[3][ut][r]);
+                const float c = fg * creg[ut][r] + ig * gg;
+                const float h = og * tanhf(c);
+                creg[ut][r] = c;
+                hl[nxt][rl][u] = h;
+                if (row < B) {
+                    const size_t o = ((size_t)row * T + t) * LH + u;
+                    hs[o] = h;
+                    cs[o] = c;
+                    if (act) {
+                        float* ar = act + ((size_t)row * T + t) * (4 * LH);
+                        ar[u] = ig;
+                        ar[LH + u] = fg;
+                        ar[2 * LH + u] = gg;
+                        ar[3 * LH + u] = og;
+                    }
+                }
+            }
+        __syncthreads();  // h_t complete before anyone starts step t+1 (and everyone is done with h_{t-1})
+    }
+}
+
+// backward: dgates[b][t][4H] (gradient wrt the gate pre-activations = wrt xp), given dhs (gradient wrt
+// every output h_t), the saved activated gates and cell states, and W_hh^T ([H][4H], k contiguous).
+__global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restrict__ dhs, const float* __restrict__ act,
+                                                           const float* __restrict__ cs, const float* __restrict__ w_hh_t,
+                                                           float* __restrict__ dgates, int B, int T) {
+    extern __shared__ __attribute__((aligned(16))) char lraw[];
+    float (*dgl)[4 * LH + 4] = reinterpret_cast<float (*)[4 * LH + 4]>(lraw);  // [16][1028]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * LROWS;
+    float dh_rec[2][4], dc_rec[2][4];
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh_rec[ut][r] = dc_rec[ut][r] = 0.f;
+
+    for (int t = T - 1; t >= 0; --t) {
+        // cell backward, lane-local: this lane owns (rows 4g+r, units 32w+16ut+li)
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * g + r;
+                const int row = row0 + rl;
+                const int u = 32 * wave + 16 * ut + li;
+                float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
+                if (row < B) {
+                    const size_t o = ((size_t)row * T + t) * LH + u;
+                    const float* ar = act + ((size_t)row * T + t) * (4 * LH);
+                    const float ig = ar[u], fg = ar[LH + u], gg = ar[2 * LH + u], og = ar[3 * LH + u];
+                    const float c = cs[o];
+                    const float cp = t > 0 ? cs[o - LH] : 0.f;
+                    const float tc = tanhf(c);
+                    const float dh = dhs[o] + dh_rec[ut][r];
+                    const float dc = dc_rec[ut][r] + dh * og * (1.f - tc * tc);
+                    di = dc * gg * ig * (1.f - ig);
+                    df = dc * cp * fg * (1.f - fg);
+                    dg = dc * ig * (1.f - gg * gg);
+                    dout = dh * tc * og * (1.f - og);
+                    dcp = dc * fg;
+                    float* dr = dgates + ((size_t)row * T + t) * (4 * LH);
+                    dr[u] = di;
+                    dr[LH + u] = df;
+                    dr[2 * LH + u] = dg;
+                    dr[3 * LH + u] = dout;
+                }
+                dc_rec[ut][r] = dcp;
+                dgl[rl][u] = di;
+                dgl[rl][LH + u] = df;
+                dgl[rl][2 * LH + u] = dg;
+                dgl[rl][3 * LH + u] = dout;
+            }
+        __syncthreads();
+        // dh_{t-1} = dgates_t @ W_hh : [16 x 1024] x [1024 x 256]; this wave's 32 hidden units
+        f32x4_ acc[2];
+        acc[0] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+#pragma unroll 4
+            for (int kb = 0; kb < (4 * LH) / 16; ++kb) {
+                const f32x4_ a = *reinterpret_cast<const f32x4_*>(&dgl[li][kb * 16 + 4 * g]);
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut) {
+                    const int n = 32 * wave + 16 * ut + li;
+                    const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh_t + (size_t)n * (4 * LH) + kb * 16 + 4 * g);
+                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[ut], 0, 0, 0);
+                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[ut], 0, 0, 0);
+                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[ut], 0, 0, 0);
+                    acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[ut], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_rec[ut][r] = acc[ut][r];
+        __syncthreads();  // everyone done reading dgl before it is overwritten
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B, int T, int hidden,
+                      void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!xp || !w_hh || !hs || !cs) return PNMN_EINVAL;
+    if (hidden != LH) return PNMN_ESHAPE;
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3((B + LROWS - 1) / LROWS), dim3(512), 0,
+                       static_cast<hipStream_t>(stream), xp, w_hh, hs, cs, act, B, T);
+    return (int)hipGetLastError();
+}
+
+int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const float* w_hh_t, float* dgates, int B,
+                      int T, int hidden, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!dhs || !act || !cs || !w_hh_t || !dgates) return PNMN_EINVAL;
+    if (hidden != LH) return PNMN_ESHAPE;
+    constexpr size_t lds = (size_t)LROWS * (4 * LH + 4) * sizeof(float);
+    static bool cfg = false;
+    if (!cfg) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        cfg = true;
+    }
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3((B + LROWS - 1) / LROWS), dim3(512), lds,
+                       static_cast<hipStream_t>(stream), dhs, act, cs, w_hh_t, dgates, B, T);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

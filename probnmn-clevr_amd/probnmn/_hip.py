@@ -55,6 +55,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
+    "pnmn_lstm_seq_fwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
+    "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
     "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }

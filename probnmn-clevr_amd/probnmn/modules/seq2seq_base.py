@@ -60,6 +60,41 @@ def lstm_cell_pointwise(gates, c_prev):
     return _LSTMCellPointwise.apply(gates, c_prev)
 
 
+class _LSTMLayerSeq(torch.autograd.Function):
+    """The recurrent half of one LSTM layer over a whole padded sequence, as ONE persistent kernel
+    launch (``pnmn_lstm_seq_fwd`` / ``_bwd``): (xp [B,T,4H] = input projection + biases, W_hh) -> all
+    hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states."""
+
+    @staticmethod
+    def forward(ctx, xp, w_hh):
+        if xp.device.type != "cuda":
+            raise _hip.HipLibraryError("LSTM layer on %s: the HIP path needs a ROCm device (no CPU fallback)" % xp.device)
+        xp, w = xp.contiguous(), w_hh.detach().contiguous()
+        B, T, H4 = xp.shape
+        Hd = H4 // 4
+        hs = torch.empty(B, T, Hd, dtype=xp.dtype, device=xp.device)
+        cs = torch.empty_like(hs)
+        act = torch.empty_like(xp)
+        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), w.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
+                                                B, T, Hd, _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
+        ctx.save_for_backward(hs, cs, act, w)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        hs, cs, act, w = ctx.saved_tensors
+        B, T, Hd = hs.shape
+        dhs = dhs.contiguous()
+        w_t = w.t().contiguous()  # [H][4H]
+        dgates = torch.empty_like(act)
+        _hip.check(_hip.lib().pnmn_lstm_seq_bwd(dhs.data_ptr(), act.data_ptr(), cs.data_ptr(), w_t.data_ptr(),
+                                                dgates.data_ptr(), B, T, Hd, _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
+        dw_hh = None
+        if ctx.needs_input_grad[1]:
+            dw_hh = dgates[:, 1:].reshape(-1, 4 * Hd).t() @ hs[:, :-1].reshape(-1, Hd) if T > 1 else torch.zeros_like(w)
+        return dgates, dw_hh
+
+
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
                   pad: int, unk: int, start: int):
     """One decoding step's token choice on the device; returns (tokens int64 [B], logprob [B] no grad)."""
@@ -102,7 +137,7 @@ def sequence_cross_entropy(logits, targets, weights, eps: float = 1e-13):
 def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
     length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
-    input GEMM batched over time and the gate math on the HIP kernel."""
+    input GEMM batched over time and the recurrence in one persistent HIP kernel per layer."""
     B, T, _ = x.shape
     inp = x
     for layer in range(lstm.num_layers):
@@ -110,15 +145,18 @@ def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor) -> torch.Ten
         w_hh = getattr(lstm, "weight_hh_l%d" % layer)
         bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
         xp = F.linear(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
-        h = x.new_zeros(B, lstm.hidden_size)
-        c = x.new_zeros(B, lstm.hidden_size)
-        w_hh_t = w_hh.t()
-        outs = []
-        for t in range(T):
-            gates = torch.addmm(xp[:, t], h, w_hh_t)
-            h, c = lstm_cell_pointwise(gates, c)
-            outs.append(h)
-        inp = torch.stack(outs, 1)
+        if lstm.hidden_size == 256:
+            inp = _LSTMLayerSeq.apply(xp, w_hh)  # one persistent launch for all T steps
+        else:  # other widths: step by step (GEMM per step + the cell kernel)
+            h = x.new_zeros(B, lstm.hidden_size)
+            c = x.new_zeros(B, lstm.hidden_size)
+            w_hh_t = w_hh.t()
+            outs = []
+            for t in range(T):
+                gates = torch.addmm(xp[:, t], h, w_hh_t)
+                h, c = lstm_cell_pointwise(gates, c)
+                outs.append(h)
+            inp = torch.stack(outs, 1)
     return inp * mask.unsqueeze(-1).to(inp.dtype)
 
 

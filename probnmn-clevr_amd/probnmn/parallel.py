@@ -20,7 +20,33 @@ def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Parameter] = (), average: bool = True) -> None:
+class EarlyReducer:
+    """Starts the all-reduce of chosen (large, loose) parameters the moment autograd has finished
+    their gradient, so that the collective overlaps the rest of backward.  For the NMN that is
+    ``classifier.4.weight``: 205 MB of the 257 MB gradient payload, final right after the
+    classifier's backward -- before the whole module-program / stem backward runs."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self._pending = {}
+        self._hooks = []
+        for p in params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._fire))
+
+    def _fire(self, p: torch.nn.Parameter) -> None:
+        if world() > 1 and p.grad is not None:
+            self._pending[id(p)] = (dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad)
+
+    def take(self, p: torch.nn.Parameter):
+        return self._pending.pop(id(p), None)
+
+    def remove(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Parameter] = (), average: bool = True,
+                         early: "EarlyReducer" = None) -> None:
     n = world()
     if n == 1:
         return
@@ -29,7 +55,12 @@ def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Param
     for a in arenas:
         handles.append((dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, async_op=True), a.grad))
     for p in loose_params:
-        if p.grad is not None:
+        if p.grad is None:
+            continue
+        started = early.take(p) if early is not None else None
+        if started is not None:
+            handles.append(started)
+        else:
             handles.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
     for h, g in handles:
         h.wait()

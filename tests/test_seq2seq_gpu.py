@@ -171,3 +171,26 @@ def test_program_prior_loss_and_gradients():
         g_ref = ref_sd[name].grad
         scale = float(g_ref.abs().max()) + 1e-12
         assert float((p.grad.cpu() - g_ref).abs().max()) / scale < 2e-3, name
+
+
+def test_persistent_lstm_layer_matches_nn_lstm():
+    """pnmn_lstm_seq_fwd/bwd against torch.nn.LSTM (one layer, hidden 256), ragged batch size."""
+    from probnmn.modules.seq2seq_base import _LSTMLayerSeq
+
+    torch.manual_seed(3)
+    B, T, D, Hd = 37, 11, 256, 256
+    lstm = torch.nn.LSTM(D, Hd, 1, batch_first=True)
+    x = torch.randn(B, T, D)
+    ref, _ = lstm(x)
+    w = torch.randn(ref.shape)
+    (ref * w).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    w_ih = lstm.weight_ih_l0.detach().to(DEV).requires_grad_(True)
+    w_hh = lstm.weight_hh_l0.detach().to(DEV).requires_grad_(True)
+    bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().to(DEV).requires_grad_(True)
+    out = _LSTMLayerSeq.apply(F.linear(xd, w_ih, bias), w_hh)
+    (out * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(w_hh.grad.cpu(), lstm.weight_hh_l0.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(w_ih.grad.cpu(), lstm.weight_ih_l0.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(bias.grad.cpu(), lstm.bias_ih_l0.grad, rtol=1e-3, atol=1e-4)
