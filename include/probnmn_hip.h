@@ -258,6 +258,29 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
                       float* dgates, int B, int T, int hidden, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Persistent attention-LSTM decoder (hidden = 256): the whole decoding loop of
+ * Seq2SeqBase._forward_loop (seq2seq_base.py:186-224 -> allennlp _prepare_output_projections) in one
+ * launch; one workgroup owns 16 batch rows for all T steps.
+ *   per step: w = masked_softmax(enc . h, mask); ctx = w . enc; gates = xe_t + ctx W_c^T + h W_hh^T;
+ *             LSTM cell; [sample != 0: logits = h W_p^T + b_p, token choice, next xe from etable]
+ *   W_ih of the reference's LSTMCell is [W_c | W_e] (input = cat(ctx, embedding)); xe / etable carry
+ *   the embedding half plus both biases.  sample: 0 teacher forced (xe), 1 sample, 2 greedy.
+ *   saved for backward: act, cs, hs, ctx, probs (softmax before masking).
+ * backward: dhs (gradient wrt every h_t) -> dgates (= d xe), denc (+=, zero on entry), dh0.
+ * S <= 64 encoder positions, V <= 128 sampled vocabulary.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_attn_lstm_fwd(const float* xe, const float* etable, const float* enc, const float* mask,
+                       const float* h0, const float* w_c, const float* w_hh, const float* w_p,
+                       const float* b_p, float* hs, float* cs, float* act, float* ctx, float* probs,
+                       int64_t* tokens, int B, int T, int S, int V, int hidden, int sample,
+                       int pad_index, int unk_index, int start_index, uint64_t seed,
+                       uint64_t row_offset, void* stream);
+int pnmn_attn_lstm_bwd(const float* dhs, const float* act, const float* cs, const float* hs,
+                       const float* ctx, const float* probs, const float* enc, const float* mask,
+                       const float* h0, const float* w_c_t, const float* w_hh_t, float* dgates,
+                       float* denc, float* dh0, int B, int T, int S, int hidden, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * One decoding step's token choice                                   seq2seq_base.py:203-220
  *   greedy:   tokens[b] = argmax softmax(logits[b])            (first maximum)
  *   sampling: weights = softmax(logits[b]) with pad/unk/start zeroed; tokens[b] ~ weights

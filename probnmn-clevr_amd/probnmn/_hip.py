@@ -57,6 +57,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_seq_fwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
     "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
+    "pnmn_attn_lstm_fwd": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P),
+    "pnmn_attn_lstm_bwd": (_P,) * 14 + (_I,) * 4 + (_P,),
     "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }

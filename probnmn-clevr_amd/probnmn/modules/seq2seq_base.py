@@ -48,8 +48,10 @@ class _LSTMCellPointwise(torch.autograd.Function):
         B, H4 = act.shape
         dgates = torch.empty_like(act)
         dc_prev = torch.empty_like(c)
-        dh_p = dh.contiguous().data_ptr() if dh is not None else None
-        dc_p = dc.contiguous().data_ptr() if dc is not None else None
+        dh = dh.contiguous() if dh is not None else None  # (kept alive until after the launch)
+        dc = dc.contiguous() if dc is not None else None
+        dh_p = dh.data_ptr() if dh is not None else None
+        dc_p = dc.data_ptr() if dc is not None else None
         _hip.check(_hip.lib().pnmn_lstm_cell_bwd(act.data_ptr(), c_prev.data_ptr(), c.data_ptr(), dh_p, dc_p,
                                                  dgates.data_ptr(), dc_prev.data_ptr(), B, H4 // 4,
                                                  _hip.stream_ptr(act.device)), "lstm_cell_bwd")
@@ -93,6 +95,77 @@ class _LSTMLayerSeq(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw_hh = dgates[:, 1:].reshape(-1, 4 * Hd).t() @ hs[:, :-1].reshape(-1, Hd) if T > 1 else torch.zeros_like(w)
         return dgates, dw_hh
+
+
+class _AttnLSTMDecoder(torch.autograd.Function):
+    """The decoding loop as one persistent kernel launch (``pnmn_attn_lstm_fwd`` / ``_bwd``).
+
+    inputs : xe [B,T,4H] (teacher forcing) or etable [V,4H] (free running), enc [B,S,H], mask [B,S] float,
+             h0 [B,H], W_c [4H,H], W_hh [4H,H], W_p [V,H], b_p [V]
+    outputs: hidden states [B,T,H], tokens [B,T] (free running only)
+    Weight gradients are batched GEMMs over what the kernels saved."""
+
+    @staticmethod
+    def forward(ctx, xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, mode, T, seed, row_offset, pad, unk, start):
+        dev = enc.device
+        if dev.type != "cuda":
+            raise _hip.HipLibraryError("decoder on %s: the HIP path needs a ROCm device (no CPU fallback)" % dev)
+        enc, mask, h0 = enc.contiguous(), mask.contiguous(), h0.contiguous()
+        w_c, w_hh = w_c.detach().contiguous(), w_hh.detach().contiguous()
+        B, S, Hd = enc.shape
+        f = dict(dtype=torch.float32, device=dev)
+        hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
+        act = torch.empty(B, T, 4 * Hd, **f)
+        probs = torch.empty(B, T, S, **f)
+        tokens = None
+        V = 0
+        if mode != 0:
+            etable, w_p, b_p = etable.contiguous(), w_p.detach().contiguous(), b_p.detach().contiguous()
+            tokens = torch.empty(B, T, dtype=torch.long, device=dev)
+            V = w_p.size(0)
+        else:
+            xe = xe.contiguous()
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        _hip.check(_hip.lib().pnmn_attn_lstm_fwd(
+            ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
+            h0.data_ptr(), w_c.data_ptr(), w_hh.data_ptr(), ptr(w_p if mode != 0 else None),
+            ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
+            probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset,
+            _hip.stream_ptr(dev)), "attn_lstm_fwd")
+        ctx.save_for_backward(hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh,
+                              tokens if tokens is not None else torch.empty(0, device=dev))
+        ctx.mode, ctx.start, ctx.vocab = mode, start, (etable.size(0) if mode != 0 else 0)
+        if tokens is not None:
+            ctx.mark_non_differentiable(tokens)
+            return hs, tokens
+        return hs, torch.empty(0, dtype=torch.long, device=dev)
+
+    @staticmethod
+    def backward(ctx, dhs, _):
+        hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, tokens = ctx.saved_tensors
+        B, T, Hd = hs.shape
+        S = enc.size(1)
+        dev = hs.device
+        dgates = torch.empty_like(act)
+        denc = torch.zeros_like(enc)
+        dh0 = torch.empty_like(h0)
+        # (named temporaries: a tensor that dies right after .data_ptr() may be recycled by the next allocation)
+        dhs_c, w_c_t, w_hh_t = dhs.contiguous(), w_c.t().contiguous(), w_hh.t().contiguous()
+        _hip.check(_hip.lib().pnmn_attn_lstm_bwd(
+            dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), cx.data_ptr(), probs.data_ptr(),
+            enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
+            denc.data_ptr(), dh0.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)), "attn_lstm_bwd")
+        flat = dgates.reshape(B * T, 4 * Hd)
+        dw_c = flat.t() @ cx.reshape(B * T, Hd)
+        hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1).reshape(B * T, Hd)
+        dw_hh = flat.t() @ hprev
+        dxe = detable = None
+        if ctx.mode == 0:
+            dxe = dgates
+        else:
+            tok_in = torch.cat((tokens.new_full((B, 1), ctx.start), tokens[:, :-1]), 1).reshape(-1)
+            detable = torch.zeros(ctx.vocab, 4 * Hd, dtype=dgates.dtype, device=dev).index_add_(0, tok_in, flat)
+        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 9
 
 
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
@@ -258,7 +331,50 @@ class Seq2SeqBase(nn.Module):
         steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
         greedy = decoding_strategy == "greedy"
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
-        last = src.new_full((B,), bos)
+        Hd = h.size(1)
+        w_ih = self._decoder_cell.weight_ih
+        w_c, w_e = w_ih[:, :Hd], w_ih[:, Hd:]  # the cell's input is cat(attended, embedding)
+        bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
+        w_p, b_p = self._output_projection_layer.weight, self._output_projection_layer.bias
+        fused = Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128
+        if fused:
+            args = (pad, self._unk_index, bos)
+            if tgt is not None:  # teacher forcing: every step's input embedding is known up front
+                xe = F.linear(self._target_embedder(tgt[:, :steps]), w_e, bias)
+                hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
+                                               0, steps, seed, self.sample_row_offset, *args)
+            else:  # free running: the kernel also picks each step's token
+                etable = F.linear(self._target_embedder.weight, w_e, bias)
+                hs, raw = _AttnLSTMDecoder.apply(None, etable, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p,
+                                                 b_p, 2 if greedy else 1, steps, seed, self.sample_row_offset, *args)
+            logits_all = self._output_projection_layer(hs)  # one GEMM for all steps
+            if tgt is not None:
+                # predictions are drawn / arg-maxed from the teacher-forced distributions (reference :196-220)
+                raw, _ = choose_tokens(logits_all.reshape(B * steps, -1), greedy, seed, self.sample_row_offset * steps,
+                                       0, pad, self._unk_index, bos)
+                raw = raw.view(B, steps)
+            logprobs = F.log_softmax(logits_all, dim=-1).gather(2, raw.unsqueeze(-1)).squeeze(-1)
+        else:
+            raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, c, tgt, steps, greedy, seed)
+
+        predictions = self._trim_predictions(raw)
+        pmask = (predictions != pad).float()
+        sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
+        output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
+        if tgt is not None:
+            tmask = tgt != pad
+            ce = sequence_cross_entropy(logits_all, tgt[:, 1:], tmask[:, 1:])
+            output_dict["loss"] = ce
+            if not self.training:
+                self._record_metrics(predictions, tgt[:, 1:], ce)
+        return output_dict
+
+    def _decode_stepwise(self, enc, fmask, h, c, tgt, steps, greedy, seed):
+        """Step-by-step decoding for shapes the persistent kernel is not built for (hidden != 256,
+        more than 64 source positions or 128 target tokens): a GEMM per step + the cell kernel."""
+        B = enc.size(0)
+        pad, bos = self._pad_index, self._start_index
+        last = fmask.new_full((B,), bos, dtype=torch.long)
         w_ih_t = self._decoder_cell.weight_ih.t()
         w_hh_t = self._decoder_cell.weight_hh.t()
         bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
@@ -274,25 +390,10 @@ class Seq2SeqBase(nn.Module):
             h, c = lstm_cell_pointwise(gates, c)
             logits = self._output_projection_layer(h)
             last, _ = choose_tokens(logits, greedy, seed, self.sample_row_offset, t, pad, self._unk_index, bos)
-            logprobs = F.log_softmax(logits, dim=-1)
             step_predictions.append(last.unsqueeze(1))
             step_logits.append(logits.unsqueeze(1))
-            step_logprobs.append(logprobs.gather(1, last.unsqueeze(1)))
-
-        raw = torch.cat(step_predictions, 1)
-        predictions = self._trim_predictions(raw)
-        logprobs = torch.cat(step_logprobs, 1)
-        pmask = (predictions != pad).float()
-        sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
-        output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
-        if tgt is not None:
-            logits = torch.cat(step_logits, 1)
-            tmask = tgt != pad
-            ce = sequence_cross_entropy(logits, tgt[:, 1:], tmask[:, 1:])
-            output_dict["loss"] = ce
-            if not self.training:
-                self._record_metrics(predictions, tgt[:, 1:], ce)
-        return output_dict
+            step_logprobs.append(F.log_softmax(logits, dim=-1).gather(1, last.unsqueeze(1)))
+        return torch.cat(step_predictions, 1), torch.cat(step_logits, 1), torch.cat(step_logprobs, 1)
 
     def _trim_predictions(self, predictions: torch.LongTensor) -> torch.LongTensor:
         """Keep each row up to and including its first @end@; a row starting with @end@ becomes all
