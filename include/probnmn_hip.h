@@ -251,6 +251,10 @@ int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, co
  *             w_hh_t is W_hh transposed ([H][4H]); dW_hh = sum_t dgates_t^T h_{t-1} is the
  *             caller's GEMM over the saved hs.
  * One workgroup owns 16 batch rows for all T steps (h in LDS, c in registers, W_hh streamed).
+ * WEIGHT LAYOUT: w_hh / w_hh_t (and w_c, w_hh, w_c_t, w_hh_t of the decoder below) are passed
+ * packed in MFMA-fragment order: for W [N][K] row-major,
+ *     packed[N/16][K/16][64][4], packed[nt][kb][16*g + li][j] = W[16*nt + li][16*kb + 4*g + j]
+ * (one wave-wide operand load = 1 KiB contiguous).
  * ------------------------------------------------------------------------------------------- */
 int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B,
                       int T, int hidden, void* stream);

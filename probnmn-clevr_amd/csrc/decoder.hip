@@ -126,10 +126,19 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
                 const f32x4 hv = *reinterpret_cast<const f32x4*>(&hl[cur][rl][4 * lane]);
                 const float* er = a.enc + (size_t)row * S * H + 4 * lane;
                 float myscore = 0.f;
-                for (int s = 0; s < S; ++s) {
-                    const f32x4 e = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
-                    const float p = wsum(e.x * hv.x + e.y * hv.y + e.z * hv.z + e.w * hv.w);
-                    if (lane == s) myscore = p;
+                // encoder rows are fetched eight at a time so that their L2 latency overlaps
+                for (int s0 = 0; s0 < S; s0 += 8) {
+                    f32x4 e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int s = s0 + k < S ? s0 + k : S - 1;
+                        e[k] = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float p = wsum(e[k].x * hv.x + e[k].y * hv.y + e[k].z * hv.z + e[k].w * hv.w);
+                        if (lane == s0 + k) myscore = p;
+                    }
                 }
                 const float m = lane < S ? a.mask[(size_t)row * S + lane] : 0.f;
                 const float v = myscore * m;  // allennlp masked_softmax: softmax(vector * mask) ...
@@ -144,10 +153,18 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
                 }
                 // context
                 f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < S; ++s) {
-                    const float ws = __shfl(wgt, s);
-                    const f32x4 e = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
-                    c4 += e * ws;
+                for (int s0 = 0; s0 < S; s0 += 8) {
+                    f32x4 e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int s = s0 + k < S ? s0 + k : S - 1;
+                        e[k] = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float ws = s0 + k < S ? __shfl(wgt, s0 + k) : 0.f;
+                        c4 += e[k] * ws;
+                    }
                 }
                 *reinterpret_cast<f32x4*>(&cl[rl][4 * lane]) = c4;
                 *reinterpret_cast<f32x4*>(a.ctx + ((size_t)row * T + t) * H + 4 * lane) = c4;
@@ -182,9 +199,9 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
             for (int gate = 0; gate < 4; ++gate)
 #pragma unroll
                 for (int ut = 0; ut < 2; ++ut) {
-                    const int n = gate * H + 32 * wave + 16 * ut + li;
-                    const f32x4 bc = *reinterpret_cast<const f32x4*>(a.w_c + (size_t)n * H + kb * 16 + 4 * g);
-                    const f32x4 bh = *reinterpret_cast<const f32x4*>(a.w_hh + (size_t)n * H + kb * 16 + 4 * g);
+                    const size_t fo = ((size_t)((gate * (H / 16) + 2 * wave + ut) * (H / 16) + kb) * 64 + lane) * 4;
+                    const f32x4 bc = *reinterpret_cast<const f32x4*>(a.w_c + fo);  // weights are packed in
+                    const f32x4 bh = *reinterpret_cast<const f32x4*>(a.w_hh + fo);  // fragment order (seq2seq.hip)
                     acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc.x, acc[gate][ut], 0, 0, 0);
                     acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc.y, acc[gate][ut], 0, 0, 0);
                     acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.z, bc.z, acc[gate][ut], 0, 0, 0);
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
                 for (int kb = 0; kb < H / 16; ++kb) {
                     const f32x4 ah = *reinterpret_cast<const f32x4*>(&hl[nxt][li][kb * 16 + 4 * g]);
                     f32x4 bp = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (vok) bp = *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g);
+                    if (vok) bp = *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g);  // (row-major: tiny)
                     lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.x, bp.x, lacc, 0, 0, 0);
                     lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.y, bp.y, lacc, 0, 0, 0);
                     lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.z, bp.z, lacc, 0, 0, 0);
@@ -394,9 +411,9 @@ __global__ __launch_bounds__(512) void attn_lstm_bwd_kernel(const BwdArgs a) {
             const f32x4 av = *reinterpret_cast<const f32x4*>(&dgl[li][kb * 16 + 4 * g]);
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
-                const int n = 32 * wave + 16 * ut + li;
-                const f32x4 bc = *reinterpret_cast<const f32x4*>(a.w_c_t + (size_t)n * G4 + kb * 16 + 4 * g);
-                const f32x4 bh = *reinterpret_cast<const f32x4*>(a.w_hh_t + (size_t)n * G4 + kb * 16 + 4 * g);
+                const size_t fo = ((size_t)((2 * wave + ut) * (G4 / 16) + kb) * 64 + lane) * 4;
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(a.w_c_t + fo);
+                const f32x4 bh = *reinterpret_cast<const f32x4*>(a.w_hh_t + fo);
                 accc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc.x, accc[ut], 0, 0, 0);
                 accc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc.y, accc[ut], 0, 0, 0);
                 accc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc.z, accc[ut], 0, 0, 0);
@@ -436,10 +453,18 @@ __global__ __launch_bounds__(512) void attn_lstm_bwd_kernel(const BwdArgs a) {
             const float wgt = q / Z;
             // d weights: dw_s = dctx . enc_s
             float dw = 0.f;
-            for (int s = 0; s < S; ++s) {
-                const f32x4 e = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
-                const float d = wsum(e.x * dc4.x + e.y * dc4.y + e.z * dc4.z + e.w * dc4.w);
-                if (lane == s) dw = d;
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                f32x4 e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int s = s0 + k < S ? s0 + k : S - 1;
+                    e[k] = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float d = wsum(e[k].x * dc4.x + e[k].y * dc4.y + e[k].z * dc4.z + e[k].w * dc4.w);
+                    if (lane == s0 + k) dw = d;
+                }
             }
             // w = q / Z ; q = p * mask ; p = softmax(score * mask)
             const float dq = dw / Z - wsum(dw * q) / (Z * Z);
@@ -448,14 +473,23 @@ __global__ __launch_bounds__(512) void attn_lstm_bwd_kernel(const BwdArgs a) {
             const float dscore = dv * m;
             // denc_s += w_s * dctx + dscore_s * h_prev ;  dh_prev += sum_s dscore_s * enc_s
             f32x4 dh4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < S; ++s) {
-                const float ws = __shfl(wgt, s);
-                const float ds = __shfl(dscore, s);
-                const f32x4 e = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
-                f32x4 d = *reinterpret_cast<f32x4*>(dr + (size_t)s * H);
-                d += dc4 * ws + hv * ds;
-                *reinterpret_cast<f32x4*>(dr + (size_t)s * H) = d;
-                dh4 += e * ds;
+            for (int s0 = 0; s0 < S; s0 += 4) {
+                f32x4 e[4], d[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int s = s0 + k < S ? s0 + k : S - 1;
+                    e[k] = *reinterpret_cast<const f32x4*>(er + (size_t)s * H);
+                    d[k] = *reinterpret_cast<const f32x4*>(dr + (size_t)s * H);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (s0 + k < S) {  // wave-uniform
+                        const float ws = __shfl(wgt, s0 + k);
+                        const float ds = __shfl(dscore, s0 + k);
+                        *reinterpret_cast<f32x4*>(dr + (size_t)(s0 + k) * H) = d[k] + dc4 * ws + hv * ds;
+                        dh4 += e[k] * ds;
+                    }
+                }
             }
             f32x4* dst = reinterpret_cast<f32x4*>(&dhl[rl][4 * lane]);
             *dst = *dst + dh4;

@@ -228,8 +228,12 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
 // lane (li, g) / register r holds (batch row 4g+r, unit 32w + 16*ut + li) -- the i, f, g, o values of
 // one (row, unit) sit in the same lane and register of four accumulators, so the cell update is
 // lane-local.  v_mfma_f32_16x16x4_f32, K consumed in the permuted order used by the conv kernels
-// (lane group g takes k = 4g..4g+3 of each 16-block) so that A (h from LDS) and B (W_hh rows from
-// global) are single 16-byte loads.
+// (lane group g takes k = 4g..4g+3 of each 16-block) so that A (h from LDS) and B (weights from
+// global) are single 16-byte loads.  Weights come PRE-PACKED in fragment order
+//     packed[n_tile][k_block][lane = 16*g + li][4] = W[16*n_tile + li][16*k_block + 4*g + 0..3]
+// so that one wave-wide B load is one contiguous 1 KiB (8 full cache lines) -- with the natural
+// row-major layout the same load touches 16 half-used lines and the kernel is bound by the
+// texture-address path, 2.5x slower.
 // =====================================================================================================
 namespace {
 
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restri
                 for (int gate = 0; gate < 4; ++gate)
 #pragma unroll
                     for (int ut = 0; ut < 2; ++ut) {
-                        const int n = gate * LH + 32 * wave + 16 * ut + li;
-                        const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh + (size_t)n * LH + kb * 16 + 4 * g);
+                        const int ntile = gate * (LH / 16) + 2 * wave + ut;
+                        const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh + ((size_t)(ntile * (LH / 16) + kb) * 64 + lane) * 4);
                         acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[gate][ut], 0, 0, 0);
                         acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[gate][ut], 0, 0, 0);
                         acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[gate][ut], 0, 0, 0);
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
                 const f32x4_ a = *reinterpret_cast<const f32x4_*>(&dgl[li][kb * 16 + 4 * g]);
 #pragma unroll
                 for (int ut = 0; ut < 2; ++ut) {
-                    const int n = 32 * wave + 16 * ut + li;
-                    const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh_t + (size_t)n * (4 * LH) + kb * 16 + 4 * g);
+                    const int ntile = 2 * wave + ut;
+                    const f32x4_ b = *reinterpret_cast<const f32x4_*>(w_hh_t + ((size_t)(ntile * (4 * LH / 16) + kb) * 64 + lane) * 4);
                     acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[ut], 0, 0, 0);
                     acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[ut], 0, 0, 0);
                     acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[ut], 0, 0, 0);

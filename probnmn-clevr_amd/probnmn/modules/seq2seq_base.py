@@ -58,6 +58,13 @@ class _LSTMCellPointwise(torch.autograd.Function):
         return dgates, dc_prev
 
 
+def pack_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] row-major -> MFMA-fragment order [N/16][K/16][64][4] (see include/probnmn_hip.h): one wave-wide
+    operand load of the persistent LSTM / decoder kernels then reads 1 KiB contiguous."""
+    n, k = w.shape
+    return w.detach().reshape(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def lstm_cell_pointwise(gates, c_prev):
     return _LSTMCellPointwise.apply(gates, c_prev)
 
@@ -77,7 +84,8 @@ class _LSTMLayerSeq(torch.autograd.Function):
         hs = torch.empty(B, T, Hd, dtype=xp.dtype, device=xp.device)
         cs = torch.empty_like(hs)
         act = torch.empty_like(xp)
-        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), w.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
+        wp = pack_fragments(w)
+        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), wp.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
                                                 B, T, Hd, _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
         ctx.save_for_backward(hs, cs, act, w)
         return hs
@@ -87,7 +95,7 @@ class _LSTMLayerSeq(torch.autograd.Function):
         hs, cs, act, w = ctx.saved_tensors
         B, T, Hd = hs.shape
         dhs = dhs.contiguous()
-        w_t = w.t().contiguous()  # [H][4H]
+        w_t = pack_fragments(w.t())  # W_hh^T [H][4H], fragment order
         dgates = torch.empty_like(act)
         _hip.check(_hip.lib().pnmn_lstm_seq_bwd(dhs.data_ptr(), act.data_ptr(), cs.data_ptr(), w_t.data_ptr(),
                                                 dgates.data_ptr(), B, T, Hd, _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
@@ -112,6 +120,7 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             raise _hip.HipLibraryError("decoder on %s: the HIP path needs a ROCm device (no CPU fallback)" % dev)
         enc, mask, h0 = enc.contiguous(), mask.contiguous(), h0.contiguous()
         w_c, w_hh = w_c.detach().contiguous(), w_hh.detach().contiguous()
+        w_c_p, w_hh_p = pack_fragments(w_c), pack_fragments(w_hh)
         B, S, Hd = enc.shape
         f = dict(dtype=torch.float32, device=dev)
         hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
@@ -128,7 +137,7 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         _hip.check(_hip.lib().pnmn_attn_lstm_fwd(
             ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
-            h0.data_ptr(), w_c.data_ptr(), w_hh.data_ptr(), ptr(w_p if mode != 0 else None),
+            h0.data_ptr(), w_c_p.data_ptr(), w_hh_p.data_ptr(), ptr(w_p if mode != 0 else None),
             ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
             probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset,
             _hip.stream_ptr(dev)), "attn_lstm_fwd")
@@ -150,7 +159,7 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         denc = torch.zeros_like(enc)
         dh0 = torch.empty_like(h0)
         # (named temporaries: a tensor that dies right after .data_ptr() may be recycled by the next allocation)
-        dhs_c, w_c_t, w_hh_t = dhs.contiguous(), w_c.t().contiguous(), w_hh.t().contiguous()
+        dhs_c, w_c_t, w_hh_t = dhs.contiguous(), pack_fragments(w_c.t()), pack_fragments(w_hh.t())
         _hip.check(_hip.lib().pnmn_attn_lstm_bwd(
             dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), cx.data_ptr(), probs.data_ptr(),
             enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
