@@ -15,7 +15,7 @@ from typing import Any, Dict
 import torch
 
 from probnmn import parallel
-from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
+from probnmn.modules.elbo import BRANCHES, JointTrainingElbo, QuestionCodingElbo
 from probnmn.optim import ClampAdam
 
 
@@ -76,18 +76,29 @@ class QuestionCodingStep(_TrainerBase):
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
         out: Dict[str, Any] = {}
         loss = torch.zeros((), device=dev)
+        sup_branches = None
         if sup.numel():
+            # the two teacher-forced passes depend on nothing: side streams, beside the ELBO chain
             prog, ques = batch["program"].to(dev)[sup_d], batch["question"][sup_d]
-            pg_loss = self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean()
-            qr_loss = self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean()
+            sup_branches = [
+                BRANCHES.run("sup_pg", dev, lambda: self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean(),
+                             ques, prog),
+                BRANCHES.run("sup_qr", dev, lambda: self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean(),
+                             ques, prog),
+            ]
+        elbo_out = None
+        if self.objective == "ours" and nosup.numel():
+            elbo_out = self.elbo(batch["question"][nosup_d])
+        if sup_branches is not None:
+            BRANCHES.join(dev, sup_branches)
+            pg_loss, qr_loss = sup_branches[0][0], sup_branches[1][0]
             w = _dp_weight(sup.numel(), dev)
             if self.objective == "baseline":
                 loss = loss + w * pg_loss + w * qr_loss
             else:
                 loss = loss + w * self.alpha * (pg_loss + qr_loss)
             out["loss"] = {"program_generation_gt": pg_loss.detach(), "question_reconstruction_gt": qr_loss.detach()}
-        if self.objective == "ours" and nosup.numel():
-            elbo_out = self.elbo(batch["question"][nosup_d])
+        if elbo_out is not None:
             loss = loss - _dp_weight(nosup.numel(), dev) * elbo_out["elbo"]
             out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
         self._finish(loss)
@@ -119,15 +130,23 @@ class JointTrainingStep(_TrainerBase):
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
         if nosup.numel() == 0:
             raise ValueError("joint training needs at least one example without program supervision in the batch")
+        sup_branches = None
+        if self.objective == "ours" and sup.numel():
+            prog, ques = batch["program"].to(dev)[sup_d], batch["question"][sup_d]
+            sup_branches = [
+                BRANCHES.run("sup_pg", dev, lambda: self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean(),
+                             ques, prog),
+                BRANCHES.run("sup_qr", dev, lambda: self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean(),
+                             ques, prog),
+            ]
         elbo_out = self.elbo(batch["question"][nosup_d], batch["image"][nosup_d], batch["answer"][nosup_d])
         nmn_loss = elbo_out.pop("nmn_loss")
         w = _dp_weight(nosup.numel(), dev)
         loss = w * (self.gamma * nmn_loss - elbo_out["elbo"])
         out: Dict[str, Any] = {"loss": {"nmn": nmn_loss.detach()}, "elbo": {k: v.detach() for k, v in elbo_out.items()}}
-        if self.objective == "ours" and sup.numel():
-            prog, ques = batch["program"].to(dev)[sup_d], batch["question"][sup_d]
-            pg_loss = self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean()
-            qr_loss = self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean()
+        if sup_branches is not None:
+            BRANCHES.join(dev, sup_branches)
+            pg_loss, qr_loss = sup_branches[0][0], sup_branches[1][0]
             loss = loss + _dp_weight(sup.numel(), dev) * self.alpha * (pg_loss + qr_loss)
             out["loss"]["program_generation_gt"] = pg_loss.detach()
             out["loss"]["question_reconstruction_gt"] = qr_loss.detach()
