@@ -85,3 +85,53 @@ class OracleJointTrainer:
         self.optimizer.step()
         return {"objective": loss.detach(), "nmn_loss": nmn_loss.detach(), "elbo": {k: v.detach() for k, v in out.items()},
                 "programs": z, "grads": grads, "baseline": self.reinforce.baseline}
+
+
+class OracleQuestionCodingTrainer:
+    """CPU restatement of one question-coding iteration (reference
+    probnmn/trainers/question_coding_trainer.py:109-168 + modules/elbo.py:130-161)."""
+
+    def __init__(self, pg_sd, qr_sd, prior_sd, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3,
+                 pg_steps=26):
+        from oracle import elbo_oracle
+
+        def leaf(sd):
+            return {k: v.detach().clone().contiguous().requires_grad_(True) for k, v in sd.items()}
+
+        self.pg, self.qr = leaf(pg_sd), leaf(qr_sd)
+        self.prior = {k: v.detach().clone() for k, v in prior_sd.items()}
+        self.objective, self.alpha, self.beta = objective, alpha, beta
+        self.reinforce = elbo_oracle.Reinforce(delta)
+        self.pg_steps = pg_steps
+        self.optimizer = torch.optim.Adam(list(self.pg.values()) + list(self.qr.values()), lr=lr)
+
+    def step(self, batch, forced_programs=None):
+        from oracle import elbo_oracle, seq2seq_oracle as so
+
+        self.optimizer.zero_grad()
+        sup = batch["supervision"].nonzero().flatten()
+        nosup = (1 - batch["supervision"]).nonzero().flatten()
+        prog, ques = batch["program"][sup], batch["question"][sup]
+        pg_sup = so.seq2seq_forward(self.pg, ques, prog, "sampling")["loss"].mean()
+        qr_sup = so.seq2seq_forward(self.qr, prog, ques, "sampling")["loss"].mean()
+        out = {}
+        if self.objective == "baseline":
+            loss = pg_sup + qr_sup
+        else:
+            q = batch["question"][nosup]
+            pg_out = so.seq2seq_forward(self.pg, q, None, "sampling", self.pg_steps, forced_predictions=forced_programs)
+            z = pg_out["predictions"]
+            qr_out = so.seq2seq_forward(self.qr, z, q, "sampling")
+            with torch.no_grad():
+                prior_loss = so.program_prior_loss(self.prior, z)
+            out = elbo_oracle.question_coding_elbo(self.reinforce, self.beta, pg_out["loss"], qr_out["loss"], prior_loss)
+            loss = -out["elbo"] + self.alpha * pg_sup + self.alpha * qr_sup
+        loss.backward()
+        for p in list(self.pg.values()) + list(self.qr.values()):
+            if p.grad is not None:
+                p.grad.clamp_(min=-5, max=5)
+        grads = {"pg": {k: (None if v.grad is None else v.grad.clone()) for k, v in self.pg.items()},
+                 "qr": {k: (None if v.grad is None else v.grad.clone()) for k, v in self.qr.items()}}
+        self.optimizer.step()
+        return {"objective": loss.detach(), "elbo": {k: v.detach() for k, v in out.items()}, "grads": grads,
+                "baseline": self.reinforce.baseline}

@@ -73,3 +73,50 @@ def test_joint_training_step_matches_oracle():
     print("elements beyond the clamp:", n_clamped)
     # sampled programs that are invalid score the constant loss and get no NMN gradient
     assert out["elbo"]["elbo"].ndim == 0
+
+
+def test_question_coding_step_matches_oracle():
+    from oracle.train_oracle import OracleQuestionCodingTrainer
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import QuestionCodingStep
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(1)
+    pg, qr, prior = ProgramGenerator(vocab), QuestionReconstructor(vocab), ProgramPrior(vocab, hidden_size=256)
+    sds = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (pg, qr, prior)]
+    sds[2].pop("_output_layer.weight")
+    batch = synthetic_batch(vocab, 14, seed=4, with_image=False)
+    batch["supervision"][:3] = 1
+    batch["supervision"][3:6] = 0
+    for m in (pg, qr, prior):
+        m.to(dev)
+    step = QuestionCodingStep(pg, qr, prior, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    dbatch["supervision"] = batch["supervision"]
+    seen = {}
+    orig = pg.forward
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        if len(a) == 1 or a[1] is None:
+            seen["z"] = out["predictions"].detach().cpu()
+        return out
+
+    pg.forward = spy
+    out = step.step(dbatch)
+    pg.forward = orig
+    torch.cuda.synchronize()
+    ref = OracleQuestionCodingTrainer(*sds, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3)
+    ref_out = ref.step(batch, forced_programs=seen["z"])
+    for k in ("elbo", "kl_divergence", "reconstruction_likelihood", "reinforce_reward"):
+        assert float(out["elbo"][k]) == pytest.approx(float(ref_out["elbo"][k]), rel=1e-4, abs=1e-4), k
+    assert float(out["objective"]) == pytest.approx(float(ref_out["objective"]), rel=1e-4, abs=1e-2)
+    for key, model in (("pg", pg), ("qr", qr)):
+        for name, p in model.named_parameters():
+            g_ref = ref_out["grads"][key][name]
+            got = p.grad.detach().cpu().clamp(-5, 5)
+            scale = float(g_ref.abs().max()) + 1e-12
+            assert float((got - g_ref).abs().max()) / scale < 5e-3, (key, name)
