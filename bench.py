@@ -110,6 +110,48 @@ def kernel_rooflines(engine, trainer, batch, passes):
     return agg
 
 
+def joint_training_extra(vocab, nmn, dev, rank, world, batch_size, steps=5, warmup=2):
+    """Side measurement (BASELINE.json configs[3] shape: joint_training_ours.yml, 128 questions per GPU):
+    ProgramGenerator sampling + QuestionReconstructor + ProgramPrior + NMN + REINFORCE/ELBO + supervised
+    cross entropies, backward, gradient all-reduce, clamp, Adam.  Random-init weights (so most sampled
+    programs are invalid and the NMN part is lighter than with a trained generator); reported next to
+    the headline, never as `value`."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep
+
+    torch.manual_seed(1)
+    pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
+    prior = ProgramPrior(vocab, hidden_size=256).to(dev)
+    for m in (pg, qr):
+        m.sample_row_offset = rank * batch_size
+    step = JointTrainingStep(pg, qr, prior, nmn, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-6)
+    batch = synthetic_batch(vocab, batch_size, seed=2000 + rank)
+    sup = batch["supervision"]
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    batch["supervision"] = sup
+    for _ in range(warmup):
+        step.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"metric": "CLEVR questions/sec (joint_training step)", "value": round(batch_size * world * steps / dt, 1),
+            "ms_per_step": round(dt / steps * 1e3, 2), "global_batch": batch_size * world, "steps": steps,
+            "config": "joint_training_ours.yml (alpha 100, beta 0.1, gamma 1, delta 0.99), %d questions per GPU, "
+                      "random-init weights, synthetic batch" % batch_size}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +162,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-joint", action="store_true", help="skip the joint_training side measurement")
+    ap.add_argument("--joint-batch", type=int, default=128, help="questions per GPU of the joint_training side measurement")
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="run weight gradients on a second stream concurrently with the data-gradient chain")
     args = ap.parse_args()
@@ -215,6 +259,13 @@ def main():
     if cpu_sd is not None:
         cpu = cpu_baseline(vocab, cpu_sd, args.cpu_sample, args.cpu_steps, seed=1000)
 
+    joint = None
+    if not args.no_joint:
+        try:
+            joint = joint_training_extra(vocab, net, dev, rank, world, args.joint_batch)
+        except Exception as exc:  # the headline line must survive a failure of the side measurement
+            joint = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world / (elapsed / args.steps)
@@ -244,6 +295,7 @@ def main():
             },
             "roofline": roof,
             "cpu_baseline": cpu,
+            "joint_training": joint,
         }
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
