@@ -1,24 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: CLEVR questions/sec of one module_training step on MI355X.
+"""Headline benchmark: CLEVR questions/sec of one joint_training step on MI355X (BASELINE.json `metric`).
 
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1]): configs/module_training.yml dims (1024x14x14 features,
-128 module channels, 1024 projection channels, 1024 classifier units, lr 1e-4), batch 256 per GPU,
-synthetic CLEVR-shaped batch (probnmn.data.synthetic, seed 0, programs from the eight template
-shapes), random-init weights (seed 0).  A step = zero_grad -> NMN forward -> mean loss -> backward
--> [gradient all-reduce] -> clamp(-5,5) -> Adam, exactly the reference's iteration
-(_trainer.py:135-151, module_training_trainer.py:88-98).  Inputs are resident in HBM before the
-timed region; programs are re-scheduled on the host every step (nothing is cached across steps
-except the per-structure templates).
+Workload (BASELINE.json configs[3] on one GPU): configs/joint_training_ours.yml (alpha 100, beta 0.1,
+gamma 1, delta 0.99, lr 1e-6), 1024 questions per GPU (weak scaling: global batch 1024 x N), 14x14x1024
+features, synthetic CLEVR-shaped batch (probnmn.data.synthetic: programs from the eight template
+shapes, half of the examples with program supervision -- what the reference's
+SupervisionWeightedRandomSampler yields, data/samplers.py:5-27).  A step is the reference's
+iteration (joint_training_trainer.py:128-198, _trainer.py:135-151): ProgramGenerator samples a
+program per unsupervised question -> QuestionReconstructor / ProgramPrior / NMN on the samples ->
+REINFORCE-ELBO + gamma * answer loss; teacher-forced cross entropies on the supervised half;
+backward -> [gradient all-reduce] -> clamp(-5,5) -> Adam over all three trainable models.
+
+Weights are random-init (seed 0) except that the ProgramGenerator is first fitted for a few hundred
+supervised iterations on the synthetic batch (outside the timed region), so that its SAMPLES are
+valid programs and the NMN part of the step does the work it does in the reference's joint phase,
+which starts from a question_coding checkpoint (an untrained generator emits invalid programs, which
+the NMN skips -- a step without its heaviest part).  `config.valid_program_fraction` reports it.
+Inputs are resident in HBM before the timed region; the sampled programs travel device -> host every
+step because they decide the NMN launch schedule (the one sync the algorithm itself requires).
 
 Besides the contract fields the JSON line carries
-  roofline      for the kernel with the largest share of step time (conv_nhwc: forward + data
-                gradients of every 3x3 / 1x1 conv): algorithmic FLOPs / launch time measured with
-                events on the launch stream in a separate instrumented pass, against the 157.3
-                TFLOP/s fp32 matrix peak of gfx950
-  cpu_baseline  the CPU oracle's identical step, timed on this host's cores on a 16-question
-                sample of the same workload (N=1 only)
+  roofline       for the kernel family with the largest share of step time (conv_nhwc: forward +
+                 data gradients of every 3x3 / 1x1 conv of the NMN): algorithmic FLOPs / launch time
+                 measured with events on the launch stream in separate instrumented steps, against
+                 the 157.3 TFLOP/s fp32 matrix peak of gfx950
+  cpu_baseline   the CPU oracle's identical step (same weights), timed on this host's cores on a
+                 bounded sample of the same workload (N=1 only)
+  module_training / question_coding / joint_training_b128
+                 side measurements of BASELINE.json configs[1], configs[2] and of configs[3] read as
+                 1024 questions over 8 GPUs (128 per GPU); never `value`
 """
 import argparse
 import json
@@ -37,6 +49,8 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 
+JOINT = dict(objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-6)
+
 
 def log(*a):
     if os.environ.get("RANK", "0") == "0":
@@ -46,12 +60,17 @@ def log(*a):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline(vocab, state_dict, sample, steps, seed):
-    """The oracle's step on this host's cores.  torch's default (one thread per physical core) is
-    far from the best setting for the reference's batch-1 convolutions -- on a 128-core host 128
-    threads run ~3x slower than 16 -- so a few thread counts are tried and the FASTEST is reported
-    (the baseline gets the benefit of the doubt); `cores` is the thread count of that run."""
-    from oracle.train_oracle import OracleModuleTrainer
+def cpu_state(module):
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def cpu_baseline(vocab, sds, sample, steps, seed):
+    """The oracle's joint-training step on this host's cores.  torch's default (one thread per
+    physical core) is far from the best setting for the reference's batch-1 convolutions -- on a
+    128-core host 128 threads run ~3x slower than 16 -- so a few thread counts are tried and the
+    FASTEST is reported (the baseline gets the benefit of the doubt); `cores` is the thread count of
+    that run."""
+    from oracle.train_oracle import OracleJointTrainer
     from probnmn.data.synthetic import synthetic_batch
 
     batch = synthetic_batch(vocab, sample, seed=seed)
@@ -60,7 +79,9 @@ def cpu_baseline(vocab, state_dict, sample, steps, seed):
         if threads > (os.cpu_count() or 1):
             continue
         torch.set_num_threads(threads)
-        trainer = OracleModuleTrainer(state_dict, vocab.get_index_to_token_vocabulary("programs"), lr=1e-4)
+        torch.manual_seed(0)
+        trainer = OracleJointTrainer(sds["pg"], sds["qr"], sds["prior"], sds["nmn"],
+                                     vocab.get_index_to_token_vocabulary("programs"), **JOINT)
         trainer.step(batch)  # warm-up (allocations, oneDNN primitive caches)
         times = []
         for _ in range(steps):
@@ -79,25 +100,24 @@ def cpu_baseline(vocab, state_dict, sample, steps, seed):
         "cores": best[1],
         "host_logical_cpus": os.cpu_count(),
         "kind": "port",
-        "sample": "%d-question batch of the same synthetic workload, %d timed steps (median) per thread "
-                  "count in {8,16,32}, best reported; PyTorch-CPU fp32 restatement of the reference step"
-                  % (sample, steps),
+        "sample": "%d-question batch of the same synthetic workload and weights, %d timed joint_training "
+                  "steps (median) per thread count in {8,16,32}, best reported; PyTorch-CPU fp32 restatement "
+                  "of the reference step" % (sample, steps),
     }
 
 
-def kernel_rooflines(engine, trainer, batch, passes):
-    """Instrumented pass: events around every conv / wgrad launch on the launch stream.  The pass
-    runs with the weight-gradient overlap switched off (one stream), so that each kernel's duration
-    is its own and not that of two kernels sharing the chip."""
+def kernel_rooflines(engine, step_fn, passes):
+    """Instrumented steps: events around every conv / wgrad launch on the launch stream (one stream,
+    so each kernel's duration is its own and not that of two kernels sharing the chip)."""
     overlap, engine.overlap_wgrad = engine.overlap_wgrad, False
     engine.event_log = []
     for _ in range(passes):
-        trainer.step(batch)
+        step_fn()
     torch.cuda.synchronize()
-    log, engine.event_log = engine.event_log, None
+    events, engine.event_log = engine.event_log, None
     engine.overlap_wgrad = overlap
     agg = {}
-    for kern, what, flops, e0, e1 in log:
+    for kern, what, flops, e0, e1 in events:
         a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "by": {}})
         ms = e0.elapsed_time(e1)
         a["flops"] += flops
@@ -110,62 +130,118 @@ def kernel_rooflines(engine, trainer, batch, passes):
     return agg
 
 
-def joint_training_extra(vocab, nmn, dev, rank, world, batch_size, steps=5, warmup=2):
-    """Side measurement (BASELINE.json configs[3] shape: joint_training_ours.yml, 128 questions per GPU):
-    ProgramGenerator sampling + QuestionReconstructor + ProgramPrior + NMN + REINFORCE/ELBO + supervised
-    cross entropies, backward, gradient all-reduce, clamp, Adam.  Random-init weights (so most sampled
-    programs are invalid and the NMN part is lighter than with a trained generator); reported next to
-    the headline, never as `value`."""
-    from probnmn.data.synthetic import synthetic_batch
-    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
-    from probnmn.trainers.joint_training import JointTrainingStep
+def roofline_object(agg, passes):
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    a = agg[dom]
+    achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    return {
+        "kernel": dom,
+        "bound": "mfma",
+        "achieved": round(achieved, 2),
+        "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+        "traffic": None,
+        "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+        "launches_per_step": a["launches"] // passes,
+        "kernels": {
+            k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / passes, 3),
+                "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1] / passes, 3)}
+                                 for w, b in v["by"].items()}}
+            for k, v in agg.items()
+        },
+    }
 
-    torch.manual_seed(1)
-    pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
-    prior = ProgramPrior(vocab, hidden_size=256).to(dev)
-    for m in (pg, qr):
-        m.sample_row_offset = rank * batch_size
-    step = JointTrainingStep(pg, qr, prior, nmn, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-6)
-    batch = synthetic_batch(vocab, batch_size, seed=2000 + rank)
+
+def timed(step_fn, steps, warmup, dev, world):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both
+    sides; returns (max-over-ranks seconds, host seconds to enqueue, host seconds blocked on the
+    staging ring)."""
+    from probnmn import _hip
+
+    for i in range(warmup):
+        step_fn()
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    w0 = _hip.ring_wait_seconds()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    host = time.perf_counter() - t0
+    blocked = _hip.ring_wait_seconds() - w0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, host, blocked
+
+
+def device_batch(vocab, n, seed, dev):
+    """A synthetic batch resident in HBM.  `supervision` stays on the host (it decides the split sizes,
+    as the data loader's CPU tensor does in the reference) and so does `program` for module training
+    (it drives the host-side launch schedule)."""
+    from probnmn.data.synthetic import synthetic_batch
+
+    batch = synthetic_batch(vocab, n, seed=seed)
     sup = batch["supervision"]
     batch = {k: v.to(dev) for k, v in batch.items()}
     batch["supervision"] = sup
-    for _ in range(warmup):
-        step.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step.step(batch)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return {"metric": "CLEVR questions/sec (joint_training step)", "value": round(batch_size * world * steps / dt, 1),
-            "ms_per_step": round(dt / steps * 1e3, 2), "global_batch": batch_size * world, "steps": steps,
-            "config": "joint_training_ours.yml (alpha 100, beta 0.1, gamma 1, delta 0.99), %d questions per GPU, "
-                      "random-init weights, synthetic batch" % batch_size}
+    return batch
+
+
+def fit_program_generator(pg, vocab, batch, dev, max_iters, target):
+    """Supervised teacher-forced iterations on the synthetic batch until the generator's samples are
+    mostly valid programs (outside every timed region).  Returns the valid fraction of a sampling pass."""
+    from probnmn import parallel
+    from probnmn.optim import ClampAdam
+    from probnmn.runtime.program_compiler import ProgramCompiler
+
+    compiler = ProgramCompiler(vocab.get_index_to_token_vocabulary("programs"))
+    opt = ClampAdam(list(pg.parameters()), lr=2e-3, clamp=5.0)
+    parallel.broadcast_parameters([], opt.loose)
+
+    def valid_fraction():
+        pg.eval()
+        with torch.no_grad():
+            z = pg(batch["question"], decoding_strategy="sampling")["predictions"].cpu()
+        pg.train()
+        t = torch.tensor([sum(1 for p in compiler.compile_batch(z) if p.valid), z.shape[0]], dtype=torch.float64, device=dev)
+        t = parallel.all_reduce_scalars(t)
+        return float(t[0] / t[1])
+
+    frac, it = valid_fraction(), 0
+    while frac < target and it < max_iters:
+        for _ in range(50):
+            opt.zero_grad()
+            pg(batch["question"], batch["program"], decoding_strategy="sampling")["loss"].mean().backward()
+            parallel.all_reduce_gradients([], opt.loose)
+            opt.step()
+        it += 50
+        frac = valid_fraction()
+        log("program generator fit: %d iterations, %.3f of sampled programs valid" % (it, frac))
+    return frac, it
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="questions per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
     ap.add_argument("--cpu-sample", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--fit-iters", type=int, default=1500, help="cap on the generator's pre-fit iterations")
+    ap.add_argument("--fit-target", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-joint", action="store_true", help="skip the joint_training side measurement")
-    ap.add_argument("--joint-batch", type=int, default=128, help="questions per GPU of the joint_training side measurement")
-    ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="run weight gradients on a second stream concurrently with the data-gradient chain")
+    ap.add_argument("--no-extras", action="store_true", help="skip the module_training / question_coding / b128 side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,121 +258,103 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from probnmn import parallel
-    from probnmn.data.synthetic import synthetic_batch
-    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep, QuestionCodingStep
     from probnmn.trainers.module_training import ModuleTrainingStep
     from probnmn.vocabulary import Vocabulary
 
-    log("building network")
+    log("building models")
     vocab = Vocabulary.clevr()
     torch.manual_seed(0)
-    net = NeuralModuleNetwork(vocab)  # module_training.yml dims are the constructor defaults
-    cpu_sd = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    net.to(dev)
-    trainer = ModuleTrainingStep(net, lr=1e-4, weight_decay=0.0, report_metrics=False)
-    net.engine.overlap_wgrad = args.overlap_wgrad
-    parallel.broadcast_parameters(trainer.optimizer.arenas, trainer.optimizer.loose)
-    # weak scaling: every rank gets its own batch of --batch questions
-    batch = synthetic_batch(vocab, args.batch, seed=1000 + rank, device=dev)
-    # programs drive the host-side launch schedule: they stay where the data loader produces them
-    # (host memory); everything the kernels read is resident in HBM
-    batch["program"] = batch["program"].cpu()
+    nmn = NeuralModuleNetwork(vocab).to(dev)  # module_training.yml / joint_training_ours.yml dims = defaults
+    pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
+    prior = ProgramPrior(vocab, hidden_size=256).to(dev)
+    for m in (pg, qr):
+        m.sample_row_offset = rank * args.batch  # distinct sampler streams per rank
 
-    log("batch ready; warmup")
-    for i in range(args.warmup):
-        trainer.step(batch)
-        torch.cuda.synchronize()
-        log("warmup step", i, "done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    from probnmn import _hip
-    w0 = _hip.ring_wait_seconds()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(batch)
-    host_elapsed = time.perf_counter() - t0
-    host_blocked = _hip.ring_wait_seconds() - w0  # part of it spent waiting for the GPU to free a staging slot  # time to ENQUEUE the steps (host scheduling + launches)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # weak scaling: every rank gets its own batch of --batch questions
+    batch = device_batch(vocab, args.batch, 1000 + rank, dev)
+    valid_fraction, fit_iters = fit_program_generator(pg, vocab, batch, dev, args.fit_iters, args.fit_target)
+
+    trainer = JointTrainingStep(pg, qr, prior, nmn, **JOINT)
+    parallel.broadcast_parameters(trainer.optimizer.arenas, trainer.optimizer.loose)
+    sds = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sds = {"pg": cpu_state(pg), "qr": cpu_state(qr), "prior": cpu_state(prior), "nmn": cpu_state(nmn)}
+
+    log("joint_training: warmup + %d timed steps" % args.steps)
+    elapsed, host, blocked = timed(lambda: trainer.step(batch), args.steps, args.warmup, dev, world)
     log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    prims = nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        agg = kernel_rooflines(net.engine, trainer, batch, passes=2)
-        dom = max(agg, key=lambda k: agg[k]["ms"])
-        a = agg[dom]
-        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
-        roof = {
-            "kernel": dom,
-            "bound": "mfma",
-            "achieved": round(achieved, 2),
-            "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-            "traffic": None,
-            "avg_launch_ms": round(a["ms"] / a["launches"], 4),
-            "launches_per_step": a["launches"] // 2,
-            "kernels": {
-                k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / 2, 3),
-                    "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1] / 2, 3)}
-                                     for w, b in v["by"].items()}}
-                for k, v in agg.items()
-            },
-        }
+        roof = roofline_object(kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2), 2)
+        log("roofline pass done")
 
-    log("roofline pass done")
     cpu = None
-    if cpu_sd is not None:
-        cpu = cpu_baseline(vocab, cpu_sd, args.cpu_sample, args.cpu_steps, seed=1000)
+    if sds is not None:
+        cpu = cpu_baseline(vocab, sds, args.cpu_sample, args.cpu_steps, seed=1000)
 
-    joint = None
-    if not args.no_joint:
-        try:
-            joint = joint_training_extra(vocab, net, dev, rank, world, args.joint_batch)
-        except Exception as exc:  # the headline line must survive a failure of the side measurement
-            joint = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    extras = {}
+    if not args.no_extras:
+        def side(name, metric, workload, n, make):
+            try:
+                b = device_batch(vocab, n, 3000 + rank, dev)
+                step = make()
+                if name == "module_training":
+                    b["program"] = b["program"].cpu()
+                e, _, _ = timed(lambda: step.step(b), 10, 3, dev, world)
+                extras[name] = {"metric": metric, "value": round(n * world * 10 / e, 1), "unit": "questions/s",
+                                "ms_per_step": round(e / 10 * 1e3, 3), "global_batch": n * world, "steps": 10,
+                                "warmup": 3, "workload": workload}
+                log("%s: %.1f questions/s" % (name, extras[name]["value"]))
+            except Exception as exc:  # the headline line must survive a failure of a side measurement
+                extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+        side("joint_training_b128", "CLEVR questions/sec (joint_training step)",
+             "joint_training_ours.yml, 128 questions per GPU (configs[3] read as 1024 over 8 GPUs)", 128,
+             lambda: trainer)
+        side("question_coding", "CLEVR questions/sec (question_coding step)",
+             "question_coding_ours.yml (ProgramGenerator + QuestionReconstructor + frozen ProgramPrior, REINFORCE-ELBO), "
+             "512 questions per GPU (configs[2])", 512,
+             lambda: QuestionCodingStep(pg, qr, prior, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3))
+        side("module_training", "CLEVR questions/sec (module_training step)",
+             "module_training.yml, 256 questions per GPU, ground-truth programs, NMN fwd+bwd+clamp+Adam (configs[1])", 256,
+             lambda: ModuleTrainingStep(nmn, lr=1e-4, weight_decay=0.0, report_metrics=False))
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world / (elapsed / args.steps)
-        plan = net.engine.last_plan
         line = {
-            "metric": "CLEVR questions/sec (module_training step)",
+            "metric": "CLEVR questions/sec (joint_training step)",
             "value": round(value, 1),
             "unit": "questions/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
-            "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
-            "host_busy_ms_per_step": round((host_elapsed - host_blocked) / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3),
+            "host_busy_ms_per_step": round((host - blocked) / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (random-init weights; ProgramGenerator pre-fitted on the synthetic batch so that "
+                    "sampled programs are valid)",
             "config": {
-                "workload": "module_training.yml, batch %d per GPU, 14x14x1024 features, programs from 8 CLEVR "
-                            "template shapes, fwd+bwd+clamp+Adam" % args.batch,
+                "workload": "joint_training_ours.yml (NMN + seq2seq + REINFORCE), batch %d per GPU, 14x14x1024 "
+                            "features, half of the batch with program supervision, fwd+bwd+clamp+Adam" % args.batch,
                 "global_batch": args.batch * world,
                 "parallelism": "dp%d" % world,
-                "streams": 2 if args.overlap_wgrad else 1,
-                "module_primitives_per_step": plan.n_prims if plan else None,
+                "valid_program_fraction": round(valid_fraction, 4),
+                "program_generator_fit_iterations": fit_iters,
+                "module_primitives_per_step": prims,
             },
             "roofline": roof,
             "cpu_baseline": cpu,
-            "joint_training": joint,
         }
+        line.update(extras)
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(line))

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile: rocprofv3 kernel trace + separate PMC passes of the bench command (DBs stay in /tmp on the box,
+# only the summaries land in gpurun_out/).   usage: bash scripts/profile_round.sh r01d
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+python -c "import torch" >/dev/null 2>&1
+cd $R
+TAG=${1:-r01d}
+# 1) headline workload only (the bench line's roofline must agree with this table)
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_prof_bench.log 2>&1
+python profiles/summarize.py $(find /tmp/prof_$TAG -name '*_results.db' | head -1) > gpurun_out/${TAG}_kernel_stats.txt 2>&1
+grep '^{' gpurun_out/${TAG}_prof_bench.log > gpurun_out/${TAG}_prof_bench.json
+# 2) HBM traffic counters, one counter per pass (MI355X_MICROARCH.md: no mixing with other trace domains)
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_$C.log 2>&1
+  python profiles/summarize.py --pmc $(find /tmp/pmc_$C -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_$C.txt 2>&1
+done
+cut -c1-400 gpurun_out/${TAG}_prof_bench.json
