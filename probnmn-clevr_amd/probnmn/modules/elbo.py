@@ -143,9 +143,14 @@ class QuestionCodingElbo(_ElboWithReinforce):
         prior_branch = BRANCHES.run("prior", dev, prior, sampled_programs)
         qr_out = self._question_reconstructor(sampled_programs, question_tokens, decoding_strategy="sampling")
         BRANCHES.join(dev, [prior_branch])
-        logprobs_reconstruction = -qr_out["loss"]
-        logprobs_generation = -pg_out["loss"]
-        logprobs_prior = -prior_branch[0]["loss"]
+        return self.combine(pg_out["loss"], qr_out["loss"], prior_branch[0]["loss"])
+
+    def combine(self, generation_loss, reconstruction_loss, prior_loss) -> Dict[str, torch.Tensor]:
+        """The objective from the three per-example negative log-likelihoods of the SAMPLED programs
+        (reference elbo.py:130-161); trainers that batch the model passes themselves call this."""
+        logprobs_reconstruction = -reconstruction_loss
+        logprobs_generation = -generation_loss
+        logprobs_prior = -prior_loss
         reinforce_reward = logprobs_reconstruction + self._beta * (logprobs_prior - logprobs_generation)
         return super()._forward(logprobs_generation, logprobs_reconstruction, reinforce_reward)
 
@@ -176,17 +181,23 @@ class JointTrainingElbo(_ElboWithReinforce):
             prior_branch = BRANCHES.run("prior", dev, prior, sampled_programs)
         nmn_out = self._nmn(image_features, sampled_programs, answer_tokens)
         BRANCHES.join(dev, [qr_branch, prior_branch])
-        qr_out = qr_branch[0]
+        prior_loss = prior_branch[0]["loss"] if prior_branch[0] is not None else None
+        qr_loss = qr_branch[0]["loss"] if qr_branch[0] is not None else None
+        return self.combine(pg_out["loss"], qr_loss, prior_loss, nmn_out)
+
+    def combine(self, generation_loss, reconstruction_loss, prior_loss, nmn_out) -> Dict[str, torch.Tensor]:
+        """The objective from the per-example losses of the SAMPLED programs (reference
+        elbo.py:220-280); trainers that batch the model passes themselves call this."""
         if self._objective == "baseline":
             reinforce_reward = -nmn_out["loss"]
             output_dict = {
-                "elbo": self._reinforce(pg_out["loss"], reinforce_reward).mean(),
+                "elbo": self._reinforce(generation_loss, reinforce_reward).mean(),
                 "reinforce_reward": reinforce_reward.mean(),
             }
         else:
-            logprobs_reconstruction = -qr_out["loss"]
-            logprobs_generation = -pg_out["loss"]
-            logprobs_prior = -prior_branch[0]["loss"]
+            logprobs_reconstruction = -reconstruction_loss
+            logprobs_generation = -generation_loss
+            logprobs_prior = -prior_loss
             logprobs_answering = -nmn_out["loss"]
             reinforce_reward = (logprobs_reconstruction + self._beta * logprobs_prior
                                 - self._beta * logprobs_generation + self._gamma * logprobs_answering)

@@ -318,24 +318,40 @@ class Seq2SeqBase(nn.Module):
         target_tokens: Optional[torch.LongTensor] = None,
         decoding_strategy: str = "sampling",
     ) -> Dict[str, torch.Tensor]:
-        if decoding_strategy not in ("sampling", "greedy"):
-            raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
+        return self.decode(self.encode(source_tokens), target_tokens, decoding_strategy)
+
+    def encode(self, source_tokens: torch.LongTensor) -> Dict[str, torch.Tensor]:
+        """Encoder half of ``forward`` (reference seq2seq_base.py ``_encode`` + ``_init_decoder_state``).
+        Rows are independent, so a trainer may encode one batch once and ``decode`` row subsets of
+        the state in different modes (``select_rows``)."""
         if source_tokens.device.type != "cuda":
             raise _hip.HipLibraryError("seq2seq input on %s: the HIP path needs a ROCm device" % source_tokens.device)
         pad, bos, eos = self._pad_index, self._start_index, self._end_index
         src = add_sentence_boundary_token_ids(source_tokens, pad, bos, eos)[:, 1:]  # @start@ is not encoded
+        src_mask = src != pad
+        enc = self._encoder(self._source_embedder(src), src_mask)
+        rows = torch.arange(src.size(0), device=src.device)
+        return {"enc": enc, "h": enc[rows, src_mask.sum(1) - 1], "fmask": src_mask.float()}
+
+    @staticmethod
+    def select_rows(state: Dict[str, torch.Tensor], rows: torch.LongTensor) -> Dict[str, torch.Tensor]:
+        return {k: v.index_select(0, rows) for k, v in state.items()}
+
+    def decode(
+        self,
+        state: Dict[str, torch.Tensor],
+        target_tokens: Optional[torch.LongTensor] = None,
+        decoding_strategy: str = "sampling",
+    ) -> Dict[str, torch.Tensor]:
+        if decoding_strategy not in ("sampling", "greedy"):
+            raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        enc, h, fmask = state["enc"], state["h"], state["fmask"]
         tgt = None
         if target_tokens is not None:
             tgt = add_sentence_boundary_token_ids(target_tokens, pad, bos, eos)
-
-        # _encode / _init_decoder_state
-        src_mask = src != pad
-        enc = self._encoder(self._source_embedder(src), src_mask)
-        B = src.size(0)
-        rows = torch.arange(B, device=src.device)
-        h = enc[rows, src_mask.sum(1) - 1]
+        B = enc.size(0)
         c = torch.zeros_like(h)
-        fmask = src_mask.float()
 
         steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
         greedy = decoding_strategy == "greedy"

@@ -15,7 +15,7 @@ from typing import Any, Dict
 import torch
 
 from probnmn import parallel
-from probnmn.modules.elbo import BRANCHES, JointTrainingElbo, QuestionCodingElbo
+from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
 from probnmn.optim import ClampAdam
 
 
@@ -36,6 +36,16 @@ def _dp_weight(n_local: int, device) -> float:
     return n_local * parallel.world() / total if total > 0 else 0.0
 
 
+def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
+    """Row-concatenate two token matrices, right-padding the narrower one."""
+    w = max(a.size(1), b.size(1))
+    if a.size(1) < w:
+        a = torch.nn.functional.pad(a, (0, w - a.size(1)), value=pad)
+    if b.size(1) < w:
+        b = torch.nn.functional.pad(b, (0, w - b.size(1)), value=pad)
+    return torch.cat((a, b), 0)
+
+
 class _TrainerBase:
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
@@ -52,6 +62,57 @@ class _TrainerBase:
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose)
         self.optimizer.step()
         self.iteration += 1
+
+    def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
+                        reconstruct: bool = True):
+        """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
+        rows of the reference's separate calls batched into as few recurrent launches as the data
+        dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
+        more rows costs the same time):
+
+          * one ProgramGenerator encoder pass over every question it will decode, then the
+            teacher-forced decode of the supervised rows and the sampling decode of the others;
+          * ONE QuestionReconstructor pass: both of the reference's calls are teacher-forced on the
+            question, with the sampled programs resp. the ground-truth programs as source.
+
+        Rows are independent in every model, so each row's loss equals the reference's separate
+        calls' (question_coding_trainer.py:128-160, joint_training_trainer.py:150-190).
+        ``reconstruct=False`` skips the reconstruction of the samples where the objective does not
+        use it (the reference's joint "baseline" objective evaluates and discards it, elbo.py:236-251)."""
+        dev = batch["question"].device
+        out = {}
+        n_sup, n_nosup = (sup_d.numel() if supervised else 0), (nosup_d.numel() if sampled else 0)
+        if n_sup == 0 and n_nosup == 0:
+            return out
+        question = batch["question"]
+        if n_sup:
+            program = batch["program"].to(dev)
+            prog_sup, ques_sup = program[sup_d], question[sup_d]
+        if n_sup and n_nosup:
+            state = self.pg.encode(question)
+            state_sup, state_nosup = self.pg.select_rows(state, sup_d), self.pg.select_rows(state, nosup_d)
+        elif n_sup:
+            state_sup = self.pg.encode(ques_sup)
+        else:
+            state_nosup = self.pg.encode(question[nosup_d])
+        if n_nosup:
+            ques_nosup = question[nosup_d]
+            out["pg"] = self.pg.decode(state_nosup, None, "sampling")
+            z = out["pg"]["predictions"]
+            out["programs"] = z
+        if n_sup:
+            out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling")["loss"].mean()
+        if n_sup and n_nosup:
+            qr_loss = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling")["loss"]
+            out["qr"], out["qr_sup"] = qr_loss[:n_nosup], qr_loss[n_nosup:].mean()
+        elif n_sup:
+            out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling")["loss"].mean()
+        elif reconstruct:
+            out["qr"] = self.qr(z, ques_nosup, "sampling")["loss"]
+        if n_nosup and prior:
+            with torch.no_grad():  # frozen model whose output only enters the detached reward
+                out["prior"] = self.prior(z)["loss"]
+        return out
 
 
 class QuestionCodingStep(_TrainerBase):
@@ -74,33 +135,19 @@ class QuestionCodingStep(_TrainerBase):
         dev = batch["question"].device
         sup, nosup = _split_supervision(batch["supervision"])
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
+        ours = self.objective == "ours"
+        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=True, sampled=ours, prior=True)
         out: Dict[str, Any] = {}
         loss = torch.zeros((), device=dev)
-        sup_branches = None
-        if sup.numel():
-            # the two teacher-forced passes depend on nothing: side streams, beside the ELBO chain
-            prog, ques = batch["program"].to(dev)[sup_d], batch["question"][sup_d]
-            sup_branches = [
-                BRANCHES.run("sup_pg", dev, lambda: self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean(),
-                             ques, prog),
-                BRANCHES.run("sup_qr", dev, lambda: self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean(),
-                             ques, prog),
-            ]
-        elbo_out = None
-        if self.objective == "ours" and nosup.numel():
-            elbo_out = self.elbo(batch["question"][nosup_d])
-        if sup_branches is not None:
-            BRANCHES.join(dev, sup_branches)
-            pg_loss, qr_loss = sup_branches[0][0], sup_branches[1][0]
+        if "pg_sup" in p:
             w = _dp_weight(sup.numel(), dev)
-            if self.objective == "baseline":
-                loss = loss + w * pg_loss + w * qr_loss
-            else:
-                loss = loss + w * self.alpha * (pg_loss + qr_loss)
-            out["loss"] = {"program_generation_gt": pg_loss.detach(), "question_reconstruction_gt": qr_loss.detach()}
-        if elbo_out is not None:
+            loss = loss + w * (self.alpha if ours else 1.0) * (p["pg_sup"] + p["qr_sup"])
+            out["loss"] = {"program_generation_gt": p["pg_sup"].detach(), "question_reconstruction_gt": p["qr_sup"].detach()}
+        if "pg" in p:
+            elbo_out = self.elbo.combine(p["pg"]["loss"], p["qr"], p["prior"])
             loss = loss - _dp_weight(nosup.numel(), dev) * elbo_out["elbo"]
             out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
+            out["programs"] = p["programs"]
         self._finish(loss)
         out["objective"] = loss.detach()
         return out
@@ -130,26 +177,19 @@ class JointTrainingStep(_TrainerBase):
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
         if nosup.numel() == 0:
             raise ValueError("joint training needs at least one example without program supervision in the batch")
-        sup_branches = None
-        if self.objective == "ours" and sup.numel():
-            prog, ques = batch["program"].to(dev)[sup_d], batch["question"][sup_d]
-            sup_branches = [
-                BRANCHES.run("sup_pg", dev, lambda: self.pg(ques, prog, decoding_strategy="sampling")["loss"].mean(),
-                             ques, prog),
-                BRANCHES.run("sup_qr", dev, lambda: self.qr(prog, ques, decoding_strategy="sampling")["loss"].mean(),
-                             ques, prog),
-            ]
-        elbo_out = self.elbo(batch["question"][nosup_d], batch["image"][nosup_d], batch["answer"][nosup_d])
+        ours = self.objective == "ours"
+        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours)
+        nmn_out = self.nmn(batch["image"][nosup_d], p["programs"], batch["answer"][nosup_d])
+        elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
         nmn_loss = elbo_out.pop("nmn_loss")
         w = _dp_weight(nosup.numel(), dev)
         loss = w * (self.gamma * nmn_loss - elbo_out["elbo"])
-        out: Dict[str, Any] = {"loss": {"nmn": nmn_loss.detach()}, "elbo": {k: v.detach() for k, v in elbo_out.items()}}
-        if sup_branches is not None:
-            BRANCHES.join(dev, sup_branches)
-            pg_loss, qr_loss = sup_branches[0][0], sup_branches[1][0]
-            loss = loss + _dp_weight(sup.numel(), dev) * self.alpha * (pg_loss + qr_loss)
-            out["loss"]["program_generation_gt"] = pg_loss.detach()
-            out["loss"]["question_reconstruction_gt"] = qr_loss.detach()
+        out: Dict[str, Any] = {"loss": {"nmn": nmn_loss.detach()}, "elbo": {k: v.detach() for k, v in elbo_out.items()},
+                               "programs": p["programs"]}
+        if "pg_sup" in p:
+            loss = loss + _dp_weight(sup.numel(), dev) * self.alpha * (p["pg_sup"] + p["qr_sup"])
+            out["loss"]["program_generation_gt"] = p["pg_sup"].detach()
+            out["loss"]["question_reconstruction_gt"] = p["qr_sup"].detach()
         self._finish(loss)
         out["objective"] = loss.detach()
         return out
