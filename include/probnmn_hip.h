@@ -257,9 +257,16 @@ int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, co
  * (one wave-wide operand load = 1 KiB contiguous).
  * ------------------------------------------------------------------------------------------- */
 int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B,
-                      int T, int hidden, void* stream);
+                      int T, int hidden, void* workspace, void* stream);
 int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const float* w_hh_t,
-                      float* dgates, int B, int T, int hidden, void* stream);
+                      float* dgates, int B, int T, int hidden, void* workspace, void* stream);
+/* Multi-CU variants: with a `workspace` of pnmn_lstm_seq_workspace_bytes(B, backward) bytes (device
+ * memory, any contents; 0 bytes = the batch already fills the chip) 4 or 8 workgroups share each
+ * 16-row tile, each holding its slice of W_hh in registers and exchanging the recurrent vector through
+ * L2 once per step.  Every accumulation keeps the operand order of the workspace == NULL kernels (one
+ * workgroup per tile); results agree to the last few ulps (fma contraction of the cell update).  The
+ * kernel needs every workgroup resident at once; the library sizes the grid for that. */
+int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward);
 
 /* ---------------------------------------------------------------------------------------------
  * Persistent attention-LSTM decoder (hidden = 256): the whole decoding loop of

@@ -397,25 +397,326 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------
+// Multi-CU variants.  One workgroup per 16 rows runs at the fp32 matrix rate of ONE CU (13.6 us per step
+// for H = 256) while the other CUs idle whenever the batch has fewer than 16 x 256 rows.  Here S
+// workgroups (S = 4 or 8, all resident at once: the host picks S so that the grid fits the chip) share
+// a row tile: workgroup p owns hidden units [p H/S, (p+1) H/S) for all four gates, keeps ITS slice of
+// W_hh in registers for the whole sequence (64 or 128 VGPRs) and exchanges only the 16 x H recurrent
+// vector with its S-1 partners through L2 once per step:
+//   forward   h_t is written to `hs` anyway; partners read h_{t-1} back from there
+//   backward  dh_{t-1} = dgates_t W_hh is a sum over gate columns: every workgroup produces a 16 x H
+//             partial from its columns, partners add the S slices they own (reduce-scatter through a
+//             double-buffered workspace)
+// Hand-off: stores -> s_waitcnt vmcnt(0) -> barrier -> one agent-scope release increment of the tile's
+// step counter; consumers spin on the counter (bounded: a trap, not a hung GPU, if the partners never
+// show up), one agent-scope acquire, barrier.  The counter is monotonic (S per step), so no reset race.
+// blockIdx -> (tile, p) keeps a tile's workgroups on one XCD (round-robin dispatch: XCD = blockIdx % 8),
+// which makes the exchange an L2 hit; correctness does not depend on that.
+// The operand order of every accumulation is the single-workgroup kernels'; results differ from theirs
+// only by the compiler's fma contraction of the cell update (last ulps), and are run-to-run identical.
+// -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cluster_wait(const int* counter, int target) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 26)) __builtin_trap();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void cluster_signal(int* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int S>
+__global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* __restrict__ xp,
+                                                                   const float* __restrict__ w_hh,
+                                                                   float* hs, float* __restrict__ cs,
+                                                                   float* __restrict__ act, int* sync, int B, int T,
+                                                                   int tiles) {
+    constexpr int UW = LH / S;          // hidden units of this workgroup
+    constexpr int UB = UW / 32;         // 16-unit blocks per wave: waves 2q and 2q+1 split gate q's UW columns
+    constexpr int J = UW * 16 / 512;    // (row, unit) pairs per thread in the cell update
+    constexpr int GLD = UW + 4;
+    __shared__ float gl[4][LROWS][GLD];
+    const int slot = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) + 8 * (slot / S), part = slot % S;
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = tile * LROWS, u0 = part * UW;
+    const int gate = wave >> 1, ub0 = (wave & 1) * UB;
+    int* counter = sync + tile;
+
+    f32x4_ wreg[UB][LH / 16];
+#pragma unroll
+    for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+        for (int kb = 0; kb < LH / 16; ++kb) {
+            const int ntile = gate * (LH / 16) + u0 / 16 + ub0 + ub;
+            wreg[ub][kb] = *reinterpret_cast<const f32x4_*>(w_hh + ((size_t)(ntile * (LH / 16) + kb) * 64 + lane) * 4);
+        }
+    float creg[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) creg[j] = 0.f;
+    const int arow = min(row0 + li, B - 1);  // A-operand row of this lane (clamped: the padding rows' results are dropped)
+
+    for (int t = 0; t < T; ++t) {
+        f32x4_ acc[UB];
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * g + r;
+                const int n = gate * LH + u0 + 16 * (ub0 + ub) + li;
+                acc[ub][r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + n] : 0.f;
+            }
+        if (t > 0) {
+            cluster_wait(counter, S * t);
+            const float* hrow = hs + ((size_t)arow * T + (t - 1)) * LH + 4 * g;
+            f32x4_ a[LH / 16];
+#pragma unroll
+            for (int kb = 0; kb < LH / 16; ++kb) a[kb] = *reinterpret_cast<const f32x4_*>(hrow + kb * 16);
+#pragma unroll
+            for (int kb = 0; kb < LH / 16; ++kb)
+#pragma unroll
+                for (int ub = 0; ub < UB; ++ub) {
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].x, wreg[ub][kb].x, acc[ub], 0, 0, 0);
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].y, wreg[ub][kb].y, acc[ub], 0, 0, 0);
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].z, wreg[ub][kb].z, acc[ub], 0, 0, 0);
+                    acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kb].w, wreg[ub][kb].w, acc[ub], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gl[gate][4 * g + r][16 * (ub0 + ub) + li] = acc[ub][r];
+        __syncthreads();
+        // cell update: thread -> (row, unit) pairs, all four gates of a pair from LDS
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int idx = tid + 512 * j;
+            const int rl = idx / UW, ul = idx % UW;
+            const int row = row0 + rl, u = u0 + ul;
+            const float ig = sigm(gl[0][rl][ul]);
+            const float fg = sigm(gl[1][rl][ul]);
+            const float gg = tanhf(gl[2][rl][ul]);
+            const float og = sigm(gl[3][rl][ul]);
+            const float c = fg * creg[j] + ig * gg;
+            const float h = og * tanhf(c);
+            creg[j] = c;
+            if (row < B) {
+                const size_t o = ((size_t)row * T + t) * LH + u;
+                hs[o] = h;
+                cs[o] = c;
+                if (act) {
+                    float* ar = act + ((size_t)row * T + t) * (4 * LH);
+                    ar[u] = ig;
+                    ar[LH + u] = fg;
+                    ar[2 * LH + u] = gg;
+                    ar[3 * LH + u] = og;
+                }
+            }
+        }
+        if (t + 1 < T) cluster_signal(counter);  // also the barrier that protects gl for the next step
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* __restrict__ dhs,
+                                                                   const float* __restrict__ act,
+                                                                   const float* __restrict__ cs,
+                                                                   const float* __restrict__ w_hh_t,
+                                                                   float* __restrict__ dgates, float* px, int* sync,
+                                                                   int B, int T, int tiles) {
+    constexpr int UW = LH / S;
+    constexpr int KB = 4 * UW / 16;     // k blocks of this workgroup's gate columns
+    constexpr int J = UW * 16 / 512;
+    constexpr int DLD = 4 * UW + 4;
+    __shared__ __attribute__((aligned(16))) float dgl[LROWS][DLD];
+    const int slot = blockIdx.x >> 3;
+    const int tile = (blockIdx.x & 7) + 8 * (slot / S), part = slot % S;
+    if (tile >= tiles) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = tile * LROWS, u0 = part * UW;
+    int* counter = sync + tile;
+    float* ptile = px + (size_t)tile * 2 * S * LROWS * LH;  // [parity][source part][16][H]
+
+    // this wave's two 16-unit output tiles x this workgroup's gate columns, register resident
+    f32x4_ wreg[2][KB];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kl = 0; kl < KB; ++kl) {
+            const int q = kl / (UW / 16), jj = kl % (UW / 16);
+            const int kb = (q * LH + u0) / 16 + jj;
+            wreg[nt][kl] = *reinterpret_cast<const f32x4_*>(w_hh_t + ((size_t)((2 * wave + nt) * (4 * LH / 16) + kb) * 64 + lane) * 4);
+        }
+    float dh_rec[J], dc_rec[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) dh_rec[j] = dc_rec[j] = 0.f;
+
+    for (int t = T - 1; t >= 0; --t) {
+        // everything of step t that does not depend on the recurrence, before the wait
+        float ig[J], fg[J], gg[J], og[J], cc[J], cp[J], dho[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int idx = tid + 512 * j;
+            const int rl = idx / UW, ul = idx % UW;
+            const int row = row0 + rl, u = u0 + ul;
+            ig[j] = fg[j] = gg[j] = og[j] = cc[j] = cp[j] = dho[j] = 0.f;
+            if (row < B) {
+                const size_t o = ((size_t)row * T + t) * LH + u;
+                const float* ar = act + ((size_t)row * T + t) * (4 * LH);
+                ig[j] = ar[u], fg[j] = ar[LH + u], gg[j] = ar[2 * LH + u], og[j] = ar[3 * LH + u];
+                cc[j] = cs[o];
+                cp[j] = t > 0 ? cs[o - LH] : 0.f;
+                dho[j] = dhs[o];
+            }
+        }
+        if (t < T - 1) {
+            cluster_wait(counter, S * (T - 1 - t));
+            const float* pp = ptile + (size_t)((t + 1) & 1) * S * LROWS * LH;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int idx = tid + 512 * j;
+                const int rl = idx / UW, ul = idx % UW;
+                float sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s) sum += pp[((size_t)s * LROWS + rl) * LH + u0 + ul];
+                dh_rec[j] = sum;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int idx = tid + 512 * j;
+            const int rl = idx / UW, ul = idx % UW;
+            const int row = row0 + rl, u = u0 + ul;
+            float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
+            if (row < B) {
+                const float tc = tanhf(cc[j]);
+                const float dh = dho[j] + dh_rec[j];
+                const float dc = dc_rec[j] + dh * og[j] * (1.f - tc * tc);
+                di = dc * gg[j] * ig[j] * (1.f - ig[j]);
+                df = dc * cp[j] * fg[j] * (1.f - fg[j]);
+                dg = dc * ig[j] * (1.f - gg[j] * gg[j]);
+                dout = dh * tc * og[j] * (1.f - og[j]);
+                dcp = dc * fg[j];
+                float* dr = dgates + ((size_t)row * T + t) * (4 * LH);
+                dr[u] = di;
+                dr[LH + u] = df;
+                dr[2 * LH + u] = dg;
+                dr[3 * LH + u] = dout;
+            }
+            dc_rec[j] = dcp;
+            dgl[rl][ul] = di;
+            dgl[rl][UW + ul] = df;
+            dgl[rl][2 * UW + ul] = dg;
+            dgl[rl][3 * UW + ul] = dout;
+        }
+        if (t == 0) break;
+        __syncthreads();
+        f32x4_ acc[2];
+        acc[0] = f32x4_{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kl = 0; kl < KB; ++kl) {
+            const f32x4_ a = *reinterpret_cast<const f32x4_*>(&dgl[li][kl * 16 + 4 * g]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[nt][kl].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[nt][kl].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[nt][kl].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[nt][kl].w, acc[nt], 0, 0, 0);
+            }
+        }
+        float* po = ptile + ((size_t)(t & 1) * S + part) * LROWS * LH;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) po[(size_t)(4 * g + r) * LH + 16 * (2 * wave + nt) + li] = acc[nt][r];
+        cluster_signal(counter);  // also: everyone is done reading dgl
+    }
+}
+
+// S workgroups per row tile such that the whole grid (8 XCD lanes x S x ceil(tiles / 8)) is resident at
+// once with one workgroup per CU; 0 = keep the one-workgroup-per-tile kernels.
+int cluster_split(int tiles) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = -1;
+    }
+    if (cus <= 0) return 0;
+    const int groups = (tiles + 7) / 8;
+    if (8 * groups * 8 <= cus) return 8;
+    if (8 * groups * 4 <= cus) return 4;
+    return 0;
+}
+
+constexpr size_t SYNC_BYTES = 4096;  // step counters of up to 1024 tiles
+
 }  // namespace
 
 extern "C" {
 
+int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward) {
+    const int tiles = (B + LROWS - 1) / LROWS;
+    const int S = cluster_split(tiles);
+    if (S == 0) return 0;
+    return (int64_t)SYNC_BYTES + (backward ? (int64_t)tiles * 2 * S * LROWS * LH * sizeof(float) : 0);
+}
+
 int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B, int T, int hidden,
-                      void* stream) {
+                      void* workspace, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!xp || !w_hh || !hs || !cs) return PNMN_EINVAL;
     if (hidden != LH) return PNMN_ESHAPE;
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3((B + LROWS - 1) / LROWS), dim3(512), 0,
-                       static_cast<hipStream_t>(stream), xp, w_hh, hs, cs, act, B, T);
+    const int tiles = (B + LROWS - 1) / LROWS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int S = workspace ? cluster_split(tiles) : 0;
+    if (S) {
+        hipError_t e = hipMemsetAsync(workspace, 0, SYNC_BYTES, st);
+        if (e != hipSuccess) return (int)e;
+        const dim3 grid(8 * S * ((tiles + 7) / 8));
+        int* sync = static_cast<int*>(workspace);
+        if (S == 8)
+            hipLaunchKernelGGL(lstm_seq_fwd_cluster_kernel<8>, grid, dim3(512), 0, st, xp, w_hh, hs, cs, act, sync, B, T, tiles);
+        else
+            hipLaunchKernelGGL(lstm_seq_fwd_cluster_kernel<4>, grid, dim3(512), 0, st, xp, w_hh, hs, cs, act, sync, B, T, tiles);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(tiles), dim3(512), 0, st, xp, w_hh, hs, cs, act, B, T);
     return (int)hipGetLastError();
 }
 
 int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const float* w_hh_t, float* dgates, int B,
-                      int T, int hidden, void* stream) {
+                      int T, int hidden, void* workspace, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!dhs || !act || !cs || !w_hh_t || !dgates) return PNMN_EINVAL;
     if (hidden != LH) return PNMN_ESHAPE;
+    const int tiles = (B + LROWS - 1) / LROWS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int S = workspace ? cluster_split(tiles) : 0;
+    if (S) {
+        hipError_t e = hipMemsetAsync(workspace, 0, SYNC_BYTES, st);
+        if (e != hipSuccess) return (int)e;
+        const dim3 grid(8 * S * ((tiles + 7) / 8));
+        int* sync = static_cast<int*>(workspace);
+        float* px = reinterpret_cast<float*>(static_cast<char*>(workspace) + SYNC_BYTES);
+        if (S == 8)
+            hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<8>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
+        else
+            hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<4>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
+        return (int)hipGetLastError();
+    }
     constexpr size_t lds = (size_t)LROWS * (4 * LH + 4) * sizeof(float);
     static bool cfg = false;
     if (!cfg) {
@@ -424,8 +725,7 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
         if (e != hipSuccess) return (int)e;
         cfg = true;
     }
-    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3((B + LROWS - 1) / LROWS), dim3(512), lds,
-                       static_cast<hipStream_t>(stream), dhs, act, cs, w_hh_t, dgates, B, T);
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(tiles), dim3(512), lds, st, dhs, act, cs, w_hh_t, dgates, B, T);
     return (int)hipGetLastError();
 }
 

@@ -55,8 +55,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
-    "pnmn_lstm_seq_fwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
-    "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P),
+    "pnmn_lstm_seq_fwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P, _P),
+    "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P, _P),
+    "pnmn_lstm_seq_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P),
     "pnmn_attn_lstm_bwd": (_P,) * 14 + (_I,) * 4 + (_P,),
     "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
@@ -76,7 +77,7 @@ def lib() -> ctypes.CDLL:
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_int64 if name.endswith("_bytes") else ctypes.c_int
             fn.argtypes = list(argtypes)
         _lib = handle
     return _lib

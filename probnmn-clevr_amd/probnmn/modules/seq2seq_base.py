@@ -14,6 +14,7 @@ plain library GEMMs (torch -> hipBLASLt).  Everything that the reference does wi
 loops and ``.cpu()`` round trips (sentence boundaries, trimming at ``@end@``) is vectorised on the
 device: a forward pass performs no host synchronisation.
 """
+import os
 from typing import Dict, Optional
 
 import torch
@@ -69,6 +70,17 @@ def lstm_cell_pointwise(gates, c_prev):
     return _LSTMCellPointwise.apply(gates, c_prev)
 
 
+def _lstm_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor]:
+    """Scratch for the multi-CU LSTM kernels (step counters + the backward's exchange buffer); ``None``
+    when the library keeps one workgroup per row tile (batch large enough to fill the chip, or
+    PNMN_LSTM_CLUSTER=0).  A fresh allocation per launch: the caching allocator orders its reuse on
+    the launch stream."""
+    if os.environ.get("PNMN_LSTM_CLUSTER", "1") == "0":
+        return None
+    n = int(_hip.lib().pnmn_lstm_seq_workspace_bytes(batch, 1 if backward else 0))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
 class _LSTMLayerSeq(torch.autograd.Function):
     """The recurrent half of one LSTM layer over a whole padded sequence, as ONE persistent kernel
     launch (``pnmn_lstm_seq_fwd`` / ``_bwd``): (xp [B,T,4H] = input projection + biases, W_hh) -> all
@@ -85,8 +97,10 @@ class _LSTMLayerSeq(torch.autograd.Function):
         cs = torch.empty_like(hs)
         act = torch.empty_like(xp)
         wp = pack_fragments(w)
+        ws = _lstm_workspace(B, False, xp.device)
         _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), wp.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
-                                                B, T, Hd, _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
+                                                B, T, Hd, ws.data_ptr() if ws is not None else None,
+                                                _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
         ctx.save_for_backward(hs, cs, act, w)
         return hs
 
@@ -97,8 +111,10 @@ class _LSTMLayerSeq(torch.autograd.Function):
         dhs = dhs.contiguous()
         w_t = pack_fragments(w.t())  # W_hh^T [H][4H], fragment order
         dgates = torch.empty_like(act)
+        ws = _lstm_workspace(B, True, hs.device)
         _hip.check(_hip.lib().pnmn_lstm_seq_bwd(dhs.data_ptr(), act.data_ptr(), cs.data_ptr(), w_t.data_ptr(),
-                                                dgates.data_ptr(), B, T, Hd, _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
+                                                dgates.data_ptr(), B, T, Hd, ws.data_ptr() if ws is not None else None,
+                                                _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
         dw_hh = None
         if ctx.needs_input_grad[1]:
             dw_hh = dgates[:, 1:].reshape(-1, 4 * Hd).t() @ hs[:, :-1].reshape(-1, Hd) if T > 1 else torch.zeros_like(w)

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "probnmn_hip.h")
 
 def declared_functions():
     text = open(HEADER).read()
-    return sorted(set(re.findall(r"^int\s+(pnmn_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t)\s+(pnmn_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

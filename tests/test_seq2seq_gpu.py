@@ -256,3 +256,39 @@ def test_decoder_sampling_is_reproducible_and_shard_invariant():
     assert torch.equal(a, b)
     assert torch.equal(a[16:], c)
     assert not torch.isin(a, torch.tensor([1, 2], device=DEV)).any()
+
+
+@pytest.mark.parametrize("batch", [5, 16, 100, 128, 512, 1000, 1024])
+def test_multi_cu_lstm_layer_matches_one_workgroup_per_tile(batch, monkeypatch):
+    """pnmn_lstm_seq_fwd/_bwd with a workspace (4 or 8 workgroups per 16-row tile, W_hh slices in
+    registers, recurrent vector exchanged through L2) against the same entry points without one."""
+    from probnmn.modules.seq2seq_base import _LSTMLayerSeq
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(batch)
+    T, H = 23, 256
+    xp = (torch.randn(batch, T, 4 * H, generator=g) * 0.7).to(dev)
+    w = (torch.randn(4 * H, H, generator=g) * 0.06).to(dev)
+    dhs = torch.randn(batch, T, H, generator=g).to(dev)
+
+    def run():
+        x, ww = xp.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        hs = _LSTMLayerSeq.apply(x, ww)
+        hs.backward(dhs)
+        return hs.detach(), x.grad, ww.grad
+
+    monkeypatch.setenv("PNMN_LSTM_CLUSTER", "0")
+    ref = run()
+    monkeypatch.setenv("PNMN_LSTM_CLUSTER", "1")
+    first = None
+    for _ in range(3):
+        got = run()
+        torch.cuda.synchronize()
+        # same operand order in every accumulation; only the compiler's fma contraction of the cell
+        # update may differ between the two kernels
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+        if first is None:
+            first = got
+        else:  # hand-off races would show up as run-to-run differences
+            assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
