@@ -49,13 +49,17 @@ class ProgramPrior(nn.Module):
         logits = self._output_layer(self._projection_layer(encoded))
         with torch.no_grad():
             probs = F.softmax(logits, dim=-1).clone()
-            probs[:, :, [self._start_index, self._pad_index, self._unk_index]] = 0
+            forbidden = self.__dict__.get("_forbidden")
+            if forbidden is None or forbidden.device != probs.device:
+                forbidden = torch.tensor([self._start_index, self._pad_index, self._unk_index]).to(probs.device)
+                self.__dict__["_forbidden"] = forbidden  # cached: building it costs a host -> device copy
+            probs.index_fill_(2, forbidden, 0.0)
             B, T, V = probs.shape
             predictions = torch.multinomial(probs.view(B * T, V), 1).view(B, T)
             predictions = predictions[:, :-1] * mask[:, 1:]
         loss = sequence_cross_entropy(logits[:, :-1], toks[:, 1:], mask[:, 1:])
         if not self.training:
-            self._log2_perplexity(loss.mean().item())
+            self._log2_perplexity(loss.mean())
         return {"predictions": predictions, "loss": loss}
 
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:

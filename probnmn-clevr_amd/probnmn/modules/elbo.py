@@ -100,7 +100,7 @@ class Reinforce(nn.Module):
             value = 0.0 if self._baseline is None else float(self._baseline)
             self._baseline = torch.full((), value, dtype=reward.dtype, device=reward.device)
         centered = reward - self._baseline
-        stats = torch.stack((centered.sum(), centered.new_tensor(float(centered.numel()))))
+        stats = torch.stack((centered.sum(), torch.full_like(self._baseline, float(centered.numel()))))
         stats = parallel.all_reduce_scalars(stats)
         self._baseline = self._baseline + self._baseline_decay * stats[0] / stats[1]
         return inputs * centered

@@ -70,6 +70,51 @@ def lstm_cell_pointwise(gates, c_prev):
     return _LSTMCellPointwise.apply(gates, c_prev)
 
 
+def wgrad_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a.t() @ b`` for tall operands (a [K, M], b [K, N], K = rows x time steps >> M, N).  A weight
+    gradient has few output tiles (1024 x 256 -> 32 workgroups on 256 CUs) and a very long reduction;
+    splitting K into chunks run as one batched GEMM fills the chip, the partial sums add up after."""
+    K = a.size(0)
+    chunks = min(16, K // 2048)
+    if chunks <= 1 or not (a.is_contiguous() and b.is_contiguous()):
+        return a.t() @ b
+    kc = K // chunks
+    main = kc * chunks
+    out = torch.bmm(a[:main].view(chunks, kc, -1).transpose(1, 2), b[:main].view(chunks, kc, -1)).sum(0)
+    if main < K:
+        out = out + a[main:].t() @ b[main:]
+    return out
+
+
+class _EmbeddingLookup(torch.autograd.Function):
+    """``F.embedding`` whose weight gradient is a (one-hot) GEMM: the vocabularies here have < 100
+    entries, so the scatter-add of B x T rows into them that torch's backward does (sort + segmented
+    reduction, ~0.4 ms per call) is a 96-column GEMM over the same rows."""
+
+    @staticmethod
+    def forward(ctx, weight, tokens, padding_idx):
+        ctx.save_for_backward(tokens)
+        ctx.vocab, ctx.padding_idx = weight.size(0), padding_idx
+        return F.embedding(tokens, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        flat = tokens.reshape(-1)
+        onehot = torch.zeros(flat.numel(), ctx.vocab, dtype=dy.dtype, device=dy.device)
+        onehot.scatter_(1, flat.unsqueeze(1), 1.0)
+        dw = wgrad_gemm(onehot, dy.reshape(flat.numel(), -1).contiguous())
+        if ctx.padding_idx is not None:
+            dw[ctx.padding_idx].zero_()
+        return dw, None, None
+
+
+def embedding_lookup(module: nn.Embedding, tokens: torch.Tensor) -> torch.Tensor:
+    if tokens.device.type != "cuda" or not torch.is_grad_enabled() or not module.weight.requires_grad:
+        return module(tokens)
+    return _EmbeddingLookup.apply(module.weight, tokens, module.padding_idx)
+
+
 def _lstm_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor]:
     """Scratch for the multi-CU LSTM kernels (step counters + the backward's exchange buffer); ``None``
     when the library keeps one workgroup per row tile (batch large enough to fill the chip, or
@@ -117,7 +162,8 @@ class _LSTMLayerSeq(torch.autograd.Function):
                                                 _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
         dw_hh = None
         if ctx.needs_input_grad[1]:
-            dw_hh = dgates[:, 1:].reshape(-1, 4 * Hd).t() @ hs[:, :-1].reshape(-1, Hd) if T > 1 else torch.zeros_like(w)
+            hprev = torch.cat((hs.new_zeros(B, 1, Hd), hs[:, :-1]), 1).reshape(B * T, Hd)  # h_{t-1} per (row, step)
+            dw_hh = wgrad_gemm(dgates.reshape(B * T, 4 * Hd), hprev)
         return dgates, dw_hh
 
 
@@ -181,9 +227,9 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
             denc.data_ptr(), dh0.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)), "attn_lstm_bwd")
         flat = dgates.reshape(B * T, 4 * Hd)
-        dw_c = flat.t() @ cx.reshape(B * T, Hd)
+        dw_c = wgrad_gemm(flat, cx.reshape(B * T, Hd))
         hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1).reshape(B * T, Hd)
-        dw_hh = flat.t() @ hprev
+        dw_hh = wgrad_gemm(flat, hprev)
         dxe = detable = None
         if ctx.mode == 0:
             dxe = dgates
@@ -275,7 +321,7 @@ class _TokenEmbedder(nn.Module):
         return getattr(self, self._key)
 
     def forward(self, tokens):
-        return self.embedding(tokens)
+        return embedding_lookup(self.embedding, tokens)
 
 
 class _Encoder(nn.Module):
@@ -381,7 +427,7 @@ class Seq2SeqBase(nn.Module):
         if fused:
             args = (pad, self._unk_index, bos)
             if tgt is not None:  # teacher forcing: every step's input embedding is known up front
-                xe = F.linear(self._target_embedder(tgt[:, :steps]), w_e, bias)
+                xe = F.linear(embedding_lookup(self._target_embedder, tgt[:, :steps]), w_e, bias)
                 hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
                                                0, steps, seed, self.sample_row_offset, *args)
             else:  # free running: the kernel also picks each step's token
@@ -456,9 +502,9 @@ class Seq2SeqBase(nn.Module):
         # unigram recall: fraction of gold tokens that appear anywhere in the prediction
         hit = (relevant_targets.unsqueeze(2) == pred.unsqueeze(1)).any(2) & mask
         recall = (hit.sum(1).float() / mask.sum(1).clamp(min=1).float()).mean()
-        self._log2_perplexity(ce.mean().item())
-        self._sequence_accuracy(correct.item())
-        self._unigram_recall(recall.item())
+        self._log2_perplexity(ce.mean())
+        self._sequence_accuracy(correct)
+        self._unigram_recall(recall)
 
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:
         if self.training:

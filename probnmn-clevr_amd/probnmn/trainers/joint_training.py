@@ -27,13 +27,14 @@ def _split_supervision(supervision: torch.Tensor):
     return sup_host.nonzero().flatten(), (1 - sup_host).nonzero().flatten()
 
 
-def _dp_weight(n_local: int, device) -> float:
-    """n_local * world / n_global (1.0 in a single process)."""
+def _dp_weight(n_local: int, device):
+    """n_local * world / n_global: 1.0 in a single process, otherwise a 0-dim device tensor (the count
+    is summed over ranks with a collective; reading it back would cost a host sync per loss term)."""
     if parallel.world() == 1:
         return 1.0
-    t = parallel.all_reduce_scalars(torch.tensor([float(n_local)], device=device))
-    total = float(t.item())
-    return n_local * parallel.world() / total if total > 0 else 0.0
+    local = torch.full((), float(n_local), device=device)
+    total = parallel.all_reduce_scalars(local.clone())
+    return torch.where(total > 0, local * parallel.world() / total.clamp(min=1.0), torch.zeros_like(total))
 
 
 def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
@@ -63,8 +64,23 @@ class _TrainerBase:
         self.optimizer.step()
         self.iteration += 1
 
+    def _host_copy(self, tokens: torch.Tensor):
+        """Start the device -> host copy of the sampled programs into a (cached) pinned buffer and
+        return (host tensor, event).  Queued right behind the sampling decode, the copy completes
+        while the GPU works through the passes launched after it, so the host can compile and
+        schedule the NMN launches for the samples without the GPU ever waiting for it."""
+        cache = self.__dict__.setdefault("_pinned_programs", {})
+        key = tuple(tokens.shape)
+        if key not in cache:
+            cache[key] = torch.empty(key, dtype=tokens.dtype, pin_memory=True)
+        host = cache[key]
+        host.copy_(tokens, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return host, event
+
     def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
-                        reconstruct: bool = True):
+                        reconstruct: bool = True, host_programs: bool = False):
         """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
         rows of the reference's separate calls batched into as few recurrent launches as the data
         dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
@@ -100,6 +116,8 @@ class _TrainerBase:
             out["pg"] = self.pg.decode(state_nosup, None, "sampling")
             z = out["pg"]["predictions"]
             out["programs"] = z
+            if host_programs:
+                out["programs_host"] = self._host_copy(z)
         if n_sup:
             out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling")["loss"].mean()
         if n_sup and n_nosup:
@@ -178,8 +196,11 @@ class JointTrainingStep(_TrainerBase):
         if nosup.numel() == 0:
             raise ValueError("joint training needs at least one example without program supervision in the batch")
         ours = self.objective == "ours"
-        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours)
-        nmn_out = self.nmn(batch["image"][nosup_d], p["programs"], batch["answer"][nosup_d])
+        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours,
+                                 host_programs=True)
+        programs_host, copied = p["programs_host"]
+        copied.synchronize()  # waits for the sampling decode only, not for the passes queued after it
+        nmn_out = self.nmn(batch["image"][nosup_d], programs_host, batch["answer"][nosup_d])
         elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
         nmn_loss = elbo_out.pop("nmn_loss")
         w = _dp_weight(nosup.numel(), dev)

@@ -5,16 +5,22 @@ import torch
 
 
 class Average:
+    """Tensor updates are summed on their device and read back only in ``get_metric`` -- an update
+    costs no host synchronisation (the reference's ``.item()`` per update does)."""
+
     def __init__(self):
         self._total = 0.0
         self._count = 0
 
     def __call__(self, value) -> None:
-        self._total += float(value)
+        if isinstance(value, torch.Tensor):
+            self._total = self._total + value.detach().float().sum()
+        else:
+            self._total += float(value)
         self._count += 1
 
     def get_metric(self, reset: bool = False) -> float:
-        value = self._total / self._count if self._count else 0.0
+        value = float(self._total) / self._count if self._count else 0.0
         if reset:
             self.reset()
         return value
@@ -36,11 +42,11 @@ class BooleanAccuracy:
         if mask is not None:
             keep = mask.reshape(mask.size(0), -1).any(dim=1)
             eq = eq[keep]
-        self._correct += float(eq.sum())
+        self._correct = self._correct + eq.sum()  # stays on the device until get_metric
         self._total += float(eq.numel())
 
     def get_metric(self, reset: bool = False) -> float:
-        value = self._correct / self._total if self._total else 0.0
+        value = float(self._correct) / self._total if self._total else 0.0
         if reset:
             self.reset()
         return value
