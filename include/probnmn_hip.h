@@ -291,6 +291,29 @@ int pnmn_attn_lstm_bwd(const float* dhs, const float* act, const float* cs, cons
                        const float* h0, const float* w_c_t, const float* w_hh_t, float* dgates,
                        float* denc, float* dh0, int B, int T, int S, int hidden, void* stream);
 
+/* Multi-CU variants of the two kernels above (decoder_multi.hip): eight workgroups per 16-row tile,
+ * each keeping its rows' encoder outputs in LDS and its slices of W_c / W_hh in registers, two L2
+ * hand-offs per step.  Same arguments and saved tensors, plus a device `workspace` of
+ * pnmn_attn_lstm_multi_workspace_bytes(B, backward) bytes (0 = device too small: use the kernels
+ * above).  Batches beyond what fits the chip at once (512 rows on 256 CUs) run as successive launches.
+ * The backward emits dctx [B,T,H] (gradient wrt every context vector) and dscore [B,T,S] (gradient
+ * wrt the attention scores) instead of accumulating denc; the caller forms
+ *     denc = w^T dctx + dscore^T h_prev      (two GEMMs per row over the T steps, w = masked softmax)
+ * Sums over source positions / gate columns are associated differently from the one-workgroup
+ * kernels: results agree to fp32 round-off, not bit for bit. */
+int64_t pnmn_attn_lstm_multi_workspace_bytes(int B, int backward);
+int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* enc, const float* mask,
+                             const float* h0, const float* w_c, const float* w_hh, const float* w_p,
+                             const float* b_p, float* hs, float* cs, float* act, float* ctx,
+                             float* probs, int64_t* tokens, int B, int T, int S, int V, int hidden,
+                             int sample, int pad_index, int unk_index, int start_index,
+                             uint64_t seed, uint64_t row_offset, void* workspace, void* stream);
+int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs, const float* hs,
+                             const float* probs, const float* enc, const float* mask,
+                             const float* h0, const float* w_c_t, const float* w_hh_t,
+                             float* dgates, float* dctx, float* dscore, float* dh0, int B, int T,
+                             int S, int hidden, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * One decoding step's token choice                                   seq2seq_base.py:203-220
  *   greedy:   tokens[b] = argmax softmax(logits[b])            (first maximum)

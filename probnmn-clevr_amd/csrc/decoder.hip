@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "sampling.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -38,38 +39,9 @@ constexpr int LD = H + 4;
 constexpr int MAXS = 64;   // encoder positions
 constexpr int MAXV = 128;  // sampled vocabulary
 
-__device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-__device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
-    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    ctr[0] = hi1 ^ ctr[1] ^ k0;
-    ctr[1] = lo1;
-    ctr[2] = hi0 ^ ctr[3] ^ k1;
-    ctr[3] = lo0;
-}
-__device__ float philox_uniform(uint64_t seed, uint64_t row, uint32_t step) {  // same stream as pnmn_sample_tokens
-    uint32_t ctr[4] = {(uint32_t)row, (uint32_t)(row >> 32), step, 0x9E3779B9u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(ctr, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return (float)(ctr[0] >> 8) * (1.0f / 16777216.0f);
-}
+using pnmn::sigm;
+using pnmn::wmax;
+using pnmn::wsum;
 
 struct FwdArgs {
     const float* xe;        // [B][T][4H] teacher-forced embedding projection (+biases), or nullptr
@@ -266,61 +238,8 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
                 const int rl = 2 * wave + rr;
                 const int row = row0 + rl;
                 if (row >= a.B) continue;
-                float v[2];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int j = lane + 64 * k;
-                    v[k] = j < V ? logl[rl][j] : -INFINITY;
-                    mx = fmaxf(mx, v[k]);
-                }
-                mx = wmax(mx);
-                int choice;
-                if (a.sample == 2) {
-                    int best = 0x7fffffff;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k)
-                        if (lane + 64 * k < V && v[k] == mx && lane + 64 * k < best) best = lane + 64 * k;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const int other = __shfl_xor(best, o);
-                        best = other < best ? other : best;
-                    }
-                    choice = best;
-                } else {
-                    float se = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) se += (lane + 64 * k < V) ? expf(v[k] - mx) : 0.f;
-                    const float lse = mx + logf(wsum(se));
-                    float w[2], tot = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int j = lane + 64 * k;
-                        const bool ok = j < V && j != a.pad && j != a.unk && j != a.start;
-                        w[k] = ok ? expf(v[k] - lse) : 0.f;
-                        tot += w[k];
-                    }
-                    tot = wsum(tot);
-                    const float target = philox_uniform(a.seed, a.row_offset + (uint64_t)row, (uint32_t)t) * tot;
-                    float before = 0.f;
-                    choice = -1;
-                    int last_ok = -1;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        float inc = w[k];
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const float tt = __shfl_up(inc, o);
-                            if (lane >= o) inc += tt;
-                        }
-                        const unsigned long long hit = __ballot((w[k] > 0.f) && (before + inc > target));
-                        if (choice < 0 && hit) choice = 64 * k + (int)__ffsll((long long)hit) - 1;
-                        const unsigned long long pos = __ballot(w[k] > 0.f);
-                        if (pos) last_ok = 64 * k + 63 - __clzll((long long)pos);
-                        before += __shfl(inc, 63);
-                    }
-                    if (choice < 0) choice = last_ok;
-                }
+                const int choice = pnmn::choose_row_token(logl[rl], V, a.sample, a.pad, a.unk, a.start, a.seed,
+                                                          a.row_offset + (uint64_t)row, (uint32_t)t);
                 if (lane == 0) {
                     tokl[rl] = choice;
                     a.tokens[(size_t)row * T + t] = choice;

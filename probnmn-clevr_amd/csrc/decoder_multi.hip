@@ -1,0 +1,547 @@
+// Multi-CU attention-LSTM decoder for gfx950: eight workgroups per 16-row tile.
+//
+// decoder.hip gives one workgroup 16 rows for all steps; a step then costs ~27 us of fp32 MFMA on ONE
+// CU plus ~40 us of attention (two rows per wave, encoder rows fetched from L2 twice), while the CUs
+// that hold no tile idle -- 8 of 256 busy at 128 rows, 32 at 512.  Here a tile is shared by EIGHT
+// workgroups that step in lockstep (cluster.h), member p owning
+//     attention   rows 2p, 2p+1 of the tile: their encoder outputs (S x 256 floats each) stay in LDS
+//                 for the whole sequence, four waves per row split the source positions
+//     gates/cell  hidden units [32p, 32p+32) of all four gates: its slices of W_c and W_hh (2 x 16
+//                 fragments = 128 VGPRs per lane) stay in registers for the whole sequence
+// and two hand-offs per step: the context rows (all-gather through the saved `ctx` tensor), then the
+// new hidden state (all-gather through the saved `hs` tensor) -- both tensors are outputs anyway, so
+// the exchange costs no extra traffic.  In sampling mode every member computes the 16 x V logits tile
+// from the gathered h_t and draws all 16 tokens itself (the Philox stream is keyed by the global row
+// and step), so tokens need no exchange.
+//
+// Backward: member p owns the same units for the cell backward and produces, from its 128 gate
+// columns, 16 x 256 PARTIAL sums of dctx = dgates W_c and dh = dgates W_hh (K split eight ways);
+// hand-off A; the row owners add the eight partials of their two rows, run the attention backward
+// against the LDS-resident encoder rows and publish the rows' complete dh_{t-1}; hand-off B.
+// The encoder-output gradient is NOT accumulated here: the kernel emits dctx [B,T,H] and dscore
+// [B,T,S] and the caller forms denc = w^T dctx + dscore^T h_prev as two batched GEMMs over time
+// (the one-workgroup kernel's per-step read-modify-write of denc is the largest part of its step).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/probnmn_hip.h"
+#include "cluster.h"
+#include "sampling.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+using pnmn::cluster_signal;
+using pnmn::cluster_wait;
+using pnmn::sigm;
+using pnmn::wmax;
+using pnmn::wsum;
+
+constexpr int H = 256;
+constexpr int G4 = 4 * H;
+constexpr int ROWS = 16;
+constexpr int MEMBERS = 8;
+constexpr int RW = ROWS / MEMBERS;   // attention rows per member
+constexpr int UW = H / MEMBERS;      // hidden units per member
+constexpr int GLD = UW + 4;
+constexpr int MAXS = 64;
+constexpr int MAXV = 128;
+
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+struct MFwdArgs {
+    const float* xe;
+    const float* etable;
+    const float* enc;
+    const float* mask;
+    const float* h0;
+    const float* w_c;     // fragment-packed [4H/16][H/16][64][4]
+    const float* w_hh;
+    const float* w_p;     // [V][H] row major
+    const float* b_p;
+    float* hs;
+    float* cs;
+    float* act;
+    float* ctx;
+    float* probs;
+    int64_t* tokens;
+    int* sync;
+    int B, T, S, V, tiles;
+    int sample;
+    int pad, unk, start;
+    uint64_t seed, row_offset;
+};
+
+constexpr size_t FWD_FIXED_LDS = sizeof(float) * (4 * ROWS * GLD + RW * 4 * H + ROWS * MAXV + RW * MAXS) + sizeof(int) * ROWS;
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_multi_kernel(const MFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char raw[];
+    const int T = a.T, S = a.S;
+    float* encl = reinterpret_cast<float*>(raw);                                       // [RW][S][H]
+    float (*gl)[ROWS][GLD] = reinterpret_cast<float (*)[ROWS][GLD]>(encl + RW * S * H);  // [4][16][36]
+    float (*cpart)[4][H] = reinterpret_cast<float (*)[4][H]>(&gl[4][0][0]);            // [RW][4][H]
+    float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]
+    float (*scl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&logl[ROWS][0]);            // [RW][64]
+    int* tokl = reinterpret_cast<int*>(&scl[RW][0]);                                   // [16]
+
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile >= a.tiles) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
+    int* counter = a.sync + tile;
+    int handoffs = 0;
+
+    for (int i = tid; i < RW * S * (H / 4); i += 512) {
+        const int rl = i / (S * (H / 4)), rem = i - rl * S * (H / 4);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (myrow0 + rl < a.B) v = *reinterpret_cast<const f32x4*>(a.enc + (size_t)(myrow0 + rl) * S * H + 4 * rem);
+        *reinterpret_cast<f32x4*>(encl + (size_t)rl * S * H + 4 * rem) = v;
+    }
+    // this wave's gate tile: gate q = wave / 2, units u0 + 16 * (wave % 2) .. + 15
+    const int gate = wave >> 1, ub = wave & 1;
+    f32x4 wc[H / 16], wh[H / 16];
+    {
+        const int ntile = gate * (H / 16) + u0 / 16 + ub;
+#pragma unroll
+        for (int kb = 0; kb < H / 16; ++kb) {
+            const size_t fo = ((size_t)(ntile * (H / 16) + kb) * 64 + lane) * 4;
+            wc[kb] = *reinterpret_cast<const f32x4*>(a.w_c + fo);
+            wh[kb] = *reinterpret_cast<const f32x4*>(a.w_hh + fo);
+        }
+    }
+    if (tid < ROWS) tokl[tid] = a.start;
+    float creg = 0.f;                       // cell state of (row tid / 32, unit u0 + tid % 32)
+    const int arow = min(row0 + li, a.B - 1);  // A-operand row (padding rows read a real row; results dropped)
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        // ---------------- attention for my rows: four waves per row split the source positions ----------------
+        {
+            const int rl = wave >> 2, q = wave & 3;
+            const int row = myrow0 + rl, rowc = min(row, a.B - 1);
+            const float* hp = t > 0 ? a.hs + ((size_t)rowc * T + (t - 1)) * H : a.h0 + (size_t)rowc * H;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 4 * lane);
+            const float* er = encl + (size_t)rl * S * H + 4 * lane;
+            for (int s = q; s < S; s += 4) {
+                const float p = wsum(dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), hv));
+                if (lane == 0) scl[rl][s] = p;
+            }
+            __syncthreads();
+            if (q == 0) {
+                const float m = lane < S ? a.mask[(size_t)rowc * S + lane] : 0.f;
+                const float v = (lane < S ? scl[rl][lane] : 0.f) * m;  // allennlp masked_softmax: softmax(vector * mask) ...
+                const float mx = wmax(lane < S ? v : -INFINITY);
+                const float ex = lane < S ? expf(v - mx) : 0.f;
+                const float p = ex / wsum(ex);
+                const float qv = p * m;                                 // ... * mask, renormalised with 1e-13
+                const float wgt = qv / (wsum(qv) + 1e-13f);
+                if (lane < S) {
+                    scl[rl][lane] = wgt;
+                    if (row < a.B) a.probs[((size_t)row * T + t) * S + lane] = p;
+                }
+            }
+            __syncthreads();
+            f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = q; s < S; s += 4) c4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * scl[rl][s];
+            *reinterpret_cast<f32x4*>(&cpart[rl][q][4 * lane]) = c4;
+            __syncthreads();
+            const int rl2 = tid >> 8, k = tid & 255;
+            const float cv = (cpart[rl2][0][k] + cpart[rl2][1][k]) + (cpart[rl2][2][k] + cpart[rl2][3][k]);
+            if (myrow0 + rl2 < a.B) a.ctx[((size_t)(myrow0 + rl2) * T + t) * H + k] = cv;
+        }
+        cluster_signal(counter);
+        cluster_wait(counter, MEMBERS * ++handoffs);
+
+        // ---------------- gates of my units on the matrix cores ----------------
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rl = 4 * g + r, row = row0 + rl;
+            const int n = gate * H + u0 + 16 * ub + li;
+            float v = 0.f;
+            if (row < a.B) v = a.sample ? a.etable[(size_t)tokl[rl] * G4 + n] : a.xe[((size_t)row * T + t) * G4 + n];
+            acc[r] = v;
+        }
+        {
+            const float* cp = a.ctx + ((size_t)arow * T + t) * H + 4 * g;
+            const float* hp = (t > 0 ? a.hs + ((size_t)arow * T + (t - 1)) * H : a.h0 + (size_t)arow * H) + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < H / 16; ++kb) {  // (fully unrolled: wc / wh are register arrays)
+                const f32x4 ac = *reinterpret_cast<const f32x4*>(cp + kb * 16);
+                const f32x4 ah = *reinterpret_cast<const f32x4*>(hp + kb * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, wc[kb].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, wc[kb].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.z, wc[kb].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.w, wc[kb].w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.x, wh[kb].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.y, wh[kb].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.z, wh[kb].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.w, wh[kb].w, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gl[gate][4 * g + r][16 * ub + li] = acc[r];
+        __syncthreads();
+        // ---------------- cell: thread -> (row, unit) ----------------
+        {
+            const int rl = tid >> 5, ul = tid & 31;
+            const int row = row0 + rl, u = u0 + ul;
+            const float ig = sigm(gl[0][rl][ul]), fg = sigm(gl[1][rl][ul]);
+            const float gg = tanhf(gl[2][rl][ul]), og = sigm(gl[3][rl][ul]);
+            const float c = fg * creg + ig * gg;
+            const float h = og * tanhf(c);
+            creg = c;
+            if (row < a.B) {
+                const size_t o = ((size_t)row * T + t) * H + u;
+                a.hs[o] = h;
+                a.cs[o] = c;
+                float* ar = a.act + ((size_t)row * T + t) * G4;
+                ar[u] = ig;
+                ar[H + u] = fg;
+                ar[2 * H + u] = gg;
+                ar[3 * H + u] = og;
+            }
+        }
+        if (t + 1 == T && !a.sample) break;  // nobody needs h_T
+        cluster_signal(counter);
+        cluster_wait(counter, MEMBERS * ++handoffs);
+
+        // ---------------- token choice for the next step (every member, all 16 rows) ----------------
+        if (a.sample) {
+            const int V = a.V;
+            if (16 * wave < V) {
+                f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int vn = 16 * wave + li;
+                const bool vok = vn < V;
+                const float* hp = a.hs + ((size_t)arow * T + t) * H + 4 * g;
+#pragma unroll 4
+                for (int kb = 0; kb < H / 16; ++kb) {
+                    const f32x4 ah = *reinterpret_cast<const f32x4*>(hp + kb * 16);
+                    f32x4 bp = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (vok) bp = *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.x, bp.x, lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.y, bp.y, lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.z, bp.z, lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.w, bp.w, lacc, 0, 0, 0);
+                }
+                const float bias = vok ? a.b_p[vn] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) logl[4 * g + r][vn < MAXV ? vn : 0] = vok ? lacc[r] + bias : -INFINITY;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int rl = 2 * wave + rr;
+                const int row = row0 + rl;
+                if (row >= a.B) continue;
+                const int choice = pnmn::choose_row_token(logl[rl], V, a.sample, a.pad, a.unk, a.start, a.seed,
+                                                          a.row_offset + (uint64_t)row, (uint32_t)t);
+                if (lane == 0) {
+                    tokl[rl] = choice;
+                    if (part == 0) a.tokens[(size_t)row * T + t] = choice;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct MBwdArgs {
+    const float* dhs;
+    const float* act;
+    const float* cs;
+    const float* hs;
+    const float* probs;
+    const float* enc;
+    const float* mask;
+    const float* h0;
+    const float* w_c_t;   // fragment-packed [H/16][4H/16][64][4]
+    const float* w_hh_t;
+    float* dgates;        // [B][T][4H]
+    float* dctx;          // [B][T][H]
+    float* dscore;        // [B][T][S]
+    float* dh0;           // [B][H]
+    float* x1;            // [tiles][2][MEMBERS][2][16][H]   partial dctx / dh of every member
+    float* x2;            // [tiles][2][16][H]               complete dh_{t-1} rows
+    int* sync;
+    int B, T, S, tiles;
+};
+
+constexpr int DLD = 4 * UW + 4;
+constexpr size_t BWD_FIXED_LDS = sizeof(float) * (ROWS * DLD + 2 * RW * H + 2 * RW * MAXS + RW * 4 * H);
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_bwd_multi_kernel(const MBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char raw[];
+    const int T = a.T, S = a.S;
+    float* encl = reinterpret_cast<float*>(raw);                                        // [RW][S][H]
+    float (*dgl)[DLD] = reinterpret_cast<float (*)[DLD]>(encl + RW * S * H);             // [16][132]
+    float (*dctxl)[H] = reinterpret_cast<float (*)[H]>(&dgl[ROWS][0]);                   // [RW][H]
+    float (*dhl)[H] = dctxl + RW;                                                        // [RW][H]
+    float (*dwl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&dhl[RW][0]);                 // [RW][64] d weights -> d scores
+    float (*dhpart)[4][H] = reinterpret_cast<float (*)[4][H]>(&dwl[2 * RW][0]);          // [RW][4][H]
+
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile >= a.tiles) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
+    int* counter = a.sync + tile;
+    int handoffs = 0;
+    float* x1t = a.x1 + (size_t)tile * 2 * MEMBERS * 2 * ROWS * H;
+    float* x2t = a.x2 + (size_t)tile * 2 * ROWS * H;
+
+    for (int i = tid; i < RW * S * (H / 4); i += 512) {
+        const int rl = i / (S * (H / 4)), rem = i - rl * S * (H / 4);
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (myrow0 + rl < a.B) v = *reinterpret_cast<const f32x4*>(a.enc + (size_t)(myrow0 + rl) * S * H + 4 * rem);
+        *reinterpret_cast<f32x4*>(encl + (size_t)rl * S * H + 4 * rem) = v;
+    }
+    // this wave's output tiles (units 32 * wave .. + 31 of all 256) x my 128 gate columns, both matrices
+    constexpr int KB = 4 * UW / 16;  // 8
+    f32x4 wc[2][KB], wh[2][KB];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kl = 0; kl < KB; ++kl) {
+            const int q = kl / (UW / 16), jj = kl % (UW / 16);
+            const int kb = (q * H + u0) / 16 + jj;
+            const size_t fo = ((size_t)((2 * wave + nt) * (G4 / 16) + kb) * 64 + lane) * 4;
+            wc[nt][kl] = *reinterpret_cast<const f32x4*>(a.w_c_t + fo);
+            wh[nt][kl] = *reinterpret_cast<const f32x4*>(a.w_hh_t + fo);
+        }
+    float dc_rec = 0.f;
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        // ---------------- cell backward of my units: thread -> (row, unit) ----------------
+        {
+            const int rl = tid >> 5, ul = tid & 31;
+            const int row = row0 + rl, u = u0 + ul;
+            float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
+            if (row < a.B) {
+                const size_t o = ((size_t)row * T + t) * H + u;
+                const float* ar = a.act + ((size_t)row * T + t) * G4;
+                const float ig = ar[u], fg = ar[H + u], gg = ar[2 * H + u], og = ar[3 * H + u];
+                const float c = a.cs[o];
+                const float cp = t > 0 ? a.cs[o - H] : 0.f;
+                const float tc = tanhf(c);
+                const float dhp = t < T - 1 ? x2t[((size_t)((t + 1) & 1) * ROWS + rl) * H + u] : 0.f;
+                const float dh = a.dhs[o] + dhp;
+                const float dc = dc_rec + dh * og * (1.f - tc * tc);
+                di = dc * gg * ig * (1.f - ig);
+                df = dc * cp * fg * (1.f - fg);
+                dg = dc * ig * (1.f - gg * gg);
+                dout = dh * tc * og * (1.f - og);
+                dcp = dc * fg;
+                float* dr = a.dgates + ((size_t)row * T + t) * G4;
+                dr[u] = di;
+                dr[H + u] = df;
+                dr[2 * H + u] = dg;
+                dr[3 * H + u] = dout;
+            }
+            dc_rec = dcp;
+            dgl[rl][ul] = di;
+            dgl[rl][UW + ul] = df;
+            dgl[rl][2 * UW + ul] = dg;
+            dgl[rl][3 * UW + ul] = dout;
+        }
+        __syncthreads();
+        // ---------------- partial dctx / dh from my gate columns ----------------
+        {
+            f32x4 accc[2], acch[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) accc[nt] = acch[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kl = 0; kl < KB; ++kl) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&dgl[li][kl * 16 + 4 * g]);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[nt][kl].x, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[nt][kl].y, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[nt][kl].z, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[nt][kl].w, accc[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wh[nt][kl].x, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wh[nt][kl].y, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wh[nt][kl].z, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wh[nt][kl].w, acch[nt], 0, 0, 0);
+                }
+            }
+            float* pc = x1t + (((size_t)(t & 1) * MEMBERS + part) * 2 + 0) * ROWS * H;
+            float* ph = pc + ROWS * H;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = (size_t)(4 * g + r) * H + 16 * (2 * wave + nt) + li;
+                    pc[o] = accc[nt][r];
+                    ph[o] = acch[nt][r];
+                }
+        }
+        cluster_signal(counter);
+        cluster_wait(counter, MEMBERS * ++handoffs);
+
+        // ---------------- my rows: gather the partials, attention backward ----------------
+        {
+            const int rl2 = tid >> 8, k = tid & 255;
+            const float* src = x1t + (size_t)(t & 1) * MEMBERS * 2 * ROWS * H + (size_t)(RW * part + rl2) * H + k;
+            float sc = 0.f, sh = 0.f;
+#pragma unroll
+            for (int s = 0; s < MEMBERS; ++s) {
+                sc += src[(size_t)(2 * s) * ROWS * H];
+                sh += src[(size_t)(2 * s + 1) * ROWS * H];
+            }
+            dctxl[rl2][k] = sc;
+            dhl[rl2][k] = sh;
+            if (myrow0 + rl2 < a.B) a.dctx[((size_t)(myrow0 + rl2) * T + t) * H + k] = sc;
+        }
+        __syncthreads();
+        {
+            const int rl = wave >> 2, q = wave & 3;
+            const int row = myrow0 + rl, rowc = min(row, a.B - 1);
+            const float* er = encl + (size_t)rl * S * H + 4 * lane;
+            const f32x4 dc4 = *reinterpret_cast<const f32x4*>(&dctxl[rl][4 * lane]);
+            for (int s = q; s < S; s += 4) {
+                const float d = wsum(dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4));
+                if (lane == 0) dwl[rl][s] = d;
+            }
+            __syncthreads();
+            if (q == 0) {
+                // forward quantities of this (row, step): p (softmax before masking), mask, q, Z
+                const float m = lane < S ? a.mask[(size_t)rowc * S + lane] : 0.f;
+                const float p = lane < S ? a.probs[((size_t)rowc * T + t) * S + lane] : 0.f;
+                const float qv = p * m;
+                const float Z = wsum(qv) + 1e-13f;
+                const float dw = lane < S ? dwl[rl][lane] : 0.f;
+                // w = q / Z ; q = p * mask ; p = softmax(score * mask)
+                const float dq = dw / Z - wsum(dw * qv) / (Z * Z);
+                const float dp = dq * m;
+                const float dv = p * (dp - wsum(dp * p));
+                const float dscore = dv * m;
+                if (lane < S) {
+                    dwl[rl][lane] = dscore;
+                    if (row < a.B) a.dscore[((size_t)row * T + t) * S + lane] = dscore;
+                }
+            }
+            __syncthreads();
+            f32x4 dh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = q; s < S; s += 4) dh4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * dwl[rl][s];
+            *reinterpret_cast<f32x4*>(&dhpart[rl][q][4 * lane]) = dh4;
+        }
+        __syncthreads();
+        {
+            const int rl2 = tid >> 8, k = tid & 255;
+            const float v = dhl[rl2][k] + ((dhpart[rl2][0][k] + dhpart[rl2][1][k]) + (dhpart[rl2][2][k] + dhpart[rl2][3][k]));
+            if (t > 0)
+                x2t[((size_t)(t & 1) * ROWS + RW * part + rl2) * H + k] = v;
+            else if (myrow0 + rl2 < a.B)
+                a.dh0[(size_t)(myrow0 + rl2) * H + k] = v;
+        }
+        if (t == 0) break;
+        cluster_signal(counter);
+        cluster_wait(counter, MEMBERS * ++handoffs);
+    }
+}
+
+// rows one launch can take: all tiles x 8 members resident, one workgroup per CU
+int rows_per_launch() {
+    const int cus = pnmn::device_cus();
+    return cus >= 8 * MEMBERS ? (cus / (8 * MEMBERS)) * 8 * ROWS : 0;
+}
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pnmn_attn_lstm_multi_workspace_bytes(int B, int backward) {
+    const int chunk = rows_per_launch();
+    if (chunk <= 0 || B <= 0) return 0;
+    const int tiles = ((B < chunk ? B : chunk) + ROWS - 1) / ROWS;
+    int64_t n = (int64_t)pnmn::CLUSTER_SYNC_BYTES;
+    if (backward) n += (int64_t)tiles * (2 * MEMBERS * 2 + 2) * ROWS * H * sizeof(float);
+    return n;
+}
+
+int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* enc, const float* mask, const float* h0,
+                             const float* w_c, const float* w_hh, const float* w_p, const float* b_p, float* hs, float* cs,
+                             float* act, float* ctx, float* probs, int64_t* tokens, int B, int T, int S, int V, int hidden,
+                             int sample, int pad_index, int unk_index, int start_index, uint64_t seed, uint64_t row_offset,
+                             void* workspace, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!enc || !mask || !h0 || !w_c || !w_hh || !hs || !cs || !act || !ctx || !probs || !workspace) return PNMN_EINVAL;
+    if (sample ? (!etable || !w_p || !b_p || !tokens) : !xe) return PNMN_EINVAL;
+    if (hidden != H || S < 1 || S > MAXS || (sample && (V < 1 || V > MAXV))) return PNMN_ESHAPE;
+    const int chunk = rows_per_launch();
+    if (chunk <= 0) return PNMN_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        hipError_t e = allow_lds(attn_lstm_fwd_multi_kernel, lds);
+        if (e != hipSuccess) return (int)e;
+        allowed = lds;
+    }
+    for (int r0 = 0; r0 < B; r0 += chunk) {
+        const int rows = B - r0 < chunk ? B - r0 : chunk;
+        const int tiles = (rows + ROWS - 1) / ROWS;
+        hipError_t e = hipMemsetAsync(workspace, 0, pnmn::CLUSTER_SYNC_BYTES, st);
+        if (e != hipSuccess) return (int)e;
+        const size_t r = (size_t)r0;
+        MFwdArgs a{xe ? xe + r * T * G4 : nullptr, etable, enc + r * S * H, mask + r * S, h0 + r * H, w_c, w_hh, w_p, b_p,
+                   hs + r * T * H, cs + r * T * H, act + r * T * G4, ctx + r * T * H, probs + r * T * S,
+                   tokens ? tokens + r * T : nullptr, static_cast<int*>(workspace), rows, T, S, V, tiles, sample,
+                   pad_index, unk_index, start_index, seed, row_offset + r};
+        hipLaunchKernelGGL(attn_lstm_fwd_multi_kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs, const float* hs, const float* probs,
+                             const float* enc, const float* mask, const float* h0, const float* w_c_t,
+                             const float* w_hh_t, float* dgates, float* dctx, float* dscore, float* dh0, int B, int T,
+                             int S, int hidden, void* workspace, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!dhs || !act || !cs || !hs || !probs || !enc || !mask || !h0 || !w_c_t || !w_hh_t || !dgates || !dctx ||
+        !dscore || !dh0 || !workspace)
+        return PNMN_EINVAL;
+    if (hidden != H || S < 1 || S > MAXS) return PNMN_ESHAPE;
+    const int chunk = rows_per_launch();
+    if (chunk <= 0) return PNMN_ESHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = BWD_FIXED_LDS + sizeof(float) * RW * S * H;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        hipError_t e = allow_lds(attn_lstm_bwd_multi_kernel, lds);
+        if (e != hipSuccess) return (int)e;
+        allowed = lds;
+    }
+    char* ws = static_cast<char*>(workspace);
+    float* x1 = reinterpret_cast<float*>(ws + pnmn::CLUSTER_SYNC_BYTES);
+    const int max_tiles = chunk / ROWS;
+    float* x2 = x1 + (size_t)((B < chunk ? (B + ROWS - 1) / ROWS : max_tiles)) * 2 * MEMBERS * 2 * ROWS * H;
+    for (int r0 = 0; r0 < B; r0 += chunk) {
+        const int rows = B - r0 < chunk ? B - r0 : chunk;
+        const int tiles = (rows + ROWS - 1) / ROWS;
+        hipError_t e = hipMemsetAsync(workspace, 0, pnmn::CLUSTER_SYNC_BYTES, st);
+        if (e != hipSuccess) return (int)e;
+        const size_t r = (size_t)r0;
+        MBwdArgs a{dhs + r * T * H, act + r * T * G4, cs + r * T * H, hs + r * T * H, probs + r * T * S, enc + r * S * H,
+                   mask + r * S, h0 + r * H, w_c_t, w_hh_t, dgates + r * T * G4, dctx + r * T * H, dscore + r * T * S,
+                   dh0 + r * H, x1, x2, static_cast<int*>(workspace), rows, T, S, tiles};
+        hipLaunchKernelGGL(attn_lstm_bwd_multi_kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "cluster.h"
 
 namespace {
 
@@ -417,23 +418,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
 // The operand order of every accumulation is the single-workgroup kernels'; results differ from theirs
 // only by the compiler's fma contraction of the cell update (last ulps), and are run-to-run identical.
 // -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cluster_wait(const int* counter, int target) {
-    if (threadIdx.x == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 26)) __builtin_trap();
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void cluster_signal(int* counter) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
+using pnmn::cluster_signal;
+using pnmn::cluster_wait;
 
 template <int S>
 __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* __restrict__ xp,
@@ -446,8 +432,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
     constexpr int J = UW * 16 / 512;    // (row, unit) pairs per thread in the cell update
     constexpr int GLD = UW + 4;
     __shared__ float gl[4][LROWS][GLD];
-    const int slot = blockIdx.x >> 3;
-    const int tile = (blockIdx.x & 7) + 8 * (slot / S), part = slot % S;
+    int tile, part;
+    pnmn::cluster_coords<S>(tile, part);
     if (tile >= tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * LROWS, u0 = part * UW;
@@ -540,8 +526,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
     constexpr int J = UW * 16 / 512;
     constexpr int DLD = 4 * UW + 4;
     __shared__ __attribute__((aligned(16))) float dgl[LROWS][DLD];
-    const int slot = blockIdx.x >> 3;
-    const int tile = (blockIdx.x & 7) + 8 * (slot / S), part = slot % S;
+    int tile, part;
+    pnmn::cluster_coords<S>(tile, part);
     if (tile >= tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * LROWS, u0 = part * UW;
@@ -645,23 +631,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
     }
 }
 
-// S workgroups per row tile such that the whole grid (8 XCD lanes x S x ceil(tiles / 8)) is resident at
-// once with one workgroup per CU; 0 = keep the one-workgroup-per-tile kernels.
-int cluster_split(int tiles) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = -1;
-    }
-    if (cus <= 0) return 0;
-    const int groups = (tiles + 7) / 8;
-    if (8 * groups * 8 <= cus) return 8;
-    if (8 * groups * 4 <= cus) return 4;
-    return 0;
-}
-
-constexpr size_t SYNC_BYTES = 4096;  // step counters of up to 1024 tiles
+using pnmn::cluster_split;
+constexpr size_t SYNC_BYTES = pnmn::CLUSTER_SYNC_BYTES;
 
 }  // namespace
 

@@ -126,6 +126,15 @@ def _lstm_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor
     return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
 
 
+def _decoder_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor]:
+    """Scratch of the multi-CU decoder kernels; ``None`` = use the one-workgroup-per-tile kernels
+    (PNMN_DECODER_CLUSTER=0, or a device too small for eight resident workgroups per tile)."""
+    if os.environ.get("PNMN_DECODER_CLUSTER", "1") == "0":
+        return None
+    n = int(_hip.lib().pnmn_attn_lstm_multi_workspace_bytes(batch, 1 if backward else 0))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
 class _LSTMLayerSeq(torch.autograd.Function):
     """The recurrent half of one LSTM layer over a whole padded sequence, as ONE persistent kernel
     launch (``pnmn_lstm_seq_fwd`` / ``_bwd``): (xp [B,T,4H] = input projection + biases, W_hh) -> all
@@ -197,12 +206,15 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         else:
             xe = xe.contiguous()
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        _hip.check(_hip.lib().pnmn_attn_lstm_fwd(
-            ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
-            h0.data_ptr(), w_c_p.data_ptr(), w_hh_p.data_ptr(), ptr(w_p if mode != 0 else None),
-            ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
-            probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset,
-            _hip.stream_ptr(dev)), "attn_lstm_fwd")
+        args = (ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
+                h0.data_ptr(), w_c_p.data_ptr(), w_hh_p.data_ptr(), ptr(w_p if mode != 0 else None),
+                ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
+                probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset)
+        ws = _decoder_workspace(B, False, dev)
+        if ws is not None:
+            _hip.check(_hip.lib().pnmn_attn_lstm_fwd_multi(*args, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_fwd_multi")
+        else:
+            _hip.check(_hip.lib().pnmn_attn_lstm_fwd(*args, _hip.stream_ptr(dev)), "attn_lstm_fwd")
         ctx.save_for_backward(hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh,
                               tokens if tokens is not None else torch.empty(0, device=dev))
         ctx.mode, ctx.start, ctx.vocab = mode, start, (etable.size(0) if mode != 0 else 0)
@@ -218,18 +230,31 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         S = enc.size(1)
         dev = hs.device
         dgates = torch.empty_like(act)
-        denc = torch.zeros_like(enc)
         dh0 = torch.empty_like(h0)
         # (named temporaries: a tensor that dies right after .data_ptr() may be recycled by the next allocation)
         dhs_c, w_c_t, w_hh_t = dhs.contiguous(), pack_fragments(w_c.t()), pack_fragments(w_hh.t())
-        _hip.check(_hip.lib().pnmn_attn_lstm_bwd(
-            dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), cx.data_ptr(), probs.data_ptr(),
-            enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
-            denc.data_ptr(), dh0.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)), "attn_lstm_bwd")
+        hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1)  # h_{t-1} of every (row, step)
+        ws = _decoder_workspace(B, True, dev)
+        if ws is not None:
+            dctx, dscore = torch.empty_like(hs), torch.empty_like(probs)
+            _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi(
+                dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), probs.data_ptr(), enc.data_ptr(),
+                mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(), dctx.data_ptr(),
+                dscore.data_ptr(), dh0.data_ptr(), B, T, S, Hd, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_bwd_multi")
+            # encoder-output gradient as two GEMMs per row over the T steps: enc_s enters step t through
+            # the context (weight w_ts) and through the score (gradient dscore_ts, times h_{t-1})
+            q = probs * mask.unsqueeze(1)
+            weights = q / (q.sum(-1, keepdim=True) + 1e-13)
+            denc = torch.baddbmm(torch.bmm(weights.transpose(1, 2), dctx), dscore.transpose(1, 2), hprev)
+        else:
+            denc = torch.zeros_like(enc)
+            _hip.check(_hip.lib().pnmn_attn_lstm_bwd(
+                dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), cx.data_ptr(), probs.data_ptr(),
+                enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
+                denc.data_ptr(), dh0.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)), "attn_lstm_bwd")
         flat = dgates.reshape(B * T, 4 * Hd)
         dw_c = wgrad_gemm(flat, cx.reshape(B * T, Hd))
-        hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1).reshape(B * T, Hd)
-        dw_hh = wgrad_gemm(flat, hprev)
+        dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
         dxe = detable = None
         if ctx.mode == 0:
             dxe = dgates

@@ -196,12 +196,14 @@ def test_persistent_lstm_layer_matches_nn_lstm():
     torch.testing.assert_close(bias.grad.cpu(), lstm.bias_ih_l0.grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("multi_cu", ["0", "1"])
 @pytest.mark.parametrize("degenerate", [False, True])
-def test_persistent_decoder_matches_stepwise_torch(degenerate):
+def test_persistent_decoder_matches_stepwise_torch(degenerate, multi_cu, monkeypatch):
     """pnmn_attn_lstm_fwd/bwd (teacher forced) against the same recurrence written with torch ops on
     the device: hidden states and every gradient (xe, enc, h0, W_c, W_hh)."""
     from probnmn.modules.seq2seq_base import _AttnLSTMDecoder, masked_softmax
 
+    monkeypatch.setenv("PNMN_DECODER_CLUSTER", multi_cu)
     torch.manual_seed(0)
     B, T, S, Hd, V = 19, 7, 11, 256, 44
     enc = torch.randn(B, S, Hd, device=DEV).requires_grad_(True)
@@ -292,3 +294,58 @@ def test_multi_cu_lstm_layer_matches_one_workgroup_per_tile(batch, monkeypatch):
             first = got
         else:  # hand-off races would show up as run-to-run differences
             assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
+
+
+@pytest.mark.parametrize("batch,steps,positions", [(7, 5, 3), (128, 27, 46), (530, 9, 27), (1024, 12, 64)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_multi_cu_decoder_matches_one_workgroup_per_tile(batch, steps, positions, mode, monkeypatch):
+    """pnmn_attn_lstm_fwd_multi / _bwd_multi (eight workgroups per tile, batches beyond 512 rows in
+    several launches) against pnmn_attn_lstm_fwd / _bwd: hidden states, chosen tokens and every gradient."""
+    from probnmn.modules.seq2seq_base import _AttnLSTMDecoder
+
+    g = torch.Generator().manual_seed(batch + mode)
+    B, T, S, Hd, V = batch, steps, positions, 256, 44
+    r = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(DEV)  # noqa: E731
+    enc0, h00 = r(B, S, Hd), r(B, Hd)
+    lens = torch.randint(1, S + 1, (B,), generator=g).to(DEV)
+    mask = (torch.arange(S, device=DEV)[None, :] < lens[:, None]).float()
+    w_c0, w_hh0 = r(4 * Hd, Hd, scale=0.05), r(4 * Hd, Hd, scale=0.05)
+    xe0, etable0 = r(B, T, 4 * Hd), r(V, 4 * Hd)
+    w_p, b_p = r(V, Hd, scale=0.3), r(V)
+    wgt = r(B, T, Hd)
+
+    def run():
+        leaves = dict(enc=enc0.clone().requires_grad_(True), h0=h00.clone().requires_grad_(True),
+                      w_c=w_c0.clone().requires_grad_(True), w_hh=w_hh0.clone().requires_grad_(True))
+        if mode == 0:
+            leaves["xe"] = xe0.clone().requires_grad_(True)
+            hs, tok = _AttnLSTMDecoder.apply(leaves["xe"], None, leaves["enc"], mask, leaves["h0"], leaves["w_c"],
+                                             leaves["w_hh"], w_p, b_p, 0, T, 5, 3, 0, 1, 2)
+        else:
+            leaves["etable"] = etable0.clone().requires_grad_(True)
+            hs, tok = _AttnLSTMDecoder.apply(None, leaves["etable"], leaves["enc"], mask, leaves["h0"], leaves["w_c"],
+                                             leaves["w_hh"], w_p, b_p, mode, T, 5, 3, 0, 1, 2)
+        (hs * wgt).sum().backward()
+        torch.cuda.synchronize()
+        return hs.detach(), tok, {k: v.grad for k, v in leaves.items()}
+
+    monkeypatch.setenv("PNMN_DECODER_CLUSTER", "0")
+    hs_ref, tok_ref, grads_ref = run()
+    monkeypatch.setenv("PNMN_DECODER_CLUSTER", "1")
+    hs, tok, grads = run()
+    hs2, tok2, grads2 = run()
+    assert torch.equal(hs, hs2) and torch.equal(tok, tok2)  # hand-off races would show up as run-to-run differences
+    for k in grads:
+        if k != "etable":  # (index_add_ with atomics: summation order varies)
+            assert torch.equal(grads[k], grads2[k]), k
+    if mode == 0:
+        same = torch.ones(B, dtype=torch.bool, device=DEV)
+    else:
+        # a token can flip where two candidates are within round-off of the draw; such a row then diverges
+        same = (tok == tok_ref).all(1)
+        assert float(same.float().mean()) > 0.97
+    assert float((hs - hs_ref)[same].abs().max()) < 2e-4
+    if bool(same.all()):
+        for k, ref in grads_ref.items():
+            scale = float(ref.abs().max()) + 1e-12
+            assert float((grads[k] - ref).abs().max()) / scale < 2e-4, k
