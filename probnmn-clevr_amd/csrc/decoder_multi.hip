@@ -33,8 +33,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-using pnmn::cluster_signal;
-using pnmn::cluster_wait;
 using pnmn::sigm;
 using pnmn::wmax;
 using pnmn::wsum;
@@ -91,8 +89,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile >= a.tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
-    int* counter = a.sync + tile;
-    int handoffs = 0;
+    pnmn::Cluster cl;
+    cl.start(a.sync + tile * pnmn::CLUSTER_COUNTER_STRIDE, MEMBERS);
 
     for (int i = tid; i < RW * S * (H / 4); i += 512) {
         const int rl = i / (S * (H / 4)), rem = i - rl * S * (H / 4);
@@ -152,8 +150,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float cv = (cpart[rl2][0][k] + cpart[rl2][1][k]) + (cpart[rl2][2][k] + cpart[rl2][3][k]);
             if (myrow0 + rl2 < a.B) a.ctx[((size_t)(myrow0 + rl2) * T + t) * H + k] = cv;
         }
-        cluster_signal(counter);
-        cluster_wait(counter, MEMBERS * ++handoffs);
+        cl.signal();
+        cl.wait();
 
         // ---------------- gates of my units on the matrix cores ----------------
         f32x4 acc;
@@ -206,8 +204,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (t + 1 == T && !a.sample) break;  // nobody needs h_T
-        cluster_signal(counter);
-        cluster_wait(counter, MEMBERS * ++handoffs);
+        cl.signal();
+        cl.wait();
 
         // ---------------- token choice for the next step (every member, all 16 rows) ----------------
         if (a.sample) {
@@ -288,8 +286,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile >= a.tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
-    int* counter = a.sync + tile;
-    int handoffs = 0;
+    pnmn::Cluster cl;
+    cl.start(a.sync + tile * pnmn::CLUSTER_COUNTER_STRIDE, MEMBERS);
     float* x1t = a.x1 + (size_t)tile * 2 * MEMBERS * 2 * ROWS * H;
     float* x2t = a.x2 + (size_t)tile * 2 * ROWS * H;
 
@@ -380,8 +378,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     ph[o] = acch[nt][r];
                 }
         }
-        cluster_signal(counter);
-        cluster_wait(counter, MEMBERS * ++handoffs);
+        cl.signal();
+        cl.wait();
 
         // ---------------- my rows: gather the partials, attention backward ----------------
         {
@@ -440,8 +438,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 a.dh0[(size_t)(myrow0 + rl2) * H + k] = v;
         }
         if (t == 0) break;
-        cluster_signal(counter);
-        cluster_wait(counter, MEMBERS * ++handoffs);
+        cl.signal();
+        cl.wait();
     }
 }
 

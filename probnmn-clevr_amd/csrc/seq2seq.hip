@@ -418,8 +418,6 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
 // The operand order of every accumulation is the single-workgroup kernels'; results differ from theirs
 // only by the compiler's fma contraction of the cell update (last ulps), and are run-to-run identical.
 // -----------------------------------------------------------------------------------------------------
-using pnmn::cluster_signal;
-using pnmn::cluster_wait;
 
 template <int S>
 __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* __restrict__ xp,
@@ -438,7 +436,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * LROWS, u0 = part * UW;
     const int gate = wave >> 1, ub0 = (wave & 1) * UB;
-    int* counter = sync + tile;
+    pnmn::Cluster cl;
+    cl.start(sync + tile * pnmn::CLUSTER_COUNTER_STRIDE, S);
 
     f32x4_ wreg[UB][LH / 16];
 #pragma unroll
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
                 acc[ub][r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + n] : 0.f;
             }
         if (t > 0) {
-            cluster_wait(counter, S * t);
+            cl.wait();
             const float* hrow = hs + ((size_t)arow * T + (t - 1)) * LH + 4 * g;
             f32x4_ a[LH / 16];
 #pragma unroll
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
                 }
             }
         }
-        if (t + 1 < T) cluster_signal(counter);  // also the barrier that protects gl for the next step
+        if (t + 1 < T) cl.signal();  // also the barrier that protects gl for the next step
     }
 }
 
@@ -531,7 +530,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
     if (tile >= tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * LROWS, u0 = part * UW;
-    int* counter = sync + tile;
+    pnmn::Cluster cl;
+    cl.start(sync + tile * pnmn::CLUSTER_COUNTER_STRIDE, S);
     float* ptile = px + (size_t)tile * 2 * S * LROWS * LH;  // [parity][source part][16][H]
 
     // this wave's two 16-unit output tiles x this workgroup's gate columns, register resident
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
             }
         }
         if (t < T - 1) {
-            cluster_wait(counter, S * (T - 1 - t));
+            cl.wait();
             const float* pp = ptile + (size_t)((t + 1) & 1) * S * LROWS * LH;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) po[(size_t)(4 * g + r) * LH + 16 * (2 * wave + nt) + li] = acc[nt][r];
-        cluster_signal(counter);  // also: everyone is done reading dgl
+        cl.signal();  // also: everyone is done reading dgl
     }
 }
 
