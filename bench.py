@@ -235,8 +235,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
-    ap.add_argument("--cpu-sample", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--fit-iters", type=int, default=1500, help="cap on the generator's pre-fit iterations")
     ap.add_argument("--fit-target", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
