@@ -117,10 +117,11 @@ def kernel_rooflines(engine, step_fn, passes):
     events, engine.event_log = engine.event_log, None
     engine.overlap_wgrad = overlap
     agg = {}
-    for kern, what, flops, e0, e1 in events:
-        a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "by": {}})
+    for kern, what, flops, e0, e1, nbytes in events:
+        a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
         ms = e0.elapsed_time(e1)
         a["flops"] += flops
+        a["bytes"] += nbytes
         a["ms"] += ms
         a["launches"] += 1
         b = a["by"].setdefault(what, [0.0, 0.0, 0])
@@ -130,10 +131,37 @@ def kernel_rooflines(engine, step_fn, passes):
     return agg
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summaries (profiles/
+    rNN_pmc_{FETCH,WRITE}_SIZE.txt: separate `rocprofv3 --pmc` passes of this same command, see
+    scripts/profile_round.sh).  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950
+    counts 128-byte read requests at 64 bytes, MI355X_MICROARCH.md, HBM).  None without summaries."""
+    import glob
+    import re
+
+    tags = sorted({os.path.basename(f).split("_pmc_")[0] for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_FETCH_SIZE.txt"))})
+    if not tags:
+        return None
+    tag, total, calls = tags[-1], 0.0, 0
+    for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.txt" % (tag, counter))
+        if not os.path.exists(path):
+            return None
+        n = 0
+        for line in open(path):
+            m = re.match(r"(\S+)\s+%s\s+(\d+)\s+([0-9.]+)" % counter, line)
+            if m and kernel in m.group(1):
+                n += int(m.group(2))
+                total += factor * 1024.0 * float(m.group(3))
+        calls = max(calls, n)
+    return {"bytes_per_launch": round(total / calls), "source": "profiles/%s_pmc_*_SIZE.txt" % tag} if calls else None
+
+
 def roofline_object(agg, passes):
     dom = max(agg, key=lambda k: agg[k]["ms"])
     a = agg[dom]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+    pmc = pmc_traffic(dom)
     return {
         "kernel": dom,
         "bound": "mfma",
@@ -141,7 +169,9 @@ def roofline_object(agg, passes):
         "peak": PEAK_FP32_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-        "traffic": None,
+        "traffic": pmc["bytes_per_launch"] if pmc else None,
+        "traffic_unit": "HBM bytes per launch (PMC, %s)" % pmc["source"] if pmc else None,
+        "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
         "launches_per_step": a["launches"] // passes,
         "kernels": {

@@ -86,6 +86,31 @@ def wgrad_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _LinearRows(torch.autograd.Function):
+    """``F.linear`` over B x T rows whose weight gradient goes through ``wgrad_gemm`` (autograd's
+    plain ``dy.t() @ x`` has 32 output tiles and a 47 000-long reduction at these shapes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.size(-1))
+        dx = (dy2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = wgrad_gemm(dy2.contiguous(), x.reshape(-1, x.size(-1)).contiguous()) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    if x.device.type != "cuda" or not torch.is_grad_enabled():
+        return F.linear(x, weight, bias)
+    return _LinearRows.apply(x, weight, bias)
+
+
 class _EmbeddingLookup(torch.autograd.Function):
     """``F.embedding`` whose weight gradient is a (one-hot) GEMM: the vocabularies here have < 100
     entries, so the scatter-add of B x T rows into them that torch's backward does (sort + segmented
@@ -313,7 +338,7 @@ def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor) -> torch.Ten
         w_ih = getattr(lstm, "weight_ih_l%d" % layer)
         w_hh = getattr(lstm, "weight_hh_l%d" % layer)
         bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
-        xp = F.linear(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
+        xp = linear_rows(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
         if lstm.hidden_size == 256:
             inp = _LSTMLayerSeq.apply(xp, w_hh)  # one persistent launch for all T steps
         else:  # other widths: step by step (GEMM per step + the cell kernel)
@@ -452,7 +477,7 @@ class Seq2SeqBase(nn.Module):
         if fused:
             args = (pad, self._unk_index, bos)
             if tgt is not None:  # teacher forcing: every step's input embedding is known up front
-                xe = F.linear(embedding_lookup(self._target_embedder, tgt[:, :steps]), w_e, bias)
+                xe = linear_rows(embedding_lookup(self._target_embedder, tgt[:, :steps]), w_e, bias)
                 hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
                                                0, steps, seed, self.sample_row_offset, *args)
             else:  # free running: the kernel also picks each step's token

@@ -119,7 +119,10 @@ class NMNEngine:
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1))
+            # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes: every item's input and
+            # output map once + one pass over the weights)
+            log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
+                        4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C)))
 
     def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
         """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
@@ -133,7 +136,8 @@ class NMNEngine:
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(stream)
-            log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1))
+            log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1,
+                        4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C)))
 
     # ---- parameters ---------------------------------------------------------------------------
     def trunk_named_parameters(self):
