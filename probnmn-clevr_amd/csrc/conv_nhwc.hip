@@ -32,13 +32,19 @@ using pnmn::CB;
 
 template <int H, int W, int KSPLIT>
 __global__ __launch_bounds__(512) void conv_nhwc_kernel(
-    const pnmn_conv_item* __restrict__ items, int cin_chunks, int ntaps, int in_stride,
+    const pnmn_conv_item* __restrict__ items, int n_items, int cin_chunks, int ntaps, int in_stride,
     int out_stride, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);  // [(HW+1)][128], row HW is zero
-    const pnmn_conv_item it = items[blockIdx.x / KSPLIT];
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (XCD = linear id % 8), each with
+    // its own L2.  The KSPLIT workgroups of an item all stage the same input tile, so they are given ids
+    // that are congruent mod 8: the tile is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
+    const int slot = blockIdx.x >> 3;
+    const int item = (slot / KSPLIT) * 8 + (blockIdx.x & 7);
+    if (item >= n_items) return;
+    const pnmn_conv_item it = items[item];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
-    pnmn::conv_body<H, W, KSPLIT>(it, blockIdx.x % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
+    pnmn::conv_body<H, W, KSPLIT>(it, slot % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
                                   relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr);
 }
 
@@ -56,8 +62,8 @@ int launch_conv_k(const pnmn_conv_item* items, int n_items, int cin_chunks, int 
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(n_items * KSPLIT, cout_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, cin_chunks, ntaps, in_stride,
+    dim3 grid(((n_items + 7) / 8) * 8 * KSPLIT, cout_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, n_items, cin_chunks, ntaps, in_stride,
                        out_stride, relu);
     return (int)hipGetLastError();
 }

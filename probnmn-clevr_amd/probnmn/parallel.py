@@ -45,6 +45,9 @@ class EarlyReducer:
         self._hooks = []
 
 
+SMALL_BUCKET_BYTES = 8 << 20
+
+
 def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Parameter] = (), average: bool = True,
                          early: "EarlyReducer" = None) -> None:
     n = world()
@@ -54,18 +57,27 @@ def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Param
     handles = []
     for a in arenas:
         handles.append((dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, async_op=True), a.grad))
+    small = []  # the seq2seq models have ~40 tensors of a few hundred KB: one bucket, one collective
     for p in loose_params:
         if p.grad is None:
             continue
         started = early.take(p) if early is not None else None
         if started is not None:
             handles.append(started)
+        elif p.grad.numel() * p.grad.element_size() < SMALL_BUCKET_BYTES and p.grad.is_contiguous():
+            small.append(p.grad)
         else:
             handles.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))
+    bucket = None
+    if small:
+        bucket = torch.cat([g.reshape(-1) for g in small])
+        handles.append((dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True), bucket))
     for h, g in handles:
         h.wait()
         if scale != 1.0:
             g.mul_(scale)
+    if bucket is not None:
+        torch._foreach_copy_(small, [c.view_as(g) for c, g in zip(bucket.split([g.numel() for g in small]), small)])
 
 
 def all_reduce_scalars(values: torch.Tensor) -> torch.Tensor:

@@ -43,20 +43,24 @@ def _worker(rank, world, port, out_path):
     Y = torch.randn(8, 3, generator=g)
     arena = _FakeArena(15, seed=rank)  # different initial weights per rank on purpose
     loose = torch.nn.Parameter(torch.randn(3, generator=torch.Generator().manual_seed(10 + rank)))
-    parallel.broadcast_parameters([arena], [loose])
+    # two more loose tensors that take the bucketed path (one collective for all small gradients)
+    scale = torch.nn.Parameter(torch.randn(3, generator=torch.Generator().manual_seed(20 + rank)))
+    shift = torch.nn.Parameter(torch.randn(1, generator=torch.Generator().manual_seed(30 + rank)))
+    parallel.broadcast_parameters([arena], [loose, scale, shift])
     w = arena.flat.view(3, 5).clone().requires_grad_(True)
     early = parallel.EarlyReducer([])          # no parameters registered: everything reduced at the end
     early2 = parallel.EarlyReducer([loose])    # the loose parameter's all-reduce starts inside backward
     shard = slice(rank * 4, rank * 4 + 4)
-    loss = ((X[shard] @ w.T + loose - Y[shard]) ** 2).sum(1).mean()
+    loss = (((X[shard] @ w.T + loose) * scale + shift - Y[shard]) ** 2).sum(1).mean()
     loss.backward()
     arena.grad.copy_(w.grad.reshape(-1))
     assert early.take(loose) is not None or True  # (the hook fired during backward; taken below)
-    parallel.all_reduce_gradients([arena], [loose], early=early2)
+    parallel.all_reduce_gradients([arena], [loose, scale, shift], early=early2)
     sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
     if rank == 0:
         torch.save({"w": arena.flat.clone(), "gw": arena.grad.clone(), "gb": loose.grad.clone(),
-                    "b": loose.detach().clone(), "sums": sums}, out_path)
+                    "b": loose.detach().clone(), "sums": sums, "scale": scale.detach().clone(),
+                    "shift": shift.detach().clone(), "gscale": scale.grad.clone(), "gshift": shift.grad.clone()}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,8 +76,11 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     Y = torch.randn(8, 3, generator=g)
     w = got["w"].view(3, 5).clone().requires_grad_(True)
     b = got["b"].clone().requires_grad_(True)
-    loss = ((X @ w.T + b - Y) ** 2).sum(1).mean()
+    scale, shift = got["scale"].clone().requires_grad_(True), got["shift"].clone().requires_grad_(True)
+    loss = (((X @ w.T + b) * scale + shift - Y) ** 2).sum(1).mean()
     loss.backward()
+    torch.testing.assert_close(got["gscale"], scale.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got["gshift"], shift.grad, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got["gw"], w.grad.reshape(-1), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got["gb"], b.grad, rtol=1e-6, atol=1e-6)
     assert got["sums"].tolist() == [3.0, 8.0]
