@@ -57,10 +57,23 @@ def _worker(rank, world, port, out_path):
     assert early.take(loose) is not None or True  # (the hook fired during backward; taken below)
     parallel.all_reduce_gradients([arena], [loose, scale, shift], early=early2)
     sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
+    # loss terms are means over data-dependent subsets: shard sizes 3 and 5 here.  The trainers weight
+    # each local mean by n_local * world / n_global so that the AVERAGED gradient is the global mean's.
+    from probnmn.modules.elbo import Reinforce
+    from probnmn.trainers.joint_training import _dp_weight
+
+    values = torch.arange(8.0)
+    mine = values[:3] if rank == 0 else values[3:]
+    weighted = _dp_weight(mine.numel(), torch.device("cpu")) * mine.mean()
+    dist.all_reduce(weighted)
+    global_mean = weighted / world
+    reinforce = Reinforce(baseline_decay=0.5)
+    reinforce(torch.ones_like(mine), mine)  # the baseline moves by decay * GLOBAL mean of (reward - baseline)
     if rank == 0:
         torch.save({"w": arena.flat.clone(), "gw": arena.grad.clone(), "gb": loose.grad.clone(),
                     "b": loose.detach().clone(), "sums": sums, "scale": scale.detach().clone(),
-                    "shift": shift.detach().clone(), "gscale": scale.grad.clone(), "gshift": shift.grad.clone()}, out_path)
+                    "shift": shift.detach().clone(), "gscale": scale.grad.clone(), "gshift": shift.grad.clone(),
+                    "global_mean": float(global_mean), "baseline": float(reinforce._reinforce_baseline)}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,6 +97,8 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     torch.testing.assert_close(got["gw"], w.grad.reshape(-1), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(got["gb"], b.grad, rtol=1e-6, atol=1e-6)
     assert got["sums"].tolist() == [3.0, 8.0]
+    assert abs(got["global_mean"] - 3.5) < 1e-6  # mean of 0..7, from shards of 3 and 5
+    assert abs(got["baseline"] - 0.5 * 3.5) < 1e-6
     # broadcast really took rank 0's values
     torch.testing.assert_close(got["w"], _FakeArena(15, seed=0).flat)
 
