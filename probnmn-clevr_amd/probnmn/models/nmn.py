@@ -34,9 +34,9 @@ class _Trunk(torch.autograd.Function):
     """stem -> module programs -> classifier conv + max-pool, as one autograd node."""
 
     @staticmethod
-    def forward(ctx, features, engine, compiled, *params):
+    def forward(ctx, features, engine, compiled, started, *params):
         need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
-        pooled, state = engine.run_forward(features, compiled, need_backward)
+        pooled, state = engine.run_forward(features, compiled, need_backward, started)
         ctx.engine, ctx.state = engine, state
         return pooled
 
@@ -45,7 +45,7 @@ class _Trunk(torch.autograd.Function):
         if ctx.state is None:
             raise RuntimeError("backward through a forward that was run without gradient tracking")
         grads = ctx.engine.run_backward(ctx.state, dpooled)
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class NeuralModuleNetwork(nn.Module):
@@ -125,7 +125,9 @@ class NeuralModuleNetwork(nn.Module):
     def engine(self):
         return self._engine
 
-    def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None):
+    def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None,
+                started=None):
+        # ``started``: token of ``begin(features)`` when the caller already launched the stem (optional)
         engine = self._engine
         arena = engine.ensure_arena()
         # the programs decide the launch schedule, so they are needed on the host (the reference
@@ -137,7 +139,7 @@ class NeuralModuleNetwork(nn.Module):
         valid = _hip.small_to_device([p.valid for p in compiled], torch.bool, features.device)
 
         params = [arena.param(n) for n in arena.names]
-        pooled = _Trunk.apply(features, engine, compiled, *params)
+        pooled = _Trunk.apply(features, engine, compiled, started, *params)
         hidden = F.relu(self.classifier[4](pooled))
         answer_logits = self.classifier[6](hidden)
 
@@ -160,6 +162,12 @@ class NeuralModuleNetwork(nn.Module):
         if self.training and self.report_batch_metrics:
             output_dict["metrics"] = self.get_metrics(reset=True)
         return output_dict
+
+    def begin(self, features: torch.Tensor):
+        """Launch the program-independent part of ``forward`` (feature layout + stem) ahead of time;
+        pass the returned token as ``forward(..., started=token)`` with the same ``features``."""
+        trains = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return self._engine.begin_forward(features, trains)
 
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:
         return {

@@ -286,7 +286,12 @@ class NMNEngine:
         return out
 
     # ---- forward --------------------------------------------------------------------------------
-    def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool):
+    def begin_forward(self, features: torch.Tensor, need_backward: bool):
+        """The part of the forward pass that does not depend on the programs: layout change of the
+        input features and the two stem convolutions.  A trainer whose programs are still being
+        produced (joint training: sampled on the device, scheduled on the host) launches this first
+        and hands the returned token to ``run_forward`` -- the GPU then has ~3 ms more work queued
+        while the host compiles and schedules the sampled programs."""
         a = self.ensure_arena()
         lib = _hip.lib()
         dev = a.device
@@ -309,6 +314,30 @@ class NMNEngine:
         if not need_backward:  # records still reference gradient buffers; point them somewhere valid
             for n in ("gstem1", "gfeat", "gfinal", "gcls"):
                 ws[n] = ws["stem1"]
+        fixed = self._fixed_records(B, ws)
+        pack = _Pack()
+        for k in ("stem1", "stem2"):
+            pack.add(k, fixed[k])
+        pack.upload(dev)
+        _hip.check(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
+        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
+        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
+        return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
+                "features": features, "pack": pack}
+
+    def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
+                    started=None):
+        if started is None:
+            started = self.begin_forward(features, need_backward)
+        elif (started["generation"] != self.generation or started["B"] != features.size(0)
+              or started["need_backward"] != need_backward):
+            raise ValueError("begin_forward token does not belong to this forward pass")
+        a = self.ensure_arena()
+        lib = _hip.lib()
+        dev = a.device
+        B, ws, fixed = started["B"], started["ws"], started["fixed"]
+        HW = self.HW
+        st = _hip.stream_ptr(dev)
 
         floats = self.scheduler.arena_floats(compiled)
         act = self._buf("act", max(floats, 1))
@@ -324,7 +353,6 @@ class NMNEngine:
         assert plan.arena_floats == floats, (plan.arena_floats, floats)
         self.last_plan = plan
 
-        fixed = self._fixed_records(B, ws)
         pack = _Pack()
         for k, rec in fixed.items():
             pack.add(k, rec)
@@ -340,9 +368,6 @@ class NMNEngine:
 
         H, W = self.H, self.W
         chk = _hip.check
-        chk(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
-        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
-        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
 
         final = ws["final"][: B * HW * C].view(B, HW * C)
         feat = ws["feat"][: B * HW * C].view(B, HW * C)

@@ -80,7 +80,7 @@ class _TrainerBase:
         return host, event
 
     def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
-                        reconstruct: bool = True, host_programs: bool = False):
+                        reconstruct: bool = True, host_programs: bool = False, after_sampling=None):
         """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
         rows of the reference's separate calls batched into as few recurrent launches as the data
         dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
@@ -118,6 +118,8 @@ class _TrainerBase:
             out["programs"] = z
             if host_programs:
                 out["programs_host"] = self._host_copy(z)
+            if after_sampling is not None:
+                out["after_sampling"] = after_sampling()
         if n_sup:
             out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling")["loss"].mean()
         if n_sup and n_nosup:
@@ -196,11 +198,14 @@ class JointTrainingStep(_TrainerBase):
         if nosup.numel() == 0:
             raise ValueError("joint training needs at least one example without program supervision in the batch")
         ours = self.objective == "ours"
+        images = batch["image"][nosup_d]
+        # the NMN stem needs no programs: queued right behind the sampling decode, it keeps the GPU busy
+        # (together with the reconstructor / prior passes) while the host schedules the sampled programs
         p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours,
-                                 host_programs=True)
+                                 host_programs=True, after_sampling=lambda: self.nmn.begin(images))
         programs_host, copied = p["programs_host"]
-        copied.synchronize()  # waits for the sampling decode only, not for the passes queued after it
-        nmn_out = self.nmn(batch["image"][nosup_d], programs_host, batch["answer"][nosup_d])
+        copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
+        nmn_out = self.nmn(images, programs_host, batch["answer"][nosup_d], started=p["after_sampling"])
         elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
         nmn_loss = elbo_out.pop("nmn_loss")
         w = _dp_weight(nosup.numel(), dev)
