@@ -281,11 +281,19 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the measured path)")
+    # test hooks for boxes with fewer GPUs than ranks (the multi-rank logic of this file can then be
+    # exercised with several processes on ONE device over gloo): never set by the driver
+    backend = os.environ.get("PNMN_BENCH_BACKEND", "nccl")
+    if "PNMN_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PNMN_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from probnmn import parallel
     from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
@@ -318,8 +326,11 @@ def main():
     prims = nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        roof = roofline_object(kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2), 2)
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (they contain the step's collectives); rank 0 reports
+        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2)
+        if rank == 0:
+            roof = roofline_object(agg, 2)
         log("roofline pass done")
 
     cpu = None
