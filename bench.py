@@ -183,6 +183,58 @@ def roofline_object(agg, passes):
     }
 
 
+def recurrent_kernel_report(dev):
+    """Launch time, latency per time step and achieved FLOP/s of the persistent recurrent kernels at
+    the shapes of the headline step (these kernels are bound by the per-step hand-off
+    latency, not by a roofline; both figures are reported)."""
+    from probnmn.modules.seq2seq_base import _AttnLSTMDecoder, _LSTMLayerSeq
+
+    g = torch.Generator().manual_seed(0)
+    r = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dev)  # noqa: E731
+
+    def clock(fn, reps=5):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {}
+    Hd = 256
+    # LSTM layer over the questions (rows, steps)
+    B, T = 1024, 46
+    xp, w = r(B, T, 4 * Hd, scale=0.5).requires_grad_(True), r(4 * Hd, Hd, scale=0.05)
+    dhs = r(B, T, Hd)
+    fwd = clock(lambda: _LSTMLayerSeq.apply(xp.detach(), w))
+    both = clock(lambda: _LSTMLayerSeq.apply(xp, w).backward(dhs))
+    flops = 2.0 * B * T * Hd * 4 * Hd
+    out["lstm_layer"] = {"rows": B, "steps": T, "fwd_ms": round(fwd, 3), "fwd_us_per_step": round(fwd / T * 1e3, 2),
+                         "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3)}
+    # decoders: the reconstructor's teacher-forced decode and the generator's sampling decode
+    for name, B, T, S, mode in (("decoder_teacher_forced", 1024, 46, 27, 0), ("decoder_sampling", 512, 26, 46, 1)):
+        V = 96 if mode == 0 else 44
+        enc, h0 = r(B, S, Hd).requires_grad_(True), r(B, Hd)
+        mask = torch.ones(B, S, device=dev)
+        w_c, w_hh = r(4 * Hd, Hd, scale=0.05), r(4 * Hd, Hd, scale=0.05)
+        w_p, b_p = r(V, Hd, scale=0.3), r(V)
+        xe = r(B, T, 4 * Hd, scale=0.5) if mode == 0 else None
+        etable = r(V, 4 * Hd, scale=0.5) if mode != 0 else None
+        dh = r(B, T, Hd)
+        run = lambda e: _AttnLSTMDecoder.apply(xe, etable, e, mask, h0, w_c, w_hh, w_p, b_p, mode, T, 5, 0, 0, 1, 2)[0]  # noqa: E731
+        fwd = clock(lambda: run(enc.detach()))
+        both = clock(lambda: run(enc).backward(dh))
+        flops = B * T * (2.0 * 2 * Hd * 4 * Hd + 4.0 * S * Hd + (2.0 * V * Hd if mode else 0.0))
+        out[name] = {"rows": B, "steps": T, "source_positions": S, "fwd_ms": round(fwd, 3),
+                     "fwd_us_per_step": round(fwd / T * 1e3 / max(1, -(-B // 512)), 2),
+                     "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3)}
+    out["note"] = "fwd_us_per_step = launch time / steps (per 512-row launch for the decoders); peak fp32 %.1f TFLOP/s" % PEAK_FP32_TFLOPS
+    return out
+
+
 def timed(step_fn, steps, warmup, dev, world):
     """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both
     sides; returns (max-over-ranks seconds, host seconds to enqueue, host seconds blocked on the
@@ -337,6 +389,13 @@ def main():
     if sds is not None:
         cpu = cpu_baseline(vocab, sds, args.cpu_sample, args.cpu_steps, seed=1000)
 
+    recurrent = None
+    if rank == 0 and not args.no_roofline:
+        try:
+            recurrent = recurrent_kernel_report(dev)
+        except Exception as exc:  # a side report must not take the headline line down
+            recurrent = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     extras = {}
     if not args.no_extras:
         def side(name, metric, workload, n, make):
@@ -394,6 +453,7 @@ def main():
             },
             "roofline": roof,
             "cpu_baseline": cpu,
+            "recurrent_kernels": recurrent,
         }
         line.update(extras)
         if cpu:
