@@ -365,6 +365,20 @@ typedef struct pnmn_task {
 int pnmn_dataflow(const pnmn_task* tasks, int n_tasks, int32_t* ctrl, int32_t* done, int H, int W,
                   int ksplit /* 1, 2 or 4 */, int n_workgroups, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Host-side batch program compiler (no device work)        nmn.py:191-238, SURVEY App. C
+ *   tokens [n_programs][length] int64 prefix programs; kinds[token] = module class of each
+ *   vocabulary entry (0 skip, 1 scene, 2 and, 3 or, 4 comparison, 5 attention, 6 query, 7 relate,
+ *   8 same; probnmn.runtime.program_compiler.classify_token).
+ *   per program: valid (the reference interpreter would not raise), n_calls, the calls in execution
+ *   order as 7 int32 each (kind, token, a, b, a_channels, b_channels, out_channels; value ids:
+ *   0 = stem features, 1 = all-ones attention, k >= 2 = output of call k-2) into
+ *   calls[n_programs][length][7], and the value id of the result.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, const int32_t* kinds,
+                          int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
+                          int32_t* calls, int32_t* result);
+
 /* Library / device self-description (no GPU needed for version). */
 int pnmn_abi_version(void);
 

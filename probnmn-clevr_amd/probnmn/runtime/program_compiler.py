@@ -60,11 +60,43 @@ class ModuleCall:
     out_channels: int
 
 
-@dataclass(frozen=True)
 class CompiledProgram:
-    valid: bool
-    calls: Tuple[ModuleCall, ...]  # empty when invalid
-    result: int  # value id of the final output (FEAT for an empty program)
+    """valid / calls / result of one program.  ``calls`` (a tuple of :class:`ModuleCall`) is built on
+    first use when the program came out of the batch compiler as an int32 table ``[n_calls, 7]``
+    (kind, token, a, b, a_channels, b_channels, out_channels) -- the scheduler only needs the table."""
+
+    __slots__ = ("valid", "result", "_raw", "_calls", "_template_id", "_template_owner", "_tokens")
+
+    def __init__(self, valid: bool, calls: Tuple[ModuleCall, ...] = (), result: int = FEAT, raw=None):
+        self.valid = valid
+        self.result = result  # value id of the final output (FEAT for an empty program)
+        self._raw = raw
+        self._calls = None if raw is not None else tuple(calls)  # empty when invalid
+        self._template_id = None
+        self._template_owner = None
+        self._tokens = None
+
+    @property
+    def calls(self) -> Tuple[ModuleCall, ...]:
+        if self._calls is None:
+            self._calls = tuple(ModuleCall(*row) for row in self._raw.tolist())
+        return self._calls
+
+    def table(self):
+        """int32 [n_calls, 7], the calls as rows."""
+        if self._raw is None:
+            import numpy as np
+
+            self._raw = np.asarray([[c.kind, c.token, c.a, c.b, c.a_channels, c.b_channels, c.out_channels]
+                                    for c in self._calls], dtype=np.int32).reshape(-1, 7)
+        return self._raw
+
+    def __eq__(self, other):
+        return (isinstance(other, CompiledProgram) and self.valid == other.valid and self.result == other.result
+                and self.calls == other.calls)
+
+    def __repr__(self):
+        return "CompiledProgram(valid=%r, calls=%r, result=%r)" % (self.valid, self.calls, self.result)
 
 
 class ProgramCompiler:
@@ -76,6 +108,8 @@ class ProgramCompiler:
             self.kinds[idx] = classify_token(tok)
         self._cache: Dict[Tuple[int, ...], CompiledProgram] = {}
         self._bytes_cache: Dict[bytes, CompiledProgram] = {}
+        self._kinds_array = None
+        self._invalid = CompiledProgram(False, (), FEAT)
 
     def compile(self, tokens: Sequence[int]) -> CompiledProgram:
         key = tuple(int(t) for t in tokens)
@@ -86,19 +120,42 @@ class ProgramCompiler:
         return hit
 
     def compile_batch(self, programs) -> List[CompiledProgram]:
-        """``programs``: (B, T) integer array (numpy), already on the host."""
+        """``programs``: (B, T) integer array (numpy), already on the host.  Programs seen before
+        come from a cache keyed by their bytes; the others are compiled together by the library's
+        host routine (``pnmn_compile_programs``, the same rules as ``_compile``)."""
         import numpy as np
 
+        from probnmn import _hip
+
         arr = np.ascontiguousarray(programs, dtype=np.int64)
-        out = []
+        if arr.ndim != 2:
+            raise ValueError("programs must be (batch, length), got shape %s" % (arr.shape,))
         cache = self._bytes_cache
-        for row in arr:
-            key = row.tobytes()
-            hit = cache.get(key)
-            if hit is None:
-                hit = self.compile(row.tolist())
-                cache[key] = hit
-            out.append(hit)
+        if len(cache) > 500000:  # bounded: sampled programs keep arriving for the whole training run
+            cache.clear()
+        keys = [row.tobytes() for row in arr]
+        out = [cache.get(k) for k in keys]
+        miss = [i for i, hit in enumerate(out) if hit is None]
+        if miss:
+            sub = np.ascontiguousarray(arr[miss])
+            n, length = sub.shape
+            if self._kinds_array is None:
+                self._kinds_array = np.asarray(self.kinds, dtype=np.int32)
+            valid = np.empty(n, np.uint8)
+            n_calls = np.empty(n, np.int32)
+            calls = np.empty((n, max(length, 1), 7), np.int32)
+            result = np.empty(n, np.int32)
+            _hip.check(_hip.lib().pnmn_compile_programs(
+                sub.ctypes.data, n, length, self._kinds_array.ctypes.data, self._kinds_array.size, self.module_channels,
+                valid.ctypes.data, n_calls.ctypes.data, calls.ctypes.data, result.ctypes.data), "compile_programs")
+            valid_l, n_l, res_l = valid.tolist(), n_calls.tolist(), result.tolist()
+            for j, i in enumerate(miss):
+                key = keys[i]
+                hit = cache.get(key)  # (the same new program may occur several times in the batch)
+                if hit is None:
+                    hit = CompiledProgram(True, result=res_l[j], raw=calls[j, : n_l[j]].copy()) if valid_l[j] else self._invalid
+                    cache[key] = hit
+                out[i] = hit
         return out
 
     # ---------------------------------------------------------------------------------

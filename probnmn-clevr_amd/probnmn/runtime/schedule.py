@@ -62,7 +62,8 @@ class Template:
 
 
 def structure_key(prog: pc.CompiledProgram) -> Tuple:
-    return tuple((c.kind, c.a, c.b) for c in prog.calls) + (prog.result,)
+    """Kinds and wiring of the calls (tokens ignored) + the result value."""
+    return (prog.table()[:, (0, 2, 3)].tobytes(), prog.result)
 
 
 def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template:
@@ -250,8 +251,8 @@ class BatchScheduler:
 
     # ---- template bank -------------------------------------------------------------------------
     def template_id(self, prog: pc.CompiledProgram) -> int:
-        tid = getattr(prog, "_template_id", None)
-        if tid is not None and getattr(prog, "_template_owner", None) is self:
+        tid = prog._template_id
+        if tid is not None and prog._template_owner is self:
             return tid
         key = structure_key(prog)
         tid = self._ids.get(key)
@@ -260,9 +261,9 @@ class BatchScheduler:
             self._templates.append(build_template(prog, self.hw, self.channels))
             self._ids[key] = tid
             self._bank = None
-        object.__setattr__(prog, "_template_id", tid)
-        object.__setattr__(prog, "_template_owner", self)
-        object.__setattr__(prog, "_tokens", np.asarray([c.token for c in prog.calls], dtype=np.int64))
+        prog._template_id = tid
+        prog._template_owner = self
+        prog._tokens = prog.table()[:, 1].astype(np.int64)
         return tid
 
     def template(self, prog: pc.CompiledProgram) -> Template:

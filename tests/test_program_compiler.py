@@ -65,3 +65,38 @@ def test_operand_order_and_values():
     assert p.result == 6
     assert comp.compile([999]).valid is False
     assert comp.compile([]).valid and comp.compile([]).result == pc.FEAT
+
+
+def test_batch_compiler_in_the_library_agrees_with_the_python_rules(golden_dir):
+    """pnmn_compile_programs (host routine of the C-ABI library, what compile_batch uses for programs it
+    has not seen) against ProgramCompiler._compile: validity, result value and every call, on the
+    golden validity cases, on template programs and on random token soup."""
+    import numpy as np
+
+    from probnmn.data.synthetic import synthetic_batch
+
+    v = Vocabulary.clevr()
+    for channels in (8, 128):
+        comp = pc.ProgramCompiler(v.get_index_to_token_vocabulary("programs"), module_channels=channels)
+        rows = []
+        for case in VALIDITY_CASES:  # (a list of space-separated programs)
+            ids = [v.get_token_index(t, "programs") for t in case.split()]
+            rows.append(ids + [0] * (26 - len(ids)))
+        rows += synthetic_batch(v, 200, seed=5, with_image=False)["program"].tolist()
+        rng = np.random.Generator(np.random.Philox(9))
+        soup = rng.integers(0, 44, (600, 26))
+        soup[rng.random((600, 26)) < 0.5] = 0          # mostly short programs
+        soup[:50, 3] = 999                             # out-of-vocabulary token
+        rows += soup.tolist()
+        arr = np.asarray(rows, dtype=np.int64)
+        got = comp.compile_batch(arr)
+        n_valid = 0
+        for row, g in zip(arr.tolist(), got):
+            want = comp._compile(tuple(row))
+            assert g.valid == want.valid and g.result == want.result, row
+            assert g.calls == want.calls, row
+            n_valid += g.valid
+        assert 200 < n_valid < len(rows)  # both verdicts are exercised
+        # second call: everything comes from the cache, same objects
+        again = comp.compile_batch(arr)
+        assert all(a is b for a, b in zip(got, again))
