@@ -20,7 +20,7 @@
 // KSPLIT workgroups of 16*8/KSPLIT output channels each; inside a workgroup the 8 waves then
 // split the 128 input channels of every tap KSPLIT ways and are summed through LDS at the end.
 // Each workgroup still stages the whole input tile, so the launcher picks the smallest split
-// that fills the chip (see pick_ksplit).
+// that fills the chip (see plan_launch).
 //
 // LDS image: row p (pixel) = 128 floats = 32 slots of 16 B; slot s is stored at s ^ (p & 15), which
 // makes the 16 pixel rows a ds_read_b128 lane-group touches land on 16 different bank slots.
@@ -68,29 +68,49 @@ int launch_conv_k(const pnmn_conv_item* items, int n_items, int cin_chunks, int 
     return (int)hipGetLastError();
 }
 
-// Smallest makespan of ceil(workgroups / CUs) rounds, each costing (contraction / split + staging).
-// Relative costs only: one tap of one 128-channel chunk = 1 unit; staging a chunk ~ 0.5 unit.
-inline int pick_ksplit(int n_items, int cout_blocks, int cin_chunks, int ntaps) {
+// Launch plan.  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
+// that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
+// work).  So the items are cut in two: as many as fill whole rounds go out with the split `s_main`,
+// the remainder follows in a second launch with a larger split `s_tail`, whose single round is
+// s_tail / s_main times shorter.  Relative costs only: one tap of one 128-channel chunk = 1 unit,
+// staging a chunk ~ 0.5 unit, a second launch ~ 0.3 unit.
+struct LaunchPlan {
+    int s_main, n_main, s_tail;
+};
+
+inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps) {
     const double work = (double)ntaps * cin_chunks;
     const double overhead = 0.5 * cin_chunks + 0.25;
-    int best = 1;
+    auto round_cost = [&](int s) { return work / s + overhead; };
+    LaunchPlan best{1, 0, 1};
     double best_t = 1e30;
     for (int s = 1; s <= 8; s *= 2) {
-        const long wgs = (long)n_items * cout_blocks * s;
-        const long rounds = (wgs + 255) / 256;
-        const double t = rounds * (work / s + overhead);
-        if (t < best_t * 0.97) {  // prefer the smaller split unless the gain is real
-            best_t = t;
-            best = s;
+        const long per_item = (long)cout_blocks * s;
+        const long full_rounds = (long)n_items * per_item / 256;
+        long n_main = full_rounds * 256 / per_item;
+        if (n_main > n_items) n_main = n_items;
+        const long n_tail = n_items - n_main;
+        const double t_main = (double)full_rounds * round_cost(s);
+        if (n_tail == 0) {
+            if (t_main < best_t * 0.97) best_t = t_main, best = LaunchPlan{s, n_items, s};
+            continue;
+        }
+        for (int st = s; st <= 8; st *= 2) {
+            const long tail_rounds = (n_tail * cout_blocks * st + 255) / 256;
+            const double t = t_main + (double)tail_rounds * round_cost(st) + (n_main > 0 ? 0.3 : 0.0);
+            if (t < best_t * 0.97) {  // prefer the smaller splits unless the gain is real
+                best_t = t;
+                best = LaunchPlan{s, (int)n_main, st};
+            }
         }
     }
     return best;
 }
 
 template <int H, int W>
-int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
-                int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    switch (pick_ksplit(n_items, cout_blocks, cin_chunks, ntaps)) {
+int launch_conv_split(int split, const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
+                      int out_stride, int cout_blocks, int relu, hipStream_t stream) {
+    switch (split) {
         case 8:
             return launch_conv_k<H, W, 8>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                           cout_blocks, relu, stream);
@@ -104,6 +124,21 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
             return launch_conv_k<H, W, 1>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                           cout_blocks, relu, stream);
     }
+}
+
+template <int H, int W>
+int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
+                int out_stride, int cout_blocks, int relu, hipStream_t stream) {
+    const LaunchPlan lp = plan_launch(n_items, cout_blocks, cin_chunks, ntaps);
+    if (lp.n_main > 0) {
+        const int rc = launch_conv_split<H, W>(lp.s_main, items, lp.n_main, cin_chunks, ntaps, in_stride, out_stride,
+                                               cout_blocks, relu, stream);
+        if (rc != 0) return rc;
+    }
+    if (lp.n_main < n_items)
+        return launch_conv_split<H, W>(lp.s_tail, items + lp.n_main, n_items - lp.n_main, cin_chunks, ntaps, in_stride,
+                                       out_stride, cout_blocks, relu, stream);
+    return 0;
 }
 
 }  // namespace
