@@ -207,8 +207,9 @@ class NMNEngine:
         self._wt_records = _hip.to_device(rec, a.device)
         self._wt_count = len(wt_items)
         self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
-        import os
-        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT, wgrad_chunk=int(os.environ.get('PNMN_WG_CHUNK', '8')), wgrad_groups=int(os.environ.get('PNMN_WG_GROUPS', '1')))
+        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT,
+                                        wgrad_chunk=int(os.environ.get("PNMN_WG_CHUNK", "8")),
+                                        wgrad_groups=int(os.environ.get("PNMN_WG_GROUPS", "1")))
 
     # ---- workspaces ---------------------------------------------------------------------------
     def _buf(self, name: str, numel: int) -> torch.Tensor:
