@@ -256,9 +256,11 @@ class NMNEngine:
             return r
 
         def jobs(dw, db, yblocks):
-            # aim at >= 512 workgroups per launch, but never fewer than 4 items per job: every job
-            # ends with an atomic add of its whole slab into the shared weight gradient
-            chunk = min(16, max(4, B * yblocks // 512))
+            # items per job: a launch of ceil(B / chunk) * yblocks workgroups costs ceil(. / 256) rounds of
+            # `chunk` items each (+ ~half an item for the atomic add of the job's slab into the shared
+            # weight gradient, which is also why a job never has fewer than 4 items); 260 workgroups cost
+            # two rounds, 208 one -- take the chunk with the shortest makespan
+            chunk = min(range(4, 33), key=lambda c: (-(-(-(-B // c) * yblocks) // 256)) * (c + 0.5))
             starts = np.arange(0, B, chunk)
             j = np.zeros(starts.size, _hip.WGRAD_JOB)
             j["dw"], j["dbias"] = dw, db
