@@ -68,6 +68,8 @@ typedef struct pnmn_conv_item {
 #define PNMN_CONV_ACCUMULATE 1
 #define PNMN_CONV_ATOMIC     2   /* with ACCUMULATE: add with fp32 atomics (concurrent writers) */
 #define PNMN_CONV_MASKBWD    4   /* fused mask backward epilogue (see the mb_* fields) */
+#define PNMN_CONV_MB_SOLE     8   /* with MASKBWD: no other item of this launch adds into the same
+                                     mb_dfeats map -> plain read-modify-write instead of atomics */
 
 int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks,
                    int ntaps /* 9 or 1 */, int in_stride, int out_stride,

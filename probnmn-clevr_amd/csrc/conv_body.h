@@ -234,10 +234,15 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                     part = v.x * f.x + v.y * f.y + v.z * f.z + v.w * f.w;
                 }
                 float* d = mb->dfeats + (size_t)p * CB + n0 + 4 * g;
-                unsafeAtomicAdd(d + 0, v.x * m);
-                unsafeAtomicAdd(d + 1, v.y * m);
-                unsafeAtomicAdd(d + 2, v.z * m);
-                unsafeAtomicAdd(d + 3, v.w * m);
+                if (it.flags & PNMN_CONV_MB_SOLE) {  // only this workgroup touches these 4 channels of pixel p
+                    f32x4* d4 = reinterpret_cast<f32x4*>(d);
+                    *d4 = *d4 + v * m;
+                } else {
+                    unsafeAtomicAdd(d + 0, v.x * m);
+                    unsafeAtomicAdd(d + 1, v.y * m);
+                    unsafeAtomicAdd(d + 2, v.z * m);
+                    unsafeAtomicAdd(d + 3, v.w * m);
+                }
             }
             if (mb->attn) {
                 part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel

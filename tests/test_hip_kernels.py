@@ -85,6 +85,36 @@ def test_conv3x3_masked_relu(hip, dilation):
     torch.testing.assert_close(from_nhwc(out, n, C), ref, rtol=RT, atol=AT)
 
 
+@pytest.mark.parametrize("n", [41, 129, 300, 520, 777])
+def test_conv_many_items_every_launch_shape(hip, n):
+    """Item counts around and beyond one round of 256 workgroups: the library cuts such launches into
+    whole rounds with one K-split plus a remainder with a larger one, and maps the splits of an item to
+    one XCD -- every item must still get exactly its own result."""
+    g = gen(n)
+    x = torch.relu(torch.randn(n, C, H, W, generator=g))
+    m = torch.sigmoid(torch.randn(n, 1, H, W, generator=g))
+    w = torch.randn(4, C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(4, C, generator=g) * 0.1
+    xd, md = nhwc(x), m.reshape(n, HW).to(dev())
+    wd = [wcl(w[k]) for k in range(4)]
+    bd = [b[k].to(dev()) for k in range(4)]
+    out = torch.full((n, HW, C), float("nan"), device=dev())
+    recs = np.zeros(n, hip.CONV_ITEM)
+    for i in range(n):
+        recs[i]["in"], recs[i]["mask"] = ptr(xd[i]), ptr(md[i])
+        recs[i]["weight"], recs[i]["bias"], recs[i]["out"] = ptr(wd[i % 4]), ptr(bd[i % 4]), ptr(out[i])
+        recs[i]["dilation"] = 1 + (i % 2)
+    run(hip, "pnmn_conv_nhwc", recs, H, W, 1, 9, C, C, 1, 1)
+    xm = (x * m).to(dev())
+    got = out.reshape(n, H, W, C).permute(0, 3, 1, 2)
+    for k in range(4):
+        for d in (1, 2):
+            rows = [i for i in range(n) if i % 4 == k and 1 + (i % 2) == d]
+            if rows:
+                ref = F.relu(F.conv2d(xm[rows], w[k].to(dev()), b[k].to(dev()), padding=d, dilation=d))
+                torch.testing.assert_close(got[rows], ref, rtol=RT, atol=AT)
+
+
 def test_conv_transpose_detecting_identity(hip):
     """A = delta weights: out channel n copies in channel (n*7+3)%128 from tap (n%9): catches
     row/col or tap-order mix-ups that random data with loose tolerance could hide."""
