@@ -19,6 +19,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace pnmn {
 
+// The records hand the kernels plain pointers that were themselves loaded from memory, so the
+// compiler cannot prove they are global addresses and emits FLAT loads -- which also count on the
+// LDS counter (lgkmcnt): every wait for an LDS fragment then waits for the weight fetch from L2 issued
+// just before it, and the software pipeline of the contraction loop collapses.  Everything the
+// records point to is device memory: say so.
+using gfloat = __attribute__((address_space(1))) float;
+using gf32x4 = __attribute__((address_space(1))) f32x4;
+__device__ __forceinline__ const gfloat* as_global(const float* p) { return (const gfloat*)p; }
+__device__ __forceinline__ gfloat* as_global(float* p) { return (gfloat*)p; }
+__device__ __forceinline__ f32x4 load4(const gfloat* p) { return *(const gf32x4*)p; }
+__device__ __forceinline__ void store4(gfloat* p, f32x4 v) { *(gf32x4*)p = v; }
+
 constexpr int CB = 128;  // channels per block (input chunk and output block)
 
 struct MaskBwd {
@@ -65,25 +77,26 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weight row of this lane: output channel n0 + li, channels 4g.. of each 16-block
-    const float* wrow = it.weight + (size_t)(n0 + li) * ntaps * cin_total + 4 * g + ks * KB * 16;
+    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * ntaps * cin_total + 4 * g + ks * KB * 16;
 
     if (tid < 32) reinterpret_cast<f32x4*>(lds + HW * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int chunk = 0; chunk < cin_chunks; ++chunk) {
         // ---- stage this 128-channel chunk of the input into LDS (fused prologue) ----
-        const float* src = (it.in2 != nullptr && chunk > 0) ? it.in2 : it.in + chunk * CB;
-        const float* gsrc = it.gate ? it.gate + chunk * CB : nullptr;
+        const gfloat* src = as_global((it.in2 != nullptr && chunk > 0) ? it.in2 : it.in + chunk * CB);
+        const gfloat* gsrc = it.gate ? as_global(it.gate + chunk * CB) : nullptr;
+        const gfloat* msrc = as_global(it.mask);
         if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk
         for (int idx = tid; idx < HW * 32; idx += NTHREADS) {
             const int p = idx >> 5;
             const int s = idx & 31;
-            f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)p * in_stride + s * 4);
-            if (it.mask) {
-                const float m = it.mask[p];
+            f32x4 v = load4(src + (size_t)p * in_stride + s * 4);
+            if (msrc) {
+                const float m = msrc[p];
                 v *= m;
             }
             if (gsrc) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(gsrc + (size_t)p * in_stride + s * 4);
+                const f32x4 gt = load4(gsrc + (size_t)p * in_stride + s * 4);
                 v.x = gt.x > 0.f ? v.x : 0.f;
                 v.y = gt.y > 0.f ? v.y : 0.f;
                 v.z = gt.z > 0.f ? v.z : 0.f;
@@ -93,7 +106,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
         }
         __syncthreads();
 
-        const float* wchunk = wrow + chunk * CB;
+        const gfloat* wchunk = wrow + chunk * CB;
 
         // LDS float offset of the (tap-shifted) pixel row of every m-tile, swizzle bits folded in:
         // q*128 + ((g ^ (q&3)) << 2), low 2 bits carry (q>>2)&3
@@ -144,17 +157,17 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                 if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.w, afrag[mt].w, acc[mt], 0, 0, 0);
         };
         load_half(0, MT, ks * KB);
-        bfrag[0] = *reinterpret_cast<const f32x4*>(wchunk);
+        bfrag[0] = load4(wchunk);
 
         for (int tap = 0; tap < ntaps; ++tap) {
             const int tn = (tap + 1 < ntaps) ? tap + 1 : tap;  // (the last tap re-requests its own data)
-            const float* wtap = wchunk + (size_t)tap * cin_total;
-            const float* wtn = wchunk + (size_t)tn * cin_total;
+            const gfloat* wtap = wchunk + (size_t)tap * cin_total;
+            const gfloat* wtn = wchunk + (size_t)tn * cin_total;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const bool last = (kb + 1 == KB);
                 const int kbg_next = last ? ks * KB : ks * KB + kb + 1;
-                bfrag[1] = *reinterpret_cast<const f32x4*>(last ? wtn : wtap + (kb + 1) * 16);
+                bfrag[1] = load4(last ? wtn : wtap + (kb + 1) * 16);
                 const f32x4 bw = bfrag[0];
                 mfma_half(0, MH, bw);
                 __builtin_amdgcn_sched_barrier(0);
@@ -192,7 +205,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
 
     // ---- epilogue: lane holds out channels n0+4g..+3 of pixel mt*16+li ----
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it.bias) bias4 = *reinterpret_cast<const f32x4*>(it.bias + n0 + 4 * g);
+    if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
     if (mb == nullptr) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -212,9 +225,9 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                     unsafeAtomicAdd(dstf + 2, v.z);
                     unsafeAtomicAdd(dstf + 3, v.w);
                 } else {
-                    f32x4* dst = reinterpret_cast<f32x4*>(dstf);
-                    if (it.flags & PNMN_CONV_ACCUMULATE) v += *dst;
-                    *dst = v;
+                    gfloat* dst = as_global(dstf);
+                    if (it.flags & PNMN_CONV_ACCUMULATE) v += load4(dst);
+                    store4(dst, v);
                 }
             }
         }
@@ -229,14 +242,14 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
             if (ok) {
                 float m = 1.f;
                 if (mb->attn) {
-                    m = mb->attn[p];
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(mb->feats + (size_t)p * CB + n0 + 4 * g);
+                    m = as_global(mb->attn)[p];
+                    const f32x4 f = load4(as_global(mb->feats) + (size_t)p * CB + n0 + 4 * g);
                     part = v.x * f.x + v.y * f.y + v.z * f.z + v.w * f.w;
                 }
                 float* d = mb->dfeats + (size_t)p * CB + n0 + 4 * g;
                 if (it.flags & PNMN_CONV_MB_SOLE) {  // only this workgroup touches these 4 channels of pixel p
-                    f32x4* d4 = reinterpret_cast<f32x4*>(d);
-                    *d4 = *d4 + v * m;
+                    gfloat* d4 = as_global(d);
+                    store4(d4, load4(d4) + v * m);
                 } else {
                     unsafeAtomicAdd(d + 0, v.x * m);
                     unsafeAtomicAdd(d + 1, v.y * m);
