@@ -27,8 +27,8 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "global_ptr.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -71,22 +71,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     for (int ii = job.item_begin; ii < job.item_end; ++ii) {
         const pnmn_wgrad_item it = items[ii];
         const int dil = it.dilation;
-        const float* xsrc = (it.x2 != nullptr && cib > 0) ? it.x2 : it.x + cib * CB;
+        // (global, not flat, loads: see conv_body.h)
+        const pnmn::gfloat* xsrc = pnmn::as_global((it.x2 != nullptr && cib > 0) ? it.x2 : it.x + cib * CB);
+        const pnmn::gfloat* xmask = pnmn::as_global(it.xmask);
+        const pnmn::gfloat* dysrc = pnmn::as_global(it.dy);
+        const pnmn::gfloat* gatesrc = pnmn::as_global(it.gate);
         __syncthreads();  // previous item fully consumed
         for (int idx = tid; idx < HW * 32; idx += 512) {
             const int p = idx >> 5;
             const int s = idx & 31;
-            f32x4 v = *reinterpret_cast<const f32x4*>(xsrc + (size_t)p * x_stride + s * 4);
-            if (it.xmask) v *= it.xmask[p];
+            f32x4 v = pnmn::load4(xsrc + (size_t)p * x_stride + s * 4);
+            if (xmask) v *= xmask[p];
             *reinterpret_cast<f32x4*>(xl + p * CB + s * 4) = v;
         }
         for (int idx = tid; idx < HW * 16; idx += 512) {
             const int p = idx >> 4;
             const int s = idx & 15;
             const size_t o = (size_t)p * dy_stride + coh * CH + s * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(it.dy + o);
-            if (it.gate) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(it.gate + o);
+            f32x4 v = pnmn::load4(dysrc + o);
+            if (gatesrc) {
+                const f32x4 gt = pnmn::load4(gatesrc + o);
                 v.x = gt.x > 0.f ? v.x : 0.f;
                 v.y = gt.y > 0.f ? v.y : 0.f;
                 v.z = gt.z > 0.f ? v.z : 0.f;
