@@ -314,8 +314,9 @@ def fit_program_generator(pg, vocab, batch, dev, max_iters, target):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps first: allocator pools, GEMM heuristics and the program / template caches settle")
     ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -404,10 +405,10 @@ def main():
                 step = make()
                 if name == "module_training":
                     b["program"] = b["program"].cpu()
-                e, _, _ = timed(lambda: step.step(b), 10, 3, dev, world)
+                e, _, _ = timed(lambda: step.step(b), 10, 6, dev, world)
                 extras[name] = {"metric": metric, "value": round(n * world * 10 / e, 1), "unit": "questions/s",
                                 "ms_per_step": round(e / 10 * 1e3, 3), "global_batch": n * world, "steps": 10,
-                                "warmup": 3, "workload": workload}
+                                "warmup": 6, "workload": workload}
                 log("%s: %.1f questions/s" % (name, extras[name]["value"]))
             except Exception as exc:  # the headline line must survive a failure of a side measurement
                 extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
