@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(
     const pnmn_conv_item* __restrict__ items, int n_items, int cin_chunks, int ntaps, int in_stride,
     int out_stride, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* lds = reinterpret_cast<float*>(smem_raw);  // [(HW+1)][128], row HW is zero
+    float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows(HW)][128], the last rows are zero
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (XCD = linear id % 8), each with
     // its own L2.  The KSPLIT workgroups of an item all stage the same input tile, so they are given ids
     // that are congruent mod 8: the tile is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void conv_nhwc_kernel(
 template <int H, int W, int KSPLIT>
 int launch_conv_k(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
                   int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    constexpr size_t lds_bytes = (size_t)(H * W + 1) * CB * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows(H * W) * CB * sizeof(float);
     static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((H * W + 15) / 16) * 64 * 16 <= lds_bytes,
                   "reduction scratch must fit in the input image");
     static bool configured = false;

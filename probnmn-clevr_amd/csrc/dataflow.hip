@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NTHREADS) void dataflow_kernel(const pnmn_task* __r
                                                             int* __restrict__ ctrl, int* __restrict__ done,
                                                             unsigned spin_limit) {
     constexpr int HW = H * W;
-    constexpr int LDS_FLOATS = (HW + 1) * CB;
+    constexpr int LDS_FLOATS = pnmn::lds_rows(HW) * CB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     int* sh = reinterpret_cast<int*>(lds + LDS_FLOATS);  // [0] task index, [1] abort
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS) void dataflow_kernel(const pnmn_task* __r
 
 template <int H, int W, int KSPLIT>
 int launch_dataflow(const pnmn_task* tasks, int n_tasks, int* ctrl, int* done, int n_workgroups, hipStream_t stream) {
-    constexpr size_t lds_bytes = (size_t)(H * W + 1) * CB * sizeof(float) + 64;
+    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows(H * W) * CB * sizeof(float) + 64;
     static bool configured = false;
     auto kern = dataflow_kernel<H, W, KSPLIT>;
     if (!configured) {
