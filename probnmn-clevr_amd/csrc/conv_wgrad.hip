@@ -43,8 +43,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     static_assert(HW % 4 == 0, "pixel count must be a multiple of the MFMA k (4)");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* xl = reinterpret_cast<float*>(smem_raw);  // [(HW+1)][128], row HW = zeros
-    float* dl = xl + (HW + 1) * CB;                  // [HW][64]
+    // x image: row p = 128 channels with channel bit 4 flipped on odd rows.  The B operand is read with
+    // ds_read_b32 (served 32 lanes at a time over 32 banks): lanes of lane-group g and g + 1 read the
+    // same 16 channels of two ADJACENT pixels, i.e. the same banks at different addresses unless the
+    // rows are skewed -- SQ_LDS_BANK_CONFLICT was 38 % of the LDS cycles without the flip.  Two zero
+    // rows (one per parity) stand in for taps outside the image.
+    float* xl = reinterpret_cast<float*>(smem_raw);  // [(HW+2)][128], rows HW, HW+1 = zeros
+    float* dl = xl + (HW + 2) * CB;                  // [HW][64]
+    // [TAPS][HW]: float offset of the x row a tap reads at each pixel, row parity << 4 folded in.  Built
+    // once per item (the dilation is per item); the contraction loop then spends one LDS read + two
+    // integer ops per tap instead of the dozen it takes to derive the shifted, bounds-checked, skewed
+    // address -- that loop was limited by those integer ops, not by the matrix cores.
+    int* qtab = reinterpret_cast<int*>(dl + HW * CH);
+    static_assert(HW % 2 == 0, "zero rows keep the parity of the pixel they replace");
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bias_acc = 0.f;  // partial of dbias for channel (tid & 63), pixels strided by 8
 
-    if (tid < 32) reinterpret_cast<f32x4*>(xl + HW * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 64) reinterpret_cast<f32x4*>(xl + HW * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int ii = job.item_begin; ii < job.item_end; ++ii) {
         const pnmn_wgrad_item it = items[ii];
@@ -77,12 +88,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
         const pnmn::gfloat* dysrc = pnmn::as_global(it.dy);
         const pnmn::gfloat* gatesrc = pnmn::as_global(it.gate);
         __syncthreads();  // previous item fully consumed
+        for (int idx = tid; idx < TAPS * HW; idx += 512) {
+            const int t = idx / HW, p = idx - t * HW;
+            int q = p;
+            if (TAPS == 9) {
+                const int yy = p / W + (t / 3 - 1) * dil;
+                const int xx = p % W + (t % 3 - 1) * dil;
+                const bool ok = ((unsigned)yy < (unsigned)H) && ((unsigned)xx < (unsigned)W);
+                const int qv = yy * W + xx;
+                q = ok ? qv : HW + (qv & 1);
+            }
+            qtab[idx] = q * CB + ((q & 1) << 4);
+        }
         for (int idx = tid; idx < HW * 32; idx += 512) {
             const int p = idx >> 5;
             const int s = idx & 31;
             f32x4 v = pnmn::load4(xsrc + (size_t)p * x_stride + s * 4);
             if (xmask) v *= xmask[p];
-            *reinterpret_cast<f32x4*>(xl + p * CB + s * 4) = v;
+            *reinterpret_cast<f32x4*>(xl + p * CB + ((s * 4) ^ ((p & 1) << 4))) = v;
         }
         for (int idx = tid; idx < HW * 16; idx += 512) {
             const int p = idx >> 4;
@@ -105,21 +128,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
             for (int p = (tid >> 6); p < HW; p += 8) bias_acc += dl[p * CH + c];
         }
 
+        const int col_lo = (wave * 16 + li) & ~16, col_bit = (wave * 16 + li) & 16;
         for (int p0 = 0; p0 < HW; p0 += 4) {
             const int p = p0 + g;  // this lane's k (pixel)
             const f32x4 a = *reinterpret_cast<const f32x4*>(dl + p * CH + li * 4);
-            const int y = p / W;
-            const int x = p % W;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                int q = p;
-                if (TAPS == 9) {
-                    const int yy = y + (t / 3 - 1) * dil;
-                    const int xx = x + (t % 3 - 1) * dil;
-                    const bool ok = ((unsigned)yy < (unsigned)H) && ((unsigned)xx < (unsigned)W);
-                    q = ok ? yy * W + xx : HW;
-                }
-                const float b = xl[q * CB + wave * 16 + li];
+                const float b = xl[(qtab[t * HW + p] ^ col_bit) + col_lo];
                 acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, acc[t][0], 0, 0, 0);
                 acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, acc[t][1], 0, 0, 0);
                 acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, acc[t][2], 0, 0, 0);
@@ -150,7 +165,7 @@ template <int H, int W, int TAPS>
 int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int cin_blocks,
                  int cout_blocks, int x_stride, int dy_stride, hipStream_t stream) {
     constexpr int HW = H * W;
-    constexpr size_t lds_bytes = ((size_t)(HW + 1) * CB + (size_t)HW * CH) * sizeof(float);
+    constexpr size_t lds_bytes = ((size_t)(HW + 2) * CB + (size_t)HW * CH + (size_t)TAPS * HW) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "tiles must fit the CU's LDS");
     static bool configured = false;
     auto kern = conv_wgrad_kernel<H, W, TAPS>;
