@@ -93,26 +93,57 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
         const gfloat* gsrc = it.gate ? as_global(it.gate + chunk * CB) : nullptr;
         const gfloat* msrc = as_global(it.mask);
         if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk
-        for (int idx = tid; idx < HW * 32; idx += NTHREADS) {
-            const int p = idx >> 5;
-            // eight consecutive lanes take the eight k-blocks of one g: their slots differ in the low three
-            // bits, which is what ds_write_b128 (served 8 lanes at a time over 32 banks) needs; the wave as
-            // a whole still reads whole 512-byte pixel rows from memory
-            const int kb = idx & 7, gg = (idx >> 3) & 3;
-            const int c4 = (kb * 4 + gg) * 4;  // first of this thread's four channels
-            f32x4 v = load4(src + (size_t)p * in_stride + c4);
+        // This thread's 16-byte pieces of the tile (and of the mask / gate) are requested in two batches
+        // of seven before any is used: a rolled loop waits out one full memory round trip per piece --
+        // 13 in a row, 12-25 us per chunk with nothing to overlap at one workgroup per CU.  (One batch of
+        // 13 would need more registers than the accumulators leave.)
+        constexpr int NST = (HW * 32 + NTHREADS - 1) / NTHREADS;
+        constexpr int BATCH = (NST + 1) / 2;
+#pragma unroll 1
+        for (int i0 = 0; i0 < NST; i0 += BATCH) {
+            f32x4 sv[BATCH];
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int idx = tid + (i0 + i) * NTHREADS;
+                // eight consecutive lanes take the eight k-blocks of one g: their slots differ in the low
+                // three bits, which is what ds_write_b128 (served 8 lanes at a time over 32 banks) needs;
+                // the wave as a whole still reads whole 512-byte pixel rows from memory
+                const int c4 = ((idx & 7) * 4 + ((idx >> 3) & 3)) * 4;  // first of this thread's four channels
+                sv[i] = idx < HW * 32 ? load4(src + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (msrc) {
-                const float m = msrc[p];
-                v *= m;
+                float mk[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int idx = tid + (i0 + i) * NTHREADS;
+                    mk[i] = idx < HW * 32 ? msrc[idx >> 5] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) sv[i] *= mk[i];
             }
             if (gsrc) {
-                const f32x4 gt = load4(gsrc + (size_t)p * in_stride + c4);
-                v.x = gt.x > 0.f ? v.x : 0.f;
-                v.y = gt.y > 0.f ? v.y : 0.f;
-                v.z = gt.z > 0.f ? v.z : 0.f;
-                v.w = gt.w > 0.f ? v.w : 0.f;
+                f32x4 gt[BATCH];
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    const int idx = tid + (i0 + i) * NTHREADS;
+                    const int c4 = ((idx & 7) * 4 + ((idx >> 3) & 3)) * 4;
+                    gt[i] = idx < HW * 32 ? load4(gsrc + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int i = 0; i < BATCH; ++i) {
+                    sv[i].x = gt[i].x > 0.f ? sv[i].x : 0.f;
+                    sv[i].y = gt[i].y > 0.f ? sv[i].y : 0.f;
+                    sv[i].z = gt[i].z > 0.f ? sv[i].z : 0.f;
+                    sv[i].w = gt[i].w > 0.f ? sv[i].w : 0.f;
+                }
             }
-            *reinterpret_cast<f32x4*>(lds + p * CB + (lds_slot(kb, gg, p) << 2)) = v;
+#pragma unroll
+            for (int i = 0; i < BATCH; ++i) {
+                const int idx = tid + (i0 + i) * NTHREADS;
+                const int p = idx >> 5;
+                if (idx < HW * 32)
+                    *reinterpret_cast<f32x4*>(lds + p * CB + (lds_slot(idx & 7, (idx >> 3) & 3, p) << 2)) = sv[i];
+            }
         }
         __syncthreads();
 
