@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "global_ptr.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -37,34 +38,66 @@ __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dot1_sigmoid_fwd_kernel(const pnmn_dot1_item* __restrict__ items,
                                                                int HW) {
+    // Each half-wave walks every eighth pixel; the pixel rows of a batch are all requested before the
+    // first reduction (one memory round trip per batch of 13 pixels instead of one per pixel -- the
+    // rolled loop made this kernel take 14 us however few items it had).
+    constexpr int NB = 13;
     const pnmn_dot1_item it = items[blockIdx.x];
     const int h = threadIdx.x & 31;
     const int hw = threadIdx.x >> 5;  // half-wave id 0..7
-    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
-    const float b = it.b[0];
-    for (int p = hw; p < HW; p += 8) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(it.in + (size_t)p * C + 4 * h);
-        const float s = half_wave_sum(dot4(x, w));
-        if (h == 0) it.out[p] = sigmoidf(s + b);
+    const pnmn::gfloat* in = pnmn::as_global(it.in);
+    pnmn::gfloat* out = pnmn::as_global(it.out);
+    const f32x4 w = pnmn::load4(pnmn::as_global(it.w) + 4 * h);
+    const float b = pnmn::as_global(it.b)[0];
+    for (int p0 = hw; p0 < HW; p0 += 8 * NB) {
+        f32x4 x[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = p0 + 8 * k;
+            x[k] = p < HW ? pnmn::load4(in + (size_t)p * C + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = p0 + 8 * k;
+            const float s = half_wave_sum(dot4(x[k], w));
+            if (h == 0 && p < HW) out[p] = sigmoidf(s + b);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void dot1_sigmoid_bwd_kernel(const pnmn_dot1_item* __restrict__ items,
                                                                int HW) {
+    constexpr int NB = 7;
     __shared__ float red[8][C + 1];
     const pnmn_dot1_item it = items[blockIdx.x];
     const int h = threadIdx.x & 31;
     const int hw = threadIdx.x >> 5;
-    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
+    const pnmn::gfloat* in = pnmn::as_global(it.in);
+    const pnmn::gfloat* outv = pnmn::as_global(it.out);
+    const pnmn::gfloat* dout = pnmn::as_global(it.dout);
+    pnmn::gfloat* din = pnmn::as_global(it.din);
+    const f32x4 w = pnmn::load4(pnmn::as_global(it.w) + 4 * h);
     f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f};
     float db = 0.f;
-    for (int p = hw; p < HW; p += 8) {
-        const float o = it.out[p];
-        const float dz = it.dout[p] * o * (1.f - o);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(it.in + (size_t)p * C + 4 * h);
-        dw += x * dz;
-        db += dz;
-        *reinterpret_cast<f32x4*>(it.din + (size_t)p * C + 4 * h) = w * dz;
+    for (int p0 = hw; p0 < HW; p0 += 8 * NB) {
+        f32x4 x[NB];
+        float o[NB], g[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = p0 + 8 * k;
+            const bool in_range = p < HW;
+            x[k] = in_range ? pnmn::load4(in + (size_t)p * C + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            o[k] = in_range ? outv[p] : 0.f;
+            g[k] = in_range ? dout[p] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int p = p0 + 8 * k;
+            const float dz = g[k] * o[k] * (1.f - o[k]);
+            dw += x[k] * dz;
+            db += dz;
+            if (p < HW) pnmn::store4(din + (size_t)p * C + 4 * h, w * dz);
+        }
     }
     red[hw][4 * h + 0] = dw.x;
     red[hw][4 * h + 1] = dw.y;
@@ -350,6 +383,27 @@ __global__ __launch_bounds__(256) void transpose_weights_kernel(const pnmn_wtran
     }
 }
 
+// global -> LDS copy loop with eight loads in flight per thread (the natural loop waits for each
+// 4-byte load before issuing the next: the compiler does not move loads across the LDS stores)
+template <typename Load, typename Store>
+__device__ __forceinline__ void copy_batched(int n, Load load, Store store) {
+    constexpr int NB = 8;
+    const int step = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += step * NB) {
+        float v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = i0 + k * step;
+            v[k] = i < n ? load(i) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = i0 + k * step;
+            if (i < n) store(i, v[k]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // NCHW <-> NHWC
 // ------------------------------------------------------------------------------------------------
@@ -362,21 +416,20 @@ __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ s
     const int ld = HW + 1;
     const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
     if (TO_NHWC) {
-        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
-            const int c = i / HW, p = i - c * HW;
-            tile[c * ld + p] = src[((size_t)n * Cn + c0 + c) * HW + p];
-        }
+        const float* s0 = src + ((size_t)n * Cn + c0) * HW;
+        copy_batched(cw * HW, [&](int i) { return s0[i]; },
+                     [&](int i, float v) { const int c = i / HW; tile[c * ld + (i - c * HW)] = v; });
         __syncthreads();
+#pragma unroll 8
         for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
             const int p = i / cw, c = i - p * cw;
             dst[((size_t)n * HW + p) * Cn + c0 + c] = tile[c * ld + p];
         }
     } else {
-        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
-            const int p = i / cw, c = i - p * cw;
-            tile[c * ld + p] = src[((size_t)n * HW + p) * Cn + c0 + c];
-        }
+        copy_batched(cw * HW, [&](int i) { const int p = i / cw; return src[((size_t)n * HW + p) * Cn + c0 + (i - p * cw)]; },
+                     [&](int i, float v) { const int p = i / cw; tile[(i - p * cw) * ld + p] = v; });
         __syncthreads();
+#pragma unroll 8
         for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
             const int c = i / HW, p = i - c * HW;
             dst[((size_t)n * Cn + c0 + c) * HW + p] = tile[c * ld + p];
@@ -396,13 +449,12 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     const int HW = H * W;
     const int PH = H / 2, PW = W / 2, PS = PH * PW;
     const float* src = in + (size_t)n * HW * Cn;
-    for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
-        const int p = i >> 6, c = i & 63;
-        tile[p * 65 + c] = src[(size_t)p * Cn + c0 + c];
-    }
+    copy_batched(HW * 64, [&](int i) { return src[(size_t)(i >> 6) * Cn + c0 + (i & 63)]; },
+                 [&](int i, float v) { tile[(i >> 6) * 65 + (i & 63)] = v; });
     __syncthreads();
     if (!BWD) {
         float* o = out + (size_t)n * Cn * PS + (size_t)c0 * PS;
+#pragma unroll 4
         for (int i = threadIdx.x; i < 64 * PS; i += blockDim.x) {
             const int c = i / PS, s = i - c * PS;
             const int y = (s / PW) * 2, x = (s % PW) * 2;
@@ -436,6 +488,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         __syncthreads();
         // rows/cols beyond the pooled area (odd H or W) receive no gradient
         float* d = out + (size_t)n * HW * Cn;
+#pragma unroll 8
         for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
             const int p = i >> 6, c = i & 63;
             const int y = p / W, x = p - y * W;
