@@ -7,7 +7,7 @@ python -c "import torch" >/dev/null 2>&1
 cd $R
 TAG=${1:-r01d}
 # 1) headline workload only (the bench line's roofline must agree with this table)
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_prof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/${TAG}_prof_bench.log 2>&1
 python profiles/summarize.py $(find /tmp/prof_$TAG -name '*_results.db' | head -1) > gpurun_out/${TAG}_kernel_stats.txt 2>&1
 grep '^{' gpurun_out/${TAG}_prof_bench.log > gpurun_out/${TAG}_prof_bench.json
 # 2) HBM traffic counters, one counter per pass (MI355X_MICROARCH.md: no mixing with other trace domains)
