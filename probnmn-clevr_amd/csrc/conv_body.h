@@ -248,7 +248,18 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
     // ---- epilogue: lane holds out channels n0+4g..+3 of pixel mt*16+li ----
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
+    // Every load of the epilogue (previous contents for accumulation, forward features, attention) is
+    // requested for all 13 m-tiles before the first use: issued one m-tile at a time they cost 13 memory
+    // round trips in a row, with the matrix cores idle.
     if (mb == nullptr) {
+        const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
+        f32x4 old[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = mt * 16 + li;
+            old[mt] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)p * out_stride + n0 + 4 * g)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + li;
@@ -267,39 +278,42 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                     unsafeAtomicAdd(dstf + 2, v.z);
                     unsafeAtomicAdd(dstf + 3, v.w);
                 } else {
-                    gfloat* dst = as_global(dstf);
-                    if (it.flags & PNMN_CONV_ACCUMULATE) v += load4(dst);
-                    store4(dst, v);
+                    store4(as_global(dstf), v + old[mt]);
                 }
             }
         }
     } else {
         // fused backward of (feats * attn): this wave owns channels n0..n0+15 of every pixel
+        const bool sole = it.flags & PNMN_CONV_MB_SOLE;
+        const gfloat* attn = as_global(mb->attn);
+        float am[MT];
+        f32x4 fv[MT], dold[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = mt * 16 + li;
+            const bool ok = p < HW;
+            am[mt] = (ok && attn) ? attn[p] : 1.f;
+            fv[mt] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)p * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dold[mt] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)p * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + li;
             const bool ok = p < HW;
             const f32x4 v = acc[mt];
-            float part = 0.f;
+            float part = v.x * fv[mt].x + v.y * fv[mt].y + v.z * fv[mt].z + v.w * fv[mt].w;
             if (ok) {
-                float m = 1.f;
-                if (mb->attn) {
-                    m = as_global(mb->attn)[p];
-                    const f32x4 f = load4(as_global(mb->feats) + (size_t)p * CB + n0 + 4 * g);
-                    part = v.x * f.x + v.y * f.y + v.z * f.z + v.w * f.w;
-                }
                 float* d = mb->dfeats + (size_t)p * CB + n0 + 4 * g;
-                if (it.flags & PNMN_CONV_MB_SOLE) {  // only this workgroup touches these 4 channels of pixel p
-                    gfloat* d4 = as_global(d);
-                    store4(d4, load4(d4) + v * m);
+                if (sole) {  // only this workgroup touches these 4 channels of pixel p
+                    store4(as_global(d), dold[mt] + v * am[mt]);
                 } else {
-                    unsafeAtomicAdd(d + 0, v.x * m);
-                    unsafeAtomicAdd(d + 1, v.y * m);
-                    unsafeAtomicAdd(d + 2, v.z * m);
-                    unsafeAtomicAdd(d + 3, v.w * m);
+                    unsafeAtomicAdd(d + 0, v.x * am[mt]);
+                    unsafeAtomicAdd(d + 1, v.y * am[mt]);
+                    unsafeAtomicAdd(d + 2, v.z * am[mt]);
+                    unsafeAtomicAdd(d + 3, v.w * am[mt]);
                 }
             }
-            if (mb->attn) {
+            if (attn) {
                 part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
                 part += __shfl_xor(part, 32);
                 if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p, part);

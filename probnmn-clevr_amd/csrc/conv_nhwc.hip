@@ -24,6 +24,8 @@
 //
 // LDS image: row p (pixel) = 128 floats = 32 slots of 16 B; slot s is stored at s ^ (p & 15), which
 // makes the 16 pixel rows a ds_read_b128 lane-group touches land on 16 different bank slots.
+#include <stdlib.h>
+
 #include "conv_body.h"
 
 namespace {
@@ -80,7 +82,11 @@ struct LaunchPlan {
 
 inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps) {
     const double work = (double)ntaps * cin_chunks;
-    const double overhead = 0.5 * cin_chunks + 0.25;
+    static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
+        const char* e = getenv("PNMN_CONV_STAGE_COST");
+        return e ? atof(e) : 0.5;
+    }();
+    const double overhead = stage_cost * cin_chunks + 0.25;
     auto round_cost = [&](int s) { return work / s + overhead; };
     LaunchPlan best{1, 0, 1};
     double best_t = 1e30;
