@@ -56,11 +56,18 @@ class _TrainerBase:
                 arenas.append(m.engine.ensure_arena())
                 m.engine.direct_grads = True
             params.extend(m.parameters())
-        return ClampAdam(params, arenas=arenas, lr=lr, weight_decay=weight_decay, clamp=5.0)
+        optimizer = ClampAdam(params, arenas=arenas, lr=lr, weight_decay=weight_decay, clamp=5.0)
+        # data parallel: the NMN's fully connected layer (205 MB of gradient) is the first thing backward
+        # finishes -- its all-reduce starts from the gradient hook and runs beside the NMN trunk backward
+        # (plain grouped launches), well before the multi-CU recurrent kernels of the seq2seq backward,
+        # which want the whole chip to themselves
+        big = [p for p in optimizer.loose if p.numel() >= (1 << 20)]
+        self._early = parallel.EarlyReducer(big) if big else None
+        return optimizer
 
     def _finish(self, loss: torch.Tensor) -> None:
         loss.backward()
-        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose)
+        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
         self.optimizer.step()
         self.iteration += 1
 
