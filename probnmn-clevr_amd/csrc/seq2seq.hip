@@ -1,7 +1,8 @@
-// Seq2seq point kernels for gfx950: the LSTM cell (gate non-linearities + state update, forward and
-// backward) and the per-step token sampler (softmax, forbidden-token masking, inverse-CDF draw from
-// a counter-based Philox stream or arg-max, log-prob gather).  The 256-wide GEMMs around them are
-// plain library GEMMs and stay with hipBLASLt.
+// Seq2seq kernels for gfx950.  First the point kernels of the step-by-step fallback: the LSTM cell (gate
+// non-linearities + state update, forward and backward) and the per-step token sampler (softmax,
+// forbidden-token masking, inverse-CDF draw from a counter-based Philox stream or arg-max, log-prob
+// gather).  Then the persistent LSTM-layer kernels (one workgroup per 16-row tile, and the multi-CU
+// variants that share a tile among 4 or 8 workgroups) -- see the notes above them.
 //
 // All are bandwidth/latency-bound: one thread per (row, hidden unit) reading the four gate
 // pre-activations (coalesced across units), one wave per sampled row with shuffle reductions.

@@ -8,11 +8,15 @@ sequences, dot-product attention with AllenNLP's ``masked_softmax``, an ``LSTMCe
 ``cat(attended, embedded)``, a linear output projection.  Parameter names follow the reference's
 ``state_dict`` so released checkpoints load.
 
-On the MI355X the per-step gate math of every LSTM step and the token choice are hand-written
-kernels (``pnmn_lstm_cell_{fwd,bwd}``, ``pnmn_sample_tokens``); the 256-wide GEMMs around them are
-plain library GEMMs (torch -> hipBLASLt).  Everything that the reference does with per-row Python
-loops and ``.cpu()`` round trips (sentence boundaries, trimming at ``@end@``) is vectorised on the
-device: a forward pass performs no host synchronisation.
+On the MI355X the recurrences are persistent hand-written kernels: one launch per LSTM layer over
+the whole padded sequence (``pnmn_lstm_seq_{fwd,bwd}``) and one per decoding loop -- attention,
+gates, cell and token choice of every step (``pnmn_attn_lstm_{fwd,bwd}[_multi]``), four or eight
+workgroups sharing each 16-row tile (csrc/seq2seq.hip, decoder_multi.hip).  What can be batched over
+time (input / output projections, losses, weight gradients) is library GEMMs over all steps; other
+hidden sizes fall back to a GEMM per step plus the cell kernel (``pnmn_lstm_cell_{fwd,bwd}``,
+``pnmn_sample_tokens``).  Everything that the reference does with per-row Python loops and ``.cpu()``
+round trips (sentence boundaries, trimming at ``@end@``) is vectorised on the device: a forward pass
+performs no host synchronisation.
 """
 import os
 from typing import Dict, Optional
