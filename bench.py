@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--settle", type=int, default=8, help="set-up iterations before the warm-up (see main)")
     ap.add_argument("--fit-iters", type=int, default=1500, help="cap on the generator's pre-fit iterations")
     ap.add_argument("--fit-target", type=float, default=0.95)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -373,6 +374,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sds = {"pg": cpu_state(pg), "qr": cpu_state(qr), "prior": cpu_state(prior), "nmn": cpu_state(nmn)}
 
+    # set-up, like the generator fit above: a few iterations so that what only happens at the start of a
+    # run (allocator pools growing, GEMM heuristics, templates of program structures seen for the first
+    # time) is over before the W warm-up + K timed steps, whatever W the caller passes
+    for _ in range(args.settle):
+        trainer.step(batch)
+    torch.cuda.synchronize()
     log("joint_training: warmup + %d timed steps" % args.steps)
     elapsed, host, blocked = timed(lambda: trainer.step(batch), args.steps, args.warmup, dev, world)
     log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
