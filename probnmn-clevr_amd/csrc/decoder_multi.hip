@@ -111,6 +111,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     if (tid < ROWS) tokl[tid] = a.start;
+    // source mask of the row this wave attends for (constant over the steps)
+    const float row_mask = lane < S ? a.mask[(size_t)min(myrow0 + (wave >> 2), a.B - 1) * S + lane] : 0.f;
     float creg = 0.f;                       // cell state of (row tid / 32, unit u0 + tid % 32)
     const int arow = min(row0 + li, a.B - 1);  // A-operand row (padding rows read a real row; results dropped)
     __syncthreads();
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads();
             if (q == 0) {
-                const float m = lane < S ? a.mask[(size_t)rowc * S + lane] : 0.f;
+                const float m = row_mask;
                 const float v = (lane < S ? scl[rl][lane] : 0.f) * m;  // allennlp masked_softmax: softmax(vector * mask) ...
                 const float mx = wmax(lane < S ? v : -INFINITY);
                 const float ex = lane < S ? expf(v - mx) : 0.f;
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             wh[nt][kl] = *reinterpret_cast<const f32x4*>(a.w_hh_t + fo);
         }
     float dc_rec = 0.f;
+    const float row_mask = lane < S ? a.mask[(size_t)min(myrow0 + (wave >> 2), a.B - 1) * S + lane] : 0.f;
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             if (q == 0) {
                 // forward quantities of this (row, step): p (softmax before masking), mask, q, Z
-                const float m = lane < S ? a.mask[(size_t)rowc * S + lane] : 0.f;
+                const float m = row_mask;
                 const float p = lane < S ? a.probs[((size_t)rowc * T + t) * S + lane] : 0.f;
                 const float qv = p * m;
                 const float Z = wsum(qv) + 1e-13f;
