@@ -117,13 +117,13 @@ def kernel_rooflines(engine, step_fn, passes):
     events, engine.event_log = engine.event_log, None
     engine.overlap_wgrad = overlap
     agg = {}
-    for kern, what, flops, e0, e1, nbytes in events:
+    for kern, what, flops, e0, e1, nbytes, launches in events:
         a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
         ms = e0.elapsed_time(e1)
         a["flops"] += flops
         a["bytes"] += nbytes
         a["ms"] += ms
-        a["launches"] += 1
+        a["launches"] += launches  # (a call with a remainder is two kernel launches)
         b = a["by"].setdefault(what, [0.0, 0.0, 0])
         b[0] += flops
         b[1] += ms

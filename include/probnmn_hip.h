@@ -74,6 +74,9 @@ typedef struct pnmn_conv_item {
 int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks,
                    int ntaps /* 9 or 1 */, int in_stride, int out_stride,
                    int cout_blocks /* cout_total / 128 */, int relu, void* stream);
+/* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 or 2: whole rounds of 256
+ * workgroups with one K-split, the remainder with a larger one) -- for per-launch accounting. */
+int pnmn_conv_nhwc_launches(int n_items, int cin_chunks, int ntaps, int cout_blocks);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped convolution weight-gradient (autograd wgrad of the convs above).

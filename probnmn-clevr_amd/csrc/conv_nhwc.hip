@@ -149,6 +149,12 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
 
 }  // namespace
 
+extern "C" int pnmn_conv_nhwc_launches(int n_items, int cin_chunks, int ntaps, int cout_blocks) {
+    if (n_items <= 0) return 0;
+    const LaunchPlan lp = plan_launch(n_items, cout_blocks, cin_chunks, ntaps);
+    return (lp.n_main > 0 ? 1 : 0) + (lp.n_main < n_items ? 1 : 0);
+}
+
 extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W,
                               int cin_chunks, int ntaps, int in_stride, int out_stride,
                               int cout_blocks, int relu, void* stream) {

@@ -64,6 +64,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, _P),
     "pnmn_attn_lstm_bwd_multi": (_P,) * 14 + (_I,) * 4 + (_P, _P),
     "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
+    "pnmn_conv_nhwc_launches": (_I, _I, _I, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }

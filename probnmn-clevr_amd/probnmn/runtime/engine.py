@@ -120,9 +120,10 @@ class NMNEngine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes: every item's input and
-            # output map once + one pass over the weights)
+            # output map once + one pass over the weights, kernel launches of this call)
             log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
-                        4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C)))
+                        4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C),
+                        _hip.lib().pnmn_conv_nhwc_launches(n, cin_chunks, ntaps, cout_blocks)))
 
     def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
         """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
@@ -137,7 +138,7 @@ class NMNEngine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(stream)
             log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1,
-                        4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C)))
+                        4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C), 1))
 
     # ---- parameters ---------------------------------------------------------------------------
     def trunk_named_parameters(self):

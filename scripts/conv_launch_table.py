@@ -24,7 +24,7 @@ nmn.engine.event_log = []
 step.step(batch)
 torch.cuda.synchronize()
 rows = []
-for kern, what, flops, e0, e1, _ in nmn.engine.event_log:
+for kern, what, flops, e0, e1, _, _ in nmn.engine.event_log:
     rows.append((kern, what, flops, e0.elapsed_time(e1)))
 tot = {}
 print("%-11s %-22s %9s %9s %8s" % ("kernel", "site", "GFLOP", "ms", "TF"))
