@@ -45,7 +45,7 @@ class ProgramPrior(nn.Module):
             raise _hip.HipLibraryError("program prior input on %s: the HIP path needs a ROCm device" % program_tokens.device)
         toks = add_sentence_boundary_token_ids(program_tokens, self._pad_index, self._start_index, self._end_index)
         mask = toks != self._pad_index
-        encoded = self._encoder(self._embedder(toks), mask)
+        encoded = self._encoder.forward_tokens(self._embedder.embedding, toks, mask)
         logits = self._output_layer(self._projection_layer(encoded))
         with torch.no_grad():
             probs = F.softmax(logits, dim=-1).clone()

@@ -332,22 +332,43 @@ def sequence_cross_entropy(logits, targets, weights, eps: float = 1e-13):
     return nll.sum(1) / (weights.sum(1) + eps)
 
 
-def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+def token_projection(embedding: nn.Embedding, tokens: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``F.linear(embedding(tokens), weight, bias)`` for a small vocabulary: project the V < 100
+    embedding rows once (a [V, 4H] table) and gather table rows per token, instead of a GEMM over all
+    B x T rows; backward is the one-hot GEMM of ``_EmbeddingLookup`` into the table and a V-row GEMM
+    from there.  The padding row of ``embedding`` (all zeros, no gradient) keeps both properties."""
+    w = embedding.weight
+    if embedding.padding_idx is not None:
+        keep = torch.ones(w.size(0), 1, dtype=w.dtype, device=w.device)
+        keep[embedding.padding_idx] = 0.0
+        w = w * keep  # value unchanged (the row is zero); stops the gradient into the padding row
+    table = F.linear(w, weight, bias)
+    if tokens.device.type != "cuda" or not torch.is_grad_enabled():
+        return F.embedding(tokens, table)
+    return _EmbeddingLookup.apply(table, tokens, None)
+
+
+def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projection: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
     length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
-    input GEMM batched over time and the recurrence in one persistent HIP kernel per layer."""
-    B, T, _ = x.shape
+    input GEMM batched over time and the recurrence in one persistent HIP kernel per layer.
+    ``first_projection``: the first layer's input projection when the caller already has it
+    (``token_projection``); ``x`` is then unused."""
+    B, T = mask.shape
     inp = x
     for layer in range(lstm.num_layers):
         w_ih = getattr(lstm, "weight_ih_l%d" % layer)
         w_hh = getattr(lstm, "weight_hh_l%d" % layer)
         bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
-        xp = linear_rows(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
+        if layer == 0 and first_projection is not None:
+            xp = first_projection
+        else:
+            xp = linear_rows(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
         if lstm.hidden_size == 256:
             inp = _LSTMLayerSeq.apply(xp, w_hh)  # one persistent launch for all T steps
         else:  # other widths: step by step (GEMM per step + the cell kernel)
-            h = x.new_zeros(B, lstm.hidden_size)
-            c = x.new_zeros(B, lstm.hidden_size)
+            h = xp.new_zeros(B, lstm.hidden_size)
+            c = xp.new_zeros(B, lstm.hidden_size)
             w_hh_t = w_hh.t()
             outs = []
             for t in range(T):
@@ -385,6 +406,13 @@ class _Encoder(nn.Module):
 
     def forward(self, x, mask):
         return masked_lstm(self._module, x, mask)
+
+    def forward_tokens(self, embedding: nn.Embedding, tokens: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """``forward(embedding(tokens), mask)`` with the first layer's input projection taken from a
+        per-token table (``token_projection``)."""
+        lstm = self._module
+        xp = token_projection(embedding, tokens, lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
+        return masked_lstm(lstm, None, mask, first_projection=xp)
 
 
 class Seq2SeqBase(nn.Module):
@@ -445,7 +473,7 @@ class Seq2SeqBase(nn.Module):
         pad, bos, eos = self._pad_index, self._start_index, self._end_index
         src = add_sentence_boundary_token_ids(source_tokens, pad, bos, eos)[:, 1:]  # @start@ is not encoded
         src_mask = src != pad
-        enc = self._encoder(self._source_embedder(src), src_mask)
+        enc = self._encoder.forward_tokens(self._source_embedder.embedding, src, src_mask)
         rows = torch.arange(src.size(0), device=src.device)
         return {"enc": enc, "h": enc[rows, src_mask.sum(1) - 1], "fmask": src_mask.float()}
 
@@ -481,7 +509,7 @@ class Seq2SeqBase(nn.Module):
         if fused:
             args = (pad, self._unk_index, bos)
             if tgt is not None:  # teacher forcing: every step's input embedding is known up front
-                xe = linear_rows(embedding_lookup(self._target_embedder, tgt[:, :steps]), w_e, bias)
+                xe = token_projection(self._target_embedder, tgt[:, :steps], w_e, bias)
                 hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
                                                0, steps, seed, self.sample_row_offset, *args)
             else:  # free running: the kernel also picks each step's token
