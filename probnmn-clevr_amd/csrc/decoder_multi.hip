@@ -168,19 +168,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         {
             const float* cp = a.ctx + ((size_t)arow * T + t) * H + 4 * g;
             const float* hp = (t > 0 ? a.hs + ((size_t)arow * T + (t - 1)) * H : a.h0 + (size_t)arow * H) + 4 * g;
+            // A operands in four batches of 4 + 4 fragments, each requested in full before its MFMAs (the
+            // compiler otherwise waits for every 16-byte fragment separately; larger batches do not fit
+            // beside the 128 weight registers).  This wave owns ONE output tile, so a single accumulator
+            // would make its 128 MFMAs one dependent chain (each waits out the previous one's full
+            // latency, ~3x the issue time): four partial sums -- context / hidden state, even / odd
+            // k-block -- keep four chains in flight and are added at the end.
+            constexpr int NB = 4;
+            f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0, ph0 = pc0, ph1 = pc0;
 #pragma unroll
-            for (int kb = 0; kb < H / 16; ++kb) {  // (fully unrolled: wc / wh are register arrays)
-                const f32x4 ac = *reinterpret_cast<const f32x4*>(cp + kb * 16);
-                const f32x4 ah = *reinterpret_cast<const f32x4*>(hp + kb * 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, wc[kb].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, wc[kb].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.z, wc[kb].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.w, wc[kb].w, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.x, wh[kb].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.y, wh[kb].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.z, wh[kb].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.w, wh[kb].w, acc, 0, 0, 0);
+            for (int part = 0; part < (H / 16) / NB; ++part) {
+                f32x4 ac[NB], ah[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    ac[j] = *reinterpret_cast<const f32x4*>(cp + (part * NB + j) * 16);
+                    ah[j] = *reinterpret_cast<const f32x4*>(hp + (part * NB + j) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; j += 2) {
+                    const int kb = part * NB + j;
+                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].x, wc[kb].x, pc0, 0, 0, 0);
+                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].x, wh[kb].x, ph0, 0, 0, 0);
+                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].x, wc[kb + 1].x, pc1, 0, 0, 0);
+                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].x, wh[kb + 1].x, ph1, 0, 0, 0);
+                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].y, wc[kb].y, pc0, 0, 0, 0);
+                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].y, wh[kb].y, ph0, 0, 0, 0);
+                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].y, wc[kb + 1].y, pc1, 0, 0, 0);
+                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].y, wh[kb + 1].y, ph1, 0, 0, 0);
+                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].z, wc[kb].z, pc0, 0, 0, 0);
+                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].z, wh[kb].z, ph0, 0, 0, 0);
+                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].z, wc[kb + 1].z, pc1, 0, 0, 0);
+                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].z, wh[kb + 1].z, ph1, 0, 0, 0);
+                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].w, wc[kb].w, pc0, 0, 0, 0);
+                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].w, wh[kb].w, ph0, 0, 0, 0);
+                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].w, wc[kb + 1].w, pc1, 0, 0, 0);
+                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].w, wh[kb + 1].w, ph1, 0, 0, 0);
+                }
             }
+            acc += (pc0 + pc1) + (ph0 + ph1);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) gl[gate][4 * g + r][16 * ub + li] = acc[r];
@@ -213,20 +238,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (a.sample) {
             const int V = a.V;
             if (16 * wave < V) {
-                f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f}, lodd = lacc;
                 const int vn = 16 * wave + li;
                 const bool vok = vn < V;
                 const float* hp = a.hs + ((size_t)arow * T + t) * H + 4 * g;
-#pragma unroll 4
-                for (int kb = 0; kb < H / 16; ++kb) {
-                    const f32x4 ah = *reinterpret_cast<const f32x4*>(hp + kb * 16);
-                    f32x4 bp = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (vok) bp = *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g);
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.x, bp.x, lacc, 0, 0, 0);
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.y, bp.y, lacc, 0, 0, 0);
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.z, bp.z, lacc, 0, 0, 0);
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah.w, bp.w, lacc, 0, 0, 0);
+                constexpr int NB = 4;
+#pragma unroll
+                for (int part = 0; part < (H / 16) / NB; ++part) {
+                    f32x4 ah[NB], bp[NB];
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int kb = part * NB + j;
+                        ah[j] = *reinterpret_cast<const f32x4*>(hp + kb * 16);
+                        bp[j] = vok ? *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < NB; j += 2) {  // two independent chains (even / odd k-block)
+                        lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].x, bp[j].x, lacc, 0, 0, 0);
+                        lodd = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].x, bp[j + 1].x, lodd, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].y, bp[j].y, lacc, 0, 0, 0);
+                        lodd = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].y, bp[j + 1].y, lodd, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].z, bp[j].z, lacc, 0, 0, 0);
+                        lodd = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].z, bp[j + 1].z, lodd, 0, 0, 0);
+                        lacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].w, bp[j].w, lacc, 0, 0, 0);
+                        lodd = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].w, bp[j + 1].w, lodd, 0, 0, 0);
+                    }
                 }
+                lacc += lodd;
                 const float bias = vok ? a.b_p[vn] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) logl[4 * g + r][vn < MAXV ? vn : 0] = vok ? lacc[r] + bias : -INFINITY;
