@@ -125,9 +125,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float* hp = t > 0 ? a.hs + ((size_t)rowc * T + (t - 1)) * H : a.h0 + (size_t)rowc * H;
             const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 4 * lane);
             const float* er = encl + (size_t)rl * S * H + 4 * lane;
-            for (int s = q; s < S; s += 4) {
-                const float p = wsum(dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), hv));
-                if (lane == 0) scl[rl][s] = p;
+            {   // this wave's positions q, q+4, ...: all partial dot products first, then the six-step wave
+                // reductions of all of them interleaved (one at a time they are 6 dependent shuffles each)
+                constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
+                for (int k0 = 0; q + 4 * k0 < S; k0 += NP) {
+                    float part[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int s = q + 4 * (k0 + k);
+                        part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), hv) : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) part[k] += __shfl_xor(part[k], o);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        if (lane == 0 && q + 4 * (k0 + k) < S) scl[rl][q + 4 * (k0 + k)] = part[k];
+                }
             }
             __syncthreads();
             if (q == 0) {
@@ -443,9 +458,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int row = myrow0 + rl, rowc = min(row, a.B - 1);
             const float* er = encl + (size_t)rl * S * H + 4 * lane;
             const f32x4 dc4 = *reinterpret_cast<const f32x4*>(&dctxl[rl][4 * lane]);
-            for (int s = q; s < S; s += 4) {
-                const float d = wsum(dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4));
-                if (lane == 0) dwl[rl][s] = d;
+            {   // (all partial products first, then the wave reductions interleaved -- as in the forward)
+                constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
+                for (int k0 = 0; q + 4 * k0 < S; k0 += NP) {
+                    float part[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int s = q + 4 * (k0 + k);
+                        part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4) : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) part[k] += __shfl_xor(part[k], o);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                        if (lane == 0 && q + 4 * (k0 + k) < S) dwl[rl][q + 4 * (k0 + k)] = part[k];
+                }
             }
             __syncthreads();
             if (q == 0) {
