@@ -427,6 +427,8 @@ def main():
              "question_coding_ours.yml (ProgramGenerator + QuestionReconstructor + frozen ProgramPrior, REINFORCE-ELBO), "
              "512 questions per GPU (configs[2])", 512,
              lambda: QuestionCodingStep(pg, qr, prior, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3))
+        if getattr(trainer, "_early", None) is not None:
+            trainer._early.remove()  # the next trainer hooks the same fully connected layer for its own early all-reduce
         side("module_training", "CLEVR questions/sec (module_training step)",
              "module_training.yml, 256 questions per GPU, ground-truth programs, NMN fwd+bwd+clamp+Adam (configs[1])", 256,
              lambda: ModuleTrainingStep(nmn, lr=1e-4, weight_decay=0.0, report_metrics=False))
