@@ -45,6 +45,9 @@ extern "C" {
  *   x         = gate[p*in_stride+c] > 0 ? x:0  if gate  (ReLU backward fused into the load)
  *   out[p*out_stride + n] = act(bias[n] + sum_{tap,c} x[shift(p,tap,dil)][c] * W[n][tap][c])
  *   (added to the previous contents of out when flags & PNMN_CONV_ACCUMULATE)
+ * Shapes: H x W = 14 x 14 (one workgroup stages the whole map) and 28 x 28 (NMN.IMAGE_FEATURE_SIZE
+ * [1024,28,28], nmn.py:46-53: four row bands per item, each staging the rows its taps touch);
+ * anything else returns PNMN_ESHAPE.
  * ------------------------------------------------------------------------------------------- */
 typedef struct pnmn_conv_item {
     const float* in;
@@ -76,7 +79,7 @@ int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int c
                    int cout_blocks /* cout_total / 128 */, int relu, void* stream);
 /* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 or 2: whole rounds of 256
  * workgroups with one K-split, the remainder with a larger one) -- for per-launch accounting. */
-int pnmn_conv_nhwc_launches(int n_items, int cin_chunks, int ntaps, int cout_blocks);
+int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks);
 
 /* ---------------------------------------------------------------------------------------------
  * Grouped convolution weight-gradient (autograd wgrad of the convs above).
@@ -331,44 +334,6 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
 int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, int B, int V,
                        int greedy, uint64_t seed, uint64_t row_offset, uint32_t step, int pad_index,
                        int unk_index, int start_index, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Persistent dataflow executor: ALL module primitives of a step's forward (or backward) pass in one
- * launch.  Replaces the level-by-level sequence of the grouped launches above for the program
- * executor of nmn.py:197-238 (and its autograd backward).  `tasks` is a topologically ordered
- * list; a task waits until done[dep[i]] >= need[i] for its (up to 3) dependencies, runs, then
- * increments done[slot].  A convolution is `ksplit` tasks (sub = 0..ksplit-1, 128/ksplit output
- * channels each) that share one slot.  ctrl[0] = task counter, ctrl[1] = error (index+1 of a task
- * whose wait timed out); the caller zeroes ctrl[0..1] and done[] before every launch.
- *   pointer slots by type:
- *     CONV        p0 in, p1 in2, p2 mask, p3 gate, p4 weight, p5 bias, p6 out,
- *                 p7 feats, p8 attn, p9 dfeats, p10 dattn (fused mask backward, flag 128)
- *                 flags: 1 accumulate, 2 atomic accumulate, 16 relu, 32 one tap (1x1),
- *                        64 two sources (256 input channels), 128 fused mask backward
- *     DOT_*       p0 in, p1 w, p2 b, p3 out, p4 dout, p5 din, p6 dw, p7 db
- *     SAME_*      p0 feats, p1 attn, p2 w, p3 b, p4 out, p5 dout, p6 dfeats, p7 dattn, p8 dw, p9 db
- *     MINMAX_*    p0 a, p1 b, p2 out, p3 dout, p4 da, p5 db; flags: 1 a has 128 ch, 2 b has 128 ch, 4 max
- * ------------------------------------------------------------------------------------------- */
-#define PNMN_TASK_CONV       0
-#define PNMN_TASK_DOT_FWD    1
-#define PNMN_TASK_DOT_BWD    2
-#define PNMN_TASK_SAME_FWD   3
-#define PNMN_TASK_SAME_BWD   4
-#define PNMN_TASK_MINMAX_FWD 5
-#define PNMN_TASK_MINMAX_BWD 6
-typedef struct pnmn_task {
-    uint64_t p[12];
-    int32_t  type;
-    int32_t  sub;
-    int32_t  dilation;
-    int32_t  flags;
-    int32_t  dep[3];
-    int32_t  need[3];
-    int32_t  slot;
-    int32_t  pad[5];
-} pnmn_task;               /* 160 bytes */
-int pnmn_dataflow(const pnmn_task* tasks, int n_tasks, int32_t* ctrl, int32_t* done, int H, int W,
-                  int ksplit /* 1, 2 or 4 */, int n_workgroups, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side batch program compiler (no device work)        nmn.py:191-238, SURVEY App. C

@@ -13,6 +13,10 @@ What is pinned:
                          from oracle/detgen.py seeds recorded in the file)
   nmn_small.npz          full network at reduced dims: logits, predictions, loss, validity and
                          every parameter gradient of loss.mean()
+  nmn_modules_full_28.npz, nmn_small_28.npz
+                         the same at 28x28 maps (BASELINE config 5; the reference modules are
+                         size-agnostic, nmn_modules.py:72-244, nmn.py:46-53,133); the network
+                         fixture adds programs of up to 40 tokens (LONG_CASES)
   nmn_validity.json      program -> valid table from the reference's try/except interpreter
   elbo_known.json        Reinforce / ELBO outputs and the moving baseline over two calls
 
@@ -200,6 +204,38 @@ VALIDITY_CASES = [
 ]
 
 
+# BASELINE config 5: "program length <= 40" -- deeper module chains than any CLEVR template
+LONG_CASES = [
+    # five hops (20 tokens)
+    "query_color unique filter_shape[cube] relate[left] unique filter_color[red] relate[behind] unique "
+    "filter_size[large] relate[front] unique filter_material[metal] relate[right] unique filter_shape[sphere] "
+    "relate[left] unique filter_color[blue] scene",
+    # comparison of two three-hop chains (27 tokens)
+    "equal_material query_material unique filter_shape[cube] relate[left] unique filter_color[red] relate[behind] "
+    "unique filter_size[large] scene query_material unique filter_color[green] relate[front] unique "
+    "filter_material[metal] relate[right] unique filter_shape[sphere] relate[left] unique filter_size[small] scene",
+    # and / or of long chains under a count, with a same-attribute hop (33 tokens)
+    "count union filter_color[red] relate[left] unique filter_shape[cube] same_size unique filter_material[rubber] "
+    "relate[front] unique filter_size[large] scene intersect filter_color[cyan] relate[behind] unique "
+    "filter_shape[cylinder] scene filter_size[small] relate[right] unique filter_material[metal] relate[left] "
+    "unique filter_color[yellow] filter_shape[sphere] scene",
+    # 40 tokens: integer comparison of two counts over four-hop chains
+    "less_than count filter_color[gray] relate[left] unique filter_shape[cube] relate[behind] unique "
+    "filter_size[large] relate[front] unique filter_material[metal] relate[right] unique filter_color[purple] "
+    "relate[left] unique filter_shape[cylinder] filter_size[small] scene "
+    "count filter_shape[sphere] filter_size[small] relate[left] unique filter_color[brown] relate[behind] unique "
+    "filter_material[rubber] relate[front] unique filter_shape[cylinder] relate[right] unique filter_color[green] "
+    "relate[behind] unique filter_material[metal] filter_size[large] scene",
+    # 40 tokens that end up invalid (a query fed by an encoding)
+    "query_shape query_color unique filter_color[gray] relate[left] unique filter_shape[cube] relate[behind] unique "
+    "filter_size[large] relate[front] unique filter_material[metal] relate[right] unique filter_color[purple] "
+    "relate[left] unique filter_shape[sphere] relate[behind] unique filter_size[small] relate[front] unique "
+    "filter_color[brown] relate[right] unique filter_material[rubber] relate[left] unique filter_shape[cylinder] "
+    "relate[front] unique filter_size[large] relate[behind] unique filter_color[cyan] filter_color[green] filter_shape[cube] scene",
+]
+assert max(len(c.split()) for c in LONG_CASES) == 40
+
+
 def encode_programs(cases, stoi, length=26):
     rows = []
     for case in cases:
@@ -217,25 +253,33 @@ SMALL_DIMS = dict(
 )
 
 
-def small_network_inputs():
+def small_dims(size=14):
+    return dict(SMALL_DIMS, image_feature_size=(16, size, size))
+
+
+def small_network_inputs(size=14):
+    """size 14: the 36 validity cases at length 26; size 28 (config 5): + LONG_CASES, length 40."""
     ns = namespaces()
     stoi = {t: i for i, t in enumerate(ns["programs"])}
-    programs = encode_programs(VALIDITY_CASES, stoi)
+    if size == 14:
+        programs = encode_programs(VALIDITY_CASES, stoi)
+    else:
+        programs = encode_programs(VALIDITY_CASES + LONG_CASES, stoi, length=40)
     B = programs.size(0)
-    gen = detgen.rng(1234)
-    features = torch.relu(detgen.normal(gen, (B, 16, 14, 14)))
+    gen = detgen.rng(1234 if size == 14 else 1234 + size)
+    features = torch.relu(detgen.normal(gen, (B, 16, size, size)))
     answers = torch.from_numpy(gen.integers(0, 28, size=(B,))).long()
-    shapes = nmn_oracle.nmn_param_shapes(ns["programs"][4:], **SMALL_DIMS)
+    shapes = nmn_oracle.nmn_param_shapes(ns["programs"][4:], **small_dims(size))
     sd = detgen.fill_state_dict(shapes, seed=99)
     return ns, programs, features, answers, sd
 
 
-def full_module_inputs():
-    gen = detgen.rng(7)
-    feats = torch.relu(detgen.normal(gen, (1, 128, 14, 14)))
-    feats2 = torch.relu(detgen.normal(gen, (1, 128, 14, 14)))
-    attn = torch.sigmoid(detgen.normal(gen, (1, 1, 14, 14), 2.0))
-    attn2 = torch.sigmoid(detgen.normal(gen, (1, 1, 14, 14), 2.0))
+def full_module_inputs(size=14):
+    gen = detgen.rng(7 if size == 14 else 7 + size)
+    feats = torch.relu(detgen.normal(gen, (1, 128, size, size)))
+    feats2 = torch.relu(detgen.normal(gen, (1, 128, size, size)))
+    attn = torch.sigmoid(detgen.normal(gen, (1, 1, size, size), 2.0))
+    attn2 = torch.sigmoid(detgen.normal(gen, (1, 1, size, size), 2.0))
     toks = {
         "attention": "filter_color[red]",
         "query": "query_color",
@@ -256,8 +300,17 @@ def main():
     ref_modules = _load("probnmn.modules.nmn_modules", "probnmn/modules/nmn_modules.py")
     ref_nmn = _load("probnmn.models.nmn", "probnmn/models/nmn.py")
 
+    for size in (14, 28):
+        _modules_golden(ref_modules, size)
+        _network_golden(ref_nmn, size)
+    _elbo_golden()
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+def _modules_golden(ref_modules, size):
     # 1. the seven modules at full size ---------------------------------------------------------
-    feats, feats2, attn, attn2, toks, sd = full_module_inputs()
+    suffix = "" if size == 14 else "_%d" % size
+    feats, feats2, attn, attn2, toks, sd = full_module_inputs(size)
 
     def build(cls, tok):
         m = cls(128)
@@ -291,14 +344,17 @@ def main():
     for k in gold:
         assert torch.equal(gold[k], mine[k]), "oracle != reference for module " + k
     np.savez_compressed(
-        os.path.join(OUT, "nmn_modules_full.npz"), **{k: v.numpy() for k, v in gold.items()}
+        os.path.join(OUT, "nmn_modules_full%s.npz" % suffix), **{k: v.numpy() for k, v in gold.items()}
     )
 
+
+def _network_golden(ref_nmn, size):
     # 2. + 3. full network at reduced dims, validity table ------------------------------------------
-    ns, programs, features, answers, sd = small_network_inputs()
+    suffix = "" if size == 14 else "_%d" % size
+    ns, programs, features, answers, sd = small_network_inputs(size)
     vocab = _Vocab(ns)
     torch.manual_seed(0)
-    net = ref_nmn.NeuralModuleNetwork(vocab, **SMALL_DIMS)
+    net = ref_nmn.NeuralModuleNetwork(vocab, **small_dims(size))
     missing = net.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     net.train()
@@ -335,10 +391,13 @@ def main():
     }
     for k, g in ref_grads.items():
         arrays["grad::" + k] = g.numpy()
-    np.savez_compressed(os.path.join(OUT, "nmn_small.npz"), **arrays)
-    with open(os.path.join(OUT, "nmn_validity.json"), "w") as f:
-        json.dump({c: int(v) for c, v in zip(VALIDITY_CASES, valid.tolist())}, f, indent=1)
+    np.savez_compressed(os.path.join(OUT, "nmn_small%s.npz" % suffix), **arrays)
+    cases = VALIDITY_CASES if size == 14 else VALIDITY_CASES + LONG_CASES
+    with open(os.path.join(OUT, "nmn_validity%s.json" % suffix), "w") as f:
+        json.dump({c: int(v) for c, v in zip(cases, valid.tolist())}, f, indent=1)
 
+
+def _elbo_golden():
     # 4. REINFORCE / ELBO known answers ----------------------------------------------------------
     sys.modules["probnmn.models"] = types.ModuleType("probnmn.models")
     for n in ("ProgramGenerator", "ProgramPrior", "QuestionReconstructor", "NeuralModuleNetwork"):
@@ -406,7 +465,6 @@ def main():
     }
     with open(os.path.join(OUT, "elbo_known.json"), "w") as f:
         json.dump(record, f, indent=1)
-    print("wrote", sorted(os.listdir(OUT)))
 
 
 if __name__ == "__main__":

@@ -1,8 +1,17 @@
-// Body of the grouped NHWC convolution (see conv_nhwc.hip for the design notes), shared by the
-// one-launch-per-level kernel (conv_nhwc.hip) and the persistent dataflow kernel (dataflow.hip).
+// Body of the grouped NHWC convolution (see conv_nhwc.hip for the design notes).
 //
-// conv_body<H, W, KSPLIT>: the calling workgroup (512 threads) computes output channels
-// [cout_block*128 + nsub*128/KSPLIT, ... + 128/KSPLIT) of one item; `lds` is lds_rows(H*W)*128 floats.
+// conv_body<H, W, TH, KSPLIT>: the calling workgroup (512 threads) computes output channels
+// [cout_block*128 + nsub*128/KSPLIT, ... + 128/KSPLIT) of the TH x W output rows [band*TH, band*TH + TH)
+// of one item; `lds` is lds_rows<W, TH, H>() * 128 floats.  TH * W is 196 output pixels (13 m-tiles) in
+// both shipped shapes: 14x14 maps are one band (TH = H, the whole map is staged once per 128-channel
+// chunk and all nine taps read it), 28x28 maps are four bands of 7 full-width rows.  A band stages only
+// the image rows its taps touch, in PASSES:
+//     dilation 1 (and 1x1):  one pass per chunk -- rows [y0 - 1, y0 + TH + 1), all taps   (252 pixels)
+//     dilation d > 1:        three passes per chunk, one per tap row ky -- rows
+//                            [y0 + ky d, y0 + TH + ky d) clipped to the image, taps (ky, -1..1)
+// so the LDS image never exceeds (TH + 2) * W pixel rows whatever the dilation (a halo of 2 d rows would
+// not fit for d = 4, 8), and full-width rows keep the LDS row index LINEAR in the pixel index, which is
+// what the conflict-free slot swizzle below relies on.  Rows outside the image read the zero rows.
 // All 512 threads must call it; it ends with the epilogue executed by the waves that own the
 // reduced accumulators and contains no barrier after the point where the other waves return.
 //
@@ -23,7 +32,11 @@ constexpr int ZERO_ROWS = 8;  // all-zero pixel rows behind the image, for taps 
 // first zero row: the image rounded up to a multiple of 8 rows, so that (row & 7) of a zero row is the
 // (position & 7) it stands in for
 __host__ __device__ constexpr int zero_base(int hw) { return (hw + 7) & ~7; }
-__host__ __device__ constexpr int lds_rows(int hw) { return zero_base(hw) + ZERO_ROWS; }
+// pixel rows of the largest region a band stages (the whole map when the band is the map)
+template <int H, int W, int TH>
+__host__ __device__ constexpr int region_pixels() { return (TH == H ? H : TH + 2) * W; }
+template <int H, int W, int TH>
+__host__ __device__ constexpr int lds_rows() { return zero_base(region_pixels<H, W, TH>()) + ZERO_ROWS; }
 
 // LDS image of one 128-channel chunk: pixel row q = 32 slots of 16 bytes (4 channels each).  The slot
 // of channels [16 kb + 4 g, +4) of row q is
@@ -46,11 +59,13 @@ struct MaskBwd {
     float* dattn;        // [HW], += (ignored when attn == nullptr)
 };
 
-template <int H, int W, int KSPLIT>
-__device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, int cout_block, int cin_chunks,
+template <int H, int W, int TH, int KSPLIT>
+__device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, int nsub, int cout_block, int cin_chunks,
                                           int ntaps, int in_stride, int out_stride, int relu, float* lds,
                                           const MaskBwd* mb) {
-    constexpr int HW = H * W;
+    constexpr bool WHOLE = (TH == H);   // the band is the whole map: one pass per chunk, compile-time region
+    constexpr int HW = TH * W;          // output pixels of this workgroup
+    constexpr int ZB = zero_base(region_pixels<H, W, TH>());  // first zero row of the LDS image
     constexpr int MT = (HW + 15) / 16;
     constexpr int NT = 8 / KSPLIT;   // 16-channel output tiles per workgroup
     constexpr int KB = 8 / KSPLIT;   // 16-channel input blocks per wave and tap
@@ -68,13 +83,15 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
     const int n0 = cout_block * CB + (nsub * NT + nt) * 16;  // this wave's 16 out channels
     const int cin_total = cin_chunks * CB;
     const int dil = it.dilation;
+    const int y0 = WHOLE ? 0 : band * TH;  // first output row of the band
+    const int p_img = y0 * W;              // image pixel index of the band's pixel 0
 
     // pixel handled by this lane in each m-tile (as the MFMA "column" index)
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int p = mt * 16 + li;
-        py[mt] = (p < HW) ? p / W : -100000;
+        py[mt] = (p < HW) ? y0 + p / W : -100000;
         px[mt] = p % W;
     }
 
@@ -85,20 +102,43 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
     // weight row of this lane: output channel n0 + li, channels 4g.. of each 16-block
     const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * ntaps * cin_total + 4 * g + ks * KB * 16;
 
-    if (tid < ZERO_ROWS * 32) reinterpret_cast<f32x4*>(lds + zero_base(HW) * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < ZERO_ROWS * 32) reinterpret_cast<f32x4*>(lds + ZB * CB)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int chunk = 0; chunk < cin_chunks; ++chunk) {
-        // ---- stage this 128-channel chunk of the input into LDS (fused prologue) ----
-        const gfloat* src = as_global((it.in2 != nullptr && chunk > 0) ? it.in2 : it.in + chunk * CB);
-        const gfloat* gsrc = it.gate ? as_global(it.gate + chunk * CB) : nullptr;
-        const gfloat* msrc = as_global(it.mask);
-        if (chunk > 0) __syncthreads();  // everyone done reading the previous chunk
+    // passes per chunk (see the header): uniform over the workgroup
+    const int npass = (WHOLE || ntaps == 1 || dil == 1) ? 1 : 3;
+    bool first = true;
+    for (int chunk = 0; chunk < cin_chunks; ++chunk)
+    for (int pass = 0; pass < npass; ++pass) {
+        // image rows [rs, re) staged by this pass and the taps [t0, t1) that read them
+        int rs = 0, re = H, t0 = 0, t1 = ntaps;
+        if (!WHOLE) {
+            if (npass == 1) {
+                const int halo = (ntaps == 1) ? 0 : 1;
+                rs = y0 - halo < 0 ? 0 : y0 - halo;
+                re = y0 + TH + halo > H ? H : y0 + TH + halo;
+            } else {
+                const int a = y0 + (pass - 1) * dil;
+                rs = a < 0 ? 0 : (a > H ? H : a);
+                re = a + TH < 0 ? 0 : (a + TH > H ? H : a + TH);
+                t0 = 3 * pass;
+                t1 = t0 + 3;
+                if (re <= rs) continue;  // the whole tap row lies outside the image: contributes nothing
+            }
+        }
+        const int NR = WHOLE ? H * W : (re - rs) * W;  // pixel rows of the region
+        const int r_img = rs * W;                      // image pixel index of region row 0
+        // ---- stage this 128-channel chunk of the region into LDS (fused prologue) ----
+        const gfloat* src = as_global((it.in2 != nullptr && chunk > 0) ? it.in2 : it.in + chunk * CB) + (size_t)r_img * in_stride;
+        const gfloat* gsrc = it.gate ? as_global(it.gate + chunk * CB) + (size_t)r_img * in_stride : nullptr;
+        const gfloat* msrc = it.mask ? as_global(it.mask) + r_img : nullptr;
+        if (!first) __syncthreads();  // everyone done reading the previous region
+        first = false;
         // This thread's 16-byte pieces of the tile (and of the mask / gate) are requested in two batches
         // of seven before any is used: a rolled loop waits out one full memory round trip per piece --
         // 13 in a row, 12-25 us per chunk with nothing to overlap at one workgroup per CU.  (One batch of
         // 13 would need more registers than the accumulators leave.)
-        constexpr int NST = (HW * 32 + NTHREADS - 1) / NTHREADS;
-        constexpr int BATCH = (NST + 1) / 2;
+        const int NST = (NR * 32 + NTHREADS - 1) / NTHREADS;
+        constexpr int BATCH = 7;
 #pragma unroll 1
         for (int i0 = 0; i0 < NST; i0 += BATCH) {
             f32x4 sv[BATCH];
@@ -109,14 +149,14 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                 // three bits, which is what ds_write_b128 (served 8 lanes at a time over 32 banks) needs;
                 // the wave as a whole still reads whole 512-byte pixel rows from memory
                 const int c4 = ((idx & 7) * 4 + ((idx >> 3) & 3)) * 4;  // first of this thread's four channels
-                sv[i] = idx < HW * 32 ? load4(src + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                sv[i] = idx < NR * 32 ? load4(src + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (msrc) {
                 float mk[BATCH];
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
                     const int idx = tid + (i0 + i) * NTHREADS;
-                    mk[i] = idx < HW * 32 ? msrc[idx >> 5] : 0.f;
+                    mk[i] = idx < NR * 32 ? msrc[idx >> 5] : 0.f;
                 }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) sv[i] *= mk[i];
@@ -127,7 +167,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                 for (int i = 0; i < BATCH; ++i) {
                     const int idx = tid + (i0 + i) * NTHREADS;
                     const int c4 = ((idx & 7) * 4 + ((idx >> 3) & 3)) * 4;
-                    gt[i] = idx < HW * 32 ? load4(gsrc + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    gt[i] = idx < NR * 32 ? load4(gsrc + (size_t)(idx >> 5) * in_stride + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int i = 0; i < BATCH; ++i) {
@@ -141,7 +181,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
             for (int i = 0; i < BATCH; ++i) {
                 const int idx = tid + (i0 + i) * NTHREADS;
                 const int p = idx >> 5;
-                if (idx < HW * 32)
+                if (idx < NR * 32)
                     *reinterpret_cast<f32x4*>(lds + p * CB + (lds_slot(idx & 7, (idx >> 3) & 3, p) << 2)) = sv[i];
             }
         }
@@ -161,9 +201,9 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
             for (int mt = 0; mt < MT; ++mt) {
                 const int yy = py[mt] + dy;
                 const int xx = px[mt] + dx;
-                const bool ok = ((unsigned)yy < (unsigned)H) && ((unsigned)xx < (unsigned)W);
-                const int qv = yy * W + xx;               // position the tap would have (any sign)
-                const int q = ok ? qv : zero_base(HW) + (qv & 7);
+                const bool ok = (yy >= rs) && (yy < re) && ((unsigned)xx < (unsigned)W);
+                const int qv = (yy - rs) * W + xx;        // region row the tap would have (any sign)
+                const int q = ok ? qv : ZB + (qv & 7);
                 rb[mt] = q * CB + (((g & 1) << 3 | (g >> 1) << 4) << 2) + (q & 7);
             }
         };
@@ -175,7 +215,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
         // its 6-7 accumulators round-robin (no dependent-issue stall).
         constexpr int MH = (MT + 1) / 2;
         int rb[MT];
-        rowbases(0, rb);
+        rowbases(t0, rb);
         f32x4 afrag[MT];
         f32x4 bfrag[2];
         auto load_half = [&](int lo, int hi, int kbg) {
@@ -199,10 +239,10 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                 if (mt >= lo && mt < hi) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw.w, afrag[mt].w, acc[mt], 0, 0, 0);
         };
         load_half(0, MT, ks * KB);
-        bfrag[0] = load4(wchunk);
+        bfrag[0] = load4(wchunk + (size_t)t0 * cin_total);
 
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int tn = (tap + 1 < ntaps) ? tap + 1 : tap;  // (the last tap re-requests its own data)
+        for (int tap = t0; tap < t1; ++tap) {
+            const int tn = (tap + 1 < t1) ? tap + 1 : tap;  // (the last tap re-requests its own data)
             const gfloat* wtap = wchunk + (size_t)tap * cin_total;
             const gfloat* wtn = wchunk + (size_t)tn * cin_total;
 #pragma unroll
@@ -257,7 +297,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + li;
-            old[mt] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)p * out_stride + n0 + 4 * g)
+            old[mt] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
                                              : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -271,7 +311,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
                     v.z = fmaxf(v.z, 0.f);
                     v.w = fmaxf(v.w, 0.f);
                 }
-                float* dstf = it.out + (size_t)p * out_stride + n0 + 4 * g;
+                float* dstf = it.out + (size_t)(p_img + p) * out_stride + n0 + 4 * g;
                 if (it.flags & PNMN_CONV_ATOMIC) {
                     unsafeAtomicAdd(dstf + 0, v.x);
                     unsafeAtomicAdd(dstf + 1, v.y);
@@ -292,9 +332,9 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
         for (int mt = 0; mt < MT; ++mt) {
             const int p = mt * 16 + li;
             const bool ok = p < HW;
-            am[mt] = (ok && attn) ? attn[p] : 1.f;
-            fv[mt] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)p * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-            dold[mt] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)p * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            am[mt] = (ok && attn) ? attn[p_img + p] : 1.f;
+            fv[mt] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dold[mt] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -303,7 +343,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
             const f32x4 v = acc[mt];
             float part = v.x * fv[mt].x + v.y * fv[mt].y + v.z * fv[mt].z + v.w * fv[mt].w;
             if (ok) {
-                float* d = mb->dfeats + (size_t)p * CB + n0 + 4 * g;
+                float* d = mb->dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
                 if (sole) {  // only this workgroup touches these 4 channels of pixel p
                     store4(as_global(d), dold[mt] + v * am[mt]);
                 } else {
@@ -316,7 +356,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int nsub, in
             if (attn) {
                 part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
                 part += __shfl_xor(part, 32);
-                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p, part);
+                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
             }
         }
     }

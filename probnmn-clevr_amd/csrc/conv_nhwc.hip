@@ -1,29 +1,32 @@
 // Grouped NHWC convolution (3x3 with dilation, or 1x1) for gfx950 -- forward and data-gradient.
 //
-// One workgroup = one (example, convolution) item x one block of 128 output channels.
-// The whole H*W x 128-channel input tile of the example is staged ONCE into LDS (14x14: 98 KiB of
-// the CU's 160 KiB) with the fused prologue (attention mask multiply, or ReLU-backward gate), and
-// all nine taps read their A operands straight out of that image at shifted pixel rows -- no
-// im2col, no halo copy: out-of-image taps point at one extra all-zero row.  Weights are never
-// staged: each wave owns 16 output channels and streams its own [16][tap][cin] slice from L2
-// into registers one tap ahead of use (nobody else in the workgroup needs that slice, so an LDS
-// round trip would be pure overhead).
+// One workgroup = one (example, convolution) item x one band of 196 output pixels x one block of 128
+// output channels.  14x14 maps are one band: the whole H*W x 128-channel input tile of the example is
+// staged ONCE into LDS (98 KiB of the CU's 160 KiB) with the fused prologue (attention mask multiply, or
+// ReLU-backward gate), and all nine taps read their A operands straight out of that image at shifted
+// pixel rows -- no im2col, no halo copy: out-of-image taps point at one extra all-zero row.  28x28 maps
+// (BASELINE config 5) are four bands of seven full-width rows, each staging only the image rows its
+// taps touch (conv_body.h: one pass with a one-row halo for dilation 1, one pass per tap row for
+// dilations 2 / 4 / 8), so the same 13 m-tiles, the same LDS layout and the same contraction loop
+// serve both shapes.  Weights are never staged: each wave owns 16 output channels and streams its own
+// [16][tap][cin] slice from L2 into registers one tap ahead of use (nobody else in the workgroup needs
+// that slice, so an LDS round trip would be pure overhead).
 //
 // Math is exact fp32 on the matrix cores: v_mfma_f32_16x16x4_f32 (weights as the A operand so
 // that each lane ends up with 4 consecutive output channels of one pixel -> 16-byte stores).
-// 16x16 tiles because H*W = 196 = 12.25 x 16: 13 m-tiles waste 5.8 % (32x32 tiles would waste
+// 16x16 tiles because 196 = 12.25 x 16: 13 m-tiles waste 5.8 % (32x32 tiles would waste
 // 12.5 %).  K is consumed in a permuted order (lane group g takes channels 4g..4g+3 of each
 // 16-channel block, one per MFMA) so that both operands are single 16-byte loads.
 //
-// Load balance: a launch rarely has exactly k x 256 items (programs differ in length, so the
-// later levels of a step have few active examples).  The K-split variants cut one item into
+// Load balance: a launch rarely has exactly k x 256 units (programs differ in length, so the
+// later levels of a step have few active examples).  The K-split variants cut one unit into
 // KSPLIT workgroups of 16*8/KSPLIT output channels each; inside a workgroup the 8 waves then
 // split the 128 input channels of every tap KSPLIT ways and are summed through LDS at the end.
-// Each workgroup still stages the whole input tile, so the launcher picks the smallest split
+// Each workgroup still stages the whole input region, so the launcher picks the smallest split
 // that fills the chip (see plan_launch).
 //
-// LDS image: row p (pixel) = 128 floats = 32 slots of 16 B; slot s is stored at s ^ (p & 15), which
-// makes the 16 pixel rows a ds_read_b128 lane-group touches land on 16 different bank slots.
+// LDS image: conv_body.h (row = pixel, 32 slots of 16 bytes, swizzled to the lane groups ds_read_b128 /
+// ds_write_b128 are served in).
 #include <stdlib.h>
 
 #include "conv_body.h"
@@ -32,47 +35,51 @@ namespace {
 
 using pnmn::CB;
 
-template <int H, int W, int KSPLIT>
+// A unit = one band of one item (14x14: unit = item; 28x28: four units per item).
+template <int H, int W, int TH, int KSPLIT>
 __global__ __launch_bounds__(512) void conv_nhwc_kernel(
-    const pnmn_conv_item* __restrict__ items, int n_items, int cin_chunks, int ntaps, int in_stride,
+    const pnmn_conv_item* __restrict__ items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
     int out_stride, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows(HW)][128], the last rows are zero
+    float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows][128], the last rows are zero
+    constexpr int NB = H / TH;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (XCD = linear id % 8), each with
-    // its own L2.  The KSPLIT workgroups of an item all stage the same input tile, so they are given ids
-    // that are congruent mod 8: the tile is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
+    // its own L2.  The KSPLIT workgroups of a unit all stage the same input region, so they are given ids
+    // that are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
     const int slot = blockIdx.x >> 3;
-    const int item = (slot / KSPLIT) * 8 + (blockIdx.x & 7);
-    if (item >= n_items) return;
-    const pnmn_conv_item it = items[item];
+    const int unit = (slot / KSPLIT) * 8 + (blockIdx.x & 7);
+    if (unit >= n_units) return;
+    const int u = unit0 + unit;
+    const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
-    pnmn::conv_body<H, W, KSPLIT>(it, slot % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
-                                  relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr);
+    pnmn::conv_body<H, W, TH, KSPLIT>(it, u % NB, slot % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
+                                      relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr);
 }
 
-template <int H, int W, int KSPLIT>
-int launch_conv_k(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
+template <int H, int W, int TH, int KSPLIT>
+int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
                   int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows(H * W) * CB * sizeof(float);
-    static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((H * W + 15) / 16) * 64 * 16 <= lds_bytes,
+    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows<H, W, TH>() * CB * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "the staged region must fit the CU's LDS");
+    static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((TH * W + 15) / 16) * 64 * 16 <= lds_bytes,
                   "reduction scratch must fit in the input image");
     static bool configured = false;
-    auto kern = conv_nhwc_kernel<H, W, KSPLIT>;
+    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(((n_items + 7) / 8) * 8 * KSPLIT, cout_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, n_items, cin_chunks, ntaps, in_stride,
+    dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT, cout_blocks);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
                        out_stride, relu);
     return (int)hipGetLastError();
 }
 
-// Launch plan.  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
+// Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
 // that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
-// work).  So the items are cut in two: as many as fill whole rounds go out with the split `s_main`,
+// work).  So the units are cut in two: as many as fill whole rounds go out with the split `s_main`,
 // the remainder follows in a second launch with a larger split `s_tail`, whose single round is
 // s_tail / s_main times shorter.  Relative costs only: one tap of one 128-channel chunk = 1 unit,
 // staging a chunk ~ 0.5 unit, a second launch ~ 0.3 unit.
@@ -113,46 +120,51 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     return best;
 }
 
-template <int H, int W>
-int launch_conv_split(int split, const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
-                      int out_stride, int cout_blocks, int relu, hipStream_t stream) {
+template <int H, int W, int TH>
+int launch_conv_split(int split, const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps,
+                      int in_stride, int out_stride, int cout_blocks, int relu, hipStream_t stream) {
     switch (split) {
         case 8:
-            return launch_conv_k<H, W, 8>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                          cout_blocks, relu, stream);
+            return launch_conv_k<H, W, TH, 8>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
+                                              cout_blocks, relu, stream);
         case 4:
-            return launch_conv_k<H, W, 4>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                          cout_blocks, relu, stream);
+            return launch_conv_k<H, W, TH, 4>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
+                                              cout_blocks, relu, stream);
         case 2:
-            return launch_conv_k<H, W, 2>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                          cout_blocks, relu, stream);
+            return launch_conv_k<H, W, TH, 2>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
+                                              cout_blocks, relu, stream);
         default:
-            return launch_conv_k<H, W, 1>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                          cout_blocks, relu, stream);
+            return launch_conv_k<H, W, TH, 1>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
+                                              cout_blocks, relu, stream);
     }
 }
 
-template <int H, int W>
+template <int H, int W, int TH>
 int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
                 int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    const LaunchPlan lp = plan_launch(n_items, cout_blocks, cin_chunks, ntaps);
+    const int n_units = n_items * (H / TH);
+    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps);
     if (lp.n_main > 0) {
-        const int rc = launch_conv_split<H, W>(lp.s_main, items, lp.n_main, cin_chunks, ntaps, in_stride, out_stride,
-                                               cout_blocks, relu, stream);
+        const int rc = launch_conv_split<H, W, TH>(lp.s_main, items, 0, lp.n_main, cin_chunks, ntaps, in_stride,
+                                                   out_stride, cout_blocks, relu, stream);
         if (rc != 0) return rc;
     }
-    if (lp.n_main < n_items)
-        return launch_conv_split<H, W>(lp.s_tail, items + lp.n_main, n_items - lp.n_main, cin_chunks, ntaps, in_stride,
-                                       out_stride, cout_blocks, relu, stream);
+    if (lp.n_main < n_units)
+        return launch_conv_split<H, W, TH>(lp.s_tail, items, lp.n_main, n_units - lp.n_main, cin_chunks, ntaps,
+                                           in_stride, out_stride, cout_blocks, relu, stream);
     return 0;
 }
 
+// bands per item of the shapes the kernels are built for (0: unsupported)
+inline int bands_of(int H, int W) { return (H == 14 && W == 14) ? 1 : (H == 28 && W == 28) ? 4 : 0; }
+
 }  // namespace
 
-extern "C" int pnmn_conv_nhwc_launches(int n_items, int cin_chunks, int ntaps, int cout_blocks) {
-    if (n_items <= 0) return 0;
-    const LaunchPlan lp = plan_launch(n_items, cout_blocks, cin_chunks, ntaps);
-    return (lp.n_main > 0 ? 1 : 0) + (lp.n_main < n_items ? 1 : 0);
+extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks) {
+    const int nb = bands_of(H, W);
+    if (n_items <= 0 || nb == 0) return 0;
+    const LaunchPlan lp = plan_launch(n_items * nb, cout_blocks, cin_chunks, ntaps);
+    return (lp.n_main > 0 ? 1 : 0) + (lp.n_main < n_items * nb ? 1 : 0);
 }
 
 extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W,
@@ -163,7 +175,10 @@ extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, i
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (H == 14 && W == 14)
-        return launch_conv<14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                   cout_blocks, relu, s);
+        return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
+                                       cout_blocks, relu, s);
+    if (H == 28 && W == 28)
+        return launch_conv<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
+                                      cout_blocks, relu, s);
     return PNMN_ESHAPE;
 }

@@ -409,66 +409,75 @@ __device__ __forceinline__ void copy_batched(int n, Load load, Store store) {
 // ------------------------------------------------------------------------------------------------
 template <bool TO_NHWC>
 __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                     int Cn, int HW) {
-    extern __shared__ float tile[];  // [64][HW+1]
+                                                     int Cn, int HW, int PT) {
+    extern __shared__ float tile[];  // [64][PT+1]: 64 channels x one chunk of PT pixels (blockIdx.z)
     const int n = blockIdx.y;
     const int c0 = blockIdx.x * 64;
-    const int ld = HW + 1;
+    const int p0 = blockIdx.z * PT;
+    const int np = (HW - p0) < PT ? (HW - p0) : PT;
+    const int ld = PT + 1;
     const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
     if (TO_NHWC) {
-        const float* s0 = src + ((size_t)n * Cn + c0) * HW;
-        copy_batched(cw * HW, [&](int i) { return s0[i]; },
-                     [&](int i, float v) { const int c = i / HW; tile[c * ld + (i - c * HW)] = v; });
+        const float* s0 = src + ((size_t)n * Cn + c0) * HW + p0;
+        copy_batched(cw * np, [&](int i) { const int c = i / np; return s0[(size_t)c * HW + (i - c * np)]; },
+                     [&](int i, float v) { const int c = i / np; tile[c * ld + (i - c * np)] = v; });
         __syncthreads();
 #pragma unroll 8
-        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
+        for (int i = threadIdx.x; i < cw * np; i += blockDim.x) {
             const int p = i / cw, c = i - p * cw;
-            dst[((size_t)n * HW + p) * Cn + c0 + c] = tile[c * ld + p];
+            dst[((size_t)n * HW + p0 + p) * Cn + c0 + c] = tile[c * ld + p];
         }
     } else {
-        copy_batched(cw * HW, [&](int i) { const int p = i / cw; return src[((size_t)n * HW + p) * Cn + c0 + (i - p * cw)]; },
+        copy_batched(cw * np, [&](int i) { const int p = i / cw; return src[((size_t)n * HW + p0 + p) * Cn + c0 + (i - p * cw)]; },
                      [&](int i, float v) { const int p = i / cw; tile[(i - p * cw) * ld + p] = v; });
         __syncthreads();
 #pragma unroll 8
-        for (int i = threadIdx.x; i < cw * HW; i += blockDim.x) {
-            const int c = i / HW, p = i - c * HW;
-            dst[((size_t)n * Cn + c0 + c) * HW + p] = tile[c * ld + p];
+        for (int i = threadIdx.x; i < cw * np; i += blockDim.x) {
+            const int c = i / np, p = i - c * np;
+            dst[((size_t)n * Cn + c0 + c) * HW + p0 + p] = tile[c * ld + p];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// MaxPool2d(2,2) + Flatten over a ReLU'd NHWC map, output in NCHW-flatten order
+// MaxPool2d(2,2) + Flatten over a ReLU'd NHWC map, output in NCHW-flatten order.  One workgroup = 64
+// channels x one band of RB (even) image rows (blockIdx.z): 14x14 maps are one band, 28x28 two.
 // ------------------------------------------------------------------------------------------------
 template <bool BWD>
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                                      float* __restrict__ out, int H, int W, int Cn) {
-    extern __shared__ float tile[];  // [HW][65]
+                                                      float* __restrict__ out, int H, int W, int Cn, int RB) {
+    extern __shared__ float tile[];  // [RB*W][65]
     const int n = blockIdx.y;
     const int c0 = blockIdx.x * 64;
+    const int y0 = blockIdx.z * RB;
+    const int rows = (H - y0) < RB ? (H - y0) : RB;
     const int HW = H * W;
+    const int NP = rows * W;  // pixels of this band
     const int PH = H / 2, PW = W / 2, PS = PH * PW;
-    const float* src = in + (size_t)n * HW * Cn;
-    copy_batched(HW * 64, [&](int i) { return src[(size_t)(i >> 6) * Cn + c0 + (i & 63)]; },
+    const int pr0 = y0 / 2;                                   // first pooled row of the band
+    const int prn = ((y0 + rows) / 2 < PH ? (y0 + rows) / 2 : PH) - pr0;  // pooled rows of the band
+    const int BS = prn * PW;                                  // pooled positions of the band
+    const float* src = in + ((size_t)n * HW + (size_t)y0 * W) * Cn;
+    copy_batched(NP * 64, [&](int i) { return src[(size_t)(i >> 6) * Cn + c0 + (i & 63)]; },
                  [&](int i, float v) { tile[(i >> 6) * 65 + (i & 63)] = v; });
     __syncthreads();
     if (!BWD) {
-        float* o = out + (size_t)n * Cn * PS + (size_t)c0 * PS;
+        float* o = out + (size_t)n * Cn * PS + (size_t)c0 * PS + pr0 * PW;
 #pragma unroll 4
-        for (int i = threadIdx.x; i < 64 * PS; i += blockDim.x) {
-            const int c = i / PS, s = i - c * PS;
+        for (int i = threadIdx.x; i < 64 * BS; i += blockDim.x) {
+            const int c = i / BS, s = i - c * BS;
             const int y = (s / PW) * 2, x = (s % PW) * 2;
             const float a = tile[(y * W + x) * 65 + c];
             const float b = tile[(y * W + x + 1) * 65 + c];
             const float d = tile[((y + 1) * W + x) * 65 + c];
             const float e = tile[((y + 1) * W + x + 1) * 65 + c];
-            o[i] = fmaxf(fmaxf(a, b), fmaxf(d, e));
+            o[(size_t)c * PS + s] = fmaxf(fmaxf(a, b), fmaxf(d, e));
         }
     } else {
         // pass 1: pooled gradient -> argmax position, written back into the tile (in place)
-        const float* g = dout + (size_t)n * Cn * PS + (size_t)c0 * PS;
-        for (int i = threadIdx.x; i < 64 * PS; i += blockDim.x) {
-            const int c = i / PS, s = i - c * PS;
+        const float* g = dout + (size_t)n * Cn * PS + (size_t)c0 * PS + pr0 * PW;
+        for (int i = threadIdx.x; i < 64 * BS; i += blockDim.x) {
+            const int c = i / BS, s = i - c * BS;
             const int y = (s / PW) * 2, x = (s % PW) * 2;
             const int q[4] = {y * W + x, y * W + x + 1, (y + 1) * W + x, (y + 1) * W + x + 1};
             float best = tile[q[0] * 65 + c];
@@ -481,18 +490,18 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
                     bi = k;
                 }
             }
-            const float gv = best > 0.f ? g[i] : 0.f;  // ReLU gate of the conv output
+            const float gv = best > 0.f ? g[(size_t)c * PS + s] : 0.f;  // ReLU gate of the conv output
 #pragma unroll
             for (int k = 0; k < 4; ++k) tile[q[k] * 65 + c] = (k == bi) ? gv : 0.f;
         }
         __syncthreads();
         // rows/cols beyond the pooled area (odd H or W) receive no gradient
-        float* d = out + (size_t)n * HW * Cn;
+        float* d = out + ((size_t)n * HW + (size_t)y0 * W) * Cn;
 #pragma unroll 8
-        for (int i = threadIdx.x; i < HW * 64; i += blockDim.x) {
+        for (int i = threadIdx.x; i < NP * 64; i += blockDim.x) {
             const int p = i >> 6, c = i & 63;
             const int y = p / W, x = p - y * W;
-            const bool covered = (y < PH * 2) && (x < PW * 2);
+            const bool covered = (y0 + y < PH * 2) && (x < PW * 2);
             d[(size_t)p * Cn + c0 + c] = covered ? tile[p * 65 + c] : 0.f;
         }
     }
@@ -583,6 +592,56 @@ inline int last_error() { return (int)hipGetLastError(); }
 
 #define STREAM(s) static_cast<hipStream_t>(s)
 
+// pixels per workgroup of the layout kernels: the whole map when 64 channels of it fit the LDS
+// budget (14x14), otherwise the smallest number of equal chunks that do (28x28: two of 392)
+static int layout_chunk(int HW) {
+    int parts = 1;
+    while ((size_t)64 * ((HW + parts - 1) / parts + 1) * sizeof(float) > 112 * 1024) ++parts;
+    return (HW + parts - 1) / parts;
+}
+
+template <bool TO_NHWC>
+static int launch_layout(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
+    if (n <= 0) return 0;
+    if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
+    const int PT = layout_chunk(HW);
+    const size_t lds = (size_t)64 * (PT + 1) * sizeof(float);
+    static bool cfg = false;
+    if (!cfg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<TO_NHWC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(layout_kernel<TO_NHWC>, dim3((Cn + 63) / 64, n, (HW + PT - 1) / PT), dim3(256), lds,
+                       STREAM(stream), src, dst, Cn, HW, PT);
+    return last_error();
+}
+
+// image rows per workgroup of the max-pool kernels (even; [rows*W][65] floats within the LDS budget)
+static int pool_band(int H, int W) {
+    int rb = (H + 1) & ~1;
+    while (rb > 2 && (size_t)rb * W * 65 * sizeof(float) > 112 * 1024) rb = ((rb / 2) + 1) & ~1;
+    return rb;
+}
+
+template <bool BWD>
+static int launch_pool(const float* in, const float* dout, float* out, int n, int H, int W, int Cn, void* stream) {
+    if (n <= 0) return 0;
+    if (!in || !out || (BWD && !dout) || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
+    const int RB = pool_band(H, W);
+    const size_t lds = (size_t)RB * W * 65 * sizeof(float);
+    if (lds > 160 * 1024) return PNMN_ESHAPE;
+    static bool cfg = false;
+    if (!cfg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<BWD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        cfg = true;
+    }
+    hipLaunchKernelGGL(maxpool_kernel<BWD>, dim3(Cn / 64, n, (H + RB - 1) / RB), dim3(256), lds, STREAM(stream), in,
+                       dout, out, H, W, Cn, RB);
+    return last_error();
+}
+
 extern "C" {
 
 int pnmn_abi_version(void) { return 1; }
@@ -655,70 +714,20 @@ int pnmn_transpose_weights(const pnmn_wtrans_item* items, int n_items, void* str
 }
 
 int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
-    if (n <= 0) return 0;
-    if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
-    const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
-    if (lds > 160 * 1024) return PNMN_ESHAPE;
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
-    hipLaunchKernelGGL(layout_kernel<true>, dim3((Cn + 63) / 64, n), dim3(256), lds, STREAM(stream), src,
-                       dst, Cn, HW);
-    return last_error();
+    return launch_layout<true>(src, dst, n, Cn, HW, stream);
 }
 
 int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
-    if (n <= 0) return 0;
-    if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
-    const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
-    if (lds > 160 * 1024) return PNMN_ESHAPE;
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
-    hipLaunchKernelGGL(layout_kernel<false>, dim3((Cn + 63) / 64, n), dim3(256), lds, STREAM(stream), src,
-                       dst, Cn, HW);
-    return last_error();
+    return launch_layout<false>(src, dst, n, Cn, HW, stream);
 }
 
 int pnmn_maxpool2_flatten_fwd(const float* in, float* out, int n, int H, int W, int Cn, void* stream) {
-    if (n <= 0) return 0;
-    if (!in || !out || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
-    const size_t lds = (size_t)H * W * 65 * sizeof(float);
-    if (lds > 160 * 1024) return PNMN_ESHAPE;
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
-    hipLaunchKernelGGL(maxpool_kernel<false>, dim3(Cn / 64, n), dim3(256), lds, STREAM(stream), in,
-                       (const float*)nullptr, out, H, W, Cn);
-    return last_error();
+    return launch_pool<false>(in, nullptr, out, n, H, W, Cn, stream);
 }
 
 int pnmn_maxpool2_flatten_bwd(const float* in, const float* dout, float* din, int n, int H, int W, int Cn,
                               void* stream) {
-    if (n <= 0) return 0;
-    if (!in || !dout || !din || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
-    const size_t lds = (size_t)H * W * 65 * sizeof(float);
-    if (lds > 160 * 1024) return PNMN_ESHAPE;
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
-    hipLaunchKernelGGL(maxpool_kernel<true>, dim3(Cn / 64, n), dim3(256), lds, STREAM(stream), in, dout, din,
-                       H, W, Cn);
-    return last_error();
+    return launch_pool<true>(in, dout, din, n, H, W, Cn, stream);
 }
 
 int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t* valid, int64_t* predictions,

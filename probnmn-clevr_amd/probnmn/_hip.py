@@ -63,8 +63,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_multi_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, _P),
     "pnmn_attn_lstm_bwd_multi": (_P,) * 14 + (_I,) * 4 + (_P, _P),
-    "pnmn_dataflow": (_P, _I, _P, _P, _I, _I, _I, _I, _P),
-    "pnmn_conv_nhwc_launches": (_I, _I, _I, _I),
+    "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
@@ -126,12 +125,7 @@ MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
-TASK = np.dtype([("p", _u64, (12,)), ("type", _i32), ("sub", _i32), ("dilation", _i32), ("flags", _i32),
-                 ("dep", _i32, (3,)), ("need", _i32, (3,)), ("slot", _i32), ("pad", _i32, (5,))])
-T_CONV, T_DOT_FWD, T_DOT_BWD, T_SAME_FWD, T_SAME_BWD, T_MINMAX_FWD, T_MINMAX_BWD = range(7)
-
 ITEM_SIZES = {
-    "pnmn_task": (TASK, 160),
     "pnmn_conv_item": (CONV_ITEM, 96),
     "pnmn_wgrad_item": (WGRAD_ITEM, 48),
     "pnmn_wgrad_job": (WGRAD_JOB, 24),

@@ -33,7 +33,6 @@ _DT = {
     "maskbwd": _hip.MASKBWD_ITEM,
     "wgrad_item": _hip.WGRAD_ITEM,
     "wgrad_job": _hip.WGRAD_JOB,
-    "task": _hip.TASK,
 }
 
 
@@ -76,13 +75,16 @@ class NMNEngine:
         if module_channels != C:
             raise NotImplementedError(
                 "the gfx950 kernels are built for module_channels == 128 (got %d)" % module_channels)
-        if (H, W) != (14, 14):
-            raise NotImplementedError("the gfx950 kernels are built for 14x14 feature maps (got %dx%d)" % (H, W))
+        if (H, W) not in ((14, 14), (28, 28)):
+            raise NotImplementedError("the gfx950 kernels are built for 14x14 and 28x28 feature maps (got %dx%d)" % (H, W))
         if cin % C or class_projection_channels % C:
             raise NotImplementedError("channel counts must be multiples of 128")
         self.net = net
         self.cin, self.H, self.W = cin, H, W
         self.HW = H * W
+        # 28x28 maps: conv / weight-gradient workgroups cover one of four 7-row bands of an item, and a
+        # weight-gradient slab is 64 x 64 channels instead of 64 x 128 (csrc/conv_wgrad.hip)
+        self.banded = (H, W) != (14, 14)
         self.cproj = class_projection_channels
         self.arena: Optional[ParamArena] = None
         self.direct_grads = False  # True: gradients stay in the arena, nothing is handed to autograd
@@ -101,13 +103,6 @@ class NMNEngine:
         # so the default is one stream, which also keeps per-kernel profiles clean.
         self.overlap_wgrad = False
         self._side_stream: Optional[torch.cuda.Stream] = None
-        # True: the module programs run in the persistent dataflow executor (one launch per pass)
-        # instead of one grouped launch per (level, kind)
-        self.dataflow = os.environ.get("PNMN_DATAFLOW", "0") == "1"
-        self.dataflow_ksplit = int(os.environ.get("PNMN_DATAFLOW_KSPLIT", "2"))
-        self.dataflow_workgroups = int(os.environ.get("PNMN_DATAFLOW_WGS", "256"))
-        self._df_state: Optional[torch.Tensor] = None  # int32: [queue head, error, completion counters...]
-        self._df_checks: list = []
 
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
         log = self.event_log
@@ -123,7 +118,7 @@ class NMNEngine:
             # output map once + one pass over the weights, kernel launches of this call)
             log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
                         4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C),
-                        _hip.lib().pnmn_conv_nhwc_launches(n, cin_chunks, ntaps, cout_blocks)))
+                        _hip.lib().pnmn_conv_nhwc_launches(n, self.H, self.W, cin_chunks, ntaps, cout_blocks)))
 
     def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
         """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
@@ -209,7 +204,7 @@ class NMNEngine:
         self._wt_count = len(wt_items)
         self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
         self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT,
-                                        wgrad_chunk=int(os.environ.get("PNMN_WG_CHUNK", "8")),
+                                        wgrad_chunk=int(os.environ.get("PNMN_WG_CHUNK", "2" if self.banded else "8")),
                                         wgrad_groups=int(os.environ.get("PNMN_WG_GROUPS", "1")))
 
     # ---- workspaces ---------------------------------------------------------------------------
@@ -261,7 +256,12 @@ class NMNEngine:
             # `chunk` items each (+ ~half an item for the atomic add of the job's slab into the shared
             # weight gradient, which is also why a job never has fewer than 4 items); 260 workgroups cost
             # two rounds, 208 one -- take the chunk with the shortest makespan
-            chunk = min(range(4, 33), key=lambda c: (-(-(-(-B // c) * yblocks) // 256)) * (c + 0.5))
+            if self.banded:  # four bands per item, twice the slabs per weight
+                yblocks *= 2
+                sizes = range(1, 9)
+            else:
+                sizes = range(4, 33)
+            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // 256)) * (c + 0.5))
             starts = np.arange(0, B, chunk)
             j = np.zeros(starts.size, _hip.WGRAD_JOB)
             j["dw"], j["dbias"] = dw, db
@@ -351,8 +351,6 @@ class NMNEngine:
             act=act.data_ptr(), gact=gact.data_ptr(), feat=ws["feat"].data_ptr(),
             gfeat=ws["gfeat"].data_ptr(), final=ws["final"].data_ptr(), gfinal=ws["gfinal"].data_ptr(),
             ones=self.ones.data_ptr())
-        self.scheduler.dataflow = self.dataflow
-        self.scheduler.dataflow_ksplit = self.dataflow_ksplit
         plan = self.scheduler.plan(compiled, bufs)
         assert plan.arena_floats == floats, (plan.arena_floats, floats)
         self.last_plan = plan
@@ -364,10 +362,6 @@ class NMNEngine:
             pack.add(k, rec)
         for k, rec in plan.wgrad_jobs.items():
             pack.add(k + "_jobs", rec)
-        if plan.fwd_tasks is not None:
-            pack.add("fwd_tasks", plan.fwd_tasks)
-            if need_backward:
-                pack.add("bwd_tasks", plan.bwd_tasks)
         pack.upload(dev)
 
         H, W = self.H, self.W
@@ -383,10 +377,7 @@ class NMNEngine:
             idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             final.index_copy_(0, idx, feat.index_select(0, idx))
 
-        if plan.fwd_tasks is not None:
-            self._run_dataflow(pack.ptr("fwd_tasks"), plan.fwd_tasks, plan.n_fwd_slots, dev, "module forward (dataflow)")
-        else:
-            self._run_forward_launches(plan, pack, st)
+        self._run_forward_launches(plan, pack, st)
 
         self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
@@ -398,53 +389,6 @@ class NMNEngine:
             state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
             state.generation = self.generation
         return pooled, state
-
-    def _run_dataflow(self, tasks_ptr: int, tasks: np.ndarray, n_slots: int, dev, what: str) -> None:
-        """One persistent launch that executes a whole task list (see csrc/dataflow.hip)."""
-        self._check_dataflow_errors()
-        need = 2 + n_slots
-        if self._df_state is None or self._df_state.numel() < need or self._df_state.device != dev:
-            self._df_state = torch.empty(max(need, 1 << 16), dtype=torch.int32, device=dev)
-        state = self._df_state
-        state[:need].zero_()
-        stream = torch.cuda.current_stream(dev)
-        log = self.event_log
-        if log is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        _hip.check(_hip.lib().pnmn_dataflow(tasks_ptr, len(tasks), state.data_ptr(), state.data_ptr() + 8, self.H, self.W,
-                                            self.dataflow_ksplit, self.dataflow_workgroups, stream.cuda_stream), what)
-        if log is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(stream)
-            conv = tasks[tasks["type"] == _hip.T_CONV]
-            taps = np.where(conv["flags"] & 32, 1, 9) * np.where(conv["flags"] & 64, 2, 1)
-            flops = float((2.0 * self.HW * (C // self.dataflow_ksplit) * taps * C).sum())
-            log.append(("dataflow", what, flops, e0, e1))
-        # error word -> pinned host memory (async copy), read without blocking at a later launch
-        if not hasattr(self, "_df_host"):
-            self._df_host = torch.zeros(64, dtype=torch.int32).pin_memory()
-            self._df_host_next = 0
-        i = self._df_host_next
-        self._df_host_next = (i + 1) % 64
-        self._df_host[i:i + 1].copy_(state[1:2], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        self._df_checks.append((ev, i, what))
-
-    def _check_dataflow_errors(self, block: bool = False) -> None:
-        pending = []
-        for ev, i, what in self._df_checks:
-            if block:
-                ev.synchronize()
-            if block or ev.query():
-                code = int(self._df_host[i])
-                if code != 0:
-                    self._df_checks = []
-                    raise _hip.HipLibraryError("%s: task %d timed out waiting for its inputs" % (what, code - 1))
-            else:
-                pending.append((ev, i, what))
-        self._df_checks = pending[-32:]
 
     def _run_forward_launches(self, plan: StepPlan, pack: _Pack, st: int) -> None:
         lib, chk, H, W, HW = _hip.lib(), _hip.check, self.H, self.W, self.HW
@@ -518,7 +462,7 @@ class NMNEngine:
         groups = list(plan.wgrad_groups or [])
         n_items3 = len(plan.records["wg3"])
         n_jobs3 = max(1, len(plan.wgrad_jobs["wg3"]))
-        for phase in ([] if plan.bwd_tasks is not None else plan.backward):
+        for phase in plan.backward:
             for l in phase:
                 n = l.end - l.begin
                 if l.kind == "dot_bwd":
@@ -543,10 +487,8 @@ class NMNEngine:
                 for _, jb, je in ready:
                     self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3,
                                 9, 1, 1, C, C, side, "module wgrad")
-        if plan.bwd_tasks is not None:
-            self._run_dataflow(pack.ptr("bwd_tasks"), plan.bwd_tasks, plan.n_bwd_slots, dev, "module backward (dataflow)")
         fork()
-        for _, jb, je in groups:  # (all of them when the dataflow executor ran the data gradients)
+        for _, jb, je in groups:
             self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3, 9, 1, 1,
                         C, C, side, "module wgrad")
         nj = len(plan.wgrad_jobs["wgp"])

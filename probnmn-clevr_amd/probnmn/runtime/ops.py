@@ -15,16 +15,21 @@ import torch
 from probnmn import _hip
 
 C = _hip.CHANNELS
-H = W = 14
-HW = H * W
+SHAPES = ((14, 14), (28, 28))  # feature-map sizes the conv kernels are built for
 
 
-def _need(t: torch.Tensor, channels: int, what: str) -> None:
+def _need(t: torch.Tensor, channels: int, what: str, like=None):
+    """Validate a map argument; returns its (H, W).  ``like``: (H, W) it has to agree with."""
     if t.device.type != "cuda":
         raise _hip.HipLibraryError("%s is on %s: the HIP path needs a ROCm device (no CPU fallback)" % (what, t.device))
-    if t.dim() != 4 or t.size(1) != channels or tuple(t.shape[2:]) != (H, W):
+    if t.dim() != 4 or t.size(1) != channels or tuple(t.shape[2:]) not in SHAPES:
         raise NotImplementedError(
-            "%s has shape %s; the gfx950 kernels are built for (n, %d, 14, 14)" % (what, tuple(t.shape), channels))
+            "%s has shape %s; the gfx950 kernels are built for (n, %d, 14, 14) and (n, %d, 28, 28)"
+            % (what, tuple(t.shape), channels, channels))
+    hw = tuple(t.shape[2:])
+    if like is not None and hw != tuple(like):
+        raise ValueError("%s is %dx%d but the other operand is %dx%d" % ((what,) + hw + tuple(like)))
+    return hw
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -32,8 +37,8 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float().permute(0, 2, 3, 1).contiguous()
 
 
-def _nchw_view(buf: torch.Tensor, n: int, c: int) -> torch.Tensor:
-    return buf.view(n, H, W, c).permute(0, 3, 1, 2)
+def _nchw_view(buf: torch.Tensor, n: int, c: int, hw) -> torch.Tensor:
+    return buf.view(n, hw[0], hw[1], c).permute(0, 3, 1, 2)
 
 
 def _wcl(w: torch.Tensor) -> torch.Tensor:
@@ -47,8 +52,10 @@ def _launch(name: str, rec: np.ndarray, dev: torch.device, *args):
     return buf
 
 
-def _conv(dev, n, inp, weight, bias, out, *, in2=None, mask=None, gate=None, dilation=1, cin_chunks=1, ntaps=9,
+def _conv(dev, n, hw, inp, weight, bias, out, *, in2=None, mask=None, gate=None, dilation=1, cin_chunks=1, ntaps=9,
           relu=1, accumulate=False):
+    H, W = hw
+    HW = H * W
     rec = np.zeros(n, _hip.CONV_ITEM)
     step = HW * C * 4
     e = np.arange(n, dtype=np.int64)
@@ -77,7 +84,9 @@ def _transpose(dev, w_cl: torch.Tensor, cout: int, cin: int, ntaps: int) -> torc
     return wt
 
 
-def _wgrad(dev, n, x, dy, gate, dw, db, *, x2=None, xmask=None, dilation=1, ntaps=9, cin_blocks=1):
+def _wgrad(dev, n, hw, x, dy, gate, dw, db, *, x2=None, xmask=None, dilation=1, ntaps=9, cin_blocks=1):
+    H, W = hw
+    HW = H * W
     items = np.zeros(n, _hip.WGRAD_ITEM)
     step = HW * C * 4
     e = np.arange(n, dtype=np.int64)
@@ -100,26 +109,30 @@ def _wgrad(dev, n, x, dy, gate, dw, db, *, x2=None, xmask=None, dilation=1, ntap
 class _Conv3x3Relu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, mask, dilation):
-        _need(x, C, "conv input")
+        hw = _need(x, C, "conv input")
+        HW = hw[0] * hw[1]
         dev, n = x.device, x.size(0)
         xh, w = _nhwc(x), _wcl(weight)
         b = bias.detach().float().contiguous()
         m = None if mask is None else mask.detach().float().reshape(n, HW).contiguous()
         y = torch.empty(n, HW, C, dtype=torch.float32, device=dev)
-        _conv(dev, n, xh, w, b, y, mask=m, dilation=dilation)
+        _conv(dev, n, hw, xh, w, b, y, mask=m, dilation=dilation)
         ctx.save_for_backward(xh, w, m if m is not None else torch.empty(0, device=dev), y)
-        ctx.dilation, ctx.has_mask = dilation, m is not None
-        return _nchw_view(y, n, C)
+        ctx.dilation, ctx.has_mask, ctx.hw = dilation, m is not None, hw
+        return _nchw_view(y, n, C, hw)
 
     @staticmethod
     def backward(ctx, dy):
         xh, w, m, y = ctx.saved_tensors
         dev, n = xh.device, xh.size(0)
+        hw = ctx.hw
+        H, W = hw
+        HW = H * W
         m = m if ctx.has_mask else None
         dyh = _nhwc(dy)
         wt = _transpose(dev, w, C, C, 9)
         dxm = torch.empty_like(xh)
-        _conv(dev, n, dyh, wt, None, dxm, gate=y, dilation=ctx.dilation, relu=0)
+        _conv(dev, n, hw, dyh, wt, None, dxm, gate=y, dilation=ctx.dilation, relu=0)
         dmask = None
         if m is not None:
             dx = torch.zeros_like(xh)
@@ -137,42 +150,46 @@ class _Conv3x3Relu(torch.autograd.Function):
             dx = dxm
         dw = torch.zeros(C, 9, C, dtype=torch.float32, device=dev)
         db = torch.zeros(C, dtype=torch.float32, device=dev)
-        _wgrad(dev, n, xh, dyh, y, dw, db, xmask=m, dilation=ctx.dilation)
-        return _nchw_view(dx, n, C), dw.view(C, 3, 3, C).permute(0, 3, 1, 2), db, dmask, None
+        _wgrad(dev, n, hw, xh, dyh, y, dw, db, xmask=m, dilation=ctx.dilation)
+        return _nchw_view(dx, n, C, hw), dw.view(C, 3, 3, C).permute(0, 3, 1, 2), db, dmask, None
 
 
 class _ProjectionRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, in1, in2, weight, bias):
-        _need(in1, C, "projection input 1")
-        _need(in2, C, "projection input 2")
+        hw = _need(in1, C, "projection input 1")
+        _need(in2, C, "projection input 2", like=hw)
         dev, n = in1.device, in1.size(0)
         a, b2, w = _nhwc(in1), _nhwc(in2), _wcl(weight)
         b = bias.detach().float().contiguous()
-        y = torch.empty(n, HW, C, dtype=torch.float32, device=dev)
-        _conv(dev, n, a, w, b, y, in2=b2, cin_chunks=2, ntaps=1)
+        y = torch.empty(n, hw[0] * hw[1], C, dtype=torch.float32, device=dev)
+        _conv(dev, n, hw, a, w, b, y, in2=b2, cin_chunks=2, ntaps=1)
         ctx.save_for_backward(a, b2, w, y)
-        return _nchw_view(y, n, C)
+        ctx.hw = hw
+        return _nchw_view(y, n, C, hw)
 
     @staticmethod
     def backward(ctx, dy):
         a, b2, w, y = ctx.saved_tensors
         dev, n = a.device, a.size(0)
+        hw = ctx.hw
         dyh = _nhwc(dy)
         wt = _transpose(dev, w, C, 2 * C, 1)  # [256][1][128]
         da, db2 = torch.empty_like(a), torch.empty_like(b2)
-        _conv(dev, n, dyh, wt[: C * C], None, da, gate=y, ntaps=1, relu=0)
-        _conv(dev, n, dyh, wt[C * C:], None, db2, gate=y, ntaps=1, relu=0)
+        _conv(dev, n, hw, dyh, wt[: C * C], None, da, gate=y, ntaps=1, relu=0)
+        _conv(dev, n, hw, dyh, wt[C * C:], None, db2, gate=y, ntaps=1, relu=0)
         dw = torch.zeros(C, 1, 2 * C, dtype=torch.float32, device=dev)
         db = torch.zeros(C, dtype=torch.float32, device=dev)
-        _wgrad(dev, n, a, dyh, y, dw, db, x2=b2, ntaps=1, cin_blocks=2)
-        return _nchw_view(da, n, C), _nchw_view(db2, n, C), dw.view(C, 2 * C, 1, 1), db
+        _wgrad(dev, n, hw, a, dyh, y, dw, db, x2=b2, ntaps=1, cin_blocks=2)
+        return _nchw_view(da, n, C, hw), _nchw_view(db2, n, C, hw), dw.view(C, 2 * C, 1, 1), db
 
 
 class _Dot1Sigmoid(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        _need(x, C, "head input")
+        hw = ctx.hw = _need(x, C, "head input")
+        H, W = hw
+        HW = H * W
         dev, n = x.device, x.size(0)
         xh = _nhwc(x)
         w = weight.detach().float().reshape(C).contiguous()
@@ -190,6 +207,8 @@ class _Dot1Sigmoid(torch.autograd.Function):
     def backward(ctx, dout):
         xh, w, b, out = ctx.saved_tensors
         dev, n = xh.device, xh.size(0)
+        hw = ctx.hw
+        HW = hw[0] * hw[1]
         do = dout.detach().float().reshape(n, HW).contiguous()
         din = torch.empty_like(xh)
         dw = torch.zeros(C, dtype=torch.float32, device=dev)
@@ -199,14 +218,16 @@ class _Dot1Sigmoid(torch.autograd.Function):
         rec["dout"], rec["din"] = do.data_ptr() + e * HW * 4, din.data_ptr() + e * HW * C * 4
         rec["dw"], rec["db"] = dw.data_ptr(), db.data_ptr()
         _launch("pnmn_dot1_sigmoid_bwd", rec, dev, HW)
-        return _nchw_view(din, n, C), dw.view(1, C, 1, 1), db
+        return _nchw_view(din, n, C, hw), dw.view(1, C, 1, 1), db
 
 
 class _Same(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, attn, weight, bias):
-        _need(feats, C, "SameModule features")
-        _need(attn, 1, "SameModule attention")
+        hw = ctx.hw = _need(feats, C, "SameModule features")
+        _need(attn, 1, "SameModule attention", like=hw)
+        H, W = hw
+        HW = H * W
         dev, n = feats.device, feats.size(0)
         fh = _nhwc(feats)
         a = attn.detach().float().reshape(n, HW).contiguous()
@@ -225,6 +246,9 @@ class _Same(torch.autograd.Function):
     def backward(ctx, dout):
         fh, a, w, b, out = ctx.saved_tensors
         dev, n = fh.device, fh.size(0)
+        hw = ctx.hw
+        H, W = hw
+        HW = H * W
         do = dout.detach().float().reshape(n, HW).contiguous()
         dfe = torch.zeros_like(fh)
         dat = torch.zeros_like(a)
@@ -235,16 +259,19 @@ class _Same(torch.autograd.Function):
         rec["dout"], rec["dfeats"] = do.data_ptr() + e * HW * 4, dfe.data_ptr() + e * HW * C * 4
         rec["dattn"], rec["dw"], rec["db"] = dat.data_ptr() + e * HW * 4, dw.data_ptr(), db.data_ptr()
         _launch("pnmn_same_bwd", rec, dev, HW)
-        return _nchw_view(dfe, n, C), dat.view(n, 1, H, W), dw.view(1, C + 1, 1, 1), db
+        return _nchw_view(dfe, n, C, hw), dat.view(n, 1, H, W), dw.view(1, C + 1, 1, 1), db
 
 
 class _MinMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, is_max):
+        hw = None
         for t, what in ((a, "first operand"), (b, "second operand")):
             if t.dim() != 4 or t.size(1) not in (1, C):
                 raise NotImplementedError("And/Or %s has %s channels; the kernels take 1 or 128" % (what, t.size(1)))
-            _need(t, t.size(1), "And/Or " + what)
+            hw = _need(t, t.size(1), "And/Or " + what, like=hw)
+        H, W = hw
+        HW = H * W
         if a.size(0) != b.size(0):
             raise NotImplementedError("And/Or operands must have the same batch size")
         dev, n = a.device, a.size(0)
@@ -260,13 +287,15 @@ class _MinMax(torch.autograd.Function):
         rec["a_channels"], rec["b_channels"], rec["is_max"] = ac, bc, int(is_max)
         _launch("pnmn_minmax_fwd", rec, dev, HW, C)
         ctx.save_for_backward(ah, bh)
-        ctx.dims = (n, ac, bc, oc)
-        return _nchw_view(out, n, oc) if oc == C else out.view(n, 1, H, W)
+        ctx.dims = (n, ac, bc, oc, hw)
+        return _nchw_view(out, n, oc, hw) if oc == C else out.view(n, 1, H, W)
 
     @staticmethod
     def backward(ctx, dout):
         ah, bh = ctx.saved_tensors
-        n, ac, bc, oc = ctx.dims
+        n, ac, bc, oc, hw = ctx.dims
+        H, W = hw
+        HW = H * W
         dev = ah.device
         do = _nhwc(dout) if oc == C else dout.detach().float().reshape(n, HW).contiguous()
         da, db = torch.zeros_like(ah), torch.zeros_like(bh)
@@ -275,8 +304,8 @@ class _MinMax(torch.autograd.Function):
         rec["dout"] = do.data_ptr() + e * HW * oc * 4
         rec["da"], rec["db"] = da.data_ptr() + e * HW * ac * 4, db.data_ptr() + e * HW * bc * 4
         _launch("pnmn_minmax_bwd", rec, dev, HW, C)
-        ga = _nchw_view(da, n, C) if ac == C else da.view(n, 1, H, W)
-        gb = _nchw_view(db, n, C) if bc == C else db.view(n, 1, H, W)
+        ga = _nchw_view(da, n, C, hw) if ac == C else da.view(n, 1, H, W)
+        gb = _nchw_view(db, n, C, hw) if bc == C else db.view(n, 1, H, W)
         return ga, gb, None
 
 
@@ -286,7 +315,7 @@ def conv3x3_relu(x, weight, bias, mask: Optional[torch.Tensor] = None, dilation:
     if tuple(weight.shape) != (C, C, 3, 3):
         raise NotImplementedError("conv3x3 weight must be (128,128,3,3), got %s" % (tuple(weight.shape),))
     if mask is not None:
-        _need(mask, 1, "attention")
+        _need(mask, 1, "attention", like=tuple(x.shape[2:]))
     return _Conv3x3Relu.apply(x, weight, bias, mask, dilation)
 
 

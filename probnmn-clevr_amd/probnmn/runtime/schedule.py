@@ -40,9 +40,8 @@ RELATE_DILATIONS = (1, 2, 4, 8, 1)  # reference nmn_modules.py:146-150
 
 # columns of a template's primitive table
 (C_KIND, C_LEVEL, C_CALL, C_WIDX, C_DIL, C_AK, C_AO, C_BK, C_BO, C_OK, C_OO, C_ACH, C_BCH, C_ISMAX,
- C_MASKED, C_SCRATCH, C_PA, C_PB, C_C0, C_C1, C_C2) = range(21)
-NCOLS = 21  # C_PA/C_PB: local index of the primitive producing input a/b (-1: stem output / ones);
-            # C_C0..2: local indices of the primitives consuming this primitive's output (-1: none)
+ C_MASKED, C_SCRATCH, C_PA, C_PB) = range(18)
+NCOLS = 18  # C_PA/C_PB: local index of the primitive producing input a/b (-1: stem output / ones)
 
 
 def _align(n: int) -> int:
@@ -59,7 +58,6 @@ class Template:
     size: int  # arena floats per example (values + backward scratch)
     result_is_feat: bool
     depth: int
-    dataflow_ok: bool = True  # False if some output has more than three consumers
 
 
 def structure_key(prog: pc.CompiledProgram) -> Tuple:
@@ -96,7 +94,7 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
     def prim(kind, level, call, widx=0, dil=1, a=(L_ONES, 0), b=(L_ONES, 0), out=(L_SLOT, 0), a_ch=0,
              b_ch=0, is_max=0, masked=0, pa=-1, pb=-1):
         rows.append([kind, level, call, widx, dil, a[0], a[1], b[0], b[1], out[0], out[1], a_ch, b_ch,
-                     is_max, masked, -1, pa, pb, -1, -1, -1])
+                     is_max, masked, -1, pa, pb])
         return len(rows) - 1
 
     for ci, c in enumerate(calls):
@@ -149,23 +147,9 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
     for r in rows:  # backward scratch: gradient wrt (FEAT * attention) of each masked conv
         if r[C_MASKED]:
             r[C_SCRATCH] = alloc(big)
-    # consumers of every primitive's output (for the backward dependencies of the dataflow executor)
-    ok = True
-    for j, r in enumerate(rows):
-        for pcol in (C_PA, C_PB):
-            src_prim = r[pcol]
-            if src_prim >= 0:
-                for ccol in (C_C0, C_C1, C_C2):
-                    if rows[src_prim][ccol] < 0:
-                        rows[src_prim][ccol] = j
-                        break
-                    if rows[src_prim][ccol] == j:  # same consumer through both operands
-                        break
-                else:
-                    ok = False
     table = np.asarray(rows, dtype=np.int64).reshape(-1, NCOLS)
     depth = int(table[:, C_LEVEL].max()) if len(rows) else 0
-    return Template(table, len(calls), cursor, prog.result < 2, depth, ok)
+    return Template(table, len(calls), cursor, prog.result < 2, depth)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -218,11 +202,6 @@ class StepPlan:
     # (lowest level of the group, first job, one past the last job) -- a group may be launched as soon
     # as the backward pass has finished the phase of its lowest level
     wgrad_groups: List[Tuple[int, int, int]] = None
-    # dataflow executor (None when a structure in the batch is not supported by it)
-    fwd_tasks: np.ndarray = None
-    bwd_tasks: np.ndarray = None
-    n_fwd_slots: int = 0
-    n_bwd_slots: int = 0
 
 
 def _cut(levels: np.ndarray) -> List[Tuple[int, int, int]]:
@@ -245,8 +224,6 @@ class BatchScheduler:
         self.wgrad_groups = wgrad_groups
         self.fuse_mask_bwd = True  # masked convs' data-gradients do the `feats * attn` backward in their epilogue
         self.sole_writer_rmw = os.environ.get("PNMN_MB_SOLE", "1") != "0"
-        self.dataflow = False      # build task lists for the persistent dataflow executor
-        self.dataflow_ksplit = 2   # sub-tasks per convolution
         self._ids: Dict[Tuple, int] = {}
         self._templates: List[Template] = []
         self._bank = None  # (tables [T, Pmax, NCOLS], nprims [T], sizes [T])
@@ -386,7 +363,7 @@ class BatchScheduler:
                 # read-modify-write instead of 25 000 atomics per item
                 _, inv, cnt = np.unique(lv.astype(np.int64) * (1 << 48) + (a_g[m] >> 4).astype(np.int64) * masked,
                                         return_inverse=True, return_counts=True)
-                sole = masked & (cnt[inv] == 1) & (not self.dataflow) & self.sole_writer_rmw  # (dataflow overlaps levels)
+                sole = masked & (cnt[inv] == 1) & self.sole_writer_rmw
                 dg[:, 7] = dil[m] + np.where(masked, 4 << 32, 0) + np.where(sole, 8 << 32, 0)
                 dg[:, 8] = np.where(masked, a_f[m], 0)
                 dg[:, 9] = mask_ptr
@@ -514,126 +491,7 @@ class BatchScheduler:
             if phase:
                 bwd.append(phase)
 
-        plan = StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N, wgroups)
-        if self.dataflow and all(self._templates[t].dataflow_ok for t in np.unique(tids)):
-            self._dataflow_tasks(plan, rows, xi, nprims[tids], tok, a_f, a_g, b_f, b_g, o_f, o_g, buf)
-        return plan
-
-    # --------------------------------------------------------------------------------------------
-    def _dataflow_tasks(self, plan, rows, xi, nprims_per_example, tok, a_f, a_g, b_f, b_g, o_f, o_g, buf):
-        """Task lists (pnmn_task records) of the persistent executor: forward in level order, backward
-        in reverse level order; a dependency is the completion slot of the producing (forward) or
-        consuming (backward) primitive."""
-        T = self.dt["task"]
-        tb, C, s = self.tables, self.channels, self.dataflow_ksplit
-        N = rows.shape[0]
-        kind, level, widx, dil = rows[:, C_KIND], rows[:, C_LEVEL], rows[:, C_WIDX], rows[:, C_DIL]
-        is_conv, is_proj = kind == K_CONV, kind == K_PROJ
-        is_dot, is_same, is_mm = kind == K_DOT, kind == K_SAME, kind == K_MINMAX
-        convlike = is_conv | is_proj
-        masked = rows[:, C_MASKED] == 1
-        rowbase = (np.cumsum(nprims_per_example) - nprims_per_example)[xi]
-
-        # parameter pointers per row
-        wsel = np.where(convlike, widx, 0)
-        tsel = np.where(convlike, tok, 0)
-        w3 = buf.params + tb.w3[tsel, wsel] * 4
-        b3 = buf.params + tb.b3[tsel, wsel] * 4
-        wt3 = buf.wt + tb.wt3[tsel, wsel] * 4
-        hsel = np.where(is_dot | is_same, tok, 0)
-        hw_, hb_ = buf.params + tb.dotw[hsel] * 4, buf.params + tb.dotb[hsel] * 4
-        ghw, ghb = buf.grads + tb.dotw[hsel] * 4, buf.grads + tb.dotb[hsel] * 4
-        ones_a = np.where(rows[:, C_AK] == L_ONES, buf.ones, a_f)
-        ones_b = np.where(rows[:, C_BK] == L_ONES, buf.ones, b_f)
-        mask_ptr = np.where(masked, b_f, 0)
-        mm_flags = (rows[:, C_ACH] == C) * 1 + (rows[:, C_BCH] == C) * 2 + rows[:, C_ISMAX] * 4
-
-        def resolve(order, count, cols, need_of_row):
-            """order: rows in task order; returns (slot_of_row, dep[N,3], need[N,3]) in row space."""
-            slot_of_row = np.empty(N, np.int64)
-            slot_of_row[order] = np.arange(N)
-            deps = np.full((N, 3), -1, np.int64)
-            needs = np.zeros((N, 3), np.int64)
-            for k, col in enumerate(cols):
-                local = rows[:, col]
-                has = local >= 0
-                src = np.where(has, rowbase + local, 0)
-                deps[:, k] = np.where(has, slot_of_row[src], -1)
-                needs[:, k] = np.where(has, need_of_row[src], 0)
-            return slot_of_row, deps, needs
-
-        def expand(order, count):
-            """item rows -> task rows: (row index per task, sub index per task)"""
-            cnt = count[order]
-            rep = np.repeat(order, cnt)
-            start = np.cumsum(cnt) - cnt
-            sub = np.arange(rep.size) - np.repeat(start, cnt)
-            return rep, sub
-
-        # ---------------- forward ----------------
-        # list scheduling by ALAP level: a program shallower than the deepest one in the batch is
-        # delayed by the difference, so that long chains run ahead and every chain ends together --
-        # otherwise the last levels of the longest programs run on a nearly empty chip
-        ex_depth = np.zeros(int(xi.max()) + 1, np.int64)
-        np.maximum.at(ex_depth, xi, level)
-        alap = level + (int(level.max()) - ex_depth[xi])
-        order = np.argsort(alap, kind="stable")
-        count = np.where(convlike, s, 1)
-        slot, deps, needs = resolve(order, count, (C_PA, C_PB), count)
-        rep, sub = expand(order, count)
-        f = np.zeros(rep.size, T)
-        P = f["p"]
-        r = rep
-        kc, kp, kd, ks_, km = is_conv[r], is_proj[r], is_dot[r], is_same[r], is_mm[r]
-        cl = kc | kp
-        P[:, 0] = np.where(km, ones_a[r], a_f[r])
-        P[:, 1] = np.where(kp, b_f[r], np.where(kd, hw_[r], np.where(km | ks_, ones_b[r], 0)))
-        P[:, 2] = np.where(kc, mask_ptr[r], np.where(kd, hb_[r], np.where(ks_, hw_[r], np.where(km, o_f[r], 0))))
-        P[:, 3] = np.where(kd, o_f[r], np.where(ks_, hb_[r], 0))
-        P[:, 4] = np.where(cl, w3[r], np.where(ks_, o_f[r], 0))
-        P[:, 5] = np.where(cl, b3[r], 0)
-        P[:, 6] = np.where(cl, o_f[r], 0)
-        f["type"] = np.select([cl, kd, ks_, km], [0, 1, 3, 5])
-        f["sub"] = sub
-        f["dilation"] = dil[r]
-        f["flags"] = np.where(kc, 16, np.where(kp, 16 | 32 | 64, np.where(km, mm_flags[r], 0)))
-        f["dep"] = deps[r]
-        f["need"] = needs[r]
-        f["slot"] = slot[r]
-        plan.fwd_tasks, plan.n_fwd_slots = f, N
-
-        # ---------------- backward ----------------
-        order = np.argsort(-level, kind="stable")
-        count = np.where(is_conv, s, np.where(is_proj, 2 * s, 1))
-        slot, deps, needs = resolve(order, count, (C_C0, C_C1, C_C2), count)
-        rep, sub = expand(order, count)
-        b = np.zeros(rep.size, T)
-        P = b["p"]
-        r = rep
-        kc, kp, kd, ks_, km = is_conv[r], is_proj[r], is_dot[r], is_same[r], is_mm[r]
-        cl = kc | kp
-        mk = masked[r] & kc
-        second = kp & (sub >= s)  # projection: second operand's half of the transposed weight
-        P[:, 0] = np.where(cl, o_g[r], np.where(km, ones_a[r], a_f[r]))
-        P[:, 1] = np.where(kd, hw_[r], np.where(km | ks_, ones_b[r], 0))
-        P[:, 2] = np.where(kd, hb_[r], np.where(ks_, hw_[r], np.where(km, o_f[r], 0)))
-        P[:, 3] = np.where(cl | kd, o_f[r], np.where(ks_, hb_[r], np.where(km, o_g[r], 0)))
-        P[:, 4] = np.where(cl, wt3[r] + second * (C * C * 4), np.where(kd, o_g[r], np.where(ks_, o_f[r], np.where(km, a_g[r], 0))))
-        P[:, 5] = np.where(kd, a_g[r], np.where(ks_, o_g[r], np.where(km, b_g[r], 0)))
-        P[:, 6] = np.where(cl, np.where(second, b_g[r], a_g[r]), np.where(kd, ghw[r], np.where(ks_, a_g[r], 0)))
-        P[:, 6] = np.where(mk, 0, P[:, 6])
-        P[:, 7] = np.where(mk, a_f[r], np.where(kd, ghb[r], np.where(ks_, b_g[r], 0)))
-        P[:, 8] = np.where(mk, mask_ptr[r], np.where(ks_, ghw[r], 0))
-        P[:, 9] = np.where(mk, a_g[r], np.where(ks_, ghb[r], 0))
-        P[:, 10] = np.where(mk & (mask_ptr[r] != 0), b_g[r], 0)
-        b["type"] = np.select([cl, kd, ks_, km], [0, 2, 4, 6])
-        b["sub"] = np.where(second, sub - s, sub)
-        b["dilation"] = dil[r]
-        b["flags"] = np.where(mk, 128, np.where(kp, 32 | 1 | 2, np.where(km, mm_flags[r], 0)))
-        b["dep"] = deps[r]
-        b["need"] = needs[r]
-        b["slot"] = slot[r]
-        plan.bwd_tasks, plan.n_bwd_slots = b, N
+        return StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N, wgroups)
 
     def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray, group=None):
         """Sort weight-gradient items by (group,) weight and cut each run into jobs of at most

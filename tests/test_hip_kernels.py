@@ -14,6 +14,18 @@ C = 128
 RT, AT = 2e-4, 2e-4
 
 
+@pytest.fixture(autouse=True, params=[14, 28], ids=["14x14", "28x28"])
+def map_size(request):
+    """Every test below runs at both feature-map sizes the kernels are built for (BASELINE configs
+    1-4: 14x14; config 5: 28x28, where a conv / weight-gradient workgroup covers a 7-row band)."""
+    global H, W, HW
+    H = W = request.param
+    HW = H * W
+    yield request.param
+    H = W = 14
+    HW = H * W
+
+
 @pytest.fixture(scope="module")
 def hip():
     from probnmn import _hip
@@ -177,7 +189,7 @@ def test_conv_stem_chunks_and_two_sources(hip):
     torch.testing.assert_close(from_nhwc(outc, n, 1024), refc, rtol=RT, atol=AT)
 
 
-@pytest.mark.parametrize("dilation", [1, 4])
+@pytest.mark.parametrize("dilation", [1, 2, 4, 8])
 def test_conv_dgrad_and_wgrad_match_autograd(hip, dilation):
     g = gen(20 + dilation)
     n = 5
@@ -228,6 +240,48 @@ def test_conv_dgrad_and_wgrad_match_autograd(hip, dilation):
     ref_dw = w.grad.permute(0, 2, 3, 1).reshape(C, 9, C)
     torch.testing.assert_close(dw.cpu(), ref_dw, rtol=RT, atol=5 * AT)
     torch.testing.assert_close(db.cpu(), b.grad, rtol=RT, atol=5 * AT)
+
+
+@pytest.mark.parametrize("sole", [0, 1])
+@pytest.mark.parametrize("dilation", [1, 2])
+def test_conv_dgrad_fused_mask_backward(hip, sole, dilation):
+    """Data-gradient of a conv whose forward input was feats * attn, with the mask backward fused into the
+    epilogue (PNMN_CONV_MASKBWD; atomics, or plain read-modify-write with PNMN_CONV_MB_SOLE)."""
+    g = gen(300 + sole + 2 * dilation)
+    n = 3
+    feats = torch.relu(torch.randn(n, C, H, W, generator=g)).requires_grad_(True)
+    attn = torch.sigmoid(torch.randn(n, 1, H, W, generator=g))
+    attn[1] = 1.0  # item 1: the all-ones attention `scene` produces (mb_attn == NULL)
+    attn.requires_grad_(True)
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    y = F.relu(F.conv2d(feats * attn, w, b, padding=dilation, dilation=dilation))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wd = wcl(w)
+    wt = torch.empty(C, 9, C, device=dev())
+    t = np.zeros(1, hip.WTRANS_ITEM)
+    t[0]["src"], t[0]["dst"], t[0]["cout"], t[0]["cin"], t[0]["ntaps"] = ptr(wd), ptr(wt), C, C, 9
+    run(hip, "pnmn_transpose_weights", t)
+    dyd, yd, fd = nhwc(dy), nhwc(y.detach()), nhwc(feats.detach())
+    ad = attn.detach().reshape(n, HW).to(dev())
+    prior = torch.randn(n, HW, C, generator=g)  # dFEAT already holds other consumers' gradients
+    dfe = prior.clone().to(dev())
+    dat = torch.zeros(n, HW, device=dev())
+    recs = np.zeros(n, hip.CONV_ITEM)
+    for i in range(n):
+        recs[i]["in"], recs[i]["gate"], recs[i]["weight"] = ptr(dyd[i]), ptr(yd[i]), ptr(wt)
+        recs[i]["dilation"] = dilation
+        recs[i]["flags"] = hip.CONV_MASKBWD | (8 if sole else 0)
+        recs[i]["mb_feats"], recs[i]["mb_dfeats"] = ptr(fd[i]), ptr(dfe[i])
+        if i != 1:
+            recs[i]["mb_attn"], recs[i]["mb_dattn"] = ptr(ad[i]), ptr(dat[i])
+    run(hip, "pnmn_conv_nhwc", recs, H, W, 1, 9, C, C, 1, 0)
+    torch.testing.assert_close(from_nhwc(dfe, n, C) - from_nhwc(prior.to(dev()), n, C), feats.grad, rtol=RT, atol=AT)
+    got = dat.cpu().reshape(n, 1, H, W)
+    keep = [0, 2]
+    torch.testing.assert_close(got[keep], attn.grad[keep], rtol=RT, atol=20 * AT)  # sums of 128 products of O(1) terms
+    assert float(got[1].abs().max()) == 0.0
 
 
 def test_wgrad_1x1_two_sources_and_wide_output(hip):
@@ -417,7 +471,7 @@ def test_maxpool_flatten_fwd_bwd(hip):
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy)
     actd = nhwc(act.detach())
-    out = torch.empty(n, CC * 49, device=dev())
+    out = torch.empty(n, CC * (H // 2) * (W // 2), device=dev())
     hip.check(hip.lib().pnmn_maxpool2_flatten_fwd(actd.data_ptr(), out.data_ptr(), n, H, W, CC, hip.stream_ptr(dev())), "maxpool fwd")
     assert torch.equal(out.cpu(), y.detach())
     din = torch.empty(n, HW, CC, device=dev())
@@ -426,7 +480,9 @@ def test_maxpool_flatten_fwd_bwd(hip):
     assert torch.equal(from_nhwc(din, n, CC), pre.grad)
 
 
-def test_answer_loss(hip):
+def test_answer_loss(hip, map_size):
+    if map_size != 14:
+        pytest.skip("independent of the map size")
     g = gen(100)
     n, A = 37, 28
     logits = (torch.randn(n, A, generator=g) * 3).requires_grad_(True)
@@ -454,7 +510,9 @@ def test_answer_loss(hip):
     torch.testing.assert_close(loss.cpu(), ref2, rtol=1e-5, atol=1e-5)
 
 
-def test_clamp_adam_matches_torch(hip):
+def test_clamp_adam_matches_torch(hip, map_size):
+    if map_size != 14:
+        pytest.skip("independent of the map size")
     g = gen(110)
     p = torch.randn(100003, generator=g)
     ref = p.clone().requires_grad_(True)

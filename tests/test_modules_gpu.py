@@ -11,6 +11,8 @@ from fixtures import full_module_inputs
 
 pytestmark = pytest.mark.gpu
 
+SIZES = pytest.mark.parametrize("size", [14, 28], ids=["14x14", "28x28"])
+
 
 def _build(cls, tok, sd, dev):
     m = cls(128)
@@ -19,11 +21,12 @@ def _build(cls, tok, sd, dev):
     return m.to(dev)
 
 
-def test_modules_match_reference_golden(golden_dir):
+@SIZES
+def test_modules_match_reference_golden(golden_dir, size):
     from probnmn.modules import nmn_modules as M
 
-    gold = np.load(os.path.join(golden_dir, "nmn_modules_full.npz"))
-    feats, feats2, attn, attn2, toks, sd = full_module_inputs()
+    gold = np.load(os.path.join(golden_dir, "nmn_modules_full%s.npz" % ("" if size == 14 else "_%d" % size)))
+    feats, feats2, attn, attn2, toks, sd = full_module_inputs(size)
     dev = torch.device("cuda:0")
     f, f2, a, a2 = (t.to(dev) for t in (feats, feats2, attn, attn2))
     with torch.no_grad():
@@ -46,12 +49,13 @@ def test_modules_match_reference_golden(golden_dir):
             np.testing.assert_allclose(v.cpu().numpy(), gold[k], rtol=1e-4, atol=1e-4, err_msg=k)
 
 
+@SIZES
 @pytest.mark.parametrize("kind", ["attention", "query", "relate", "same", "comparison", "and"])
-def test_module_gradients_match_oracle(kind):
+def test_module_gradients_match_oracle(kind, size):
     from oracle import nmn_oracle
     from probnmn.modules import nmn_modules as M
 
-    feats, feats2, attn, attn2, toks, sd = full_module_inputs()
+    feats, feats2, attn, attn2, toks, sd = full_module_inputs(size)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
 
@@ -99,5 +103,7 @@ def test_unsupported_shapes_fail_loudly():
     dev = torch.device("cuda:0")
     with pytest.raises(NotImplementedError):
         M.AttentionModule(64).to(dev)(torch.zeros(1, 64, 14, 14, device=dev), torch.ones(1, 1, 14, 14, device=dev))
+    with pytest.raises(NotImplementedError):
+        M.AttentionModule(128).to(dev)(torch.zeros(1, 128, 20, 20, device=dev), torch.ones(1, 1, 20, 20, device=dev))
     with pytest.raises(_hip.HipLibraryError):
         M.AttentionModule(128)(torch.zeros(1, 128, 14, 14), torch.ones(1, 1, 14, 14))

@@ -5,22 +5,22 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import VALIDITY_CASES, encode_programs
+from fixtures import LONG_CASES, VALIDITY_CASES, encode_programs
 
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=0, cases=VALIDITY_CASES):
+def _setup(seed=0, cases=VALIDITY_CASES, size=14, length=26):
     from probnmn.models.nmn import NeuralModuleNetwork
     from probnmn.vocabulary import Vocabulary
 
     vocab = Vocabulary.clevr()
     torch.manual_seed(seed)
-    net = NeuralModuleNetwork(vocab)
-    programs = encode_programs(cases, vocab.get_token_to_index_vocabulary("programs"))
+    net = NeuralModuleNetwork(vocab, image_feature_size=(1024, size, size))
+    programs = encode_programs(cases, vocab.get_token_to_index_vocabulary("programs"), length=length)
     B = programs.size(0)
     g = torch.Generator().manual_seed(seed + 1)
-    features = torch.relu(torch.randn(B, 1024, 14, 14, generator=g))
+    features = torch.relu(torch.randn(B, 1024, size, size, generator=g))
     answers = torch.randint(0, 28, (B,), generator=g)
     return vocab, net, programs, features, answers
 
@@ -119,6 +119,43 @@ def test_gradients_per_program_tight():
     assert np.median(w) < 5e-5
     assert np.mean(w < 2e-4) >= 0.75
     assert w.max() < 5e-2
+
+
+# BASELINE config 5: 28x28 feature maps, programs of up to 40 tokens.  A slice of the golden cases that
+# uses every module kind, both verdicts and every long chain (the oracle's classifier alone is
+# 200704 x 1024 weights: the CPU side of this test is what bounds the batch).
+CONFIG5_CASES = [VALIDITY_CASES[i] for i in (0, 3, 9, 11, 12, 13, 14, 15, 16, 17, 22, 34)] + LONG_CASES
+
+
+def test_config5_28x28_long_programs_match_oracle():
+    vocab, net, programs, features, answers = _setup(seed=5, cases=CONFIG5_CASES, size=28, length=40)
+    cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert tuple(cpu_sd["classifier.4.weight"].shape) == (1024, 1024 * 14 * 14)
+    ref, ref_sd = _oracle(vocab, cpu_sd, programs, features, answers)
+
+    dev = torch.device("cuda:0")
+    net.to(dev).train()
+    out = net(features.to(dev), programs.to(dev), answers.to(dev))
+    out["loss"].mean().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out["predictions"].cpu(), ref["predictions"])
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    n_invalid = int((ref["valid"] == 0).sum())
+    assert 0 < n_invalid < len(CONFIG5_CASES)
+    assert out["metrics"]["average_invalid"] == n_invalid
+    errs = _grad_errors(net, ref_sd)
+    assert len(errs) > 60
+    worst = max(errs, key=errs.get)
+    print("28x28 worst relative gradient error", worst, errs[worst])
+    assert np.median(list(errs.values())) < 1e-4
+    assert errs[worst] < 2e-2, (worst, errs[worst])
+    # evaluation pass (no answers, no gradient) on the same network
+    net.eval()
+    with torch.no_grad():
+        ev = net(features.to(dev), programs.to(dev))
+    ref_ev, _ = _oracle(vocab, cpu_sd, programs, features, None)
+    assert torch.equal(ev["predictions"].cpu(), ref_ev["predictions"])
+    torch.testing.assert_close(ev["loss"].cpu(), ref_ev["loss"].detach(), rtol=1e-4, atol=1e-4)
 
 
 def test_eval_without_answers_and_repeat_is_deterministic():

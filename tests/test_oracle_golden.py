@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import nmn_oracle
@@ -10,9 +11,17 @@ from oracle import nmn_oracle
 from fixtures import full_module_inputs, small_network_inputs
 
 
-def test_modules_match_reference_vectors(golden_dir):
-    gold = np.load(os.path.join(golden_dir, "nmn_modules_full.npz"))
-    feats, feats2, attn, attn2, toks, sd = full_module_inputs()
+SIZES = pytest.mark.parametrize("size", [14, 28], ids=["14x14", "28x28"])
+
+
+def _suffix(size):
+    return "" if size == 14 else "_%d" % size
+
+
+@SIZES
+def test_modules_match_reference_vectors(golden_dir, size):
+    gold = np.load(os.path.join(golden_dir, "nmn_modules_full%s.npz" % _suffix(size)))
+    feats, feats2, attn, attn2, toks, sd = full_module_inputs(size)
     with torch.no_grad():
         mine = {
             "and_1_1": nmn_oracle.and_module(attn, attn2),
@@ -31,9 +40,12 @@ def test_modules_match_reference_vectors(golden_dir):
         np.testing.assert_allclose(v.numpy(), gold[k], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-def test_network_matches_reference_vectors(golden_dir):
-    gold = np.load(os.path.join(golden_dir, "nmn_small.npz"))
-    ns, programs, features, answers, sd = small_network_inputs()
+@SIZES
+def test_network_matches_reference_vectors(golden_dir, size):
+    """size 28 = BASELINE config 5: 28x28 maps and programs of up to 40 tokens."""
+    gold = np.load(os.path.join(golden_dir, "nmn_small%s.npz" % _suffix(size)))
+    ns, programs, features, answers, sd = small_network_inputs(size)
+    assert programs.size(1) == (26 if size == 14 else 40)
     itos = dict(enumerate(ns["programs"]))
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out = nmn_oracle.nmn_forward(sd, itos, features, programs, answers)

@@ -1,10 +1,12 @@
 import json
+
+import pytest
 import os
 
 from probnmn.runtime import program_compiler as pc
 from probnmn.vocabulary import Vocabulary
 
-from fixtures import VALIDITY_CASES, namespaces
+from fixtures import LONG_CASES, VALIDITY_CASES, namespaces
 
 
 def test_vocabulary_matches_reference_layout():
@@ -38,17 +40,26 @@ def test_module_table_counts():
     assert kinds.count(pc.AND) == 1 and kinds.count(pc.OR) == 1 and kinds.count(pc.SCENE) == 1
 
 
-def test_validity_matches_reference_interpreter(golden_dir):
-    """The static rules reproduce the reference's try/except verdict on every golden case."""
-    with open(os.path.join(golden_dir, "nmn_validity.json")) as f:
+@pytest.mark.parametrize("fixture,cases", [("nmn_validity.json", VALIDITY_CASES),
+                                           ("nmn_validity_28.json", VALIDITY_CASES + LONG_CASES)])
+def test_validity_matches_reference_interpreter(golden_dir, fixture, cases):
+    """The static rules reproduce the reference's try/except verdict on every golden case (the second
+    table: the reference at 28x28 maps, with programs of up to 40 tokens -- BASELINE config 5)."""
+    with open(os.path.join(golden_dir, fixture)) as f:
         table = json.load(f)
     v = Vocabulary.clevr()
     comp = pc.ProgramCompiler(v.get_index_to_token_vocabulary("programs"), module_channels=8)
-    assert set(table) == set(VALIDITY_CASES)
+    assert set(table) == set(cases)
+    rows = []
     for case, valid in table.items():
         ids = [v.get_token_index(t, "programs") for t in case.split()]
         got = comp.compile(ids + [0] * 3)
         assert got.valid == bool(valid), case
+        rows.append(ids + [0] * (40 - len(ids)))
+    import numpy as np
+
+    batch = comp.compile_batch(np.asarray(rows, dtype=np.int64))  # the library's batch compiler, length 40
+    assert [p.valid for p in batch] == [bool(x) for x in table.values()]
 
 
 def test_operand_order_and_values():
