@@ -28,9 +28,10 @@ Besides the contract fields the JSON line carries
                  the 157.3 TFLOP/s fp32 matrix peak of gfx950
   cpu_baseline   the CPU oracle's identical step (same weights), timed on this host's cores on a
                  bounded sample of the same workload (N=1 only)
-  module_training / question_coding / joint_training_b128
-                 side measurements of BASELINE.json configs[1], configs[2] and of configs[3] read as
-                 1024 questions over 8 GPUs (128 per GPU); never `value`
+  module_training / question_coding / joint_training_b128 / joint_training_28x28
+                 side measurements of BASELINE.json configs[1], configs[2], of configs[3] read as
+                 1024 questions over 8 GPUs (128 per GPU) and of configs[4] (28x28 maps, programs of up
+                 to 40 tokens, 128 per GPU); never `value`
 """
 import argparse
 import json
@@ -235,11 +236,14 @@ def recurrent_kernel_report(dev):
     return out
 
 
-def timed(step_fn, steps, warmup, dev, world):
+def timed(step_fn, steps, warmup, dev, world, trainer=None):
     """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both
-    sides; returns (max-over-ranks seconds, host seconds to enqueue, host seconds blocked on the
-    staging ring)."""
+    sides; returns (max-over-ranks seconds, host seconds to enqueue, host seconds blocked on the GPU:
+    waiting for a staging-ring slot or -- joint training -- for the sampled programs to arrive)."""
     from probnmn import _hip
+
+    def blocked_now():
+        return _hip.ring_wait_seconds() + (getattr(trainer, "blocked_seconds", 0.0) if trainer is not None else 0.0)
 
     for i in range(warmup):
         step_fn()
@@ -247,12 +251,12 @@ def timed(step_fn, steps, warmup, dev, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    w0 = _hip.ring_wait_seconds()
+    w0 = blocked_now()
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
     host = time.perf_counter() - t0
-    blocked = _hip.ring_wait_seconds() - w0
+    blocked = blocked_now() - w0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -265,13 +269,13 @@ def timed(step_fn, steps, warmup, dev, world):
     return elapsed, host, blocked
 
 
-def device_batch(vocab, n, seed, dev):
+def device_batch(vocab, n, seed, dev, **kw):
     """A synthetic batch resident in HBM.  `supervision` stays on the host (it decides the split sizes,
     as the data loader's CPU tensor does in the reference) and so does `program` for module training
     (it drives the host-side launch schedule)."""
     from probnmn.data.synthetic import synthetic_batch
 
-    batch = synthetic_batch(vocab, n, seed=seed)
+    batch = synthetic_batch(vocab, n, seed=seed, **kw)
     sup = batch["supervision"]
     batch = {k: v.to(dev) for k, v in batch.items()}
     batch["supervision"] = sup
@@ -311,6 +315,62 @@ def fit_program_generator(pg, vocab, batch, dev, max_iters, target):
     return frac, it
 
 
+def config5_side(vocab, prior, dev, rank, world, args):
+    """BASELINE configs[4]: joint_training_ours.yml with 28x28 feature maps and programs of up to 40
+    tokens (deeper module chains), 128 questions per GPU (1024 over 8 GPUs, as BASELINE.md tabulates it).
+    Own models (the NMN's classifier is 200704 -> 1024 at this size, the generator decodes 40 steps), own
+    pre-fit of the generator on the deep synthetic programs, own conv roofline."""
+    from probnmn import parallel
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep
+
+    n = args.batch28
+    torch.manual_seed(5)
+    nmn = NeuralModuleNetwork(vocab, image_feature_size=(1024, 28, 28)).to(dev)
+    pg, qr = ProgramGenerator(vocab, max_decoding_steps=40).to(dev), QuestionReconstructor(vocab).to(dev)
+    for m in (pg, qr):
+        m.sample_row_offset = rank * n
+    batch = device_batch(vocab, n, 5000 + rank, dev, image_feature_size=(1024, 28, 28), deep=True)
+    valid_fraction, fit_iters = fit_program_generator(pg, vocab, batch, dev, args.fit_iters, args.fit_target)
+    trainer = JointTrainingStep(pg, qr, prior, nmn, **JOINT)
+    parallel.broadcast_parameters(trainer.optimizer.arenas, trainer.optimizer.loose)
+    for _ in range(4):
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    elapsed, host, blocked = timed(lambda: trainer.step(batch), 10, 4, dev, world, trainer)
+    agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2)
+    out = None
+    if rank == 0:
+        conv = agg["conv_nhwc"]
+        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        out = {
+            "metric": "CLEVR questions/sec (joint_training step)",
+            "value": round(n * world * 10 / elapsed, 1), "unit": "questions/s", "ms_per_step": round(elapsed / 10 * 1e3, 3),
+            "global_batch": n * world, "steps": 10, "warmup": 4,
+            "workload": "joint_training_ours.yml with NMN.IMAGE_FEATURE_SIZE [1024,28,28] and programs of up to 40 tokens "
+                        "(ProgramGenerator max_decoding_steps 40; synthetic deep programs, mean %.1f tokens), %d questions "
+                        "per GPU (configs[4])" % (float((batch["program"] != 0).sum(1).float().mean()), n),
+            "valid_program_fraction": round(valid_fraction, 4),
+            "program_generator_fit_iterations": fit_iters,
+            "module_primitives_per_step": nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None,
+            "host_busy_ms_per_step": round((host - blocked) / 10 * 1e3, 3),
+            "host_blocked_ms_per_step": round(blocked / 10 * 1e3, 3),
+            "roofline": {
+                "kernel": "conv_nhwc", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                "kernels": {
+                    k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / 2, 3),
+                        "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1] / 2, 3)}
+                                         for w, b in v["by"].items()}}
+                    for k, v in agg.items()},
+            },
+        }
+    trainer.close()
+    del trainer, nmn, pg, qr, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +378,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10,
                     help="untimed steps first: allocator pools, GEMM heuristics and the program / template caches settle")
     ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
+    ap.add_argument("--batch28", type=int, default=128, help="questions per GPU of the 28x28 / 40-token side measurement")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--settle", type=int, default=8, help="set-up iterations before the warm-up (see main)")
@@ -381,7 +442,7 @@ def main():
         trainer.step(batch)
     torch.cuda.synchronize()
     log("joint_training: warmup + %d timed steps" % args.steps)
-    elapsed, host, blocked = timed(lambda: trainer.step(batch), args.steps, args.warmup, dev, world)
+    elapsed, host, blocked = timed(lambda: trainer.step(batch), args.steps, args.warmup, dev, world, trainer)
     log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
     prims = nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None
 
@@ -412,10 +473,11 @@ def main():
                 step = make()
                 if name == "module_training":
                     b["program"] = b["program"].cpu()
-                e, _, _ = timed(lambda: step.step(b), 10, 6, dev, world)
+                e, h, bl = timed(lambda: step.step(b), 10, 6, dev, world, step)
                 extras[name] = {"metric": metric, "value": round(n * world * 10 / e, 1), "unit": "questions/s",
                                 "ms_per_step": round(e / 10 * 1e3, 3), "global_batch": n * world, "steps": 10,
-                                "warmup": 6, "workload": workload}
+                                "warmup": 6, "host_busy_ms_per_step": round((h - bl) / 10 * 1e3, 3),
+                                "host_blocked_ms_per_step": round(bl / 10 * 1e3, 3), "workload": workload}
                 log("%s: %.1f questions/s" % (name, extras[name]["value"]))
             except Exception as exc:  # the headline line must survive a failure of a side measurement
                 extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -427,11 +489,18 @@ def main():
              "question_coding_ours.yml (ProgramGenerator + QuestionReconstructor + frozen ProgramPrior, REINFORCE-ELBO), "
              "512 questions per GPU (configs[2])", 512,
              lambda: QuestionCodingStep(pg, qr, prior, objective="ours", alpha=100.0, beta=0.1, delta=0.99, lr=1e-3))
-        if getattr(trainer, "_early", None) is not None:
-            trainer._early.remove()  # the next trainer hooks the same fully connected layer for its own early all-reduce
+        trainer.close()  # (the next trainer hooks the same fully connected layer for its own early all-reduce)
         side("module_training", "CLEVR questions/sec (module_training step)",
              "module_training.yml, 256 questions per GPU, ground-truth programs, NMN fwd+bwd+clamp+Adam (configs[1])", 256,
              lambda: ModuleTrainingStep(nmn, lr=1e-4, weight_decay=0.0, report_metrics=False))
+
+    if not args.no_extras:
+        try:
+            extras["joint_training_28x28"] = config5_side(vocab, prior, dev, rank, world, args)
+            if rank == 0:
+                log("joint_training_28x28: %.1f questions/s" % extras["joint_training_28x28"]["value"])
+        except Exception as exc:
+            extras["joint_training_28x28"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -446,6 +515,7 @@ def main():
             "ms_per_step": round(ms, 3),
             "host_enqueue_ms_per_step": round(host / args.steps * 1e3, 3),
             "host_busy_ms_per_step": round((host - blocked) / args.steps * 1e3, 3),
+            "host_blocked_ms_per_step": round(blocked / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -8,6 +8,10 @@ dtypes and value ranges of real preprocessed CLEVR, drawn from numpy's Philox ge
                                       prefix order, random filter / relate / query arguments
   answer       (B,)         int64     U{0..27}
   supervision  (B,)         int64     Bernoulli(0.5)
+
+``deep=True`` (BASELINE config 5, "program length <= 40 ... deeper module chains"): programs are drawn
+from the eight CLEVR shapes and eight deeper ones of 16-40 tokens (up to ten hops, comparisons and
+unions of multi-hop chains), zero-padded to 40.
 """
 from typing import Dict, List, Optional
 
@@ -52,25 +56,66 @@ def template_program(t: int, rng: np.random.Generator) -> List[str]:
     raise ValueError(t)
 
 
+NUM_DEEP_TEMPLATES = 8
+DEEP_PROGRAM_LENGTH = 40
+
+
+def deep_template_program(t: int, rng: np.random.Generator) -> List[str]:
+    """Deeper module chains than any CLEVR template, at most 40 tokens (prefix order)."""
+    F = lambda: _FILTERS[rng.integers(len(_FILTERS))]  # noqa: E731
+    R = lambda: _RELATES[rng.integers(len(_RELATES))]  # noqa: E731
+    Q = lambda: _QUERIES[rng.integers(len(_QUERIES))]  # noqa: E731
+
+    def chain(hops: int, filters: int = 1) -> List[str]:
+        """`filters` filters on the scene, then `hops` x (unique, relate, filter), outermost first."""
+        out: List[str] = []
+        for _ in range(hops):
+            out += [F(), R(), "unique"]
+        return out + [F() for _ in range(filters)] + ["scene"]
+
+    if t == 0:
+        return [Q(), "unique"] + chain(4)
+    if t == 1:
+        return [Q(), "unique"] + chain(6, 2)
+    if t == 2:
+        return [["count", "exist"][rng.integers(2)]] + chain(10, 2)
+    if t == 3:  # attribute comparison of the ends of two three-hop chains
+        k = rng.integers(4)
+        return [_EQUALS[k], _QUERIES[k], "unique"] + chain(3) + [_QUERIES[k], "unique"] + chain(3, 2)
+    if t == 4:  # integer comparison of two counts over five-hop chains (40 tokens)
+        return [_INT_CMP[rng.integers(3)], "count"] + chain(5, 2) + ["count"] + chain(5, 3)
+    if t == 5:  # and / or of two five-hop chains
+        return ["count", ["intersect", "union"][rng.integers(2)]] + chain(5, 2) + chain(5)
+    if t == 6:  # same-attribute between hops
+        return [Q(), "unique"] + chain(2)[:-1] + [_SAMES[rng.integers(4)], "unique"] + chain(3, 2)
+    if t == 7:  # a deep stack of filters over a two-hop chain
+        return [["count", "exist"][rng.integers(2)]] + [F() for _ in range(20)] + chain(3, 6)
+    raise ValueError(t)
+
+
 def synthetic_batch(
     vocabulary,
     batch_size: int,
     image_feature_size=(1024, 14, 14),
     seed: int = 0,
     question_length: int = 45,
-    program_length: int = 26,
+    program_length: Optional[int] = None,
     with_image: bool = True,
     device: Optional[torch.device] = None,
+    deep: bool = False,
 ) -> Dict[str, torch.Tensor]:
     rng = np.random.Generator(np.random.Philox(seed))
     stoi = vocabulary.get_token_to_index_vocabulary("programs")
     vq = vocabulary.get_vocab_size("questions")
     num_answers = vocabulary.get_vocab_size("answers") - 1
+    if program_length is None:
+        program_length = DEEP_PROGRAM_LENGTH if deep else 26
 
     programs = np.zeros((batch_size, program_length), np.int64)
-    templates = rng.integers(0, NUM_TEMPLATES, batch_size)
+    templates = rng.integers(0, NUM_TEMPLATES + (NUM_DEEP_TEMPLATES if deep else 0), batch_size)
     for i, t in enumerate(templates):
-        ids = [stoi[tok] for tok in template_program(int(t), rng)]
+        toks = template_program(int(t), rng) if t < NUM_TEMPLATES else deep_template_program(int(t) - NUM_TEMPLATES, rng)
+        ids = [stoi[tok] for tok in toks]
         programs[i, : len(ids)] = ids
     questions = np.zeros((batch_size, question_length), np.int64)
     lengths = rng.integers(5, 44, batch_size)

@@ -102,8 +102,17 @@ class Reinforce(nn.Module):
         centered = reward - self._baseline
         stats = torch.stack((centered.sum(), torch.full_like(self._baseline, float(centered.numel()))))
         stats = parallel.all_reduce_scalars(stats)
-        self._baseline = self._baseline + self._baseline_decay * stats[0] / stats[1]
+        # (a rank whose shard holds no sampled rows still takes part in the collective -- see `idle`;
+        # with no rows anywhere the baseline stays where it is)
+        self._baseline = self._baseline + self._baseline_decay * stats[0] / stats[1].clamp(min=1.0)
         return inputs * centered
+
+    def idle(self, device, dtype=torch.float32) -> None:
+        """Data parallel: this rank has no sampled rows in this iteration.  Takes part in the baseline's
+        all-reduce with an empty contribution, so that every rank issues the same collectives and ends
+        the iteration with the same baseline."""
+        empty = torch.zeros(0, dtype=dtype, device=device)
+        self.forward(empty, empty)
 
 
 class _ElboWithReinforce(nn.Module):

@@ -10,6 +10,7 @@ scaled by 1/world so that equal-sized shards reproduce the single-process mean l
 The element-wise clamp happens AFTER the reduce, as in the reference, where the clamp sees the
 whole-batch gradient (joint_training_trainer.py:181-188).
 """
+import weakref
 from typing import Iterable, Sequence
 
 import torch
@@ -20,29 +21,62 @@ def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+_HOOK_OWNER = weakref.WeakValueDictionary()  # id(parameter) -> the EarlyReducer whose hook is live on it
+
+
 class EarlyReducer:
     """Starts the all-reduce of chosen (large, loose) parameters the moment autograd has finished
     their gradient, so that the collective overlaps the rest of backward.  For the NMN that is
     ``classifier.4.weight``: 205 MB of the 257 MB gradient payload, final right after the
-    classifier's backward -- before the whole module-program / stem backward runs."""
+    classifier's backward -- before the whole module-program / stem backward runs.
+
+    One live hook per parameter: a reducer that registers on a parameter another reducer already hooks
+    (a second trainer over the same NMN -- the reference's phase pipeline, bench.py) takes the parameter
+    over, so a gradient is never all-reduced twice."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self._pending = {}
-        self._hooks = []
-        for p in params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._fire))
+        self._hooks = {}
+        self._ready = set()
+        self._next = 0  # collectives are ISSUED in registration order, whatever order autograd finishes in
+        self.params = list(params)
+        for p in self.params:
+            old = _HOOK_OWNER.get(id(p))
+            if old is not None and old is not self:
+                old._drop(p)
+            self._hooks[id(p)] = p.register_post_accumulate_grad_hook(self._fire)
+            _HOOK_OWNER[id(p)] = self
+
+    def _drop(self, p: torch.nn.Parameter) -> None:
+        h = self._hooks.pop(id(p), None)
+        if h is not None:
+            h.remove()
+        self._pending.pop(id(p), None)
+        self.params = [q for q in self.params if q is not p]
+        self.reset()
 
     def _fire(self, p: torch.nn.Parameter) -> None:
-        if world() > 1 and p.grad is not None:
-            self._pending[id(p)] = (dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad)
+        if world() == 1 or p.grad is None:
+            return
+        # autograd may finish the hooked gradients in a different order on different ranks (their graphs
+        # differ when a loss term has no rows in a shard): a collective is started only once every
+        # parameter registered before it has been started, so the order is the same everywhere
+        self._ready.add(id(p))
+        while self._next < len(self.params) and id(self.params[self._next]) in self._ready:
+            q = self.params[self._next]
+            self._pending[id(q)] = (dist.all_reduce(q.grad, op=dist.ReduceOp.SUM, async_op=True), q.grad)
+            self._next += 1
 
     def take(self, p: torch.nn.Parameter):
         return self._pending.pop(id(p), None)
 
+    def reset(self) -> None:
+        self._ready.clear()
+        self._next = 0
+
     def remove(self) -> None:
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
+        for p in list(self.params):
+            self._drop(p)
 
 
 SMALL_BUCKET_BYTES = 8 << 20
@@ -50,21 +84,38 @@ SMALL_BUCKET_BYTES = 8 << 20
 
 def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Parameter] = (), average: bool = True,
                          early: "EarlyReducer" = None) -> None:
+    """Sum (and average) every gradient over the ranks.  The SEQUENCE of collectives is the same on every
+    rank whatever happened locally: a parameter that received no gradient on this rank (its loss term had
+    no rows in this shard) contributes zeros, and the parameters of ``early`` always come first, in
+    registration order -- where their hook already fired during backward that collective IS the first,
+    where it did not (no local rows) it is issued here, before anything else."""
     n = world()
     if n == 1:
         return
     scale = 1.0 / n if average else 1.0
     handles = []
+    loose_params = list(loose_params)
+    for p in loose_params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    first = set()
+    if early is not None:
+        for p in early.params:
+            first.add(id(p))
+            started = early.take(p)
+            if started is None:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                started = (dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad)
+            handles.append(started)
+        early.reset()
     for a in arenas:
         handles.append((dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, async_op=True), a.grad))
     small = []  # the seq2seq models have ~40 tensors of a few hundred KB: one bucket, one collective
     for p in loose_params:
-        if p.grad is None:
+        if id(p) in first:
             continue
-        started = early.take(p) if early is not None else None
-        if started is not None:
-            handles.append(started)
-        elif p.grad.numel() * p.grad.element_size() < SMALL_BUCKET_BYTES and p.grad.is_contiguous():
+        if p.grad.numel() * p.grad.element_size() < SMALL_BUCKET_BYTES and p.grad.is_contiguous():
             small.append(p.grad)
         else:
             handles.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad))

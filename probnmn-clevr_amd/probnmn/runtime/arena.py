@@ -55,6 +55,11 @@ class ParamArena:
             return seg.view(co, kh, kw, ci).permute(0, 3, 1, 2)
         return seg.view(p.shape)
 
+    def view_of(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        """The slice of an arena-shaped buffer (e.g. an optimizer moment) that mirrors parameter ``name``,
+        in the parameter's logical shape."""
+        return self._view(buf, name, self._params[name])
+
     def intact(self) -> bool:
         """True while every parameter still aliases the arena (``.to()`` / ``.data =`` breaks it)."""
         return all(self._params[n].data_ptr() == self._views[n].data_ptr() for n in self.names)

@@ -10,6 +10,7 @@ would weight shards wrongly; each local mean is rescaled by (n_local * world / n
 backward, which makes the averaged all-reduced gradient equal the single-process gradient
 (SURVEY.md 8e).
 """
+import time
 from typing import Any, Dict
 
 import torch
@@ -17,6 +18,7 @@ import torch
 from probnmn import parallel
 from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
 from probnmn.optim import ClampAdam
+from probnmn.trainers._base import StepBase
 
 
 def _split_supervision(supervision: torch.Tensor):
@@ -47,7 +49,7 @@ def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
     return torch.cat((a, b), 0)
 
 
-class _TrainerBase:
+class _TrainerBase(StepBase):
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
         params = []
@@ -66,7 +68,8 @@ class _TrainerBase:
         return optimizer
 
     def _finish(self, loss: torch.Tensor) -> None:
-        loss.backward()
+        if loss.requires_grad:  # (false only for a data-parallel shard without any row: it contributes zeros)
+            loss.backward()
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
         self.optimizer.step()
         self.iteration += 1
@@ -145,14 +148,16 @@ class _TrainerBase:
 class QuestionCodingStep(_TrainerBase):
     def __init__(self, program_generator, question_reconstructor, program_prior, objective: str = "ours",
                  alpha: float = 100.0, beta: float = 0.1, delta: float = 0.99, lr: float = 1e-3,
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, lr_gamma: float = 0.5, lr_patience: int = 3):
         if objective not in ("ours", "baseline"):
             raise ValueError("objective must be 'ours' or 'baseline'")
         self.pg, self.qr, self.prior = program_generator, question_reconstructor, program_prior
         self.objective, self.alpha = objective, alpha
         self.prior.eval()
         self.elbo = QuestionCodingElbo(self.pg, self.qr, self.prior, beta=beta, baseline_decay=delta)
+        self.models = {"program_generator": self.pg, "question_reconstructor": self.qr}
         self.optimizer = self._make_optimizer([self.pg, self.qr], lr, weight_decay)
+        self._init_schedule(lr_gamma, lr_patience)
         self.iteration = 0
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
@@ -166,15 +171,20 @@ class QuestionCodingStep(_TrainerBase):
         p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=True, sampled=ours, prior=True)
         out: Dict[str, Any] = {}
         loss = torch.zeros((), device=dev)
+        # Data parallel: both weights are computed (one collective each) and the REINFORCE baseline is
+        # synchronised on EVERY rank, whatever this rank's shard holds -- a rank without supervised (or
+        # without unsupervised) rows must issue the same sequence of collectives as the others.
+        w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
         if "pg_sup" in p:
-            w = _dp_weight(sup.numel(), dev)
-            loss = loss + w * (self.alpha if ours else 1.0) * (p["pg_sup"] + p["qr_sup"])
+            loss = loss + w_sup * (self.alpha if ours else 1.0) * (p["pg_sup"] + p["qr_sup"])
             out["loss"] = {"program_generation_gt": p["pg_sup"].detach(), "question_reconstruction_gt": p["qr_sup"].detach()}
         if "pg" in p:
             elbo_out = self.elbo.combine(p["pg"]["loss"], p["qr"], p["prior"])
-            loss = loss - _dp_weight(nosup.numel(), dev) * elbo_out["elbo"]
+            loss = loss - w_nosup * elbo_out["elbo"]
             out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
             out["programs"] = p["programs"]
+        elif ours and parallel.world() > 1:
+            self.elbo._reinforce.idle(dev)
         self._finish(loss)
         out["objective"] = loss.detach()
         return out
@@ -183,7 +193,7 @@ class QuestionCodingStep(_TrainerBase):
 class JointTrainingStep(_TrainerBase):
     def __init__(self, program_generator, question_reconstructor, program_prior, nmn, objective: str = "ours",
                  alpha: float = 100.0, beta: float = 0.1, gamma: float = 1.0, delta: float = 0.99,
-                 lr: float = 1e-6, weight_decay: float = 0.0):
+                 lr: float = 1e-6, weight_decay: float = 0.0, lr_gamma: float = 0.5, lr_patience: int = 3):
         if objective not in ("ours", "baseline"):
             raise ValueError("objective must be 'ours' or 'baseline'")
         self.pg, self.qr, self.prior, self.nmn = program_generator, question_reconstructor, program_prior, nmn
@@ -191,8 +201,11 @@ class JointTrainingStep(_TrainerBase):
         self.prior.eval()
         self.elbo = JointTrainingElbo(self.pg, self.qr, self.prior, self.nmn, beta=beta, gamma=gamma,
                                       baseline_decay=delta, objective=objective)
+        self.models = {"program_generator": self.pg, "question_reconstructor": self.qr, "nmn": self.nmn}
         self.optimizer = self._make_optimizer([self.pg, self.qr, self.nmn], lr, weight_decay)
+        self._init_schedule(lr_gamma, lr_patience)
         self.iteration = 0
+        self.blocked_seconds = 0.0  # host time spent waiting for the sampled programs (diagnostic, bench.py)
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         self.optimizer.zero_grad()
@@ -202,25 +215,39 @@ class JointTrainingStep(_TrainerBase):
         dev = batch["question"].device
         sup, nosup = _split_supervision(batch["supervision"])
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
-        if nosup.numel() == 0:
+        if nosup.numel() == 0 and parallel.world() == 1:
             raise ValueError("joint training needs at least one example without program supervision in the batch")
         ours = self.objective == "ours"
-        images = batch["image"][nosup_d]
-        # the NMN stem needs no programs: queued right behind the sampling decode, it keeps the GPU busy
-        # (together with the reconstructor / prior passes) while the host schedules the sampled programs
-        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours,
-                                 host_programs=True, after_sampling=lambda: self.nmn.begin(images))
-        programs_host, copied = p["programs_host"]
-        copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
-        nmn_out = self.nmn(images, programs_host, batch["answer"][nosup_d], started=p["after_sampling"])
-        elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
-        nmn_loss = elbo_out.pop("nmn_loss")
-        w = _dp_weight(nosup.numel(), dev)
-        loss = w * (self.gamma * nmn_loss - elbo_out["elbo"])
-        out: Dict[str, Any] = {"loss": {"nmn": nmn_loss.detach()}, "elbo": {k: v.detach() for k, v in elbo_out.items()},
-                               "programs": p["programs"]}
+        # Data parallel: every rank issues the same collectives in the same order (both loss weights, the
+        # REINFORCE baseline, the gradient all-reduces) whatever its shard holds; a shard without
+        # unsupervised rows contributes zeros to the terms it has no rows for.
+        w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
+        out: Dict[str, Any] = {"loss": {}}
+        if nosup.numel():
+            images = batch["image"][nosup_d]
+            # the NMN stem needs no programs: queued right behind the sampling decode, it keeps the GPU busy
+            # (together with the reconstructor / prior passes) while the host schedules the sampled programs
+            p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours,
+                                     host_programs=True, after_sampling=lambda: self.nmn.begin(images))
+            programs_host, copied = p["programs_host"]
+            t0 = time.perf_counter()
+            copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
+            self.blocked_seconds += time.perf_counter() - t0
+            nmn_out = self.nmn(images, programs_host, batch["answer"][nosup_d], started=p["after_sampling"])
+            elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
+            nmn_loss = elbo_out.pop("nmn_loss")
+            loss = w_nosup * (self.gamma * nmn_loss - elbo_out["elbo"])
+            out["loss"]["nmn"] = nmn_loss.detach()
+            out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
+            out["programs"] = p["programs"]
+        else:
+            p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=False, prior=False)
+            self.elbo._reinforce.idle(dev)
+            for a in self.optimizer.arenas:  # no NMN backward on this rank, which is what zeroes them
+                a.grad.zero_()
+            loss = torch.zeros((), device=dev)
         if "pg_sup" in p:
-            loss = loss + _dp_weight(sup.numel(), dev) * self.alpha * (p["pg_sup"] + p["qr_sup"])
+            loss = loss + w_sup * self.alpha * (p["pg_sup"] + p["qr_sup"])
             out["loss"]["program_generation_gt"] = p["pg_sup"].detach()
             out["loss"]["question_reconstruction_gt"] = p["qr_sup"].detach()
         self._finish(loss)

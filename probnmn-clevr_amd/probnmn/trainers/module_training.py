@@ -8,11 +8,12 @@ import torch
 
 from probnmn import parallel
 from probnmn.optim import ClampAdam
+from probnmn.trainers._base import StepBase
 
 
-class ModuleTrainingStep:
+class ModuleTrainingStep(StepBase):
     def __init__(self, nmn, lr: float = 1e-4, weight_decay: float = 0.0, program_generator=None,
-                 report_metrics: bool = False):
+                 report_metrics: bool = False, lr_gamma: float = 0.5, lr_patience: int = 1000000):
         self.nmn = nmn
         self.program_generator = program_generator
         self.report_metrics = report_metrics
@@ -22,6 +23,8 @@ class ModuleTrainingStep:
         # data parallel: the big loose FC gradient starts its all-reduce while the trunk is still in backward
         big = [p for p in self.optimizer.loose if p.numel() >= (1 << 20)]
         self._early = parallel.EarlyReducer(big) if big else None
+        self.models = {"nmn": nmn}  # (the frozen program generator is not checkpointed by this phase)
+        self._init_schedule(lr_gamma, lr_patience)
         self.iteration = 0
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:

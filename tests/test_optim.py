@@ -1,0 +1,140 @@
+"""ClampAdam as the reference's optimizer object (reference: probnmn/trainers/_trainer.py:103-130):
+a torch.optim.Optimizer that ReduceLROnPlateau can drive and whose state_dict is torch.optim.Adam's.
+The CPU tests cover the host logic (groups, scheduler, state layout); the fused update itself is a HIP
+kernel and is tested on the MI355X."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+from probnmn.optim import ClampAdam
+
+
+def _model():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Linear(6, 5), nn.Tanh(), nn.Linear(5, 3))
+
+
+def test_is_an_optimizer_with_one_group_and_adam_state_layout():
+    m = _model()
+    opt = ClampAdam(m.parameters(), lr=3e-4, weight_decay=0.01)
+    assert isinstance(opt, torch.optim.Optimizer)
+    assert len(opt.param_groups) == 1 and opt.param_groups[0]["lr"] == 3e-4
+    assert opt.param_groups[0]["betas"] == (0.9, 0.999) and opt.param_groups[0]["eps"] == 1e-8
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(_model().parameters(), lr=3e-4, weight_decay=0.01)
+    assert sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
+    assert set(sd["state"]) == set(range(4))
+    for st, p in zip(sd["state"].values(), m.parameters()):
+        assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and st["exp_avg"].shape == p.shape
+    with pytest.raises(ValueError):
+        opt.add_param_group({"params": [nn.Parameter(torch.zeros(2))]})
+
+
+def test_reduce_lr_on_plateau_drives_it():
+    """ReduceLROnPlateau(mode="max", factor=LR_GAMMA, patience=LR_PATIENCE, threshold=1e-3), as _trainer.py:110-118."""
+    opt = ClampAdam(_model().parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.5, patience=2, threshold=1e-3)
+    for metric in (0.50, 0.5001, 0.5002, 0.5003):  # flat within the threshold: patience 2 -> halves on the 4th
+        sched.step(metric)
+    assert opt.param_groups[0]["lr"] == pytest.approx(5e-4) and opt.lr == pytest.approx(5e-4)
+    sched.step(0.9)
+    assert opt.lr == pytest.approx(5e-4)
+    # the scheduler's own state round-trips next to the optimizer's, as the reference's checkpoints hold both
+    sched2 = torch.optim.lr_scheduler.ReduceLROnPlateau(ClampAdam(_model().parameters(), lr=1e-3), mode="max", factor=0.5, patience=2)
+    sched2.load_state_dict(sched.state_dict())
+    assert sched2.best == sched.best
+
+
+def test_state_dict_round_trips_with_torch_adam():
+    """Optimizer state written by torch.optim.Adam (what a reference checkpoint holds) loads into
+    ClampAdam and back, moments and step included."""
+    m = _model()
+    adam = torch.optim.Adam(m.parameters(), lr=2e-3)
+    for _ in range(3):
+        adam.zero_grad()
+        m(torch.randn(4, 6)).pow(2).sum().backward()
+        adam.step()
+    sd = copy.deepcopy(adam.state_dict())
+    m2 = copy.deepcopy(m)
+    opt = ClampAdam(m2.parameters(), lr=1.0)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 3 and opt.lr == 2e-3
+    for (p, (mom, var)), st in zip(zip(opt.loose, opt._loose_state), sd["state"].values()):
+        assert torch.equal(mom, st["exp_avg"]) and torch.equal(var, st["exp_avg_sq"])
+        assert opt.state[p]["exp_avg"].data_ptr() == mom.data_ptr()  # state aliases the buffers the kernel updates
+    back = opt.state_dict()
+    adam2 = torch.optim.Adam(copy.deepcopy(m).parameters(), lr=1.0)
+    adam2.load_state_dict(back)
+    for a, b in zip(adam2.state_dict()["state"].values(), sd["state"].values()):
+        assert float(a["step"]) == float(b["step"]) == 3.0
+        assert torch.equal(a["exp_avg"], b["exp_avg"]) and torch.equal(a["exp_avg_sq"], b["exp_avg_sq"])
+
+
+@pytest.mark.gpu
+def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
+    """On the MI355X: (1) ClampAdam == clamp + torch.optim.Adam over an NMN arena + loose tensors;
+    (2) after ReduceLROnPlateau halves the lr the next fused step uses it; (3) a state_dict saved mid-run
+    restores into a fresh optimizer (and into torch.optim.Adam) and both continue identically."""
+    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(1)
+    net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=32).to(dev)
+    arena = net.engine.ensure_arena()
+    names = [n for n, _ in net.named_parameters()]
+    opt = ClampAdam(net.parameters(), arenas=[arena], lr=1e-2, weight_decay=0.01)
+    ref_params = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    ref = torch.optim.Adam(ref_params, lr=1e-2, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.5, patience=0, threshold=1e-3)
+    sched_ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode="max", factor=0.5, patience=0, threshold=1e-3)
+    g = torch.Generator().manual_seed(2)
+
+    def one_step(optimizers):
+        grads = [torch.randn(p.shape, generator=g) * 4 for p in ref_params]  # |g| > 5 occurs: the clamp matters
+        arena.grad.zero_()
+        for p, gr in zip(net.parameters(), grads):
+            p.grad = None
+        arena.attach_grads()
+        for p, gr in zip(net.parameters(), grads):
+            if p.grad is not None:
+                p.grad.copy_(gr.to(dev))
+            else:
+                p.grad = gr.to(dev)
+        for p, gr in zip(ref_params, grads):
+            p.grad = gr.clamp(-5, 5)
+        for o in optimizers:
+            o.step()
+
+    def check(tag, tol=2e-6):
+        for n, p, r in zip(names, net.parameters(), ref_params):
+            torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=1e-5, atol=tol, msg=lambda m: "%s %s: %s" % (tag, n, m))
+
+    one_step([opt, ref])
+    one_step([opt, ref])
+    check("two steps")
+    sched.step(0.5), sched_ref.step(0.5)
+    sched.step(0.5), sched_ref.step(0.5)  # no improvement, patience 0 -> lr halves
+    assert opt.lr == pytest.approx(5e-3) == ref.param_groups[0]["lr"]
+    one_step([opt, ref])
+    check("after the lr change")
+
+    # checkpoint mid-run: ClampAdam -> fresh ClampAdam, and -> torch.optim.Adam
+    sd = copy.deepcopy(opt.state_dict())
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    opt2 = ClampAdam(net.parameters(), arenas=[arena], lr=123.0)
+    opt2.load_state_dict(sd)
+    ref2 = torch.optim.Adam(ref_params, lr=123.0)
+    ref2.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                          "param_groups": sd["param_groups"]})
+    assert opt2.lr == pytest.approx(5e-3) and opt2.step_count == 3
+    one_step([opt2, ref2])
+    check("resumed")
+
+    # a model moved after the optimizer was built is detected, not silently ignored
+    net.stem[0].weight.data = net.stem[0].weight.data.clone()
+    with pytest.raises(Exception, match="arena"):
+        opt2.step()
