@@ -25,7 +25,7 @@ from probnmn.modules.nmn_modules import (
     SameModule,
 )
 from probnmn.runtime import program_compiler as pc
-from probnmn.utils.metrics import Average, BooleanAccuracy
+from probnmn.running_metrics import Average, BooleanAccuracy
 
 INVALID_PROGRAM_LOSS = 3.33  # ~ ln(28), the reference's constant (nmn.py:260,269)
 

@@ -11,7 +11,7 @@ from torch.nn import functional as F
 from probnmn import _hip
 from probnmn.modules.seq2seq_base import (_Encoder, _TokenEmbedder, add_sentence_boundary_token_ids,
                                           sequence_cross_entropy)
-from probnmn.utils.metrics import Average
+from probnmn.running_metrics import Average
 
 
 class ProgramPrior(nn.Module):

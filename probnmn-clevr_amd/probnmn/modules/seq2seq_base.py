@@ -26,7 +26,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from probnmn import _hip
-from probnmn.utils.metrics import Average
+from probnmn.running_metrics import BLEU, Average
 
 
 class _LSTMCellPointwise(torch.autograd.Function):
@@ -452,6 +452,8 @@ class Seq2SeqBase(nn.Module):
         self._log2_perplexity = Average()
         self._sequence_accuracy = Average()
         self._unigram_recall = Average()
+        # SimpleSeq2Seq(use_bleu=True): BLEU over evaluation predictions, special indices excluded
+        self._bleu = BLEU(exclude_indices={self._pad_index, self._end_index, self._start_index})
         # row offset of this rank's shard in the global batch (keeps the sample stream shard-invariant)
         self.sample_row_offset = 0
 
@@ -536,6 +538,7 @@ class Seq2SeqBase(nn.Module):
             output_dict["loss"] = ce
             if not self.training:
                 self._record_metrics(predictions, tgt[:, 1:], ce)
+                self._bleu(predictions, tgt)  # (reference :260: against the targets WITH their @start@, as allennlp)
         return output_dict
 
     def _decode_stepwise(self, enc, fmask, h, c, tgt, steps, greedy, seed):
@@ -592,6 +595,7 @@ class Seq2SeqBase(nn.Module):
         if self.training:
             return {}
         return {
+            **self._bleu.get_metric(reset=True),  # (the reference resets BLEU unconditionally, :367)
             "perplexity": 2 ** self._log2_perplexity.get_metric(reset=reset),
             "sequence_accuracy": self._sequence_accuracy.get_metric(reset=reset),
             "word_error_rate": 1 - self._unigram_recall.get_metric(reset=reset),

@@ -18,7 +18,7 @@ import torch
 from probnmn import parallel
 from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
 from probnmn.optim import ClampAdam
-from probnmn.trainers._base import StepBase
+from ._base import StepBase
 
 
 def _split_supervision(supervision: torch.Tensor):

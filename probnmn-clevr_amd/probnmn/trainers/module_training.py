@@ -8,7 +8,7 @@ import torch
 
 from probnmn import parallel
 from probnmn.optim import ClampAdam
-from probnmn.trainers._base import StepBase
+from ._base import StepBase
 
 
 class ModuleTrainingStep(StepBase):

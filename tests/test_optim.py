@@ -87,7 +87,7 @@ def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
     arena = net.engine.ensure_arena()
     names = [n for n, _ in net.named_parameters()]
     opt = ClampAdam(net.parameters(), arenas=[arena], lr=1e-2, weight_decay=0.01)
-    ref_params = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in net.parameters()]
     ref = torch.optim.Adam(ref_params, lr=1e-2, weight_decay=0.01)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.5, patience=0, threshold=1e-3)
     sched_ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode="max", factor=0.5, patience=0, threshold=1e-3)

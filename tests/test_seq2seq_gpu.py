@@ -142,7 +142,7 @@ def test_teacher_forced_and_sampled_match_oracle(which):
     # 4. eval with targets records metrics
     model(src.to(DEV), tgt.to(DEV), decoding_strategy="greedy")
     m = model.get_metrics()
-    assert set(m) == {"perplexity", "sequence_accuracy", "word_error_rate"}
+    assert set(m) == {"BLEU", "perplexity", "sequence_accuracy", "word_error_rate"} and 0.0 <= m["BLEU"] <= 1.0
 
 
 def test_trim_predictions_matches_reference_rule():
