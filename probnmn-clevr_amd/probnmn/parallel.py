@@ -138,6 +138,19 @@ def all_reduce_scalars(values: torch.Tensor) -> torch.Tensor:
     return values
 
 
+def mean_weight(n_local: int, device):
+    """n_local * world / n_global: the factor that turns a rank's local MEAN over n_local rows into its share
+    of the global mean once gradients are averaged over ranks (shards need not be equal; subsets may be
+    empty).  1.0 in a single process, otherwise a 0-dim device tensor -- the count is summed with a
+    collective, reading it back would cost a host sync per loss term.  Every rank must call it the same
+    number of times in the same order."""
+    if world() == 1:
+        return 1.0
+    local = torch.full((), float(n_local), device=device)
+    total = all_reduce_scalars(local.clone())
+    return torch.where(total > 0, local * world() / total.clamp(min=1.0), torch.zeros_like(total))
+
+
 def broadcast_parameters(arenas: Sequence, loose_params: Iterable[torch.nn.Parameter] = (), src: int = 0) -> None:
     if world() == 1:
         return

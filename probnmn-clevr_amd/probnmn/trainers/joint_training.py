@@ -29,14 +29,7 @@ def _split_supervision(supervision: torch.Tensor):
     return sup_host.nonzero().flatten(), (1 - sup_host).nonzero().flatten()
 
 
-def _dp_weight(n_local: int, device):
-    """n_local * world / n_global: 1.0 in a single process, otherwise a 0-dim device tensor (the count
-    is summed over ranks with a collective; reading it back would cost a host sync per loss term)."""
-    if parallel.world() == 1:
-        return 1.0
-    local = torch.full((), float(n_local), device=device)
-    total = parallel.all_reduce_scalars(local.clone())
-    return torch.where(total > 0, local * parallel.world() / total.clamp(min=1.0), torch.zeros_like(total))
+_dp_weight = parallel.mean_weight  # (n_local * world / n_global, see probnmn.parallel)
 
 
 def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:

@@ -38,7 +38,9 @@ class ModuleTrainingStep(StepBase):
         self.nmn.report_batch_metrics = self.report_metrics
         out = self.nmn(batch["image"], programs, batch["answer"])
         loss = out["loss"].mean()
-        loss.backward()
+        # data parallel: the reference's loss is the mean over the whole batch (module_training_trainer.py:91);
+        # weighting the local mean by n_local * world / n_global keeps that exact for unequal shards
+        (loss * parallel.mean_weight(out["loss"].numel(), out["loss"].device)).backward()
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=self._early)
         self.optimizer.step()
         self.iteration += 1
