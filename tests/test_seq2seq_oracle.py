@@ -109,3 +109,64 @@ def test_program_prior_loss_ties_output_to_embedding():
     # gradient reaches the embedding both as input lookup and as output layer: rows of tokens that
     # never appear as inputs still get gradient through the tied softmax
     assert float(w.grad[40].abs().sum()) > 0
+
+
+# ---- second, independent restatement (oracle/seq2seq_modules.py) against the first -------------------
+def _ragged(B, T, V, seed, min_len=1):
+    g = torch.Generator().manual_seed(seed)
+    out = torch.zeros(B, T, dtype=torch.long)
+    lens = torch.randint(min_len, T + 1, (B,), generator=g)
+    lens[0], lens[1] = T, min_len
+    for i in range(B):
+        out[i, : lens[i]] = torch.randint(4, V, (int(lens[i]),), generator=g)
+    return out
+
+
+def test_two_independent_restatements_agree_whole_model():
+    """Losses, predictions and every parameter gradient of the functional oracle (seq2seq_oracle.py) equal
+    those of the nn.Module restatement (seq2seq_modules.py: nn.Embedding + packed nn.LSTM + nn.LSTMCell),
+    teacher-forced, replayed samples, free-running greedy, and the program prior."""
+    from oracle import seq2seq_modules as sm
+
+    for v_src, v_tgt, t_src, t_tgt, seed in ((100, 44, 19, 13, 0), (44, 100, 13, 19, 1)):  # generator-like, reconstructor-like
+        sd = _sd(so.seq2seq_param_shapes(v_src, v_tgt), 40 + seed)
+        net = sm.ModuleSeq2Seq(v_src, v_tgt, max_decoding_steps=9)
+        missing = net.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        src, tgt = _ragged(9, t_src, v_src, 50 + seed), _ragged(9, t_tgt, v_tgt, 60 + seed)
+
+        def both(target, strategy, forced=None):
+            leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+            a = so.seq2seq_forward(leaves, src, target, strategy, max_decoding_steps=9, forced_predictions=forced)
+            a["loss"].mean().backward()
+            net.zero_grad()
+            b = net(src, target, strategy, forced)
+            b["loss"].mean().backward()
+            assert torch.equal(a["predictions"], b["predictions"])
+            torch.testing.assert_close(a["loss"].detach(), b["loss"].detach(), rtol=1e-5, atol=1e-6)
+            for name, p in net.named_parameters():
+                torch.testing.assert_close(p.grad, leaves[name].grad, rtol=1e-4, atol=1e-6, msg=lambda m: name + ": " + m)
+            return a
+
+        both(tgt, "greedy")                                   # teacher forced: CE loss
+        g = torch.Generator().manual_seed(70 + seed)
+        forced = torch.randint(3, v_tgt, (9, 9), generator=g)  # replayed "samples", @end@ (3) included
+        forced[0, 0] = 3                                       # a row whose first token is @end@ -> all padding
+        forced[1] = 7                                          # a row that never ends
+        both(None, "sampling", forced)
+        free = both(None, "greedy")                           # free-running arg-max decode
+        assert free["predictions"].shape == (9, 9)
+
+    vocab = 44
+    sd = _sd(so.prior_param_shapes(vocab), 80)
+    prior = sm.ModulePrior(vocab)
+    assert not prior.load_state_dict(sd, strict=True).missing_keys
+    progs = _ragged(7, 11, vocab, 81)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    a = so.program_prior_loss(leaves, progs)
+    a.mean().backward()
+    b = prior(progs)
+    b.mean().backward()
+    torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=1e-6)
+    for name, p in prior.named_parameters():
+        torch.testing.assert_close(p.grad, leaves[name].grad, rtol=1e-4, atol=1e-6, msg=lambda m: name + ": " + m)
