@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
 Workload (BASELINE.json configs[3] on one GPU): configs/joint_training_ours.yml (alpha 100, beta 0.1,
-gamma 1, delta 0.99, lr 1e-6), 1024 questions per GPU (weak scaling: global batch 1024 x N), 14x14x1024
+gamma 1, delta 0.99, lr 1e-6), 1024 questions per GPU (weak scaling: global batch 1024 x N; `--scaling
+strong` keeps the global batch at 1024 and gives every rank 1024 / N -- configs[3] as written), 14x14x1024
 features, synthetic CLEVR-shaped batch (probnmn.data.synthetic: programs from the eight template
 shapes, half of the examples with program supervision -- what the reference's
 SupervisionWeightedRandomSampler yields, data/samplers.py:5-27).  A step is the reference's
@@ -372,12 +373,20 @@ def config5_side(vocab, prior, dev, rank, world, args):
 
 
 def main():
+    if os.environ.get("PNMN_DUMP_AFTER"):  # debugging aid: where is the host if the run has not finished by then?
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["PNMN_DUMP_AFTER"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10,
                     help="untimed steps first: allocator pools, GEMM heuristics and the program / template caches settle")
-    ap.add_argument("--batch", type=int, default=1024, help="questions per GPU of the joint_training step")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="questions of the joint_training step: per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch questions per GPU (global batch grows with N); strong: --batch questions in "
+                         "total, split evenly over the N ranks (BASELINE configs[3] as written: 1024 over 8 GPUs)")
     ap.add_argument("--batch28", type=int, default=128, help="questions per GPU of the 28x28 / 40-token side measurement")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -396,6 +405,11 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the measured path)")
+    global_batch = args.batch * world if args.scaling == "weak" else args.batch
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong needs --batch divisible by the number of ranks")
+        args.batch //= world  # from here on: questions per rank
     # test hooks for boxes with fewer GPUs than ranks (the multi-rank logic of this file can then be
     # exercised with several processes on ONE device over gloo): never set by the driver
     backend = os.environ.get("PNMN_BENCH_BACKEND", "nccl")
@@ -517,7 +531,7 @@ def main():
             "host_busy_ms_per_step": round((host - blocked) / args.steps * 1e3, 3),
             "host_blocked_ms_per_step": round(blocked / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (random-init weights; ProgramGenerator pre-fitted on the synthetic batch so that "
@@ -525,7 +539,7 @@ def main():
             "config": {
                 "workload": "joint_training_ours.yml (NMN + seq2seq + REINFORCE), batch %d per GPU, 14x14x1024 "
                             "features, half of the batch with program supervision, fwd+bwd+clamp+Adam" % args.batch,
-                "global_batch": args.batch * world,
+                "global_batch": global_batch,
                 "parallelism": "dp%d" % world,
                 "valid_program_fraction": round(valid_fraction, 4),
                 "program_generator_fit_iterations": fit_iters,

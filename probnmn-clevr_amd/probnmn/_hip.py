@@ -87,10 +87,58 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_TRACE = None  # debugging aid (PNMN_TRACE_LAUNCHES=<seconds>): see _start_trace
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         kind = "argument/shape error" if code < 0 else "hipError_t"
         raise HipLibraryError("%s failed: %s %d" % (what, kind, code))
+    if _TRACE is not None:
+        stream = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        _TRACE.append((what, stream.cuda_stream, ev))
+        del _TRACE[:-4000]
+
+
+def mark(what: str) -> None:
+    """A named point on the current stream's timeline (only when launch tracing is on)."""
+    if _TRACE is not None:
+        check(0, "mark: " + what)
+
+
+def _start_trace(seconds: float) -> None:
+    """Every library launch leaves an event behind; a watchdog thread reports, `seconds` after start, the
+    first launch of each stream whose event has not completed -- i.e. the kernel a stalled GPU is stuck in
+    (or waiting behind).  For diagnosing cross-stream stalls; costs one event per launch."""
+    import sys
+    import threading
+
+    global _TRACE
+    _TRACE = []
+
+    def watch():
+        time.sleep(seconds)
+        per_stream = {}
+        for what, stream, ev in list(_TRACE):
+            st = per_stream.setdefault(stream, {"done": None, "stuck": None, "pending": 0})
+            if ev.query():
+                if st["stuck"] is None:
+                    st["done"] = what
+            else:
+                st["pending"] += 1
+                if st["stuck"] is None:
+                    st["stuck"] = what
+        for stream, st in per_stream.items():
+            print("[pnmn trace] stream %#x: last completed launch = %s; first incomplete = %s (%d launches pending)"
+                  % (stream, st["done"], st["stuck"], st["pending"]), file=sys.stderr, flush=True)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
+if os.environ.get("PNMN_TRACE_LAUNCHES"):
+    _start_trace(float(os.environ["PNMN_TRACE_LAUNCHES"]))
 
 
 # ---- item record layouts (must match include/probnmn_hip.h byte for byte) -------------------------

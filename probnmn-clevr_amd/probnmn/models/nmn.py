@@ -126,8 +126,12 @@ class NeuralModuleNetwork(nn.Module):
         return self._engine
 
     def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None,
-                started=None):
+                started=None, trunk_stream=None):
         # ``started``: token of ``begin(features)`` when the caller already launched the stem (optional)
+        # ``trunk_stream``: run the trunk (stem, module programs, classifier conv + pool -- this build's own
+        # kernels, none of which waits for another workgroup) on that stream, forward and backward, beside
+        # whatever the caller queues on the current stream; the fully connected layers and the loss stay on
+        # the current stream (see DESIGN 6 for why the library GEMMs must not leave it)
         engine = self._engine
         arena = engine.ensure_arena()
         # the programs decide the launch schedule, so they are needed on the host (the reference
@@ -139,9 +143,20 @@ class NeuralModuleNetwork(nn.Module):
         valid = _hip.small_to_device([p.valid for p in compiled], torch.bool, features.device)
 
         params = [arena.param(n) for n in arena.names]
-        pooled = _Trunk.apply(features, engine, compiled, started, *params)
+        if trunk_stream is not None:
+            current = torch.cuda.current_stream(features.device)
+            with torch.cuda.stream(trunk_stream):
+                pooled = _Trunk.apply(features, engine, compiled, started, *params)
+            current.wait_stream(trunk_stream)
+            pooled.record_stream(current)
+        else:
+            pooled = _Trunk.apply(features, engine, compiled, started, *params)
         hidden = F.relu(self.classifier[4](pooled))
         answer_logits = self.classifier[6](hidden)
+        _hip.mark("classifier FC forward done")
+        if answer_logits.requires_grad:
+            answer_logits.register_hook(lambda g: _hip.mark("d(answer logits) arrives"))
+            pooled.register_hook(lambda g: _hip.mark("d(pooled) computed (FC backward done)"))
 
         answer_logprobs = F.log_softmax(answer_logits, dim=-1)
         best_logprobs, answer_predictions = torch.max(answer_logprobs, dim=1)

@@ -422,10 +422,12 @@ class NMNEngine:
         ws = self._ws
         dpooled = dpooled.contiguous()
 
+        _hip.mark("trunk backward begins (dpooled ready)")
         a.grad.zero_()
         if plan.arena_floats:
             ws["gact"][: plan.arena_floats].zero_()
         ws["gfeat"][: B * HW * C].zero_()
+        _hip.mark("gradient buffers zeroed")
         chk(lib.pnmn_transpose_weights(self._wt_records.data_ptr(), self._wt_count, st), "transpose weights")
 
         main = torch.cuda.current_stream(dev)

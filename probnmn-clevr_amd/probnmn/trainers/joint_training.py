@@ -10,12 +10,13 @@ would weight shards wrongly; each local mean is rescaled by (n_local * world / n
 backward, which makes the averaged all-reduced gradient equal the single-process gradient
 (SURVEY.md 8e).
 """
+import os
 import time
 from typing import Any, Dict
 
 import torch
 
-from probnmn import parallel
+from probnmn import _hip, parallel
 from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
 from probnmn.optim import ClampAdam
 from ._base import StepBase
@@ -62,7 +63,12 @@ class _TrainerBase(StepBase):
 
     def _finish(self, loss: torch.Tensor) -> None:
         if loss.requires_grad:  # (false only for a data-parallel shard without any row: it contributes zeros)
+            _hip.mark("backward begins")
             loss.backward()
+            _hip.mark("backward issued")
+        side = getattr(self, "_side", None)
+        if side is not None:  # the NMN's backward ran on its own stream: gradients are used below on this one
+            torch.cuda.current_stream(side.device).wait_stream(side)
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
         self.optimizer.step()
         self.iteration += 1
@@ -199,6 +205,14 @@ class JointTrainingStep(_TrainerBase):
         self._init_schedule(lr_gamma, lr_patience)
         self.iteration = 0
         self.blocked_seconds = 0.0  # host time spent waiting for the sampled programs (diagnostic, bench.py)
+        # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
+        self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
+        self._side = None
+
+    def _nmn_stream(self, dev) -> "torch.cuda.Stream":
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         self.optimizer.zero_grad()
@@ -217,17 +231,37 @@ class JointTrainingStep(_TrainerBase):
         w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
         out: Dict[str, Any] = {"loss": {}}
         if nosup.numel():
-            images = batch["image"][nosup_d]
-            # the NMN stem needs no programs: queued right behind the sampling decode, it keeps the GPU busy
-            # (together with the reconstructor / prior passes) while the host schedules the sampled programs
-            p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours, reconstruct=ours,
-                                     host_programs=True, after_sampling=lambda: self.nmn.begin(images))
+            images, answers = batch["image"][nosup_d], batch["answer"][nosup_d]
+            main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            side = self._nmn_stream(dev) if (self.nmn_stream and main is not None) else None
+            if side is not None:
+                # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
+                # starts at once (next to the generator's encoder and sampling decode); its module programs
+                # and classifier run next to the reconstructor / prior / supervised passes, and autograd
+                # replays each side's backward on the stream its forward ran on, so the two backward passes
+                # overlap as well.  Only this build's trunk kernels go to the side stream -- none of them waits
+                # for another workgroup, so they always drain; the recurrent multi-CU kernels AND the library
+                # GEMMs (fully connected layers included) stay on the main stream, one after the other: two
+                # kernels that each wait for their own not-yet-resident workgroups can starve each other of
+                # CUs forever (that is what stalled the side-stream experiment of round 1).
+                side.wait_stream(main)  # images / answers / index tensors were produced on the main stream
+                with torch.cuda.stream(side):
+                    started = self.nmn.begin(images)
+                p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
+                                         reconstruct=ours, host_programs=True)
+            else:
+                # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
+                # (with the reconstructor / prior passes) while the host schedules the sampled programs
+                p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
+                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images))
+                started = p["after_sampling"]
             programs_host, copied = p["programs_host"]
             t0 = time.perf_counter()
             copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
             self.blocked_seconds += time.perf_counter() - t0
-            nmn_out = self.nmn(images, programs_host, batch["answer"][nosup_d], started=p["after_sampling"])
+            nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side)
             elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
+            _hip.mark("elbo combined")
             nmn_loss = elbo_out.pop("nmn_loss")
             loss = w_nosup * (self.gamma * nmn_loss - elbo_out["elbo"])
             out["loss"]["nmn"] = nmn_loss.detach()

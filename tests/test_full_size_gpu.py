@@ -109,3 +109,49 @@ def test_sampling_decode_1024_rows_is_shard_invariant():
         pg.sample_row_offset = 0
     same = (full[512:] == tail).all(1)
     assert float(same.float().mean()) > 0.995  # (a draw within round-off of a CDF boundary may flip a row)
+
+
+@pytest.mark.timeout(240)
+def test_joint_step_1024_rows_with_the_nmn_on_its_own_stream():
+    """Regression for the round-1 stall (side streams stopped the GPU at batch >= 768).  Root cause, found
+    with the launch tracer (PNMN_TRACE_LAUNCHES): a hipBLASLt GEMM of the NMN's fully connected layer on
+    the side stream and a multi-CU recurrent kernel on the main stream each waited for workgroups of its
+    own that the other's resident, spinning workgroups kept off the CUs.  The joint step now sends only the
+    trunk's own kernels (which never wait for another workgroup) to the side stream; at the headline size
+    it must (1) finish -- the timeout is the assertion -- and (2) produce the same losses and gradients as
+    the single-stream schedule."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    batch = synthetic_batch(vocab, 1024, seed=5)
+    sup = batch["supervision"]
+    batch = {k: v.to(DEV) for k, v in batch.items()}
+    batch["supervision"] = sup
+    results = []
+    for use_side_stream in (True, False):
+        torch.manual_seed(0)
+        nmn = NeuralModuleNetwork(vocab).to(DEV)
+        pg, qr = ProgramGenerator(vocab).to(DEV), QuestionReconstructor(vocab).to(DEV)
+        prior = ProgramPrior(vocab, hidden_size=256).to(DEV)
+        step = JointTrainingStep(pg, qr, prior, nmn, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-6)
+        step.nmn_stream = use_side_stream
+        torch.manual_seed(1)
+        for _ in range(3):
+            out = step.step(batch)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for m in (pg, qr, nmn) for n, p in m.named_parameters() if p.grad is not None}
+        results.append((out, grads))
+        step.close()
+        del step, nmn, pg, qr, prior
+    (a, ga), (b, gb) = results
+    assert torch.equal(a["programs"], b["programs"])
+    for k in a["elbo"]:
+        torch.testing.assert_close(a["elbo"][k], b["elbo"][k], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a["objective"], b["objective"], rtol=1e-5, atol=1e-5)
+    assert len(ga) > 200
+    for n in ga:
+        ok, err = _close(ga[n], gb[n], typical=1e-4, worst=5e-2)  # (atomics order; lr 1e-6 keeps the weights equal)
+        assert ok, (n, err)
