@@ -221,6 +221,37 @@ int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t*
                      int unknown_index, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-sequence masked-mean negative log-likelihood            seq2seq_base.py:235-254 (sampled programs:
+ * -sum_t logprob_t mask_t / (sum mask + 1e-12)), :334-341 -> allennlp sequence_cross_entropy_with_logits
+ * (average=None, eps 1e-13), program_prior.py:146-151
+ *   w[b][t]  = mask_tokens[b][t] != pad
+ *   loss[b]  = sum_t w * (logsumexp(logits[b][t]) - logits[b][t][tokens[b][t]]) / (sum_t w + eps)
+ *   lse[b][t] (saved for the backward);  dlogits[b][t][k] = dloss[b] * w / (sum w + eps) * (softmax_k - [k == token])
+ * Row strides are in elements (logits: between sequences, T*V for a contiguous tensor; tokens / mask_tokens:
+ * between rows), so views such as logits[:, :-1] and targets[:, 1:] are passed without a copy.
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_seq_nll_fwd(const float* logits, int64_t logits_bstride, const int64_t* tokens, int64_t tok_bstride,
+                     const int64_t* mask_tokens, int64_t mask_bstride, int pad, float* loss, float* lse,
+                     int B, int T, int V, float eps, void* stream);
+int pnmn_seq_nll_bwd(const float* logits, int64_t logits_bstride, const int64_t* tokens, int64_t tok_bstride,
+                     const int64_t* mask_tokens, int64_t mask_bstride, int pad, const float* lse,
+                     const float* dloss, float* dlogits, int64_t dlogits_bstride, int B, int T, int V,
+                     float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * REINFORCE / ELBO combination over the sampled rows   elbo.py:28-34 (Reinforce.forward), :61-89
+ * (_ElboWithReinforce._forward), :150-160 / :253-270 (the "ours" rewards)
+ *   inputs: per-row negative log-likelihoods pg (= -log q), qr (= -log p(x|z)), prior (= -log p(z), or NULL),
+ *           nmn (= -log p(a|z,i), or NULL), the moving baseline b (device scalar)
+ *   R = -qr - beta * prior + beta * pg - gamma * nmn ;  c = R - b ;  kl = -pg * c + beta * pg ;  elbo = -qr - kl
+ *   sums[6] = sum(-qr), sum(kl), sum(elbo), sum(R), sum(nmn), sum(c)   (the caller divides by n, all-reduces
+ *             sum(c) for the baseline update b += decay * mean(c))
+ *   dpg[n]  = d sum(elbo) / d pg[n] = c[n] - beta   (d / d qr[n] = -1; R is a constant of the estimator)
+ * ------------------------------------------------------------------------------------------- */
+int pnmn_elbo_rows(const float* pg_loss, const float* qr_loss, const float* prior_loss, const float* nmn_loss,
+                   const float* baseline, float beta, float gamma, int n, float* sums, float* dpg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused gradient clamp + Adam (trainers: clamp_(-5,5) then optimizer.step()).
  * module_training_trainer.py:94-96, joint_training_trainer.py:182-188, _trainer.py:103-108,193
  * torch.optim.Adam semantics (no amsgrad): g = clamp(g) + wd*p; m,v EMA; bias correction with

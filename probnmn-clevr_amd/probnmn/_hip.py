@@ -52,6 +52,10 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_maxpool2_flatten_fwd": (_P, _P, _I, _I, _I, _I, _P),
     "pnmn_maxpool2_flatten_bwd": (_P, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_answer_loss": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P),
+    "pnmn_seq_nll_fwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _I, _I, _I, _F, _P),
+    "pnmn_seq_nll_bwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _P, ctypes.c_int64,
+                         _I, _I, _I, _F, _P),
+    "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),

@@ -48,6 +48,37 @@ class _Trunk(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+class _AnswerLoss(torch.autograd.Function):
+    """``pnmn_answer_loss``: log-softmax over the answers, arg-max prediction, cross entropy, the
+    invalid-program overrides (prediction @@UNKNOWN@@, constant loss 3.33, no gradient) and d loss / d logits
+    in one launch (reference nmn.py:245-269)."""
+
+    @staticmethod
+    def forward(ctx, logits, answers, valid, unknown_index):
+        from probnmn import _hip
+
+        logits = logits.contiguous()
+        B, A = logits.shape
+        dev = logits.device
+        predictions = torch.empty(B, dtype=torch.long, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        dlogits = torch.empty(B, A, dtype=torch.float32, device=dev) if answers is not None else None
+        _hip.check(_hip.lib().pnmn_answer_loss(
+            logits.data_ptr(), 0 if answers is None else answers.data_ptr(), valid.data_ptr(), predictions.data_ptr(),
+            loss.data_ptr(), 0 if dlogits is None else dlogits.data_ptr(), B, A, unknown_index, 1.0,
+            _hip.stream_ptr(dev)), "answer_loss")
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(predictions)
+        return loss, predictions
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (dlogits,) = ctx.saved_tensors
+        if dlogits is None:
+            raise RuntimeError("the answer loss without answers (-max log-probability) is an evaluation quantity")
+        return dlogits * dloss.unsqueeze(1), None, None, None
+
+
 class NeuralModuleNetwork(nn.Module):
     def __init__(
         self,
@@ -140,7 +171,7 @@ class NeuralModuleNetwork(nn.Module):
         compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
         from probnmn import _hip
 
-        valid = _hip.small_to_device([p.valid for p in compiled], torch.bool, features.device)
+        valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, features.device)
 
         params = [arena.param(n) for n in arena.names]
         if trunk_stream is not None:
@@ -158,20 +189,14 @@ class NeuralModuleNetwork(nn.Module):
             answer_logits.register_hook(lambda g: _hip.mark("d(answer logits) arrives"))
             pooled.register_hook(lambda g: _hip.mark("d(pooled) computed (FC backward done)"))
 
-        answer_logprobs = F.log_softmax(answer_logits, dim=-1)
-        best_logprobs, answer_predictions = torch.max(answer_logprobs, dim=1)
-        answer_predictions = torch.where(
-            valid, answer_predictions, torch.full_like(answer_predictions, self._unknown_answer))
-
+        # log-softmax, arg-max, cross entropy (or -max log-probability without answers) and the
+        # invalid-program overrides -- prediction @@UNKNOWN@@, constant loss 3.33, no gradient -- in one kernel
         if answers is not None:
-            loss = F.cross_entropy(answer_logits, answers, reduction="none")
-            if self.report_batch_metrics or not self.training:
-                self._answer_accuracy(answer_predictions, answers)
-                self._average_invalid_programs(sum(1 for p in compiled if not p.valid))
-        else:
-            loss = -best_logprobs
-        # invalid programs: constant loss, no gradient (reference nmn.py:260,269)
-        loss = torch.where(valid, loss, torch.full_like(loss, INVALID_PROGRAM_LOSS))
+            answers = answers.contiguous()
+        loss, answer_predictions = _AnswerLoss.apply(answer_logits, answers, valid, self._unknown_answer)
+        if answers is not None and (self.report_batch_metrics or not self.training):
+            self._answer_accuracy(answer_predictions, answers)
+            self._average_invalid_programs(sum(1 for p in compiled if not p.valid))
 
         output_dict = {"predictions": answer_predictions, "loss": loss}
         if self.training and self.report_batch_metrics:

@@ -9,8 +9,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from probnmn import _hip
-from probnmn.modules.seq2seq_base import (_Encoder, _TokenEmbedder, add_sentence_boundary_token_ids,
-                                          sequence_cross_entropy)
+from probnmn.modules.seq2seq_base import _Encoder, _TokenEmbedder, add_sentence_boundary_token_ids, sequence_nll
 from probnmn.running_metrics import Average
 
 
@@ -40,13 +39,19 @@ class ProgramPrior(nn.Module):
                    hidden_size=_C.PROGRAM_PRIOR.HIDDEN_SIZE, num_layers=_C.PROGRAM_PRIOR.NUM_LAYERS,
                    dropout=_C.PROGRAM_PRIOR.DROPOUT)
 
-    def forward(self, program_tokens: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def forward(self, program_tokens: torch.Tensor, need_predictions: bool = True) -> Dict[str, torch.Tensor]:
+        # ``need_predictions=False``: skip the per-position samples (reference :119-143), which no trainer reads
         if program_tokens.device.type != "cuda":
             raise _hip.HipLibraryError("program prior input on %s: the HIP path needs a ROCm device" % program_tokens.device)
         toks = add_sentence_boundary_token_ids(program_tokens, self._pad_index, self._start_index, self._end_index)
         mask = toks != self._pad_index
         encoded = self._encoder.forward_tokens(self._embedder.embedding, toks, mask)
         logits = self._output_layer(self._projection_layer(encoded))
+        loss = sequence_nll(logits[:, :-1], toks[:, 1:], toks[:, 1:], self._pad_index, 1e-13)
+        if not self.training:
+            self._log2_perplexity(loss.mean())
+        if not need_predictions:
+            return {"loss": loss}
         with torch.no_grad():
             probs = F.softmax(logits, dim=-1).clone()
             forbidden = self.__dict__.get("_forbidden")
@@ -57,9 +62,6 @@ class ProgramPrior(nn.Module):
             B, T, V = probs.shape
             predictions = torch.multinomial(probs.view(B * T, V), 1).view(B, T)
             predictions = predictions[:, :-1] * mask[:, 1:]
-        loss = sequence_cross_entropy(logits[:, :-1], toks[:, 1:], mask[:, 1:])
-        if not self.training:
-            self._log2_perplexity(loss.mean())
         return {"predictions": predictions, "loss": loss}
 
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:

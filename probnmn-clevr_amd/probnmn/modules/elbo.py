@@ -115,6 +115,38 @@ class Reinforce(nn.Module):
         self.forward(empty, empty)
 
 
+class _FusedElbo(torch.autograd.Function):
+    """``pnmn_elbo_rows``: reward, centring, KL surrogate, ELBO and the five batch sums in one launch; the
+    backward is analytic (d sum(elbo) / d pg_loss[n] = (R[n] - b) - beta, d / d qr_loss[n] = -1, the reward
+    itself is a constant of the estimator -- reference elbo.py:28-34,76-82)."""
+
+    @staticmethod
+    def forward(ctx, pg_loss, qr_loss, prior_loss, nmn_loss, baseline, beta, gamma):
+        n = pg_loss.numel()
+        dev = pg_loss.device
+        sums = torch.empty(6, dtype=torch.float32, device=dev)
+        dpg = torch.empty(n, dtype=torch.float32, device=dev)
+        from probnmn import _hip
+
+        keep = [t.detach().contiguous() if t is not None else None for t in (pg_loss, qr_loss, prior_loss, nmn_loss)]
+        _hip.check(_hip.lib().pnmn_elbo_rows(*[0 if t is None else t.data_ptr() for t in keep], baseline.data_ptr(),
+                                             float(beta), float(gamma), n, sums.data_ptr(), dpg.data_ptr(),
+                                             _hip.stream_ptr(dev)), "elbo_rows")
+        ctx.save_for_backward(dpg)
+        ctx.has_nmn = nmn_loss is not None
+        return sums
+
+    @staticmethod
+    def backward(ctx, dsums):
+        (dpg,) = ctx.saved_tensors
+        # sums = [sum rec, sum kl, sum elbo, sum R, sum nmn, sum c]; with rec = -qr, kl = -pg c + beta pg, elbo = rec - kl:
+        #   d/d pg[n] = -dsums[1] (c - beta) + dsums[2] (c - beta);  d/d qr[n] = -dsums[0] - dsums[2];  d/d nmn[n] = dsums[4]
+        d_pg = (dsums[2] - dsums[1]) * dpg
+        d_qr = -(dsums[0] + dsums[2]).expand_as(dpg)
+        d_nmn = dsums[4].expand_as(dpg) if ctx.has_nmn else None
+        return d_pg, d_qr, None, d_nmn, None, None, None
+
+
 class _ElboWithReinforce(nn.Module):
     def __init__(self, beta: float = 0.1, baseline_decay: float = 0.99):
         super().__init__()
@@ -130,6 +162,26 @@ class _ElboWithReinforce(nn.Module):
             "elbo": fully_monte_carlo_elbo.mean(),
             "reinforce_reward": reinforce_reward.mean(),
         }
+
+    def _fused(self, generation_loss, reconstruction_loss, prior_loss, nmn_loss, gamma: float) -> Dict[str, torch.Tensor]:
+        """The "ours" objectives on the device in one launch (same arithmetic as ``combine`` -> ``_forward``
+        -> ``Reinforce.forward``; the baseline update and its data-parallel all-reduce stay here)."""
+        r = self._reinforce
+        if r._baseline is None or r._baseline.device != generation_loss.device:
+            value = 0.0 if r._baseline is None else float(r._baseline)
+            r._baseline = torch.full((), value, dtype=torch.float32, device=generation_loss.device)
+        n = generation_loss.numel()
+        sums = _FusedElbo.apply(generation_loss, reconstruction_loss, prior_loss, nmn_loss, r._baseline, self._beta, gamma)
+        with torch.no_grad():
+            stats = torch.stack((sums[5], torch.full_like(sums[5], float(n))))
+            stats = parallel.all_reduce_scalars(stats)
+            r._baseline = r._baseline + r._baseline_decay * stats[0] / stats[1].clamp(min=1.0)
+        means = sums / n
+        out = {"reconstruction_likelihood": means[0], "kl_divergence": means[1], "elbo": means[2],
+               "reinforce_reward": means[3]}
+        if nmn_loss is not None:
+            out["nmn_loss"] = means[4]
+        return out
 
 
 class QuestionCodingElbo(_ElboWithReinforce):
@@ -157,6 +209,8 @@ class QuestionCodingElbo(_ElboWithReinforce):
     def combine(self, generation_loss, reconstruction_loss, prior_loss) -> Dict[str, torch.Tensor]:
         """The objective from the three per-example negative log-likelihoods of the SAMPLED programs
         (reference elbo.py:130-161); trainers that batch the model passes themselves call this."""
+        if generation_loss.is_cuda:
+            return self._fused(generation_loss, reconstruction_loss, prior_loss, None, 0.0)
         logprobs_reconstruction = -reconstruction_loss
         logprobs_generation = -generation_loss
         logprobs_prior = -prior_loss
@@ -203,6 +257,8 @@ class JointTrainingElbo(_ElboWithReinforce):
                 "elbo": self._reinforce(generation_loss, reinforce_reward).mean(),
                 "reinforce_reward": reinforce_reward.mean(),
             }
+        elif generation_loss.is_cuda:
+            return self._fused(generation_loss, reconstruction_loss, prior_loss, nmn_out["loss"], self._gamma)
         else:
             logprobs_reconstruction = -reconstruction_loss
             logprobs_generation = -generation_loss

@@ -326,10 +326,56 @@ def masked_softmax(vector: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
 
 def sequence_cross_entropy(logits, targets, weights, eps: float = 1e-13):
     """Per-sequence masked-mean cross entropy (allennlp sequence_cross_entropy_with_logits,
-    average=None)."""
+    average=None) with explicit weights -- plain torch ops (the kernels take a token mask, see
+    ``sequence_nll``)."""
     weights = weights.float()
     nll = -F.log_softmax(logits, dim=-1).gather(2, targets.unsqueeze(-1)).squeeze(-1) * weights
     return nll.sum(1) / (weights.sum(1) + eps)
+
+
+class _SeqNLL(torch.autograd.Function):
+    """``pnmn_seq_nll_{fwd,bwd}``: one launch instead of log_softmax / gather / mask / sum / divide."""
+
+    @staticmethod
+    def forward(ctx, logits, tokens, mask_tokens, pad, eps):
+        B, T, V = logits.shape
+        if logits.stride(2) != 1 or logits.stride(1) != V:
+            logits = logits.contiguous()
+        if tokens.stride(1) != 1:
+            tokens = tokens.contiguous()
+        if mask_tokens.stride(1) != 1:
+            mask_tokens = mask_tokens.contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(B, T, dtype=torch.float32, device=logits.device)
+        _hip.check(_hip.lib().pnmn_seq_nll_fwd(logits.data_ptr(), logits.stride(0), tokens.data_ptr(), tokens.stride(0),
+                                               mask_tokens.data_ptr(), mask_tokens.stride(0), pad, loss.data_ptr(),
+                                               lse.data_ptr(), B, T, V, eps, _hip.stream_ptr(logits.device)), "seq_nll_fwd")
+        ctx.save_for_backward(logits, tokens, mask_tokens, lse)
+        ctx.pad, ctx.eps = pad, eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, tokens, mask_tokens, lse = ctx.saved_tensors
+        B, T, V = logits.shape
+        dlogits = torch.empty(B, T, V, dtype=torch.float32, device=logits.device)
+        dloss = dloss.contiguous()
+        _hip.check(_hip.lib().pnmn_seq_nll_bwd(logits.data_ptr(), logits.stride(0), tokens.data_ptr(), tokens.stride(0),
+                                               mask_tokens.data_ptr(), mask_tokens.stride(0), ctx.pad, lse.data_ptr(),
+                                               dloss.data_ptr(), dlogits.data_ptr(), T * V, B, T, V, ctx.eps,
+                                               _hip.stream_ptr(logits.device)), "seq_nll_bwd")
+        return dlogits, None, None, None, None
+
+
+def sequence_nll(logits: torch.Tensor, tokens: torch.Tensor, mask_tokens: torch.Tensor, pad: int, eps: float) -> torch.Tensor:
+    """loss[b] = sum_t w_t (-log_softmax(logits[b,t])[tokens[b,t]]) / (sum_t w_t + eps), w = mask_tokens != pad.
+    Covers both sequence losses of the reference: teacher-forced cross entropy (tokens = mask_tokens =
+    targets, eps 1e-13: allennlp's sequence_cross_entropy_with_logits) and the negative mean log-probability
+    of a sampled sequence (tokens = the raw samples, mask_tokens = the trimmed predictions, eps 1e-12:
+    seq2seq_base.py:235-244)."""
+    if logits.device.type != "cuda":
+        raise _hip.HipLibraryError("sequence loss input on %s: the HIP path needs a ROCm device" % logits.device)
+    return _SeqNLL.apply(logits, tokens, mask_tokens, pad, eps)
 
 
 def token_projection(embedding: nn.Embedding, tokens: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
@@ -463,8 +509,9 @@ class Seq2SeqBase(nn.Module):
         source_tokens: torch.LongTensor,
         target_tokens: Optional[torch.LongTensor] = None,
         decoding_strategy: str = "sampling",
+        need_predictions: bool = True,
     ) -> Dict[str, torch.Tensor]:
-        return self.decode(self.encode(source_tokens), target_tokens, decoding_strategy)
+        return self.decode(self.encode(source_tokens), target_tokens, decoding_strategy, need_predictions)
 
     def encode(self, source_tokens: torch.LongTensor) -> Dict[str, torch.Tensor]:
         """Encoder half of ``forward`` (reference seq2seq_base.py ``_encode`` + ``_init_decoder_state``).
@@ -488,7 +535,10 @@ class Seq2SeqBase(nn.Module):
         state: Dict[str, torch.Tensor],
         target_tokens: Optional[torch.LongTensor] = None,
         decoding_strategy: str = "sampling",
+        need_predictions: bool = True,
     ) -> Dict[str, torch.Tensor]:
+        """``need_predictions=False`` (teacher forcing only): skip drawing the per-step predictions from the
+        teacher-forced distributions (reference :196-220) -- training iterations never read them."""
         if decoding_strategy not in ("sampling", "greedy"):
             raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
         pad, bos, eos = self._pad_index, self._start_index, self._end_index
@@ -520,22 +570,28 @@ class Seq2SeqBase(nn.Module):
                                                  b_p, 2 if greedy else 1, steps, seed, self.sample_row_offset, *args)
             logits_all = self._output_projection_layer(hs)  # one GEMM for all steps
             if tgt is not None:
-                # predictions are drawn / arg-maxed from the teacher-forced distributions (reference :196-220)
-                raw, _ = choose_tokens(logits_all.reshape(B * steps, -1), greedy, seed, self.sample_row_offset * steps,
-                                       0, pad, self._unk_index, bos)
-                raw = raw.view(B, steps)
-            logprobs = F.log_softmax(logits_all, dim=-1).gather(2, raw.unsqueeze(-1)).squeeze(-1)
+                output_dict = {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], pad, 1e-13)}
+                if need_predictions or not self.training:
+                    # predictions are drawn / arg-maxed from the teacher-forced distributions (reference :196-220)
+                    raw, _ = choose_tokens(logits_all.reshape(B * steps, -1), greedy, seed, self.sample_row_offset * steps,
+                                           0, pad, self._unk_index, bos)
+                    output_dict["predictions"] = self._trim_predictions(raw.view(B, steps))
+            else:
+                predictions = self._trim_predictions(raw)
+                output_dict = {"predictions": predictions, "loss": sequence_nll(logits_all, raw, predictions, pad, 1e-12)}
+            ce = output_dict["loss"]
+            predictions = output_dict.get("predictions")
         else:
             raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, c, tgt, steps, greedy, seed)
-
-        predictions = self._trim_predictions(raw)
-        pmask = (predictions != pad).float()
-        sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
-        output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
+            predictions = self._trim_predictions(raw)
+            pmask = (predictions != pad).float()
+            sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
+            output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
+            if tgt is not None:
+                tmask = tgt != pad
+                ce = sequence_cross_entropy(logits_all, tgt[:, 1:], tmask[:, 1:])
+                output_dict["loss"] = ce
         if tgt is not None:
-            tmask = tgt != pad
-            ce = sequence_cross_entropy(logits_all, tgt[:, 1:], tmask[:, 1:])
-            output_dict["loss"] = ce
             if not self.training:
                 self._record_metrics(predictions, tgt[:, 1:], ce)
                 self._bleu(predictions, tgt)  # (reference :260: against the targets WITH their @start@, as allennlp)

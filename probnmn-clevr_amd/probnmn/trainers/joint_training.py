@@ -130,17 +130,17 @@ class _TrainerBase(StepBase):
             if after_sampling is not None:
                 out["after_sampling"] = after_sampling()
         if n_sup:
-            out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling")["loss"].mean()
+            out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"].mean()
         if n_sup and n_nosup:
-            qr_loss = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling")["loss"]
+            qr_loss = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
             out["qr"], out["qr_sup"] = qr_loss[:n_nosup], qr_loss[n_nosup:].mean()
         elif n_sup:
-            out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling")["loss"].mean()
+            out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"].mean()
         elif reconstruct:
-            out["qr"] = self.qr(z, ques_nosup, "sampling")["loss"]
+            out["qr"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
         if n_nosup and prior:
             with torch.no_grad():  # frozen model whose output only enters the detached reward
-                out["prior"] = self.prior(z)["loss"]
+                out["prior"] = self.prior(z, need_predictions=False)["loss"]
         return out
 
 

@@ -36,4 +36,6 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step.step(batch)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumulative").print_stats("probnmn|autograd|bench", 45)

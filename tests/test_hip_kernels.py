@@ -510,6 +510,44 @@ def test_answer_loss(hip, map_size):
     torch.testing.assert_close(loss.cpu(), ref2, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("V,T", [(44, 27), (100, 46), (130, 5)])
+def test_sequence_nll_fwd_bwd(hip, map_size, V, T):
+    """pnmn_seq_nll_{fwd,bwd} against log_softmax / gather / masked mean, incl. strided views (logits[:, :-1],
+    targets[:, 1:]) and a mask taken from a different token matrix (sampled vs trimmed programs)."""
+    if map_size != 14:
+        pytest.skip("independent of the map size")
+    g = gen(400 + V)
+    B = 9
+    full = (torch.randn(B, T + 1, V, generator=g) * 3).requires_grad_(True)
+    toks = torch.randint(1, V, (B, T + 1), generator=g)
+    masks = toks.clone()
+    lens = torch.randint(0, T + 1, (B,), generator=g)
+    lens[0], lens[1] = T + 1, 0  # a full row and an all-padding row (loss 0, no gradient)
+    for b in range(B):
+        masks[b, int(lens[b]):] = 0
+    logits, tk, mk = full[:, :-1], toks[:, 1:], masks[:, 1:]
+    w = (mk != 0).float()
+    nll = -F.log_softmax(logits, dim=-1).gather(2, tk.unsqueeze(-1)).squeeze(-1) * w
+    ref = nll.sum(1) / (w.sum(1) + 1e-13)
+    dl = torch.randn(B, generator=g)
+    ref.backward(dl)
+    fd = full.detach().to(dev())
+    ld, td, md = fd[:, :-1], toks.to(dev())[:, 1:], masks.to(dev())[:, 1:]
+    loss = torch.empty(B, device=dev())
+    lse = torch.empty(B, T, device=dev())
+    st = hip.stream_ptr(dev())
+    hip.check(hip.lib().pnmn_seq_nll_fwd(ld.data_ptr(), ld.stride(0), td.data_ptr(), td.stride(0), md.data_ptr(), md.stride(0),
+                                         0, loss.data_ptr(), lse.data_ptr(), B, T, V, 1e-13, st), "seq_nll_fwd")
+    dlog = torch.zeros(B, T, V, device=dev())
+    dld = dl.to(dev())
+    hip.check(hip.lib().pnmn_seq_nll_bwd(ld.data_ptr(), ld.stride(0), td.data_ptr(), td.stride(0), md.data_ptr(), md.stride(0),
+                                         0, lse.data_ptr(), dld.data_ptr(), dlog.data_ptr(), T * V, B, T, V, 1e-13, st), "seq_nll_bwd")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dlog.cpu(), full.grad[:, :-1], rtol=1e-4, atol=1e-6)
+    assert float(loss[1]) == 0.0 and float(dlog[1].abs().max()) == 0.0
+
+
 def test_clamp_adam_matches_torch(hip, map_size):
     if map_size != 14:
         pytest.skip("independent of the map size")

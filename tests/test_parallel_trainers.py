@@ -36,7 +36,7 @@ class _Toy(torch.nn.Module):
     def row_loss(self, x, offset):
         return (x @ self.w).pow(2) + (x @ self.big).pow(2) + offset
 
-    def forward(self, images, programs, answers, started=None):  # the NMN stand-in
+    def forward(self, images, programs, answers, started=None, trunk_stream=None):  # the NMN stand-in
         return {"loss": self.row_loss(images, 0.25)}
 
 
