@@ -200,6 +200,14 @@ int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream);
 int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
 int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream);
 
+/* Feature ingest: replaces the per-item h5 read + float cast + collate + .to(device) of
+ * probnmn/data/readers.py:63-108, datasets.py:137-142, trainers/_trainer.py:272-287 AND the layout change
+ * above.  `store` is a DEVICE-VISIBLE pointer to page-locked HOST memory holding [n_store][C][HW] fp32
+ * (hipHostMalloc / a torch pinned tensor); `indices` [n] int64 on the device; dst [n][HW][C] on the
+ * device.  The kernel reads the selected rows over PCIe. */
+int pnmn_gather_features(const float* store, const int64_t* indices, float* dst, int n, int64_t n_store,
+                         int C, int HW, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * classifier.1-3: ReLU (already applied by the conv) + MaxPool2d(2,2) + Flatten   nmn.py:77-79
  *   in  [n][H*W][C] NHWC  ->  out [n][C*(H/2)*(W/2)] in the reference's NCHW-flatten order

@@ -49,6 +49,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_accumulate": (_P, _I, _P),
     "pnmn_nchw_to_nhwc": (_P, _P, _I, _I, _I, _P),
     "pnmn_nhwc_to_nchw": (_P, _P, _I, _I, _I, _P),
+    "pnmn_gather_features": (_P, _P, _P, _I, ctypes.c_int64, _I, _I, _P),
     "pnmn_maxpool2_flatten_fwd": (_P, _P, _I, _I, _I, _I, _P),
     "pnmn_maxpool2_flatten_bwd": (_P, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_answer_loss": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P),

@@ -66,7 +66,7 @@ class _Pack:
 
 
 class _State:
-    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples")
+    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features")
 
 
 class NMNEngine:
@@ -304,7 +304,12 @@ class NMNEngine:
         B = features.size(0)
         if tuple(features.shape[1:]) != (self.cin, self.H, self.W):
             raise ValueError("expected features (B,%d,%d,%d), got %s" % (self.cin, self.H, self.W, tuple(features.shape)))
-        features = features.contiguous().float()
+        # features already in the kernels' layout (a `channels_last` tensor, e.g. from
+        # probnmn.data.feature_store: the ingest kernel writes NHWC): used in place, no layout pass
+        nhwc = (features.dtype == torch.float32 and not features.is_contiguous()
+                and features.is_contiguous(memory_format=torch.channels_last))
+        if not nhwc:
+            features = features.contiguous().float()
         HW = self.HW
         st = _hip.stream_ptr(dev)
         self.generation += 1
@@ -314,7 +319,11 @@ class NMNEngine:
         if need_backward:
             names += ["gstem1", "gfeat", "gfinal", "gcls"]
             sizes += [B * HW * C, B * HW * C, B * HW * C, B * HW * self.cproj]
+        if nhwc:
+            names, sizes = names[1:], sizes[1:]
         ws = {n: self._buf(n, s) for n, s in zip(names, sizes)}
+        if nhwc:
+            ws["xin"] = features.permute(0, 2, 3, 1).reshape(-1)  # a view of the caller's storage
         if not need_backward:  # records still reference gradient buffers; point them somewhere valid
             for n in ("gstem1", "gfeat", "gfinal", "gcls"):
                 ws[n] = ws["stem1"]
@@ -323,7 +332,8 @@ class NMNEngine:
         for k in ("stem1", "stem2"):
             pack.add(k, fixed[k])
         pack.upload(dev)
-        _hip.check(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
+        if not nhwc:
+            _hip.check(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
         self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
         self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
@@ -387,6 +397,7 @@ class NMNEngine:
         if need_backward:
             state = _State()
             state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
+            state.features = started["features"]  # (the stem's weight gradient reads the input again)
             state.generation = self.generation
         return pooled, state
 

@@ -1,0 +1,82 @@
+"""Feature ingest: pinned host store -> one gather kernel -> NHWC device batch, used by the
+network in place; prefetching loader.  Reference behaviour being replaced: readers.py:63-108 (row lookup),
+datasets.py:137-142 (float cast), _trainer.py:272-287 (.to(device))."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("size,dtype", [(14, np.float64), (28, np.float32)])
+def test_gather_equals_host_indexing(size, dtype):
+    from probnmn.data.feature_store import PinnedFeatureStore
+
+    rng = np.random.Generator(np.random.Philox(size))
+    feats = rng.standard_normal((37, 1024, size, size)).astype(dtype)  # h5 features are float64 (extract_features.py:119-121)
+    store = PinnedFeatureStore(feats, chunk_rows=10)
+    assert len(store) == 37 and store.image_feature_size == (1024, size, size)
+    idx = torch.tensor([5, 0, 36, 5, 17, 22, 1])
+    got = store.gather(idx, DEV)
+    assert got.shape == (7, 1024, size, size) and got.is_contiguous(memory_format=torch.channels_last)
+    want = torch.from_numpy(feats[idx.numpy()]).float()  # the reference's lookup + cast
+    assert torch.equal(got.cpu(), want)
+    with pytest.raises(IndexError):
+        store.gather(torch.tensor([37]), DEV)
+    # indices already on the device
+    assert torch.equal(store.gather(idx.to(DEV), DEV).cpu(), want)
+
+
+def test_network_takes_the_gathered_batch_in_place():
+    """A channels_last batch (what the store produces) goes through the network without a layout pass and
+    gives bit-identical outputs and gradients to the same batch handed over as contiguous NCHW."""
+    from probnmn.data.feature_store import PinnedFeatureStore
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(0)
+    nmn = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(DEV)
+    nmn.train()
+    b = synthetic_batch(vocab, 12, seed=4)
+    store = PinnedFeatureStore(b["image"].numpy())
+    gathered = store.gather(torch.arange(12), DEV)
+    plain = b["image"].to(DEV)
+    res = []
+    for img in (gathered, plain):
+        nmn.zero_grad(set_to_none=True)
+        out = nmn(img, b["program"], b["answer"].to(DEV))
+        out["loss"].mean().backward()
+        res.append((out["loss"].detach().clone(), out["predictions"].clone(),
+                    {n: p.grad.detach().clone() for n, p in nmn.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for n in res[0][2]:
+        a, c = res[0][2][n], res[1][2][n]
+        assert float((a - c).abs().max()) <= 2e-5 * float(c.abs().max()) + 1e-12, n  # (fp32 atomics order only)
+
+
+def test_prefetching_loader_yields_every_batch_with_its_features():
+    from probnmn.data.feature_store import PinnedFeatureStore, PrefetchingLoader
+
+    rng = np.random.Generator(np.random.Philox(1))
+    feats = rng.standard_normal((50, 1024, 14, 14)).astype(np.float32)
+    store = PinnedFeatureStore(feats)
+    host_batches = []
+    for k in range(5):
+        idx = torch.from_numpy(rng.integers(0, 50, 8 if k != 3 else 5))
+        host_batches.append({"image_index": idx, "question": torch.full((idx.numel(), 4), k), "answer": idx % 28,
+                             "supervision": (idx % 2)})
+    seen = 0
+    for k, batch in enumerate(PrefetchingLoader(host_batches, store, DEV)):
+        hb = host_batches[k]
+        assert set(batch) == {"image", "question", "answer", "supervision"}
+        assert batch["supervision"].device.type == "cpu" and batch["question"].is_cuda
+        # consume on the compute stream (a kernel that reads the whole batch), then check
+        total = batch["image"].double().sum()
+        assert torch.equal(batch["image"].cpu(), torch.from_numpy(feats[hb["image_index"].numpy()]))
+        assert abs(float(total) - float(feats[hb["image_index"].numpy()].astype(np.float64).sum())) < 1e-3 * abs(float(total)) + 1e-2
+        assert torch.equal(batch["question"].cpu(), hb["question"])
+        seen += 1
+    assert seen == 5
