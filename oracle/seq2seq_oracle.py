@@ -215,3 +215,34 @@ def program_prior_loss(sd: Dict[str, torch.Tensor], program_tokens: torch.Tensor
     proj = F.linear(enc, sd["_projection_layer.weight"])
     logits = F.linear(proj, w)  # tied output layer, no bias
     return sequence_cross_entropy_with_logits(logits[:, :-1], toks[:, 1:], mask[:, 1:])
+
+
+def program_prior_sample(sd: Dict[str, torch.Tensor], forced: torch.Tensor, max_sequence_length: int):
+    """ProgramPrior.sample (program_prior.py:174-301) with the multinomial draws replaced by ``forced``
+    (num_samples, max_sequence_length - 1): stepwise LSTM from @start@, per-step log-probability gathered
+    from log_softmax of the PROJECTION (the reference's own quirk, :243-244), trim at the first @end@,
+    masked mean, most likely first."""
+    n = forced.size(0)
+    w = sd["_embedder.token_embedder_programs.weight"]
+    layers = 2
+    hidden = sd["_encoder._module.weight_hh_l0"].shape[1]
+    h = [torch.zeros(n, hidden) for _ in range(layers)]
+    c = [torch.zeros(n, hidden) for _ in range(layers)]
+    last = torch.full((n,), START, dtype=torch.long)
+    lps, preds = [], []
+    for t in range(max_sequence_length - 1):
+        x = F.embedding(last, w, padding_idx=PAD)
+        for layer in range(layers):
+            h[layer], c[layer] = lstm_cell(x, h[layer], c[layer], sd["_encoder._module.weight_ih_l%d" % layer],
+                                           sd["_encoder._module.weight_hh_l%d" % layer],
+                                           sd["_encoder._module.bias_ih_l%d" % layer], sd["_encoder._module.bias_hh_l%d" % layer])
+            x = h[layer]
+        proj = F.linear(x, sd["_projection_layer.weight"])
+        last = forced[:, t]
+        preds.append(last.unsqueeze(1))
+        lps.append(F.log_softmax(proj, dim=-1).gather(1, last.unsqueeze(1)))
+    predictions = trim_predictions(torch.cat(preds, 1))
+    mask = (predictions != PAD).float()
+    seq = (torch.cat(lps, 1) * mask).sum(-1) / (mask.sum(-1) + 1e-12)
+    order = (-seq).sort()[1]
+    return {"predictions": predictions[order], "loss": -seq[order]}

@@ -64,5 +64,40 @@ class ProgramPrior(nn.Module):
             predictions = predictions[:, :-1] * mask[:, 1:]
         return {"predictions": predictions, "loss": loss}
 
+    @torch.no_grad()
+    def sample(self, num_samples: int = 1, max_sequence_length: int = 28, _forced=None) -> Dict[str, torch.Tensor]:
+        """Free-running categorical samples from the prior, most likely first (reference :174-301; inspection
+        only, no trainer calls it -- written with torch ops, one step at a time, on the model's device).
+        Reproduced as the reference has it, including that the per-step log-probability is gathered from
+        ``log_softmax`` of the 256-wide PROJECTION, not of the vocabulary logits (:243-244,257-259).
+        ``_forced`` (steps = max_sequence_length - 1 columns) replaces the draws in tests."""
+        device = self._output_layer.weight.device
+        lstm = self._encoder._module
+        last = torch.full((num_samples, 1), self._start_index, dtype=torch.long, device=device)
+        h = torch.zeros(lstm.num_layers, num_samples, lstm.hidden_size, device=device)
+        c = torch.zeros_like(h)
+        step_logprobs, step_predictions = [], []
+        for t in range(max_sequence_length - 1):
+            encoded, (h, c) = lstm(self._embedder.embedding(last), (h, c))
+            projection = self._projection_layer(encoded)
+            probabilities = F.softmax(self._output_layer(projection), dim=-1)
+            logprobs = F.log_softmax(projection, dim=-1)
+            probabilities[:, :, [self._start_index, self._pad_index, self._unk_index]] = 0
+            last = torch.multinomial(probabilities.squeeze(1), 1) if _forced is None else _forced[:, t:t + 1].to(device)
+            step_predictions.append(last)
+            step_logprobs.append(torch.gather(logprobs, 2, last.unsqueeze(1)).squeeze(-1))
+        raw = torch.cat(step_predictions, 1)
+        # keep up to and including the first @end@; a row starting with @end@ becomes padding (:270-280)
+        steps = raw.size(1)
+        is_end = raw == self._end_index
+        first = is_end.float().argmax(1, keepdim=True)
+        pos = torch.arange(steps, device=device).unsqueeze(0)
+        keep = torch.where(is_end.any(1, keepdim=True), (pos <= first) & (first > 0), torch.ones_like(is_end))
+        predictions = raw * keep
+        mask = (predictions != self._pad_index).float()
+        sequence_logprobs = (torch.cat(step_logprobs, 1) * mask).sum(-1) / (mask.sum(-1) + 1e-12)
+        order = (-sequence_logprobs).sort()[1]
+        return {"predictions": predictions[order], "loss": -sequence_logprobs[order]}
+
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:
         return {"perplexity": 2 ** self._log2_perplexity.get_metric(reset=reset)}

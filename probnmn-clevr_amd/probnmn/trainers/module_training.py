@@ -45,3 +45,29 @@ class ModuleTrainingStep(StepBase):
         self.optimizer.step()
         self.iteration += 1
         return {"loss": loss.detach(), "metrics": out.get("metrics")}
+
+
+class ProgramPriorStep(StepBase):
+    """One program-prior iteration (reference: probnmn/trainers/program_prior_trainer.py:79-90 and
+    _trainer.py:135-151): mean over the batch of the per-sequence cross entropy of the LSTM language model,
+    backward, clamp to [-5, 5], Adam.  ``after_validation`` takes 1 / perplexity (higher is better), as
+    program_prior_trainer.py:112 does."""
+
+    def __init__(self, program_prior, lr: float = 1e-2, weight_decay: float = 0.0, lr_gamma: float = 0.5,
+                 lr_patience: int = 3):
+        self.prior = program_prior
+        self.optimizer = ClampAdam(program_prior.parameters(), lr=lr, weight_decay=weight_decay, clamp=5.0)
+        self.models = {"program_prior": program_prior}
+        self._init_schedule(lr_gamma, lr_patience)
+        self.iteration = 0
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        self.optimizer.zero_grad()
+        self.prior.train()
+        loss_rows = self.prior(batch["program"], need_predictions=False)["loss"]
+        loss = loss_rows.mean()
+        (loss * parallel.mean_weight(loss_rows.numel(), loss_rows.device)).backward()
+        parallel.all_reduce_gradients([], self.optimizer.loose)
+        self.optimizer.step()
+        self.iteration += 1
+        return {"loss": loss.detach()}

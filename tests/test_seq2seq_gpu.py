@@ -411,3 +411,38 @@ def test_config5_forty_step_programs():
         got = prior(programs.to(DEV))["loss"].cpu()
     psd = {k: v for k, v in sds["prior"].items() if k != "_output_layer.weight"}
     torch.testing.assert_close(got, so.program_prior_loss(psd, programs).detach(), rtol=1e-4, atol=1e-4)
+
+
+def test_program_prior_sample_and_training_step():
+    """ProgramPrior.sample (program_prior.py:174-301) against the oracle on forced draws, its free
+    draws' invariants, and one ProgramPriorStep (program_prior_trainer.py:79-90) against the oracle's
+    gradient (compared before Adam)."""
+    from oracle import seq2seq_oracle as so
+    from probnmn.trainers.module_training import ProgramPriorStep
+
+    vocab, _, _, prior = _models(seed=4)
+    sd = {k: v.detach().clone() for k, v in prior.state_dict().items() if k != "_output_layer.weight"}
+    prior.to(DEV).eval()
+    g = torch.Generator().manual_seed(12)
+    forced = torch.randint(3, 44, (9, 27), generator=g)
+    forced[0, 0] = 3   # starts with @end@ -> all padding
+    forced[1] = 9      # never ends -> kept whole
+    got = prior.sample(9, 28, _forced=forced)
+    want = so.program_prior_sample(sd, forced, 28)
+    assert torch.equal(got["predictions"].cpu(), want["predictions"])
+    torch.testing.assert_close(got["loss"].cpu(), want["loss"], rtol=1e-4, atol=1e-5)
+    free = prior.sample(64, 28)
+    assert free["predictions"].shape == (64, 27) and not torch.isin(free["predictions"], torch.tensor([1, 2], device=DEV)).any()
+    assert bool((free["loss"][1:] >= free["loss"][:-1] - 1e-6).all())  # most likely (smallest loss) first
+
+    progs = _tokens(16, 26, 44, 13)
+    step = ProgramPriorStep(prior, lr=1e-2)
+    out = step.step({"program": progs.to(DEV)})
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = so.program_prior_loss(ref_sd, progs).mean()
+    ref.backward()
+    assert float(out["loss"]) == pytest.approx(float(ref), rel=1e-4)
+    for name, p in prior.named_parameters():
+        want_g = ref_sd[name].grad
+        assert float((p.grad.cpu() - want_g).abs().max()) / (float(want_g.abs().max()) + 1e-12) < 2e-3, name
+    assert step.after_validation(1.0 / 3.0) == 1e-2 and set(step.state_dict()) == {"program_prior", "optimizer", "scheduler", "iteration"}

@@ -56,8 +56,6 @@ def test_every_reference_class_exists_with_the_same_signatures(surface):
     for cls_name, entry in surface["classes"].items():
         cls = _product_class(cls_name)
         for method, m in entry["methods"].items():
-            if cls_name == "ProgramPrior" and method == "sample":
-                continue  # inspection helper outside the hot path
             if method == "_forward_loop":
                 continue  # private; recorded for its return-dict keys only
             assert hasattr(cls, method), (cls_name, method)
