@@ -108,16 +108,23 @@ def cpu_baseline(vocab, sds, sample, steps, seed):
     }
 
 
-def kernel_rooflines(engine, step_fn, passes):
-    """Instrumented steps: events around every conv / wgrad launch on the launch stream (one stream,
-    so each kernel's duration is its own and not that of two kernels sharing the chip)."""
+def kernel_rooflines(engine, step_fn, passes, trainer=None):
+    """Instrumented steps: events around every conv / wgrad launch on the launch stream.  ONE stream, so
+    that each kernel's duration is its own and not that of two kernels sharing the chip: a trainer that
+    runs the NMN beside the seq2seq passes (small batches) is switched to its single-stream schedule for
+    these passes."""
     overlap, engine.overlap_wgrad = engine.overlap_wgrad, False
+    side_stream = getattr(trainer, "nmn_stream", None)
+    if side_stream is not None:
+        trainer.nmn_stream = False
     engine.event_log = []
     for _ in range(passes):
         step_fn()
     torch.cuda.synchronize()
     events, engine.event_log = engine.event_log, None
     engine.overlap_wgrad = overlap
+    if side_stream is not None:
+        trainer.nmn_stream = side_stream
     agg = {}
     for kern, what, flops, e0, e1, nbytes, launches in events:
         a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
@@ -339,7 +346,7 @@ def config5_side(vocab, prior, dev, rank, world, args):
         trainer.step(batch)
     torch.cuda.synchronize()
     elapsed, host, blocked = timed(lambda: trainer.step(batch), 10, 4, dev, world, trainer)
-    agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2)
+    agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2, trainer=trainer)
     out = None
     if rank == 0:
         conv = agg["conv_nhwc"]
@@ -463,7 +470,7 @@ def main():
     roof = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the step's collectives); rank 0 reports
-        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2)
+        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2, trainer=trainer)
         if rank == 0:
             roof = roofline_object(agg, 2)
         log("roofline pass done")

@@ -138,7 +138,8 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
         // 13 in a row, 12-25 us per chunk with nothing to overlap at one workgroup per CU.  (One batch of
         // 13 would need more registers than the accumulators leave.)
         const int NST = (NR * 32 + NTHREADS - 1) / NTHREADS;
-        constexpr int BATCH = 7;
+        // (half-map tiles run two workgroups per CU on a 128-register budget: smaller batches)
+        constexpr int BATCH = (MT > 8) ? 7 : 4;
 #pragma unroll 1
         for (int i0 = 0; i0 < NST; i0 += BATCH) {
             f32x4 sv[BATCH];
@@ -289,36 +290,45 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
     // Every load of the epilogue (previous contents for accumulation, forward features, attention) is
-    // requested for all 13 m-tiles before the first use: issued one m-tile at a time they cost 13 memory
-    // round trips in a row, with the matrix cores idle.
+    // requested for a whole group of m-tiles before the first use: issued one m-tile at a time they cost
+    // one memory round trip each, in a row, with the matrix cores idle.
+    // EG m-tiles at a time: all of them where the register budget allows (one workgroup per CU), four where
+    // two workgroups share a CU (the other workgroup's MFMAs cover the extra round trips)
+    constexpr int EG = (MT > 8) ? MT : 4;
     if (mb == nullptr) {
         const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
-        f32x4 old[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = mt * 16 + li;
-            old[mt] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int m0 = 0; m0 < MT; m0 += EG) {
+            f32x4 old[EG];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = mt * 16 + li;
-            if (p < HW) {
-                f32x4 v = acc[mt] + bias4;
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.f);
-                    v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f);
-                    v.w = fmaxf(v.w, 0.f);
-                }
-                float* dstf = it.out + (size_t)(p_img + p) * out_stride + n0 + 4 * g;
-                if (it.flags & PNMN_CONV_ATOMIC) {
-                    unsafeAtomicAdd(dstf + 0, v.x);
-                    unsafeAtomicAdd(dstf + 1, v.y);
-                    unsafeAtomicAdd(dstf + 2, v.z);
-                    unsafeAtomicAdd(dstf + 3, v.w);
-                } else {
-                    store4(as_global(dstf), v + old[mt]);
+            for (int j = 0; j < EG; ++j) {
+                const int mt = m0 + j;
+                const int p = mt * 16 + li;
+                old[j] = (mt < MT && accumulate && p < HW)
+                             ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < EG; ++j) {
+                const int mt = m0 + j;
+                const int p = mt * 16 + li;
+                if (mt < MT && p < HW) {
+                    f32x4 v = acc[mt < MT ? mt : 0] + bias4;
+                    if (relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    float* dstf = it.out + (size_t)(p_img + p) * out_stride + n0 + 4 * g;
+                    if (it.flags & PNMN_CONV_ATOMIC) {
+                        unsafeAtomicAdd(dstf + 0, v.x);
+                        unsafeAtomicAdd(dstf + 1, v.y);
+                        unsafeAtomicAdd(dstf + 2, v.z);
+                        unsafeAtomicAdd(dstf + 3, v.w);
+                    } else {
+                        store4(as_global(dstf), v + old[j]);
+                    }
                 }
             }
         }
@@ -326,37 +336,43 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
         // fused backward of (feats * attn): this wave owns channels n0..n0+15 of every pixel
         const bool sole = it.flags & PNMN_CONV_MB_SOLE;
         const gfloat* attn = as_global(mb->attn);
-        float am[MT];
-        f32x4 fv[MT], dold[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = mt * 16 + li;
-            const bool ok = p < HW;
-            am[mt] = (ok && attn) ? attn[p_img + p] : 1.f;
-            fv[mt] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-            dold[mt] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int m0 = 0; m0 < MT; m0 += EG) {
+            float am[EG];
+            f32x4 fv[EG], dold[EG];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = mt * 16 + li;
-            const bool ok = p < HW;
-            const f32x4 v = acc[mt];
-            float part = v.x * fv[mt].x + v.y * fv[mt].y + v.z * fv[mt].z + v.w * fv[mt].w;
-            if (ok) {
-                float* d = mb->dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
-                if (sole) {  // only this workgroup touches these 4 channels of pixel p
-                    store4(as_global(d), dold[mt] + v * am[mt]);
-                } else {
-                    unsafeAtomicAdd(d + 0, v.x * am[mt]);
-                    unsafeAtomicAdd(d + 1, v.y * am[mt]);
-                    unsafeAtomicAdd(d + 2, v.z * am[mt]);
-                    unsafeAtomicAdd(d + 3, v.w * am[mt]);
-                }
+            for (int j = 0; j < EG; ++j) {
+                const int mt = m0 + j;
+                const int p = mt * 16 + li;
+                const bool ok = mt < MT && p < HW;
+                am[j] = (ok && attn) ? attn[p_img + p] : 1.f;
+                fv[j] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+                dold[j] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (attn) {
-                part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
-                part += __shfl_xor(part, 32);
-                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+#pragma unroll
+            for (int j = 0; j < EG; ++j) {
+                const int mt = m0 + j;
+                if (mt >= MT) continue;
+                const int p = mt * 16 + li;
+                const bool ok = p < HW;
+                const f32x4 v = acc[mt < MT ? mt : 0];
+                float part = v.x * fv[j].x + v.y * fv[j].y + v.z * fv[j].z + v.w * fv[j].w;
+                if (ok) {
+                    float* d = mb->dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
+                    if (sole) {  // only this workgroup touches these 4 channels of pixel p
+                        store4(as_global(d), dold[j] + v * am[j]);
+                    } else {
+                        unsafeAtomicAdd(d + 0, v.x * am[j]);
+                        unsafeAtomicAdd(d + 1, v.y * am[j]);
+                        unsafeAtomicAdd(d + 2, v.z * am[j]);
+                        unsafeAtomicAdd(d + 3, v.w * am[j]);
+                    }
+                }
+                if (attn) {
+                    part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
+                    part += __shfl_xor(part, 32);
+                    if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+                }
             }
         }
     }

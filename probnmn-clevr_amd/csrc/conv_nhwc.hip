@@ -28,6 +28,7 @@
 // LDS image: conv_body.h (row = pixel, 32 slots of 16 bytes, swizzled to the lane groups ds_read_b128 /
 // ds_write_b128 are served in).
 #include <stdlib.h>
+#include <string.h>
 
 #include "conv_body.h"
 
@@ -35,9 +36,12 @@ namespace {
 
 using pnmn::CB;
 
-// A unit = one band of one item (14x14: unit = item; 28x28: four units per item).
-template <int H, int W, int TH, int KSPLIT>
-__global__ __launch_bounds__(512) void conv_nhwc_kernel(
+// A unit = one band of one item (14x14: unit = item, or one of two 7-row half maps; 28x28: four units per
+// item).  WPS = minimum waves per SIMD the register allocation must leave room for: 2 = one workgroup per
+// CU (the 98 KiB tile allows no more), 4 = two (half-map tiles of 68 KiB: one workgroup stages or stores
+// while the other one's MFMAs run).
+template <int H, int W, int TH, int KSPLIT, int WPS>
+__global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     const pnmn_conv_item* __restrict__ items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
     int out_stride, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -60,11 +64,12 @@ template <int H, int W, int TH, int KSPLIT>
 int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
                   int out_stride, int cout_blocks, int relu, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)pnmn::lds_rows<H, W, TH>() * CB * sizeof(float);
+    constexpr int WPS = (2 * lds_bytes <= 160 * 1024) ? 4 : 2;
     static_assert(lds_bytes <= 160 * 1024, "the staged region must fit the CU's LDS");
     static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((TH * W + 15) / 16) * 64 * 16 <= lds_bytes,
                   "reduction scratch must fit in the input image");
     static bool configured = false;
-    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT>;
+    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT, WPS>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -174,9 +179,19 @@ extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, i
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (H == 14 && W == 14)
+    if (H == 14 && W == 14) {
+        static const char* force = getenv("PNMN_CONV_FORCE");  // experiment hook: "<band rows>:<K-split>", one launch
+        if (force) {
+            const int th = atoi(force), ks = strchr(force, ':') ? atoi(strchr(force, ':') + 1) : 1;
+            if (th == 7)
+                return launch_conv_split<14, 14, 7>(ks, items, 0, n_items * 2, cin_chunks, ntaps, in_stride, out_stride,
+                                                    cout_blocks, relu, s);
+            return launch_conv_split<14, 14, 14>(ks, items, 0, n_items, cin_chunks, ntaps, in_stride, out_stride,
+                                                 cout_blocks, relu, s);
+        }
         return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                        cout_blocks, relu, s);
+    }
     if (H == 28 && W == 28)
         return launch_conv<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                       cout_blocks, relu, s);

@@ -207,6 +207,7 @@ class JointTrainingStep(_TrainerBase):
         self.blocked_seconds = 0.0  # host time spent waiting for the sampled programs (diagnostic, bench.py)
         # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
+        self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
@@ -233,7 +234,10 @@ class JointTrainingStep(_TrainerBase):
         if nosup.numel():
             images, answers = batch["image"][nosup_d], batch["answer"][nosup_d]
             main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-            side = self._nmn_stream(dev) if (self.nmn_stream and main is not None) else None
+            # (beyond ~320 sampled rows either side fills the chip on its own: sharing it gains < 1 % and
+            # only blurs per-kernel timings, so larger batches stay on one stream)
+            side = self._nmn_stream(dev) if (self.nmn_stream and main is not None
+                                             and nosup.numel() <= self.nmn_stream_max_rows) else None
             if side is not None:
                 # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
                 # starts at once (next to the generator's encoder and sampling decode); its module programs

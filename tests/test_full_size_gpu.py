@@ -137,7 +137,7 @@ def test_joint_step_1024_rows_with_the_nmn_on_its_own_stream():
         pg, qr = ProgramGenerator(vocab).to(DEV), QuestionReconstructor(vocab).to(DEV)
         prior = ProgramPrior(vocab, hidden_size=256).to(DEV)
         step = JointTrainingStep(pg, qr, prior, nmn, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-6)
-        step.nmn_stream = use_side_stream
+        step.nmn_stream, step.nmn_stream_max_rows = use_side_stream, 1 << 30
         torch.manual_seed(1)
         for _ in range(3):
             out = step.step(batch)
