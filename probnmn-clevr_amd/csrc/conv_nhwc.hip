@@ -28,7 +28,6 @@
 // LDS image: conv_body.h (row = pixel, 32 slots of 16 bytes, swizzled to the lane groups ds_read_b128 /
 // ds_write_b128 are served in).
 #include <stdlib.h>
-#include <string.h>
 
 #include "conv_body.h"
 
@@ -180,15 +179,13 @@ extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, i
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (H == 14 && W == 14) {
-        static const char* force = getenv("PNMN_CONV_FORCE");  // experiment hook: "<band rows>:<K-split>", one launch
-        if (force) {
-            const int th = atoi(force), ks = strchr(force, ':') ? atoi(strchr(force, ':') + 1) : 1;
-            if (th == 7)
-                return launch_conv_split<14, 14, 7>(ks, items, 0, n_items * 2, cin_chunks, ntaps, in_stride, out_stride,
-                                                    cout_blocks, relu, s);
-            return launch_conv_split<14, 14, 14>(ks, items, 0, n_items, cin_chunks, ntaps, in_stride, out_stride,
+        // tuning hook: PNMN_CONV_KSPLIT=<1|2|4|8> forces one launch with that K-split (scripts/conv_modes.py).
+        // (Measured and rejected: two 7-row half maps per item with two workgroups per CU -- the M-split
+        // counterpart of K-split 2 -- is within 3 % of it at every launch size.)
+        static const char* force = getenv("PNMN_CONV_KSPLIT");
+        if (force)
+            return launch_conv_split<14, 14, 14>(atoi(force), items, 0, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                                  cout_blocks, relu, s);
-        }
         return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                        cout_blocks, relu, s);
     }

@@ -1,10 +1,10 @@
 """TFLOP/s of one grouped module-conv launch (128 -> 128, 3x3, masked, ReLU; 14x14) by number of items and
-launch mode (band rows : K-split), each mode forced through PNMN_CONV_FORCE in its own process.
-usage: python scripts/conv_modes.py <mode> [dgrad]"""
+K-split, each forced through PNMN_CONV_KSPLIT in its own process ("auto": the library's launch planner).
+usage: python scripts/conv_modes.py <auto|1|2|4|8>"""
 import os, sys
 mode = sys.argv[1]
 if mode != "auto":
-    os.environ["PNMN_CONV_FORCE"] = mode
+    os.environ["PNMN_CONV_KSPLIT"] = mode
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "probnmn-clevr_amd")]
 import numpy as np, torch
