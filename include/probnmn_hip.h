@@ -388,7 +388,9 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
-/* Library / device self-description (no GPU needed for version). */
+/* Library self-description (no GPU needed).  2 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+ * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
+ * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);
 
 #ifdef __cplusplus

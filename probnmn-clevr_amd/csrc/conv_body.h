@@ -78,6 +78,8 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     const int li = lane & 15;
     const int g = lane >> 4;
 
+    // (Measured and rejected: a static s_setprio 1 for waves 4-7 -- MI355X_MICROARCH.md, two waves per SIMD,
+    // item 4 -- changes no launch size by more than 1 %.)
     const int nt = wave % NT;
     const int ks = wave / NT;  // which slice of the input channels this wave contracts
     const int n0 = cout_block * CB + (nsub * NT + nt) * 16;  // this wave's 16 out channels

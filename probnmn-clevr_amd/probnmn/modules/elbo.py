@@ -16,74 +16,6 @@ from torch import nn
 from probnmn import parallel
 
 
-class _Branches:
-    """Run independent sub-computations on side streams of the current device.
-
-    The seq2seq passes of one iteration are latency-bound persistent kernels that occupy a handful of
-    CUs each (one workgroup per 16 batch rows), and several of them are mutually independent (question
-    reconstruction, program prior and the NMN all consume the sampled programs; the two supervised
-    passes depend on nothing).  Issued on separate streams they overlap on the 256-CU chip; autograd
-    replays each branch's backward on the stream its forward ran on, so the overlap carries over."""
-
-    def __init__(self):
-        import os
-
-        self._streams = {}
-        # OFF by default: with the branches on side streams the step is 1.4-1.7x faster at batch <= 512
-        # (joint B=128: 43 -> 26 ms) but the GPU reproducibly stops making progress at batch >= 768
-        # (host blocked in synchronize; not explained by hardware-queue sharing -- GPU_MAX_HW_QUEUES=16
-        # does not help); until that is understood the passes run back to back on one stream.
-        self.enabled = os.environ.get("PNMN_BRANCHES", "0") == "1"
-
-    # ROCm gives a process a small number of hardware queues (GPU_MAX_HW_QUEUES, default 4); HIP streams
-    # beyond that share a queue, and a stream whose barrier packet waits for an event that a LATER packet
-    # of the same hardware queue will signal never makes progress (observed: GPU hang with five streams
-    # at batch >= 768).  All branches are therefore folded onto two side streams: with the main stream
-    # that is three queues, leaving one for RCCL.
-    _ALIASES = {"sup_pg": "side0", "sup_qr": "side0", "qr": "side1", "prior": "side1"}
-
-    def stream(self, key: str, device) -> "torch.cuda.Stream":
-        key = self._ALIASES.get(key, key)
-        s = self._streams.get((key, device))
-        if s is None:
-            s = self._streams[(key, device)] = torch.cuda.Stream(device=device)
-        return s
-
-    def run(self, key: str, device, fn, *inputs):
-        """fn() on the side stream `key`, ordered after everything queued on the current stream.
-        ``inputs``: the activation tensors fn reads that were allocated on the current stream -- the
-        caching allocator must know the side stream uses them, or it may recycle their memory for a
-        later allocation while the branch (which runs behind the host) is still reading."""
-        if device.type != "cuda" or not self.enabled:
-            return fn(), None
-        main = torch.cuda.current_stream(device)
-        side = self.stream(key, device)
-        side.wait_stream(main)
-        for t in inputs:
-            if isinstance(t, torch.Tensor) and t.is_cuda:
-                t.record_stream(side)
-        with torch.cuda.stream(side):
-            out = fn()
-        return out, side
-
-    @staticmethod
-    def join(device, outputs_and_streams):
-        """Make the current stream wait for the branches; their tensors may then be used on it."""
-        if device.type != "cuda":
-            return
-        main = torch.cuda.current_stream(device)
-        for out, side in outputs_and_streams:
-            if side is None:
-                continue
-            main.wait_stream(side)
-            for t in (out.values() if isinstance(out, dict) else [out]):
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(main)
-
-
-BRANCHES = _Branches()
-
-
 class Reinforce(nn.Module):
     def __init__(self, baseline_decay: float = 0.99):
         super().__init__()
@@ -195,16 +127,10 @@ class QuestionCodingElbo(_ElboWithReinforce):
     def forward(self, question_tokens: torch.LongTensor):
         pg_out = self._program_generator(question_tokens, decoding_strategy="sampling")
         sampled_programs = pg_out["predictions"]
-        dev = sampled_programs.device if isinstance(sampled_programs, torch.Tensor) else torch.device("cpu")
-
-        def prior():
-            with torch.no_grad():  # frozen model whose output only enters the detached reward
-                return self._program_prior(sampled_programs)
-
-        prior_branch = BRANCHES.run("prior", dev, prior, sampled_programs)
+        with torch.no_grad():  # frozen model whose output only enters the detached reward
+            prior_out = self._program_prior(sampled_programs)
         qr_out = self._question_reconstructor(sampled_programs, question_tokens, decoding_strategy="sampling")
-        BRANCHES.join(dev, [prior_branch])
-        return self.combine(pg_out["loss"], qr_out["loss"], prior_branch[0]["loss"])
+        return self.combine(pg_out["loss"], qr_out["loss"], prior_out["loss"])
 
     def combine(self, generation_loss, reconstruction_loss, prior_loss) -> Dict[str, torch.Tensor]:
         """The objective from the three per-example negative log-likelihoods of the SAMPLED programs
@@ -232,20 +158,14 @@ class JointTrainingElbo(_ElboWithReinforce):
     def forward(self, question_tokens, image_features, answer_tokens):
         pg_out = self._program_generator(question_tokens, decoding_strategy="sampling")
         sampled_programs = pg_out["predictions"]
-        dev = sampled_programs.device
-        # question reconstruction and the prior run beside the NMN (all three only need the samples)
-        qr_branch = BRANCHES.run("qr", dev, lambda: self._question_reconstructor(
-            sampled_programs, question_tokens, decoding_strategy="sampling"), sampled_programs, question_tokens)
-        prior_branch = (None, None)
+        # (one stream: the recurrent kernels and the library GEMMs of these passes must not share the chip
+        # with each other -- DESIGN.md 6; the batched joint step in probnmn.trainers overlaps the NMN trunk)
+        qr_loss = self._question_reconstructor(sampled_programs, question_tokens, decoding_strategy="sampling")["loss"]
+        prior_loss = None
         if self._objective != "baseline":
-            def prior():
-                with torch.no_grad():  # frozen model whose output only enters the detached reward
-                    return self._program_prior(sampled_programs)
-            prior_branch = BRANCHES.run("prior", dev, prior, sampled_programs)
+            with torch.no_grad():  # frozen model whose output only enters the detached reward
+                prior_loss = self._program_prior(sampled_programs)["loss"]
         nmn_out = self._nmn(image_features, sampled_programs, answer_tokens)
-        BRANCHES.join(dev, [qr_branch, prior_branch])
-        prior_loss = prior_branch[0]["loss"] if prior_branch[0] is not None else None
-        qr_loss = qr_branch[0]["loss"] if qr_branch[0] is not None else None
         return self.combine(pg_out["loss"], qr_loss, prior_loss, nmn_out)
 
     def combine(self, generation_loss, reconstruction_loss, prior_loss, nmn_out) -> Dict[str, torch.Tensor]:
