@@ -103,6 +103,20 @@ inline int cluster_split(int tiles, bool allow4 = true) {
 
 // one counter per tile, each on its own 256-byte line: the members of up to 64 tiles poll and increment
 // concurrently, and counters sharing a line would serialise all of them on one L2 channel
+// The hand-off counters are zeroed by a KERNEL in front of every multi-CU launch, not by hipMemsetAsync:
+// when the launch sequence is captured into a hipGraph (torch.cuda.make_graphed_callables over a whole
+// seq2seq pass), a memset node was seen to run out of order with the kernel nodes around it -- zeroing
+// the counters of a multi-CU kernel that was still running (the workspace of the next launch reuses the
+// freed block) and trapping it.  Kernel nodes keep stream order.
+static __global__ void cluster_zero_kernel(int* words, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) words[i] = 0;
+}
+
+inline hipError_t cluster_zero(void* workspace, size_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(cluster_zero_kernel, dim3(8), dim3(256), 0, stream, static_cast<int*>(workspace), (int)(bytes / sizeof(int)));
+    return hipGetLastError();
+}
+
 constexpr int CLUSTER_COUNTER_STRIDE = 64;                                     // ints
 constexpr size_t CLUSTER_SYNC_BYTES = 128 * CLUSTER_COUNTER_STRIDE * sizeof(int);  // up to 128 tiles
 

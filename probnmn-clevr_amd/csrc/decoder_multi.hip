@@ -560,7 +560,7 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
         const int tiles = (rows + ROWS - 1) / ROWS;
-        hipError_t e = hipMemsetAsync(workspace, 0, pnmn::CLUSTER_SYNC_BYTES, st);
+        hipError_t e = pnmn::cluster_zero(workspace, pnmn::CLUSTER_SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
         const size_t r = (size_t)r0;
         MFwdArgs a{xe ? xe + r * T * G4 : nullptr, etable, enc + r * S * H, mask + r * S, h0 + r * H, w_c, w_hh, w_p, b_p,
@@ -600,7 +600,7 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
         const int tiles = (rows + ROWS - 1) / ROWS;
-        hipError_t e = hipMemsetAsync(workspace, 0, pnmn::CLUSTER_SYNC_BYTES, st);
+        hipError_t e = pnmn::cluster_zero(workspace, pnmn::CLUSTER_SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
         const size_t r = (size_t)r0;
         MBwdArgs a{dhs + r * T * H, act + r * T * G4, cs + r * T * H, hs + r * T * H, probs + r * T * S, enc + r * S * H,

@@ -655,7 +655,7 @@ int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
-        hipError_t e = hipMemsetAsync(workspace, 0, SYNC_BYTES, st);
+        hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(8 * S * ((tiles + 7) / 8));
         int* sync = static_cast<int*>(workspace);
@@ -678,7 +678,7 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
-        hipError_t e = hipMemsetAsync(workspace, 0, SYNC_BYTES, st);
+        hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(8 * S * ((tiles + 7) / 8));
         int* sync = static_cast<int*>(workspace);

@@ -48,10 +48,10 @@ class ProgramPrior(nn.Module):
         encoded = self._encoder.forward_tokens(self._embedder.embedding, toks, mask)
         logits = self._output_layer(self._projection_layer(encoded))
         loss = sequence_nll(logits[:, :-1], toks[:, 1:], toks[:, 1:], self._pad_index, 1e-13)
+        if not need_predictions:  # (the trainers' reward path: no samples, no validation metric)
+            return {"loss": loss}
         if not self.training:
             self._log2_perplexity(loss.mean())
-        if not need_predictions:
-            return {"loss": loss}
         with torch.no_grad():
             probs = F.softmax(logits, dim=-1).clone()
             forbidden = self.__dict__.get("_forbidden")
