@@ -375,6 +375,40 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
                        int unk_index, int start_index, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Host-side launch sequencer (no device work of its own): `list` is a HOST array; entry i calls the entry
+ * point named by `op` with (a, b, c, n, p[...]) in that entry point's argument order (pointers first, then
+ * the item count, then the integer arguments), all on `stream`; stops at the first non-zero return code.
+ * Replaces ~160 one-by-one calls per step of the per-example interpreter loop (nmn.py:197-238) with two.
+ *   CONV  a items, n, p = H, W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu
+ *   WGRAD a items, b jobs, n = n_jobs, p = H, W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride
+ *   TRANSPOSE_WEIGHTS a items, n      DOT_* / SAME_* / MASK_BWD a items, n, p = HW      MINMAX_* p = HW, C
+ *   MAXPOOL_FWD a in, b out, n, p = H, W, C       MAXPOOL_BWD a in, b dout, c din, n, p = H, W, C
+ *   NCHW_TO_NHWC a src, b dst, n, p = C, HW
+ * ------------------------------------------------------------------------------------------- */
+#define PNMN_OP_CONV              0
+#define PNMN_OP_WGRAD             1
+#define PNMN_OP_TRANSPOSE_WEIGHTS 2
+#define PNMN_OP_DOT_FWD           3
+#define PNMN_OP_DOT_BWD           4
+#define PNMN_OP_SAME_FWD          5
+#define PNMN_OP_SAME_BWD          6
+#define PNMN_OP_MINMAX_FWD        7
+#define PNMN_OP_MINMAX_BWD        8
+#define PNMN_OP_MASK_BWD          9
+#define PNMN_OP_MAXPOOL_FWD       10
+#define PNMN_OP_MAXPOOL_BWD       11
+#define PNMN_OP_NCHW_TO_NHWC      12
+typedef struct pnmn_launch {
+    const void* a;
+    const void* b;
+    const void* c;
+    int32_t     op;
+    int32_t     n;
+    int32_t     p[8];
+} pnmn_launch;             /* 64 bytes */
+int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side batch program compiler (no device work)        nmn.py:191-238, SURVEY App. C
  *   tokens [n_programs][length] int64 prefix programs; kinds[token] = module class of each
  *   vocabulary entry (0 skip, 1 scene, 2 and, 3 or, 4 comparison, 5 attention, 6 query, 7 relate,

@@ -69,6 +69,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, _P),
     "pnmn_attn_lstm_bwd_multi": (_P,) * 14 + (_I,) * 4 + (_P, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
+    "pnmn_run_launches": (_P, _I, _P),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
@@ -178,7 +179,36 @@ MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
+LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
+(OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
+ OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC) = range(13)
+
+
+class LaunchList:
+    """A sequence of grouped launches for ``pnmn_run_launches`` (one binding call instead of one per launch).
+    Rows are kept as tuples of eight 64-bit words -- the byte image of ``pnmn_launch`` (a, b, c, op | n << 32,
+    p0 | p1 << 32, ...) -- and turned into one array when the list runs."""
+
+    def __init__(self):
+        self._rows = []
+
+    def add(self, op: int, n: int, a: int, b: int = 0, c: int = 0, p=()) -> None:
+        q = tuple(p) + (0,) * (8 - len(p))
+        self._rows.append((a, b, c, op | (n << 32), q[0] | (q[1] << 32), q[2] | (q[3] << 32), q[4] | (q[5] << 32),
+                           q[6] | (q[7] << 32)))
+
+    def __len__(self) -> int:
+        return len(self._rows)
+
+    def run(self, stream: int, what: str) -> None:
+        if self._rows:
+            rec = np.array(self._rows, dtype=np.uint64)
+            check(lib().pnmn_run_launches(rec.ctypes.data, len(self._rows), stream), what)
+            self._rows = []
+
+
 ITEM_SIZES = {
+    "pnmn_launch": (LAUNCH, 64),
     "pnmn_conv_item": (CONV_ITEM, 96),
     "pnmn_wgrad_item": (WGRAD_ITEM, 48),
     "pnmn_wgrad_job": (WGRAD_JOB, 24),

@@ -37,7 +37,7 @@ class _Trunk(torch.autograd.Function):
     def forward(ctx, features, engine, compiled, started, *params):
         need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
         pooled, state = engine.run_forward(features, compiled, need_backward, started)
-        ctx.engine, ctx.state = engine, state
+        ctx.engine, ctx.state, ctx.n_params = engine, state, len(params)
         return pooled
 
     @staticmethod
@@ -45,7 +45,7 @@ class _Trunk(torch.autograd.Function):
         if ctx.state is None:
             raise RuntimeError("backward through a forward that was run without gradient tracking")
         grads = ctx.engine.run_backward(ctx.state, dpooled)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, *grads[: ctx.n_params])
 
 
 class _AnswerLoss(torch.autograd.Function):
@@ -173,7 +173,13 @@ class NeuralModuleNetwork(nn.Module):
 
         valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, features.device)
 
+        # the trunk's parameters as inputs of its autograd node -- all of them when autograd is to receive
+        # their gradients; ONE anchor when a trainer reads the gradients straight from the arena
+        # (engine.direct_grads): 218 inputs cost ~0.5 ms of host time per step in apply() and in 218
+        # AccumulateGrad visits that carry nothing
         params = [arena.param(n) for n in arena.names]
+        if engine.direct_grads:
+            params = params[:1]
         if trunk_stream is not None:
             current = torch.cuda.current_stream(features.device)
             with torch.cuda.stream(trunk_stream):

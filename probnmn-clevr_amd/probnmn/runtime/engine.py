@@ -103,9 +103,16 @@ class NMNEngine:
         # so the default is one stream, which also keeps per-kernel profiles clean.
         self.overlap_wgrad = False
         self._side_stream: Optional[torch.cuda.Stream] = None
+        # launches of a pass are collected and issued by ONE library call (pnmn_run_launches) unless they are
+        # being timed one by one (event_log) or spread over two streams (overlap_wgrad)
+        self._list: Optional[_hip.LaunchList] = None
+        self.launch_lists = os.environ.get("PNMN_LAUNCH_LISTS", "1") != "0"
 
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
         log = self.event_log
+        if self._list is not None:  # (collected into one pnmn_run_launches call)
+            self._list.add(_hip.OP_CONV, n, ptr, p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
+            return
         if log is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -124,6 +131,9 @@ class NMNEngine:
         """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
         log = self.event_log
         st = stream.cuda_stream
+        if self._list is not None:
+            self._list.add(_hip.OP_WGRAD, n_jobs, items, jobs, p=(self.H, self.W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride))
+            return
         if log is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -134,6 +144,25 @@ class NMNEngine:
             e1.record(stream)
             log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1,
                         4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C), 1))
+
+    def _op(self, op: int, name: str, n: int, a: int, st: int, what: str, b: int = 0, c: int = 0, p=()) -> None:
+        """One grouped launch of a non-conv kernel: into the pass's launch list, or directly."""
+        if self._list is not None:
+            self._list.add(op, n, a, b, c, p)
+            return
+        fn = getattr(_hip.lib(), name)
+        args = [x for x in (a, b, c) if x]
+        _hip.check(fn(*args, n, *p, st), what)
+
+    def _begin_list(self) -> None:
+        # (a list left over from a pass that raised is dropped here)
+        self._list = _hip.LaunchList() if (self.event_log is None and not self.overlap_wgrad and self.launch_lists) else None
+
+    def _flush_list(self, st: int, what: str, end: bool = False) -> None:
+        if self._list is not None:
+            self._list.run(st, what)
+            if end:
+                self._list = None
 
     # ---- parameters ---------------------------------------------------------------------------
     def trunk_named_parameters(self):
@@ -332,10 +361,13 @@ class NMNEngine:
         for k in ("stem1", "stem2"):
             pack.add(k, fixed[k])
         pack.upload(dev)
+        self._begin_list()
         if not nhwc:
-            _hip.check(lib.pnmn_nchw_to_nhwc(features.data_ptr(), ws["xin"].data_ptr(), B, self.cin, HW, st), "nchw_to_nhwc")
+            self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc", B, features.data_ptr(), st, "nchw_to_nhwc",
+                     b=ws["xin"].data_ptr(), p=(self.cin, HW))
         self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
         self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
+        self._flush_list(st, "stem", end=True)
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
                 "features": features, "pack": pack}
 
@@ -387,11 +419,13 @@ class NMNEngine:
             idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             final.index_copy_(0, idx, feat.index_select(0, idx))
 
-        self._run_forward_launches(plan, pack, st)
-
-        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
-        chk(lib.pnmn_maxpool2_flatten_fwd(ws["cls"].data_ptr(), pooled.data_ptr(), B, H, W, self.cproj, st), "maxpool")
+        self._begin_list()
+        self._run_forward_launches(plan, pack, st)
+        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
+        self._op(_hip.OP_MAXPOOL_FWD, "pnmn_maxpool2_flatten_fwd", B, ws["cls"].data_ptr(), st, "maxpool",
+                 b=pooled.data_ptr(), p=(H, W, self.cproj))
+        self._flush_list(st, "module programs (forward)", end=True)
 
         state = None
         if need_backward:
@@ -410,11 +444,11 @@ class NMNEngine:
             elif l.kind == "proj":
                 self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection")
             elif l.kind == "dot":
-                chk(lib.pnmn_dot1_sigmoid_fwd(pack.ptr("dot", l.begin), n, HW, st), "dot1")
+                self._op(_hip.OP_DOT_FWD, "pnmn_dot1_sigmoid_fwd", n, pack.ptr("dot", l.begin), st, "dot1", p=(HW,))
             elif l.kind == "same":
-                chk(lib.pnmn_same_fwd(pack.ptr("same", l.begin), n, HW, st), "same")
+                self._op(_hip.OP_SAME_FWD, "pnmn_same_fwd", n, pack.ptr("same", l.begin), st, "same", p=(HW,))
             elif l.kind == "minmax":
-                chk(lib.pnmn_minmax_fwd(pack.ptr("minmax", l.begin), n, HW, C, st), "minmax")
+                self._op(_hip.OP_MINMAX_FWD, "pnmn_minmax_fwd", n, pack.ptr("minmax", l.begin), st, "minmax", p=(HW, C))
             else:
                 raise AssertionError(l.kind)
 
@@ -439,7 +473,9 @@ class NMNEngine:
             ws["gact"][: plan.arena_floats].zero_()
         ws["gfeat"][: B * HW * C].zero_()
         _hip.mark("gradient buffers zeroed")
-        chk(lib.pnmn_transpose_weights(self._wt_records.data_ptr(), self._wt_count, st), "transpose weights")
+        self._begin_list()
+        self._op(_hip.OP_TRANSPOSE_WEIGHTS, "pnmn_transpose_weights", self._wt_count, self._wt_records.data_ptr(), st,
+                 "transpose weights")
 
         main = torch.cuda.current_stream(dev)
         if self.overlap_wgrad:
@@ -457,14 +493,15 @@ class NMNEngine:
                 side.wait_event(ev)
 
         # classifier conv
-        chk(lib.pnmn_maxpool2_flatten_bwd(ws["cls"].data_ptr(), dpooled.data_ptr(), ws["gcls"].data_ptr(), B, H, W,
-                                          self.cproj, st), "maxpool bwd")
+        self._op(_hip.OP_MAXPOOL_BWD, "pnmn_maxpool2_flatten_bwd", B, ws["cls"].data_ptr(), st, "maxpool bwd",
+                 b=dpooled.data_ptr(), c=ws["gcls"].data_ptr(), p=(H, W, self.cproj))
         fork()
         nj = len(state.fixed["cls_wg_jobs"])
         self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
                     "classifier wgrad")
         self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
         if plan.feat_result_examples.size:
+            self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
             idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
             gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
             gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
@@ -479,17 +516,17 @@ class NMNEngine:
             for l in phase:
                 n = l.end - l.begin
                 if l.kind == "dot_bwd":
-                    chk(lib.pnmn_dot1_sigmoid_bwd(pack.ptr("dot", l.begin), n, HW, st), "dot1 bwd")
+                    self._op(_hip.OP_DOT_BWD, "pnmn_dot1_sigmoid_bwd", n, pack.ptr("dot", l.begin), st, "dot1 bwd", p=(HW,))
                 elif l.kind == "same_bwd":
-                    chk(lib.pnmn_same_bwd(pack.ptr("same", l.begin), n, HW, st), "same bwd")
+                    self._op(_hip.OP_SAME_BWD, "pnmn_same_bwd", n, pack.ptr("same", l.begin), st, "same bwd", p=(HW,))
                 elif l.kind == "minmax_bwd":
-                    chk(lib.pnmn_minmax_bwd(pack.ptr("minmax", l.begin), n, HW, C, st), "minmax bwd")
+                    self._op(_hip.OP_MINMAX_BWD, "pnmn_minmax_bwd", n, pack.ptr("minmax", l.begin), st, "minmax bwd", p=(HW, C))
                 elif l.kind == "dgrad":
                     self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad")
                 elif l.kind == "pdgrad":
                     self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad")
                 elif l.kind == "maskbwd":
-                    chk(lib.pnmn_mask_bwd(pack.ptr("maskbwd", l.begin), n, HW, st), "mask bwd")
+                    self._op(_hip.OP_MASK_BWD, "pnmn_mask_bwd", n, pack.ptr("maskbwd", l.begin), st, "mask bwd", p=(HW,))
                 else:
                     raise AssertionError(l.kind)
             level = phase[0].level
@@ -521,6 +558,7 @@ class NMNEngine:
             ev = torch.cuda.Event()
             ev.record(side)
             main.wait_event(ev)
+        self._flush_list(st, "trunk backward", end=True)
 
         if self.direct_grads:
             a.attach_grads()
