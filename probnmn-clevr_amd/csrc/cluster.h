@@ -81,14 +81,14 @@ __device__ __forceinline__ void cluster_coords(int& tile, int& member) {
 }
 
 inline int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = -1;
-    }
-    return cus;
+    // cached per device: the design is one process per GPU, but a process that drives several devices must
+    // not size a grid for device 1 from device 0's CU count
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus[dev] = -1;
+    return cus[dev];
 }
 
 // Members per tile such that the whole grid is resident with one workgroup per CU; 0 = does not fit.

@@ -111,6 +111,10 @@ class Config:
             if isinstance(value, str) and not isinstance(old, str):
                 value = yaml.safe_load(value)
             node[parts[-1]] = value
+        for section in ("PROGRAM_PRIOR", "PROGRAM_GENERATOR", "QUESTION_RECONSTRUCTOR"):
+            if float(root[section]["DROPOUT"]) != 0.0:  # (fails here, with the key named, not deep inside a constructor)
+                raise NotImplementedError("%s.DROPOUT = %s: the gfx950 recurrent kernels are built without dropout "
+                                          "(no reference config sets it)" % (section, root[section]["DROPOUT"]))
         root.freeze()
         object.__setattr__(self, "_root", root)
 
