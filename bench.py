@@ -108,6 +108,28 @@ def cpu_baseline(vocab, sds, sample, steps, seed):
     }
 
 
+def cpu_config1(vocab, nmn_sd, threads, steps=3, batch=32):
+    """BASELINE configs[0]: module_training.yml, batch 32, 14x14x1024 random features, the CPU path -- the
+    oracle's module-training iteration (ground-truth programs) on this host's cores, at the thread count the
+    joint-step baseline found best.  A plumbing number: it shows the CPU restatement runs the configuration."""
+    from oracle.train_oracle import OracleModuleTrainer
+    from probnmn.data.synthetic import synthetic_batch
+
+    torch.set_num_threads(threads)
+    b = synthetic_batch(vocab, batch, seed=2000)
+    trainer = OracleModuleTrainer(nmn_sd, vocab.get_index_to_token_vocabulary("programs"), lr=1e-4)
+    trainer.step(b)
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        trainer.step(b)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return {"metric": "CLEVR questions/sec (module_training step)", "value": round(batch / times[len(times) // 2], 2),
+            "unit": "questions/s", "cores": threads, "global_batch": batch, "steps": steps, "kind": "port",
+            "workload": "module_training.yml, batch 32, CPU oracle (configs[0])"}
+
+
 def kernel_rooflines(engine, step_fn, passes, trainer=None):
     """Instrumented steps: events around every conv / wgrad launch on the launch stream.  ONE stream, so
     that each kernel's duration is its own and not that of two kernels sharing the chip: a trainer that
@@ -475,9 +497,14 @@ def main():
             roof = roofline_object(agg, 2)
         log("roofline pass done")
 
-    cpu = None
+    cpu = cpu1 = None
     if sds is not None:
         cpu = cpu_baseline(vocab, sds, args.cpu_sample, args.cpu_steps, seed=1000)
+        try:
+            cpu1 = cpu_config1(vocab, sds["nmn"], cpu["cores"])
+            log("cpu module_training (configs[0]): %.1f questions/s" % cpu1["value"])
+        except Exception as exc:
+            cpu1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     recurrent = None
     if rank == 0 and not args.no_roofline:
@@ -554,6 +581,7 @@ def main():
             },
             "roofline": roof,
             "cpu_baseline": cpu,
+            "module_training_cpu_b32": cpu1,
             "recurrent_kernels": recurrent,
         }
         line.update(extras)
