@@ -148,6 +148,13 @@ def kernel_rooflines(engine, step_fn, passes, trainer=None):
     if side_stream is not None:
         trainer.nmn_stream = side_stream
     agg = {}
+    table = os.environ.get("PNMN_LAUNCH_TABLE")  # debugging aid: one line per conv / wgrad call of the instrumented steps
+    if table:
+        with open(table, "a") as f:
+            for kern, what, flops, e0, e1, nbytes, launches in events:
+                ms = e0.elapsed_time(e1)
+                f.write("%-11s %-20s %9.3f GFLOP %8.4f ms %7.1f TF  %d launches\n" % (kern, what, flops / 1e9, ms, flops / ms / 1e9, launches))
+            f.write("\n")
     for kern, what, flops, e0, e1, nbytes, launches in events:
         a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
         ms = e0.elapsed_time(e1)

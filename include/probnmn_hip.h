@@ -229,6 +229,46 @@ int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t*
                      int unknown_index, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Glue of the seq2seq passes (csrc/seqglue.hip): what the reference -- through AllenNLP 0.9.0 -- does with
+ * chains of small tensor ops and per-row Python loops, one launch each.
+ *
+ * pnmn_token_prep          allennlp.nn.util.add_sentence_boundary_token_ids + get_text_field_mask +
+ *                          the index get_final_encoder_states gathers (seq2seq_base.py:97-141 call sites):
+ *     full[b] = [bos, tokens[b][0..T), 0],  full[b][1 + n_b] = eos,  n_b = #(tokens[b] != pad)
+ *     out = full ([B][T+2]; drop_first = 0) or full[:, 1:] ([B][T+1]; drop_first = 1)
+ *     fmask = (out != pad) as float (may be null), last[b] = sum(fmask[b]) - 1 (may be null)
+ * pnmn_trim_predictions    seq2seq_base.py:278-293: keep a row up to and including its first `end`; all zeros
+ *                          when it starts with `end`; whole when it has none
+ * pnmn_mask_last_fwd/bwd   PytorchSeq2SeqWrapper's zeroed padded steps + get_final_encoder_states:
+ *     enc = hs * fmask[..., None],  hlast[b] = enc[b][last[b]]  (negative index: from the end)
+ *     dhs = (denc + [t == last[b]] dhlast[b]) * fmask        (denc, dhlast may be null)
+ * pnmn_embedding_grad      dw[v] += sum_{rows with token v} dy[row]   (V <= 128, C % 64 == 0, dw zeroed by
+ *                          the caller; rows = (b, t) of tokens [B][T]; shift = 1: row (b, t) takes token
+ *                          (b, t-1) and `start` at t = 0; token `skip` contributes nothing)
+ * pnmn_derive_params       once per optimiser step and model: MFMA-fragment copies of the recurrent weights
+ *                          (kind 0: of src [n][k]; kind 1: of its transpose, src stored [k][n]; ld = row
+ *                          stride of src) and bias sums (kind 2: dst = src + src2, n floats).
+ *                          max_quads = max over jobs of n*k/4 (kinds 0, 1) or n/4 (kind 2).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* src;
+    const float* src2;
+    float* dst;
+    int32_t n, k, ld, kind;
+} pnmn_derive_job;
+
+int pnmn_token_prep(const int64_t* tokens, int64_t token_row_stride, int B, int T, int pad, int bos, int eos,
+                    int drop_first, int64_t* out, float* fmask, int* last, void* stream);
+int pnmn_trim_predictions(const int64_t* raw, int B, int T, int end, int64_t* out, void* stream);
+int pnmn_mask_last_fwd(const float* hs, const float* fmask, const int* last, int B, int T, int H, float* enc,
+                       float* hlast, void* stream);
+int pnmn_mask_last_bwd(const float* denc, const float* dhlast, const float* fmask, const int* last, int B, int T,
+                       int H, float* dhs, void* stream);
+int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
+                        int V, int shift, int start, int skip, float* dw, void* stream);
+int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int max_quads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-sequence masked-mean negative log-likelihood            seq2seq_base.py:235-254 (sampled programs:
  * -sum_t logprob_t mask_t / (sum mask + 1e-12)), :334-341 -> allennlp sequence_cross_entropy_with_logits
  * (average=None, eps 1e-13), program_prior.py:146-151

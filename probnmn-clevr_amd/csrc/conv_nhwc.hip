@@ -42,7 +42,7 @@ using pnmn::CB;
 template <int H, int W, int TH, int KSPLIT, int WPS>
 __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     const pnmn_conv_item* __restrict__ items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
-    int out_stride, int relu) {
+    int out_stride, int relu, int per_xcd) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows][128], the last rows are zero
     constexpr int NB = H / TH;
@@ -50,8 +50,9 @@ __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     // its own L2.  The KSPLIT workgroups of a unit all stage the same input region, so they are given ids
     // that are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
     const int slot = blockIdx.x >> 3;
-    const int unit = (slot / KSPLIT) * 8 + (blockIdx.x & 7);
-    if (unit >= n_units) return;
+    const int j = slot / KSPLIT;
+    const int unit = per_xcd ? (blockIdx.x & 7) * per_xcd + j : j * 8 + (blockIdx.x & 7);
+    if (unit >= n_units || (per_xcd && j >= per_xcd)) return;
     const int u = unit0 + unit;
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
@@ -76,8 +77,9 @@ int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_c
         configured = true;
     }
     dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT, cout_blocks);
+    static const bool ranges = getenv("PNMN_CONV_XCD_RANGES") != nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
-                       out_stride, relu);
+                       out_stride, relu, ranges ? (n_units + 7) / 8 : 0);
     return (int)hipGetLastError();
 }
 

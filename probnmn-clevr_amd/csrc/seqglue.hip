@@ -1,0 +1,236 @@
+// Glue kernels of the seq2seq passes for gfx950: the token bookkeeping, masking, state selection and
+// embedding gradients that the reference does with chains of tiny tensor ops (allennlp's
+// add_sentence_boundary_token_ids / get_text_field_mask / get_final_encoder_states, reference
+// probnmn/modules/seq2seq_base.py:97-141,278-293) -- one launch each.  At 128 questions per GPU the step is
+// bound by the NUMBER of launches (host time and ~5 us of GPU time apiece), not by their work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/probnmn_hip.h"
+
+namespace {
+
+// ---- sentence boundaries + masks -------------------------------------------------------------------------
+// One wave per row.  tokens [B][T] (row stride `tstride`), right padded.
+//   full[b] = [bos, tokens[b][0..T), 0]  with  full[b][1 + n_b] = eos,  n_b = #(tokens[b] != pad)      ([B][T+2])
+// drop_first = 0: out = full (T+2 columns);  1: out = full[:, 1:] (T+1 columns: what an encoder reads).
+// fmask = (out != pad) as float, last[b] = #(out[b] != pad) - 1 (the index get_final_encoder_states gathers).
+__global__ __launch_bounds__(256) void token_prep_kernel(const int64_t* __restrict__ tokens, int64_t tstride, int B, int T,
+                                                         int pad, int bos, int eos, int drop_first,
+                                                         int64_t* __restrict__ out, float* __restrict__ fmask,
+                                                         int* __restrict__ last) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int64_t* row = tokens + (size_t)b * tstride;
+    int n = 0;
+    for (int t = lane; t < T; t += 64) n += row[t] != pad;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    const int W = T + 2 - drop_first;
+    int valid = 0;
+    for (int j = lane; j < W; j += 64) {
+        const int f = j + drop_first;  // column of the full row
+        int64_t v = (f == 0) ? bos : (f <= T ? row[f - 1] : 0);
+        if (f == n + 1) v = eos;
+        out[(size_t)b * W + j] = v;
+        const bool m = v != pad;
+        if (fmask) fmask[(size_t)b * W + j] = m ? 1.f : 0.f;
+        valid += m;
+    }
+    if (last) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+        if (lane == 0) last[b] = valid - 1;
+    }
+}
+
+// ---- trim predictions at the first @end@ (reference seq2seq_base.py:278-293) -------------------------------
+// keep a row up to and including its first `end`; a row that starts with `end` becomes all zeros; a row
+// without `end` is kept whole.  One wave per row.
+__global__ __launch_bounds__(256) void trim_predictions_kernel(const int64_t* __restrict__ raw, int B, int T, int end,
+                                                               int64_t* __restrict__ out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int64_t* row = raw + (size_t)b * T;
+    int first = T;  // first column holding `end`
+    for (int t = lane; t < T; t += 64)
+        if (row[t] == end && t < first) first = t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    for (int t = lane; t < T; t += 64) {
+        const bool keep = (first == T) || (first > 0 && t <= first);
+        out[(size_t)b * T + t] = keep ? row[t] : 0;
+    }
+}
+
+// ---- zero the padded steps of an encoder output and gather each row's last valid state ---------------------
+//   enc[b][t] = hs[b][t] * fmask[b][t];   hlast[b] = enc[b][last[b]]   (last[b] < 0 counts from the end, as a
+//   negative index does)
+__global__ __launch_bounds__(256) void mask_last_fwd_kernel(const float* __restrict__ hs, const float* __restrict__ fmask,
+                                                            const int* __restrict__ last, int T, int H,
+                                                            float* __restrict__ enc, float* __restrict__ hlast) {
+    const int b = blockIdx.x;
+    int l = last[b];
+    if (l < 0) l += T;
+    const int h4 = H >> 2;
+    const float4* src = reinterpret_cast<const float4*>(hs + (size_t)b * T * H);
+    float4* dst = reinterpret_cast<float4*>(enc + (size_t)b * T * H);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < T * h4; i += gridDim.y * 256) {
+        const int t = i / h4;
+        const float m = fmask[(size_t)b * T + t];
+        float4 v = src[i];
+        v.x *= m, v.y *= m, v.z *= m, v.w *= m;
+        dst[i] = v;
+        if (t == l) reinterpret_cast<float4*>(hlast + (size_t)b * H)[i - t * h4] = v;
+    }
+}
+
+//   dhs[b][t] = (denc[b][t] + [t == last[b]] dhlast[b]) * fmask[b][t]        (denc / dhlast may be null)
+__global__ __launch_bounds__(256) void mask_last_bwd_kernel(const float* __restrict__ denc, const float* __restrict__ dhlast,
+                                                            const float* __restrict__ fmask, const int* __restrict__ last,
+                                                            int T, int H, float* __restrict__ dhs) {
+    const int b = blockIdx.x;
+    int l = last[b];
+    if (l < 0) l += T;
+    const int h4 = H >> 2;
+    const float4* src = denc ? reinterpret_cast<const float4*>(denc + (size_t)b * T * H) : nullptr;
+    float4* dst = reinterpret_cast<float4*>(dhs + (size_t)b * T * H);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < T * h4; i += gridDim.y * 256) {
+        const int t = i / h4;
+        const float m = fmask[(size_t)b * T + t];
+        float4 v = src ? src[i] : float4{0.f, 0.f, 0.f, 0.f};
+        if (dhlast && t == l) {
+            const float4 d = reinterpret_cast<const float4*>(dhlast + (size_t)b * H)[i - t * h4];
+            v.x += d.x, v.y += d.y, v.z += d.z, v.w += d.w;
+        }
+        v.x *= m, v.y *= m, v.z *= m, v.w *= m;
+        dst[i] = v;
+    }
+}
+
+// ---- embedding gradient for a small vocabulary ------------------------------------------------------------
+//   dw[v][c] += sum over rows r with tokens[r] == v of dy[r][c]          (dw zeroed by the caller, V <= 128)
+// grid (C / 64, row splits); a workgroup sums its rows into an LDS table [V][64] (ds_add_f32), then adds the
+// table into dw.  `shift` = 1: row (b, t) takes the token of (b, t - 1) and `start` for t = 0 (the input
+// token of decoding step t), tokens being [B][T].
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ dy, const int64_t* __restrict__ tokens,
+                                                             int64_t tok_bstride, int B, int T, int C, int V, int shift,
+                                                             int start, int skip, float* __restrict__ dw) {
+    extern __shared__ float table[];  // [V][64]
+    for (int i = threadIdx.x; i < V * 64; i += 256) table[i] = 0.f;
+    __syncthreads();
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const int R = B * T;
+    const int per = (R + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
+    for (int r = r0 + sub; r < r1; r += 4) {
+        const int b = r / T, t = r - b * T;
+        int64_t v;
+        if (shift)
+            v = t == 0 ? start : tokens[(size_t)b * tok_bstride + t - 1];
+        else
+            v = tokens[(size_t)b * tok_bstride + t];
+        if (v == skip || v < 0 || v >= V) continue;
+        unsafeAtomicAdd(&table[(int)v * 64 + col], dy[(size_t)r * C + c]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V * 64; i += 256) {
+        const float s = table[i];
+        if (s != 0.f) unsafeAtomicAdd(dw + (size_t)(i >> 6) * C + blockIdx.x * 64 + (i & 63), s);
+    }
+}
+
+// ---- derived parameters of the recurrent kernels, one launch for a whole model ------------------------------
+// kind 0: dst = MFMA-fragment order of the [n][k] matrix src (row stride ld):
+//             dst[i][j][a][r][c] = src[(16 i + r) ld + 16 j + 4 a + c]      ([n/16][k/16][4][16][4])
+// kind 1: the same of the TRANSPOSE of src ([k][n] as stored, row stride ld): M[x][y] = src[y ld + x]
+// kind 2: dst[i] = src[i] + src2[i], i < n   (b_ih + b_hh)
+__global__ __launch_bounds__(256) void derive_params_kernel(const pnmn_derive_job* __restrict__ jobs) {
+    const pnmn_derive_job jb = jobs[blockIdx.y];
+    const int q = blockIdx.x * 256 + threadIdx.x;  // group of four consecutive dst elements
+    if (jb.kind == 2) {
+        if (q * 4 < jb.n) {
+            const float4 a = reinterpret_cast<const float4*>(jb.src)[q], b = reinterpret_cast<const float4*>(jb.src2)[q];
+            reinterpret_cast<float4*>(jb.dst)[q] = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        }
+        return;
+    }
+    if ((size_t)q * 4 >= (size_t)jb.n * jb.k) return;
+    const int r = q & 15, a = (q >> 4) & 3, kb = jb.k >> 4;
+    const int j = (q >> 6) % kb, i = (q >> 6) / kb;
+    const int x = 16 * i + r, y = 16 * j + 4 * a;
+    float4 v;
+    if (jb.kind == 0) {
+        v = *reinterpret_cast<const float4*>(jb.src + (size_t)x * jb.ld + y);
+    } else {
+        v.x = jb.src[(size_t)(y + 0) * jb.ld + x];
+        v.y = jb.src[(size_t)(y + 1) * jb.ld + x];
+        v.z = jb.src[(size_t)(y + 2) * jb.ld + x];
+        v.w = jb.src[(size_t)(y + 3) * jb.ld + x];
+    }
+    reinterpret_cast<float4*>(jb.dst)[q] = v;
+}
+
+}  // namespace
+
+extern "C" int pnmn_token_prep(const int64_t* tokens, int64_t token_row_stride, int B, int T, int pad, int bos, int eos,
+                               int drop_first, int64_t* out, float* fmask, int* last, void* stream) {
+    if (B <= 0) return 0;
+    if (!tokens || !out || T < 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(token_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), tokens,
+                       token_row_stride, B, T, pad, bos, eos, drop_first, out, fmask, last);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_trim_predictions(const int64_t* raw, int B, int T, int end, int64_t* out, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!raw || !out) return PNMN_EINVAL;
+    hipLaunchKernelGGL(trim_predictions_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), raw, B, T,
+                       end, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_mask_last_fwd(const float* hs, const float* fmask, const int* last, int B, int T, int H, float* enc,
+                                  float* hlast, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!hs || !fmask || !last || !enc || !hlast || (H & 3)) return PNMN_EINVAL;
+    const int per_row = (T * (H >> 2) + 255) / 256;
+    hipLaunchKernelGGL(mask_last_fwd_kernel, dim3(B, per_row < 8 ? per_row : 8), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), hs, fmask, last, T, H, enc, hlast);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_mask_last_bwd(const float* denc, const float* dhlast, const float* fmask, const int* last, int B, int T,
+                                  int H, float* dhs, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!fmask || !last || !dhs || (H & 3)) return PNMN_EINVAL;
+    const int per_row = (T * (H >> 2) + 255) / 256;
+    hipLaunchKernelGGL(mask_last_bwd_kernel, dim3(B, per_row < 8 ? per_row : 8), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), denc, dhlast, fmask, last, T, H, dhs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
+                                   int V, int shift, int start, int skip, float* dw, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    if (!dy || !tokens || !dw || (C & 63) || V < 1 || V > 128) return PNMN_EINVAL;
+    const long rows = (long)B * T;
+    int splits = (int)((rows + 255) / 256);  // >= 256 rows per workgroup
+    const int cap = 1024 / (C / 64) > 1 ? 1024 / (C / 64) : 1;
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(embedding_grad_kernel, dim3(C / 64, splits), dim3(256), (size_t)V * 64 * sizeof(float),
+                       static_cast<hipStream_t>(stream), dy, tokens, token_row_stride, B, T, C, V, shift, start, skip, dw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int max_quads, void* stream) {
+    if (n_jobs <= 0) return 0;
+    if (!jobs || max_quads <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(derive_params_kernel, dim3((max_quads + 255) / 256, n_jobs), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), jobs);
+    return (int)hipGetLastError();
+}

@@ -56,6 +56,12 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_seq_nll_fwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _I, _I, _I, _F, _P),
     "pnmn_seq_nll_bwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _P, ctypes.c_int64,
                          _I, _I, _I, _F, _P),
+    "pnmn_token_prep": (_P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P),
+    "pnmn_trim_predictions": (_P, _I, _I, _I, _P, _P),
+    "pnmn_mask_last_fwd": (_P, _P, _P, _I, _I, _I, _P, _P, _P),
+    "pnmn_mask_last_bwd": (_P, _P, _P, _P, _I, _I, _I, _P, _P),
+    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _P, _P),
+    "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
@@ -177,6 +183,7 @@ MINMAX_ITEM = np.dtype(
 )
 MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats", _u64), ("dattn", _u64)])
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
+DERIVE_JOB = np.dtype([("src", _u64), ("src2", _u64), ("dst", _u64), ("n", _i32), ("k", _i32), ("ld", _i32), ("kind", _i32)])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
@@ -219,6 +226,7 @@ ITEM_SIZES = {
     "pnmn_maskbwd_item": (MASKBWD_ITEM, 40),
     "pnmn_axpy_item": (AXPY_ITEM, 24),
     "pnmn_adam_item": (ADAM_ITEM, 40),
+    "pnmn_derive_job": (DERIVE_JOB, 40),
 }
 
 

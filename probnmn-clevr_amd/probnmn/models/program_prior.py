@@ -9,7 +9,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from probnmn import _hip
-from probnmn.modules.seq2seq_base import _Encoder, _TokenEmbedder, add_sentence_boundary_token_ids, sequence_nll
+from probnmn.modules.seq2seq_base import (DerivedParams, _Encoder, _TokenEmbedder, _TokenPrep, lstm_derived_specs,
+                                          sequence_nll)
 from probnmn.running_metrics import Average
 
 
@@ -29,6 +30,13 @@ class ProgramPrior(nn.Module):
         self._output_layer = nn.Linear(input_size, vocab_size, bias=False)
         self._output_layer.weight = self._embedder.embedding.weight  # tied
         self._log2_perplexity = Average()
+        self.__dict__["_derived_cache"] = DerivedParams()  # (packed recurrent weights; not part of the state_dict)
+
+    def _derived(self):
+        lstm = self._encoder._module
+        if lstm.hidden_size != 256 or lstm.weight_hh_l0.device.type != "cuda":
+            return None
+        return self._derived_cache.get(lstm_derived_specs(lstm))
 
     @classmethod
     def from_config(cls, config):
@@ -43,9 +51,9 @@ class ProgramPrior(nn.Module):
         # ``need_predictions=False``: skip the per-position samples (reference :119-143), which no trainer reads
         if program_tokens.device.type != "cuda":
             raise _hip.HipLibraryError("program prior input on %s: the HIP path needs a ROCm device" % program_tokens.device)
-        toks = add_sentence_boundary_token_ids(program_tokens, self._pad_index, self._start_index, self._end_index)
-        mask = toks != self._pad_index
-        encoded = self._encoder.forward_tokens(self._embedder.embedding, toks, mask)
+        toks, fmask, _ = _TokenPrep.run(program_tokens, self._pad_index, self._start_index, self._end_index,
+                                        drop_first=False, want_mask=True)
+        encoded = self._encoder.forward_tokens(self._embedder.embedding, toks, fmask, derived=self._derived())
         logits = self._output_layer(self._projection_layer(encoded))
         loss = sequence_nll(logits[:, :-1], toks[:, 1:], toks[:, 1:], self._pad_index, 1e-13)
         if not need_predictions:  # (the trainers' reward path: no samples, no validation metric)
@@ -61,7 +69,7 @@ class ProgramPrior(nn.Module):
             probs.index_fill_(2, forbidden, 0.0)
             B, T, V = probs.shape
             predictions = torch.multinomial(probs.view(B * T, V), 1).view(B, T)
-            predictions = predictions[:, :-1] * mask[:, 1:]
+            predictions = predictions[:, :-1] * (toks[:, 1:] != self._pad_index)
         return {"predictions": predictions, "loss": loss}
 
     @torch.no_grad()

@@ -90,6 +90,165 @@ def wgrad_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class DerivedParams:
+    """Per-model cache of what the recurrent kernels read instead of the raw parameters: MFMA-fragment copies
+    of W_hh / W_c (and of their transposes, for the backward kernels) and the bias sums b_ih + b_hh.  All of
+    them are produced by ONE ``pnmn_derive_params`` launch per model and optimiser step, where the straight-line
+    code issued a permute + copy per weight and pass and an add per bias and pass (~25 launches per step).
+    The cache is keyed on the parameters' version counters and on ``probnmn.optim.parameter_epoch()`` (the
+    fused optimiser updates parameters through their pointers, which bumps no version counter)."""
+
+    def __init__(self):
+        self._key = None
+        self._out: Dict[str, torch.Tensor] = {}
+
+    def get(self, specs) -> Dict[str, torch.Tensor]:
+        """``specs``: list of (name, kind, a, b) -- kind "pack" (fragment order of the [N][K] matrix ``a``),
+        "packT" (of its transpose), "sum" (a + b)."""
+        from probnmn.optim import parameter_epoch
+
+        dev = specs[0][2].device
+        key = (parameter_epoch(), dev, tuple((t.data_ptr(), t._version, None if u is None else (u.data_ptr(), u._version))
+                                             for _, _, t, u in specs))
+        if key == self._key:
+            return self._out
+        import numpy as np
+
+        total = sum(a.numel() for _, _, a, _ in specs)
+        buf = torch.empty(total, dtype=torch.float32, device=dev)
+        rec = np.zeros(len(specs), _hip.DERIVE_JOB)
+        out, off, max_quads = {}, 0, 0
+        for i, (name, kind, a, b) in enumerate(specs):
+            dst = buf[off:off + a.numel()]
+            rec[i]["src"], rec[i]["dst"] = a.data_ptr(), dst.data_ptr()
+            if kind == "sum":
+                if not (a.is_contiguous() and b.is_contiguous()):
+                    raise _hip.HipLibraryError("bias vectors must be contiguous")
+                rec[i]["src2"], rec[i]["n"], rec[i]["kind"] = b.data_ptr(), a.numel(), 2
+                out[name] = dst
+            else:
+                n, k = a.shape
+                if a.stride(1) != 1 or n % 16 or k % 16:
+                    raise _hip.HipLibraryError("recurrent weight of shape %s / strides %s" % (tuple(a.shape), a.stride()))
+                if kind == "pack":
+                    rec[i]["n"], rec[i]["k"], rec[i]["kind"] = n, k, 0
+                else:  # fragment order of a.t(): logical [k][n]
+                    rec[i]["n"], rec[i]["k"], rec[i]["kind"] = k, n, 1
+                rec[i]["ld"] = a.stride(0)
+                out[name] = dst
+            max_quads = max(max_quads, a.numel() // 4)
+            off += a.numel()
+        jobs = _hip.to_device(rec, dev)
+        _hip.check(_hip.lib().pnmn_derive_params(jobs.data_ptr(), len(specs), max_quads, _hip.stream_ptr(dev)), "derive_params")
+        self._key, self._out, self._jobs = key, out, jobs
+        return out
+
+
+class _Alias(torch.autograd.Function):
+    """``value`` (computed elsewhere from ``a`` and ``b`` as a + b) enters the graph as if it were ``a + b``."""
+
+    @staticmethod
+    def forward(ctx, a, b, value):
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None
+
+
+class _TokenTable(torch.autograd.Function):
+    """``F.linear(embedding.weight, weight, bias)`` ([V, 4H]) where the embedding's padding row receives no
+    gradient (nn.Embedding(padding_idx=...) never updates it; its value is zero, so the table row is the bias)."""
+
+    @staticmethod
+    def forward(ctx, emb, weight, bias, padding_idx):
+        ctx.save_for_backward(emb, weight)
+        ctx.padding_idx = padding_idx
+        return torch.addmm(bias, emb, weight.t())
+
+    @staticmethod
+    def backward(ctx, dtable):
+        emb, weight = ctx.saved_tensors
+        demb = dweight = dbias = None
+        if ctx.needs_input_grad[0]:
+            demb = dtable @ weight
+            if ctx.padding_idx is not None:
+                demb[ctx.padding_idx].zero_()
+        if ctx.needs_input_grad[1]:
+            dweight = dtable.t() @ emb
+        if ctx.needs_input_grad[2]:
+            dbias = dtable.sum(0)
+        return demb, dweight, dbias, None
+
+
+class _TokenPrep(object):
+    """``pnmn_token_prep`` (see include/probnmn_hip.h): sentence boundaries, mask and last-token index of a
+    right-padded token matrix in one launch."""
+
+    @staticmethod
+    def run(tokens: torch.Tensor, pad: int, bos: int, eos: int, drop_first: bool, want_mask: bool):
+        if tokens.device.type != "cuda":
+            raise _hip.HipLibraryError("token input on %s: the HIP path needs a ROCm device" % tokens.device)
+        if tokens.dtype != torch.long:
+            tokens = tokens.long()
+        if tokens.stride(1) != 1:
+            tokens = tokens.contiguous()
+        B, T = tokens.shape
+        W = T + 2 - int(drop_first)
+        out = torch.empty(B, W, dtype=torch.long, device=tokens.device)
+        fmask = torch.empty(B, W, dtype=torch.float32, device=tokens.device) if want_mask else None
+        last = torch.empty(B, dtype=torch.int32, device=tokens.device) if want_mask else None
+        _hip.check(_hip.lib().pnmn_token_prep(tokens.data_ptr(), tokens.stride(0), B, T, pad, bos, eos, int(drop_first),
+                                              out.data_ptr(), fmask.data_ptr() if want_mask else None,
+                                              last.data_ptr() if want_mask else None, _hip.stream_ptr(tokens.device)),
+                   "token_prep")
+        return out, fmask, last
+
+
+class _MaskAndLast(torch.autograd.Function):
+    """(hs [B,T,H], fmask [B,T], last [B]) -> (hs * fmask[..., None], its row ``last[b]`` per example): the
+    zeroed padded steps of ``PytorchSeq2SeqWrapper`` and ``get_final_encoder_states`` in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, hs, fmask, last):
+        hs = hs.contiguous()
+        B, T, H = hs.shape
+        enc = torch.empty_like(hs)
+        hlast = torch.empty(B, H, dtype=hs.dtype, device=hs.device)
+        _hip.check(_hip.lib().pnmn_mask_last_fwd(hs.data_ptr(), fmask.data_ptr(), last.data_ptr(), B, T, H, enc.data_ptr(),
+                                                 hlast.data_ptr(), _hip.stream_ptr(hs.device)), "mask_last_fwd")
+        ctx.save_for_backward(fmask, last)
+        ctx.shape = (B, T, H)
+        return enc, hlast
+
+    @staticmethod
+    def backward(ctx, denc, dhlast):
+        fmask, last = ctx.saved_tensors
+        B, T, H = ctx.shape
+        denc = denc.contiguous() if denc is not None else None
+        dhlast = dhlast.contiguous() if dhlast is not None else None
+        dhs = torch.empty(B, T, H, dtype=fmask.dtype, device=fmask.device)
+        _hip.check(_hip.lib().pnmn_mask_last_bwd(denc.data_ptr() if denc is not None else None,
+                                                 dhlast.data_ptr() if dhlast is not None else None, fmask.data_ptr(),
+                                                 last.data_ptr(), B, T, H, dhs.data_ptr(), _hip.stream_ptr(fmask.device)),
+                   "mask_last_bwd")
+        return dhs, None, None
+
+
+def embedding_grad(dy: torch.Tensor, tokens: torch.Tensor, vocab: int, shift: bool = False, start: int = 0,
+                   skip: int = -1) -> torch.Tensor:
+    """dW[v] = sum of the rows of ``dy`` ([B, T, C]) whose token is v (``pnmn_embedding_grad``)."""
+    B, T = tokens.shape
+    C = dy.size(-1)
+    dy = dy.contiguous()
+    if tokens.stride(1) != 1:
+        tokens = tokens.contiguous()
+    dw = torch.zeros(vocab, C, dtype=dy.dtype, device=dy.device)
+    _hip.check(_hip.lib().pnmn_embedding_grad(dy.data_ptr(), tokens.data_ptr(), tokens.stride(0), B, T, C, vocab, int(shift),
+                                              start, skip, dw.data_ptr(), _hip.stream_ptr(dy.device)), "embedding_grad")
+    return dw
+
+
 class _LinearRows(torch.autograd.Function):
     """``F.linear`` over B x T rows whose weight gradient goes through ``wgrad_gemm`` (autograd's
     plain ``dy.t() @ x`` has 32 output tiles and a 47 000-long reduction at these shapes)."""
@@ -116,9 +275,9 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> to
 
 
 class _EmbeddingLookup(torch.autograd.Function):
-    """``F.embedding`` whose weight gradient is a (one-hot) GEMM: the vocabularies here have < 100
-    entries, so the scatter-add of B x T rows into them that torch's backward does (sort + segmented
-    reduction, ~0.4 ms per call) is a 96-column GEMM over the same rows."""
+    """``F.embedding`` whose weight gradient is one kernel: the vocabularies here have < 100 entries, so the
+    scatter-add of B x T rows into them that torch's backward does (sort + segmented reduction, ~0.4 ms per
+    call) is a sum into an LDS-resident table (``pnmn_embedding_grad``; larger vocabularies: a one-hot GEMM)."""
 
     @staticmethod
     def forward(ctx, weight, tokens, padding_idx):
@@ -129,6 +288,9 @@ class _EmbeddingLookup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (tokens,) = ctx.saved_tensors
+        if ctx.vocab <= 128 and dy.size(-1) % 64 == 0 and tokens.dim() == 2:
+            skip = ctx.padding_idx if ctx.padding_idx is not None else -1
+            return embedding_grad(dy, tokens, ctx.vocab, skip=skip), None, None
         flat = tokens.reshape(-1)
         onehot = torch.zeros(flat.numel(), ctx.vocab, dtype=dy.dtype, device=dy.device)
         onehot.scatter_(1, flat.unsqueeze(1), 1.0)
@@ -170,16 +332,18 @@ class _LSTMLayerSeq(torch.autograd.Function):
     hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states."""
 
     @staticmethod
-    def forward(ctx, xp, w_hh):
+    def forward(ctx, xp, w_hh, wp=None, w_t=None):
         if xp.device.type != "cuda":
             raise _hip.HipLibraryError("LSTM layer on %s: the HIP path needs a ROCm device (no CPU fallback)" % xp.device)
-        xp, w = xp.contiguous(), w_hh.detach().contiguous()
+        xp, w = xp.contiguous(), w_hh.detach()
         B, T, H4 = xp.shape
         Hd = H4 // 4
         hs = torch.empty(B, T, Hd, dtype=xp.dtype, device=xp.device)
         cs = torch.empty_like(hs)
         act = torch.empty_like(xp)
-        wp = pack_fragments(w)
+        if wp is None:
+            wp = pack_fragments(w)
+        ctx.w_t = w_t  # (fragment order of W_hh^T from the model's DerivedParams, else packed in backward)
         ws = _lstm_workspace(B, False, xp.device)
         _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), wp.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
                                                 B, T, Hd, ws.data_ptr() if ws is not None else None,
@@ -192,7 +356,7 @@ class _LSTMLayerSeq(torch.autograd.Function):
         hs, cs, act, w = ctx.saved_tensors
         B, T, Hd = hs.shape
         dhs = dhs.contiguous()
-        w_t = pack_fragments(w.t())  # W_hh^T [H][4H], fragment order
+        w_t = ctx.w_t if ctx.w_t is not None else pack_fragments(w.t())  # W_hh^T [H][4H], fragment order
         dgates = torch.empty_like(act)
         ws = _lstm_workspace(B, True, hs.device)
         _hip.check(_hip.lib().pnmn_lstm_seq_bwd(dhs.data_ptr(), act.data_ptr(), cs.data_ptr(), w_t.data_ptr(),
@@ -202,7 +366,7 @@ class _LSTMLayerSeq(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             hprev = torch.cat((hs.new_zeros(B, 1, Hd), hs[:, :-1]), 1).reshape(B * T, Hd)  # h_{t-1} per (row, step)
             dw_hh = wgrad_gemm(dgates.reshape(B * T, 4 * Hd), hprev)
-        return dgates, dw_hh
+        return dgates, dw_hh, None, None
 
 
 class _AttnLSTMDecoder(torch.autograd.Function):
@@ -214,13 +378,19 @@ class _AttnLSTMDecoder(torch.autograd.Function):
     Weight gradients are batched GEMMs over what the kernels saved."""
 
     @staticmethod
-    def forward(ctx, xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, mode, T, seed, row_offset, pad, unk, start):
+    def forward(ctx, xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, mode, T, seed, row_offset, pad, unk, start,
+                packs=None):
         dev = enc.device
         if dev.type != "cuda":
             raise _hip.HipLibraryError("decoder on %s: the HIP path needs a ROCm device (no CPU fallback)" % dev)
         enc, mask, h0 = enc.contiguous(), mask.contiguous(), h0.contiguous()
-        w_c, w_hh = w_c.detach().contiguous(), w_hh.detach().contiguous()
-        w_c_p, w_hh_p = pack_fragments(w_c), pack_fragments(w_hh)
+        w_c, w_hh = w_c.detach(), w_hh.detach()
+        if packs is not None:  # (w_c, w_hh, w_c^T, w_hh^T in fragment order, from the model's DerivedParams)
+            w_c_p, w_hh_p = packs[0], packs[1]
+            ctx.packs_t = (packs[2], packs[3])
+        else:
+            w_c_p, w_hh_p = pack_fragments(w_c), pack_fragments(w_hh)
+            ctx.packs_t = None
         B, S, Hd = enc.shape
         f = dict(dtype=torch.float32, device=dev)
         hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
@@ -261,7 +431,8 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         dgates = torch.empty_like(act)
         dh0 = torch.empty_like(h0)
         # (named temporaries: a tensor that dies right after .data_ptr() may be recycled by the next allocation)
-        dhs_c, w_c_t, w_hh_t = dhs.contiguous(), pack_fragments(w_c.t()), pack_fragments(w_hh.t())
+        dhs_c = dhs.contiguous()
+        w_c_t, w_hh_t = ctx.packs_t if ctx.packs_t is not None else (pack_fragments(w_c.t()), pack_fragments(w_hh.t()))
         hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1)  # h_{t-1} of every (row, step)
         ws = _decoder_workspace(B, True, dev)
         if ws is not None:
@@ -288,9 +459,12 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         if ctx.mode == 0:
             dxe = dgates
         else:
-            tok_in = torch.cat((tokens.new_full((B, 1), ctx.start), tokens[:, :-1]), 1).reshape(-1)
-            detable = torch.zeros(ctx.vocab, 4 * Hd, dtype=dgates.dtype, device=dev).index_add_(0, tok_in, flat)
-        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 9
+            if ctx.vocab <= 128:  # step t's input is the token chosen at step t - 1 (@start@ first)
+                detable = embedding_grad(dgates, tokens, ctx.vocab, shift=True, start=ctx.start)
+            else:
+                tok_in = torch.cat((tokens.new_full((B, 1), ctx.start), tokens[:, :-1]), 1).reshape(-1)
+                detable = torch.zeros(ctx.vocab, 4 * Hd, dtype=dgates.dtype, device=dev).index_add_(0, tok_in, flat)
+        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 10
 
 
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
@@ -383,35 +557,54 @@ def token_projection(embedding: nn.Embedding, tokens: torch.Tensor, weight: torc
     embedding rows once (a [V, 4H] table) and gather table rows per token, instead of a GEMM over all
     B x T rows; backward is the one-hot GEMM of ``_EmbeddingLookup`` into the table and a V-row GEMM
     from there.  The padding row of ``embedding`` (all zeros, no gradient) keeps both properties."""
-    w = embedding.weight
-    if embedding.padding_idx is not None:
-        keep = torch.ones(w.size(0), 1, dtype=w.dtype, device=w.device)
-        keep[embedding.padding_idx] = 0.0
-        w = w * keep  # value unchanged (the row is zero); stops the gradient into the padding row
-    table = F.linear(w, weight, bias)
     if tokens.device.type != "cuda" or not torch.is_grad_enabled():
-        return F.embedding(tokens, table)
+        return F.embedding(tokens, F.linear(embedding.weight, weight, bias))
+    table = _TokenTable.apply(embedding.weight, weight, bias, embedding.padding_idx)
     return _EmbeddingLookup.apply(table, tokens, None)
 
 
-def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projection: Optional[torch.Tensor] = None) -> torch.Tensor:
+def lstm_derived_specs(lstm: nn.LSTM, prefix: str = "l"):
+    """DerivedParams specs of an ``nn.LSTM``: per layer the fragment-order W_hh, its transpose and b_ih + b_hh."""
+    specs = []
+    for layer in range(lstm.num_layers):
+        w_hh = getattr(lstm, "weight_hh_l%d" % layer)
+        specs.append(("%s%d.hh" % (prefix, layer), "pack", w_hh, None))
+        specs.append(("%s%d.hhT" % (prefix, layer), "packT", w_hh, None))
+        specs.append(("%s%d.b" % (prefix, layer), "sum", getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)))
+    return specs
+
+
+def lstm_bias(lstm: nn.LSTM, layer: int, derived: Optional[Dict[str, torch.Tensor]], prefix: str = "l") -> torch.Tensor:
+    b_ih, b_hh = getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)
+    if derived is None:
+        return b_ih + b_hh
+    return _Alias.apply(b_ih, b_hh, derived["%s%d.b" % (prefix, layer)])
+
+
+def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projection: Optional[torch.Tensor] = None,
+                derived: Optional[Dict[str, torch.Tensor]] = None, last: Optional[torch.Tensor] = None):
     """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
     length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
     input GEMM batched over time and the recurrence in one persistent HIP kernel per layer.
     ``first_projection``: the first layer's input projection when the caller already has it
-    (``token_projection``); ``x`` is then unused."""
+    (``token_projection``); ``x`` is then unused.  ``derived``: the model's ``DerivedParams`` output (packed
+    weights, bias sums).  ``last`` ([B] int32, ``mask`` then being the float mask): also return each row's
+    state at that step -- (outputs, last states) from one launch."""
     B, T = mask.shape
     inp = x
     for layer in range(lstm.num_layers):
         w_ih = getattr(lstm, "weight_ih_l%d" % layer)
         w_hh = getattr(lstm, "weight_hh_l%d" % layer)
-        bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
         if layer == 0 and first_projection is not None:
             xp = first_projection
         else:
-            xp = linear_rows(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
+            xp = linear_rows(inp, w_ih, lstm_bias(lstm, layer, derived))  # (B,T,4H): one GEMM for all time steps
         if lstm.hidden_size == 256:
-            inp = _LSTMLayerSeq.apply(xp, w_hh)  # one persistent launch for all T steps
+            # one persistent launch for all T steps
+            if derived is not None:
+                inp = _LSTMLayerSeq.apply(xp, w_hh, derived["l%d.hh" % layer], derived["l%d.hhT" % layer])
+            else:
+                inp = _LSTMLayerSeq.apply(xp, w_hh)
         else:  # other widths: step by step (GEMM per step + the cell kernel)
             h = xp.new_zeros(B, lstm.hidden_size)
             c = xp.new_zeros(B, lstm.hidden_size)
@@ -422,6 +615,8 @@ def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projec
                 h, c = lstm_cell_pointwise(gates, c)
                 outs.append(h)
             inp = torch.stack(outs, 1)
+    if last is not None:
+        return _MaskAndLast.apply(inp, mask, last)
     return inp * mask.unsqueeze(-1).to(inp.dtype)
 
 
@@ -453,12 +648,13 @@ class _Encoder(nn.Module):
     def forward(self, x, mask):
         return masked_lstm(self._module, x, mask)
 
-    def forward_tokens(self, embedding: nn.Embedding, tokens: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    def forward_tokens(self, embedding: nn.Embedding, tokens: torch.Tensor, mask: torch.Tensor,
+                       derived: Optional[Dict[str, torch.Tensor]] = None, last: Optional[torch.Tensor] = None):
         """``forward(embedding(tokens), mask)`` with the first layer's input projection taken from a
-        per-token table (``token_projection``)."""
+        per-token table (``token_projection``); with ``last`` also each row's state at that step."""
         lstm = self._module
-        xp = token_projection(embedding, tokens, lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
-        return masked_lstm(lstm, None, mask, first_projection=xp)
+        xp = token_projection(embedding, tokens, lstm.weight_ih_l0, lstm_bias(lstm, 0, derived))
+        return masked_lstm(lstm, None, mask, first_projection=xp, derived=derived, last=last)
 
 
 class Seq2SeqBase(nn.Module):
@@ -502,6 +698,21 @@ class Seq2SeqBase(nn.Module):
         self._bleu = BLEU(exclude_indices={self._pad_index, self._end_index, self._start_index})
         # row offset of this rank's shard in the global batch (keeps the sample stream shard-invariant)
         self.sample_row_offset = 0
+        self.__dict__["_derived_cache"] = DerivedParams()  # (not a submodule, not part of the state_dict)
+
+    def _derived(self) -> Optional[Dict[str, torch.Tensor]]:
+        """Packed recurrent weights and bias sums of this model (``DerivedParams``), None for shapes the
+        persistent kernels are not built for."""
+        lstm, cell = self._encoder._module, self._decoder_cell
+        Hd = cell.hidden_size
+        if lstm.hidden_size != 256 or Hd != 256 or lstm.weight_hh_l0.device.type != "cuda":
+            return None
+        w_c = cell.weight_ih[:, :Hd]
+        specs = lstm_derived_specs(lstm) + [
+            ("d.c", "pack", w_c, None), ("d.hh", "pack", cell.weight_hh, None),
+            ("d.cT", "packT", w_c, None), ("d.hhT", "packT", cell.weight_hh, None),
+            ("d.b", "sum", cell.bias_ih, cell.bias_hh)]
+        return self._derived_cache.get(specs)
 
     # ---------------------------------------------------------------------------------------------
     def forward(
@@ -520,11 +731,10 @@ class Seq2SeqBase(nn.Module):
         if source_tokens.device.type != "cuda":
             raise _hip.HipLibraryError("seq2seq input on %s: the HIP path needs a ROCm device" % source_tokens.device)
         pad, bos, eos = self._pad_index, self._start_index, self._end_index
-        src = add_sentence_boundary_token_ids(source_tokens, pad, bos, eos)[:, 1:]  # @start@ is not encoded
-        src_mask = src != pad
-        enc = self._encoder.forward_tokens(self._source_embedder.embedding, src, src_mask)
-        rows = torch.arange(src.size(0), device=src.device)
-        return {"enc": enc, "h": enc[rows, src_mask.sum(1) - 1], "fmask": src_mask.float()}
+        # boundaries (@start@ is not encoded), mask and index of the last real token: one launch
+        src, fmask, last = _TokenPrep.run(source_tokens, pad, bos, eos, drop_first=True, want_mask=True)
+        enc, h = self._encoder.forward_tokens(self._source_embedder.embedding, src, fmask, derived=self._derived(), last=last)
+        return {"enc": enc, "h": h, "fmask": fmask}
 
     @staticmethod
     def select_rows(state: Dict[str, torch.Tensor], rows: torch.LongTensor) -> Dict[str, torch.Tensor]:
@@ -545,9 +755,8 @@ class Seq2SeqBase(nn.Module):
         enc, h, fmask = state["enc"], state["h"], state["fmask"]
         tgt = None
         if target_tokens is not None:
-            tgt = add_sentence_boundary_token_ids(target_tokens, pad, bos, eos)
+            tgt = _TokenPrep.run(target_tokens, pad, bos, eos, drop_first=False, want_mask=False)[0]
         B = enc.size(0)
-        c = torch.zeros_like(h)
 
         steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
         greedy = decoding_strategy == "greedy"
@@ -555,11 +764,17 @@ class Seq2SeqBase(nn.Module):
         Hd = h.size(1)
         w_ih = self._decoder_cell.weight_ih
         w_c, w_e = w_ih[:, :Hd], w_ih[:, Hd:]  # the cell's input is cat(attended, embedding)
-        bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
         w_p, b_p = self._output_projection_layer.weight, self._output_projection_layer.bias
         fused = Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128
+        derived = self._derived() if fused else None
+        if derived is not None:
+            bias = _Alias.apply(self._decoder_cell.bias_ih, self._decoder_cell.bias_hh, derived["d.b"])
+            packs = (derived["d.c"], derived["d.hh"], derived["d.cT"], derived["d.hhT"])
+        else:
+            bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
+            packs = None
         if fused:
-            args = (pad, self._unk_index, bos)
+            args = (pad, self._unk_index, bos, packs)
             if tgt is not None:  # teacher forcing: every step's input embedding is known up front
                 xe = token_projection(self._target_embedder, tgt[:, :steps], w_e, bias)
                 hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
@@ -582,7 +797,7 @@ class Seq2SeqBase(nn.Module):
             ce = output_dict["loss"]
             predictions = output_dict.get("predictions")
         else:
-            raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, c, tgt, steps, greedy, seed)
+            raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, torch.zeros_like(h), tgt, steps, greedy, seed)
             predictions = self._trim_predictions(raw)
             pmask = (predictions != pad).float()
             sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
@@ -626,6 +841,13 @@ class Seq2SeqBase(nn.Module):
     def _trim_predictions(self, predictions: torch.LongTensor) -> torch.LongTensor:
         """Keep each row up to and including its first @end@; a row starting with @end@ becomes all
         padding, a row without @end@ is kept whole (reference :278-293), without leaving the device."""
+        if predictions.device.type == "cuda" and predictions.dtype == torch.long and predictions.dim() == 2:
+            predictions = predictions.contiguous()
+            out = torch.empty_like(predictions)
+            _hip.check(_hip.lib().pnmn_trim_predictions(predictions.data_ptr(), predictions.size(0), predictions.size(1),
+                                                        self._end_index, out.data_ptr(), _hip.stream_ptr(predictions.device)),
+                       "trim_predictions")
+            return out
         steps = predictions.size(1)
         is_end = predictions == self._end_index
         has_end = is_end.any(1, keepdim=True)

@@ -29,6 +29,16 @@ from torch import nn
 from probnmn import _hip
 
 
+_PARAMETER_EPOCH = 0
+
+
+def parameter_epoch() -> int:
+    """Counts the fused optimiser steps of this process.  ``pnmn_clamp_adam`` writes the parameters through
+    their pointers, which bumps no tensor version counter; caches of derived parameters
+    (``probnmn.modules.seq2seq_base.DerivedParams``) key on this as well."""
+    return _PARAMETER_EPOCH
+
+
 class ClampAdam(torch.optim.Optimizer):
     def __init__(
         self,
@@ -118,6 +128,8 @@ class ClampAdam(torch.optim.Optimizer):
     def step(self, closure=None) -> None:
         if closure is not None:
             raise ValueError("ClampAdam.step takes no closure")
+        global _PARAMETER_EPOCH
+        _PARAMETER_EPOCH += 1
         group = self.param_groups[0]
         self.step_count += 1
         items = []

@@ -364,6 +364,8 @@ class BatchScheduler:
                 _, inv, cnt = np.unique(lv.astype(np.int64) * (1 << 48) + (a_g[m] >> 4).astype(np.int64) * masked,
                                         return_inverse=True, return_counts=True)
                 sole = masked & (cnt[inv] == 1) & self.sole_writer_rmw
+                if os.environ.get("PNMN_MB_SOLE") == "2":  # timing experiment only (wrong gradients)
+                    sole = masked
                 dg[:, 7] = dil[m] + np.where(masked, 4 << 32, 0) + np.where(sole, 8 << 32, 0)
                 dg[:, 8] = np.where(masked, a_f[m], 0)
                 dg[:, 9] = mask_ptr

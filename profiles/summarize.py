@@ -47,8 +47,40 @@ def pmc(path):
         print("%-72s %-12s %8d %14.1f %12.2f" % (name.replace(".kd", "")[:72], ctr, n, tot, avg))
 
 
+def steady(path, nsteps):
+    """Per-STEP kernel table of the last `nsteps` training iterations of the trace (an iteration ends with its
+    clamp_adam_kernel dispatch): what the timed region of bench.py looks like without the set-up work."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
+    suffix = tab.replace("rocpd_kernel_dispatch", "")
+    rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch{suffix} d
+                                join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id order by d.start"""))
+    marks = [r[2] for r in rows if "clamp_adam_kernel" in r[0]]
+    t0, t1 = marks[-nsteps - 1], marks[-1]
+    win = [r for r in rows if r[1] >= t0 and r[2] <= t1]
+    agg = {}
+    for name, a, b in win:
+        e = agg.setdefault(name.replace(".kd", ""), [0, 0])
+        e[0] += 1
+        e[1] += b - a
+    busy, cur_end = 0, t0
+    for _, a, b in win:  # union of the kernel intervals (two streams overlap)
+        if b > cur_end:
+            busy += b - max(a, cur_end)
+            cur_end = b
+    total = sum(v[1] for v in agg.values())
+    print("# last %d iterations of %s: %.3f ms per iteration wall, %.3f ms GPU busy (union), %.3f ms sum of kernels, %d dispatches per iteration"
+          % (nsteps, path, (t1 - t0) / 1e6 / nsteps, busy / 1e6 / nsteps, total / 1e6 / nsteps, len(win) // nsteps))
+    print("%-88s %10s %12s %10s %6s" % ("kernel", "calls/it", "ms/it", "avg_us", "pct"))
+    for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-88s %10.1f %12.4f %10.1f %6.2f" % (name[:88], n / nsteps, t / 1e6 / nsteps, t / 1e3 / n, 100.0 * t / total))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--pmc":
         pmc(sys.argv[2])
+    elif sys.argv[1] == "--steady":
+        steady(sys.argv[3], int(sys.argv[2]))
     else:
         main(sys.argv[1])

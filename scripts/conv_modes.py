@@ -24,7 +24,11 @@ for n in (16, 32, 64, 96, 128, 192, 256, 320, 384, 512, 768, 1024):
     rec = np.zeros(n, _hip.CONV_ITEM)
     e = np.arange(n, dtype=np.int64)
     rec["in"], rec["mask"], rec["out"] = x.data_ptr() + e * HW * C * 4, m.data_ptr() + e * HW * 4, y.data_ptr() + e * HW * C * 4
-    rec["weight"] = np.asarray([ws[i % 15].data_ptr() for i in range(n)], dtype=np.uint64)
+    NW = int(os.environ.get("NW", "15"))
+    if os.environ.get("SORTED"):
+        rec["weight"] = np.asarray([ws[i * NW // n].data_ptr() for i in range(n)], dtype=np.uint64)
+    else:
+        rec["weight"] = np.asarray([ws[i % NW].data_ptr() for i in range(n)], dtype=np.uint64)
     rec["bias"], rec["dilation"] = b.data_ptr(), 1
     items = _hip.to_device(rec, dev)
     st = _hip.stream_ptr(dev)
