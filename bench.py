@@ -41,7 +41,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "probnmn-clevr_amd")):
+# (PNMN_PKG_DIR: A/B aid -- time another checkout of the package against the same library, scripts/ab.sh)
+for p in (ROOT, os.environ.get("PNMN_PKG_DIR") or os.path.join(ROOT, "probnmn-clevr_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

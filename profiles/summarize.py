@@ -77,8 +77,34 @@ def steady(path, nsteps):
         print("%-88s %10.1f %12.4f %10.1f %6.2f" % (name[:88], n / nsteps, t / 1e6 / nsteps, t / 1e3 / n, 100.0 * t / total))
 
 
+def timeline(path):
+    """Every dispatch of the LAST training iteration in start order: offset, duration, queue, kernel."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
+    suffix = tab.replace("rocpd_kernel_dispatch", "")
+    cols = [r[1] for r in cur.execute(f"pragma table_info({tab})")]
+    qcol = "d.stream_id" if "stream_id" in cols else ("d.queue_id" if "queue_id" in cols else "0")
+    rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end, {qcol} from rocpd_kernel_dispatch{suffix} d
+                                join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id order by d.start"""))
+    marks = [r[2] for r in rows if "clamp_adam_kernel" in r[0]]
+    t0, t1 = marks[-2], marks[-1]
+    print("# columns of %s: %s" % (tab, ", ".join(cols)))
+    print("# last iteration: %.3f ms" % ((t1 - t0) / 1e6))
+    prev_end = {}
+    for name, a, b, q in rows:
+        if a < t0 or b > t1:
+            continue
+        gap = (a - prev_end[q]) / 1e3 if q in prev_end else 0.0
+        prev_end[q] = b
+        short = name.replace(".kd", "").replace("_ZN12_GLOBAL__N_1", "").replace("_ZN2at6native", "at::")[:70]
+        print("%9.1f us  +%8.1f us  gap %7.1f  q%-3s %s" % ((a - t0) / 1e3, (b - a) / 1e3, gap, q, short))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--pmc":
+    if sys.argv[1] == "--timeline":
+        timeline(sys.argv[2])
+    elif sys.argv[1] == "--pmc":
         pmc(sys.argv[2])
     elif sys.argv[1] == "--steady":
         steady(sys.argv[3], int(sys.argv[2]))

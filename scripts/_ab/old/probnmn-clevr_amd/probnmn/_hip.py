@@ -56,12 +56,6 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_seq_nll_fwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _I, _I, _I, _F, _P),
     "pnmn_seq_nll_bwd": (_P, ctypes.c_int64, _P, ctypes.c_int64, _P, ctypes.c_int64, _I, _P, _P, _P, ctypes.c_int64,
                          _I, _I, _I, _F, _P),
-    "pnmn_token_prep": (_P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P),
-    "pnmn_trim_predictions": (_P, _I, _I, _I, _P, _P),
-    "pnmn_mask_last_fwd": (_P, _P, _P, _I, _I, _I, _P, _P, _P),
-    "pnmn_mask_last_bwd": (_P, _P, _P, _P, _I, _I, _I, _P, _P),
-    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _P, _P),
-    "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
@@ -183,7 +177,6 @@ MINMAX_ITEM = np.dtype(
 )
 MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats", _u64), ("dattn", _u64)])
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
-DERIVE_JOB = np.dtype([("src", _u64), ("src2", _u64), ("dst", _u64), ("n", _i32), ("k", _i32), ("ld", _i32), ("kind", _i32)])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
@@ -226,7 +219,6 @@ ITEM_SIZES = {
     "pnmn_maskbwd_item": (MASKBWD_ITEM, 40),
     "pnmn_axpy_item": (AXPY_ITEM, 24),
     "pnmn_adam_item": (ADAM_ITEM, 40),
-    "pnmn_derive_job": (DERIVE_JOB, 40),
 }
 
 
@@ -240,50 +232,33 @@ class _PinnedRing:
     ``Tensor.pin_memory()`` costs a hipHostMalloc (milliseconds) per call; a training step uploads
     its work lists every iteration, so staging memory is allocated once and recycled.  A slot is
     reused only after the copy that last read it has completed (event), which lets the host run
-    several steps ahead of the GPU without overwriting bytes that are still to be copied.
-    Two size classes: many fixed 16 KiB slots carved out of one allocation for the short records (optimiser
-    items, derived-parameter jobs, index vectors: a copy is stream ordered, so waiting for a slot means
-    waiting for everything queued before its last use -- with few slots the host could never run ahead), and a
-    few growable slots for the per-step work lists."""
-
-    SMALL, SMALL_SLOTS = 16 << 10, 64
+    several steps ahead of the GPU without overwriting bytes that are still to be copied."""
 
     def __init__(self, slots: int = 6):
         self._bufs = [None] * slots
         self._events = [None] * slots
         self._next = 0
-        self._small = None
-        self._small_events = [None] * self.SMALL_SLOTS
-        self._small_next = 0
         self.wait_seconds = 0.0  # time the host spent blocked on the GPU (diagnostic)
 
-    def _wait(self, ev) -> None:
+    def stage(self, raw: np.ndarray, device: torch.device) -> torch.Tensor:
+        i = self._next
+        self._next = (i + 1) % len(self._bufs)
+        ev = self._events[i]
         if ev is not None and not ev.query():
             t0 = time.perf_counter()
-            ev.synchronize()  # the host is far ahead of the GPU: wait for the slot
+            ev.synchronize()  # the host is >= 2 steps ahead of the GPU: wait for the slot
             self.wait_seconds += time.perf_counter() - t0
-
-    def stage(self, raw: np.ndarray, device: torch.device) -> torch.Tensor:
         n = raw.size
-        if n <= self.SMALL:
-            if self._small is None:
-                self._small = torch.empty(self.SMALL * self.SMALL_SLOTS, dtype=torch.uint8).pin_memory()
-            i = self._small_next
-            self._small_next = (i + 1) % self.SMALL_SLOTS
-            events, buf = self._small_events, self._small[i * self.SMALL:(i + 1) * self.SMALL]
-        else:
-            i = self._next
-            self._next = (i + 1) % len(self._bufs)
-            events, buf = self._events, self._bufs[i]
-        self._wait(events[i])
+        buf = self._bufs[i]
         if buf is None or buf.numel() < n:
             buf = torch.empty(max(n * 2, 1 << 16), dtype=torch.uint8).pin_memory()
             self._bufs[i] = buf
         buf.numpy()[:n] = raw
         out = buf[:n].to(device, non_blocking=True)
-        if events[i] is None:
-            events[i] = torch.cuda.Event()
-        events[i].record(torch.cuda.current_stream(device))
+        if ev is None:
+            ev = torch.cuda.Event()
+            self._events[i] = ev
+        ev.record(torch.cuda.current_stream(device))
         return out
 
 

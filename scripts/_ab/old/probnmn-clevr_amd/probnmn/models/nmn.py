@@ -1,0 +1,222 @@
+"""``NeuralModuleNetwork`` -- class surface of the reference's ``probnmn.models.nmn`` (reference:
+probnmn/models/nmn.py:23-296) executed by the gfx950 engine.
+
+Same constructor / ``from_config`` arguments, same submodule and ``state_dict`` names (``stem.0``,
+``stem.2``, ``classifier.{0,4,6}``, one child per program token), same ``forward`` signature and
+return dict.  What differs is how ``forward`` gets there: programs are compiled statically
+(validity included -- the reference's bare ``except`` is not reproduced, kernel errors surface),
+all module calls of the batch run as grouped kernels, and stem / classifier conv / max-pool are
+part of the same explicit forward+backward schedule (``probnmn.runtime.engine``).
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from probnmn.modules.nmn_modules import (
+    AndModule,
+    AttentionModule,
+    ComparisonModule,
+    Flatten,
+    OrModule,
+    QueryModule,
+    RelateModule,
+    SameModule,
+)
+from probnmn.runtime import program_compiler as pc
+from probnmn.running_metrics import Average, BooleanAccuracy
+
+INVALID_PROGRAM_LOSS = 3.33  # ~ ln(28), the reference's constant (nmn.py:260,269)
+
+
+class _Trunk(torch.autograd.Function):
+    """stem -> module programs -> classifier conv + max-pool, as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, features, engine, compiled, started, *params):
+        need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
+        pooled, state = engine.run_forward(features, compiled, need_backward, started)
+        ctx.engine, ctx.state, ctx.n_params = engine, state, len(params)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        if ctx.state is None:
+            raise RuntimeError("backward through a forward that was run without gradient tracking")
+        grads = ctx.engine.run_backward(ctx.state, dpooled)
+        return (None, None, None, None, *grads[: ctx.n_params])
+
+
+class _AnswerLoss(torch.autograd.Function):
+    """``pnmn_answer_loss``: log-softmax over the answers, arg-max prediction, cross entropy, the
+    invalid-program overrides (prediction @@UNKNOWN@@, constant loss 3.33, no gradient) and d loss / d logits
+    in one launch (reference nmn.py:245-269)."""
+
+    @staticmethod
+    def forward(ctx, logits, answers, valid, unknown_index):
+        from probnmn import _hip
+
+        logits = logits.contiguous()
+        B, A = logits.shape
+        dev = logits.device
+        predictions = torch.empty(B, dtype=torch.long, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        dlogits = torch.empty(B, A, dtype=torch.float32, device=dev) if answers is not None else None
+        _hip.check(_hip.lib().pnmn_answer_loss(
+            logits.data_ptr(), 0 if answers is None else answers.data_ptr(), valid.data_ptr(), predictions.data_ptr(),
+            loss.data_ptr(), 0 if dlogits is None else dlogits.data_ptr(), B, A, unknown_index, 1.0,
+            _hip.stream_ptr(dev)), "answer_loss")
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(predictions)
+        return loss, predictions
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (dlogits,) = ctx.saved_tensors
+        if dlogits is None:
+            raise RuntimeError("the answer loss without answers (-max log-probability) is an evaluation quantity")
+        return dlogits * dloss.unsqueeze(1), None, None, None
+
+
+class NeuralModuleNetwork(nn.Module):
+    def __init__(
+        self,
+        vocabulary,
+        image_feature_size: Tuple[int, int, int] = (1024, 14, 14),
+        module_channels: int = 128,
+        class_projection_channels: int = 1024,
+        classifier_linear_size: int = 1024,
+    ):
+        super().__init__()
+        self.vocabulary = vocabulary
+        channels, height, width = image_feature_size
+        # "@@UNKNOWN@@" is never produced by the classifier (reference nmn.py:60-63)
+        num_answers = len(vocabulary.get_index_to_token_vocabulary(namespace="answers")) - 1
+
+        self.stem = nn.Sequential(
+            nn.Conv2d(channels, module_channels, kernel_size=3, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(module_channels, module_channels, kernel_size=3, padding=1),
+            nn.ReLU(),
+        )
+        self.classifier = nn.Sequential(
+            nn.Conv2d(module_channels, class_projection_channels, kernel_size=1),
+            nn.ReLU(),
+            nn.MaxPool2d(kernel_size=2, stride=2),
+            Flatten(),
+            nn.Linear(class_projection_channels * height * width // 4, classifier_linear_size),
+            nn.ReLU(),
+            nn.Linear(classifier_linear_size, num_answers),
+        )
+
+        # one child module per program token, named by the token (reference nmn.py:86-115)
+        self._function_modules: Dict[str, Optional[nn.Module]] = {}
+        factories = {pc.AND: AndModule, pc.OR: OrModule}
+        sized = {pc.CMP: ComparisonModule, pc.QUERY: QueryModule, pc.REL: RelateModule,
+                 pc.SAME: SameModule, pc.ATT: AttentionModule}
+        for token in vocabulary.get_token_to_index_vocabulary("programs"):
+            kind = pc.classify_token(token)
+            if kind == pc.SKIP:
+                continue
+            if kind == pc.SCENE:
+                module = None
+            elif kind in factories:
+                module = factories[kind]()
+            else:
+                module = sized[kind](module_channels)
+            self._function_modules[token] = module
+            self.add_module(token, module)
+
+        self._unknown_answer = vocabulary.get_token_index("@@UNKNOWN@@", namespace="answers")
+        self._answer_accuracy = BooleanAccuracy()
+        self._average_invalid_programs = Average()
+        # reference behaviour: every training forward returns batch metrics as Python floats, which
+        # costs a device->host sync per step; trainers that log less often switch this off
+        self.report_batch_metrics = True
+
+        from probnmn.runtime.engine import NMNEngine
+
+        self._engine = NMNEngine(self, tuple(image_feature_size), module_channels, class_projection_channels)
+
+    @classmethod
+    def from_config(cls, config):
+        from probnmn.vocabulary import Vocabulary
+
+        _C = config
+        return cls(
+            vocabulary=Vocabulary.from_files(_C.DATA.VOCABULARY),
+            image_feature_size=tuple(_C.NMN.IMAGE_FEATURE_SIZE),
+            module_channels=_C.NMN.MODULE_CHANNELS,
+            class_projection_channels=_C.NMN.CLASS_PROJECTION_CHANNELS,
+            classifier_linear_size=_C.NMN.CLASSIFIER_LINEAR_SIZE,
+        )
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None,
+                started=None, trunk_stream=None):
+        # ``started``: token of ``begin(features)`` when the caller already launched the stem (optional)
+        # ``trunk_stream``: run the trunk (stem, module programs, classifier conv + pool -- this build's own
+        # kernels, none of which waits for another workgroup) on that stream, forward and backward, beside
+        # whatever the caller queues on the current stream; the fully connected layers and the loss stay on
+        # the current stream (see DESIGN 6 for why the library GEMMs must not leave it)
+        engine = self._engine
+        arena = engine.ensure_arena()
+        # the programs decide the launch schedule, so they are needed on the host (the reference
+        # also reads them back, once per example: nmn.py:203)
+        # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
+        compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
+        from probnmn import _hip
+
+        valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, features.device)
+
+        # the trunk's parameters as inputs of its autograd node -- all of them when autograd is to receive
+        # their gradients; ONE anchor when a trainer reads the gradients straight from the arena
+        # (engine.direct_grads): 218 inputs cost ~0.5 ms of host time per step in apply() and in 218
+        # AccumulateGrad visits that carry nothing
+        params = [arena.param(n) for n in arena.names]
+        if engine.direct_grads:
+            params = params[:1]
+        if trunk_stream is not None:
+            current = torch.cuda.current_stream(features.device)
+            with torch.cuda.stream(trunk_stream):
+                pooled = _Trunk.apply(features, engine, compiled, started, *params)
+            current.wait_stream(trunk_stream)
+            pooled.record_stream(current)
+        else:
+            pooled = _Trunk.apply(features, engine, compiled, started, *params)
+        hidden = F.relu(self.classifier[4](pooled))
+        answer_logits = self.classifier[6](hidden)
+        _hip.mark("classifier FC forward done")
+        if answer_logits.requires_grad:
+            answer_logits.register_hook(lambda g: _hip.mark("d(answer logits) arrives"))
+            pooled.register_hook(lambda g: _hip.mark("d(pooled) computed (FC backward done)"))
+
+        # log-softmax, arg-max, cross entropy (or -max log-probability without answers) and the
+        # invalid-program overrides -- prediction @@UNKNOWN@@, constant loss 3.33, no gradient -- in one kernel
+        if answers is not None:
+            answers = answers.contiguous()
+        loss, answer_predictions = _AnswerLoss.apply(answer_logits, answers, valid, self._unknown_answer)
+        if answers is not None and (self.report_batch_metrics or not self.training):
+            self._answer_accuracy(answer_predictions, answers)
+            self._average_invalid_programs(sum(1 for p in compiled if not p.valid))
+
+        output_dict = {"predictions": answer_predictions, "loss": loss}
+        if self.training and self.report_batch_metrics:
+            output_dict["metrics"] = self.get_metrics(reset=True)
+        return output_dict
+
+    def begin(self, features: torch.Tensor):
+        """Launch the program-independent part of ``forward`` (feature layout + stem) ahead of time;
+        pass the returned token as ``forward(..., started=token)`` with the same ``features``."""
+        trains = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return self._engine.begin_forward(features, trains)
+
+    def get_metrics(self, reset: bool = True) -> Dict[str, float]:
+        return {
+            "answer_accuracy": self._answer_accuracy.get_metric(reset=reset),
+            "average_invalid": self._average_invalid_programs.get_metric(reset=reset),
+        }

@@ -1,0 +1,658 @@
+"""``Seq2SeqBase`` -- class surface of the reference's ``probnmn.modules.seq2seq_base`` (reference:
+probnmn/modules/seq2seq_base.py:19-375), without AllenNLP.
+
+The reference subclasses ``allennlp.models.encoder_decoders.SimpleSeq2Seq`` (AllenNLP 0.9.0, not
+part of this build); the pieces it inherits are restated here from the reference's call sites
+and SURVEY.md App. A: token embedder with a zero padding row, a 2-layer LSTM encoder over packed
+sequences, dot-product attention with AllenNLP's ``masked_softmax``, an ``LSTMCell`` decoder fed
+``cat(attended, embedded)``, a linear output projection.  Parameter names follow the reference's
+``state_dict`` so released checkpoints load.
+
+On the MI355X the recurrences are persistent hand-written kernels: one launch per LSTM layer over
+the whole padded sequence (``pnmn_lstm_seq_{fwd,bwd}``) and one per decoding loop -- attention,
+gates, cell and token choice of every step (``pnmn_attn_lstm_{fwd,bwd}[_multi]``), four or eight
+workgroups sharing each 16-row tile (csrc/seq2seq.hip, decoder_multi.hip).  What can be batched over
+time (input / output projections, losses, weight gradients) is library GEMMs over all steps; other
+hidden sizes fall back to a GEMM per step plus the cell kernel (``pnmn_lstm_cell_{fwd,bwd}``,
+``pnmn_sample_tokens``).  Everything that the reference does with per-row Python loops and ``.cpu()``
+round trips (sentence boundaries, trimming at ``@end@``) is vectorised on the device: a forward pass
+performs no host synchronisation.
+"""
+import os
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from probnmn import _hip
+from probnmn.running_metrics import BLEU, Average
+
+
+class _LSTMCellPointwise(torch.autograd.Function):
+    """(gate pre-activations [B,4H], c_prev [B,H]) -> (h, c) on the gfx950 kernel."""
+
+    @staticmethod
+    def forward(ctx, gates, c_prev):
+        if gates.device.type != "cuda":
+            raise _hip.HipLibraryError("LSTM cell on %s: the HIP path needs a ROCm device (no CPU fallback)" % gates.device)
+        gates, c_prev = gates.contiguous(), c_prev.contiguous()
+        B, H4 = gates.shape
+        Hd = H4 // 4
+        h = torch.empty_like(c_prev)
+        c = torch.empty_like(c_prev)
+        act = torch.empty_like(gates)
+        _hip.check(_hip.lib().pnmn_lstm_cell_fwd(gates.data_ptr(), c_prev.data_ptr(), h.data_ptr(), c.data_ptr(),
+                                                 act.data_ptr(), B, Hd, _hip.stream_ptr(gates.device)), "lstm_cell_fwd")
+        ctx.save_for_backward(act, c_prev, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        act, c_prev, c = ctx.saved_tensors
+        B, H4 = act.shape
+        dgates = torch.empty_like(act)
+        dc_prev = torch.empty_like(c)
+        dh = dh.contiguous() if dh is not None else None  # (kept alive until after the launch)
+        dc = dc.contiguous() if dc is not None else None
+        dh_p = dh.data_ptr() if dh is not None else None
+        dc_p = dc.data_ptr() if dc is not None else None
+        _hip.check(_hip.lib().pnmn_lstm_cell_bwd(act.data_ptr(), c_prev.data_ptr(), c.data_ptr(), dh_p, dc_p,
+                                                 dgates.data_ptr(), dc_prev.data_ptr(), B, H4 // 4,
+                                                 _hip.stream_ptr(act.device)), "lstm_cell_bwd")
+        return dgates, dc_prev
+
+
+def pack_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] row-major -> MFMA-fragment order [N/16][K/16][64][4] (see include/probnmn_hip.h): one wave-wide
+    operand load of the persistent LSTM / decoder kernels then reads 1 KiB contiguous."""
+    n, k = w.shape
+    return w.detach().reshape(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def lstm_cell_pointwise(gates, c_prev):
+    return _LSTMCellPointwise.apply(gates, c_prev)
+
+
+def wgrad_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``a.t() @ b`` for tall operands (a [K, M], b [K, N], K = rows x time steps >> M, N).  A weight
+    gradient has few output tiles (1024 x 256 -> 32 workgroups on 256 CUs) and a very long reduction;
+    splitting K into chunks run as one batched GEMM fills the chip, the partial sums add up after."""
+    K = a.size(0)
+    chunks = min(16, K // 2048)
+    if chunks <= 1 or not (a.is_contiguous() and b.is_contiguous()):
+        return a.t() @ b
+    kc = K // chunks
+    main = kc * chunks
+    out = torch.bmm(a[:main].view(chunks, kc, -1).transpose(1, 2), b[:main].view(chunks, kc, -1)).sum(0)
+    if main < K:
+        out = out + a[main:].t() @ b[main:]
+    return out
+
+
+class _LinearRows(torch.autograd.Function):
+    """``F.linear`` over B x T rows whose weight gradient goes through ``wgrad_gemm`` (autograd's
+    plain ``dy.t() @ x`` has 32 output tiles and a 47 000-long reduction at these shapes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.size(-1))
+        dx = (dy2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = wgrad_gemm(dy2.contiguous(), x.reshape(-1, x.size(-1)).contiguous()) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    if x.device.type != "cuda" or not torch.is_grad_enabled():
+        return F.linear(x, weight, bias)
+    return _LinearRows.apply(x, weight, bias)
+
+
+class _EmbeddingLookup(torch.autograd.Function):
+    """``F.embedding`` whose weight gradient is a (one-hot) GEMM: the vocabularies here have < 100
+    entries, so the scatter-add of B x T rows into them that torch's backward does (sort + segmented
+    reduction, ~0.4 ms per call) is a 96-column GEMM over the same rows."""
+
+    @staticmethod
+    def forward(ctx, weight, tokens, padding_idx):
+        ctx.save_for_backward(tokens)
+        ctx.vocab, ctx.padding_idx = weight.size(0), padding_idx
+        return F.embedding(tokens, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        flat = tokens.reshape(-1)
+        onehot = torch.zeros(flat.numel(), ctx.vocab, dtype=dy.dtype, device=dy.device)
+        onehot.scatter_(1, flat.unsqueeze(1), 1.0)
+        dw = wgrad_gemm(onehot, dy.reshape(flat.numel(), -1).contiguous())
+        if ctx.padding_idx is not None:
+            dw[ctx.padding_idx].zero_()
+        return dw, None, None
+
+
+def embedding_lookup(module: nn.Embedding, tokens: torch.Tensor) -> torch.Tensor:
+    if tokens.device.type != "cuda" or not torch.is_grad_enabled() or not module.weight.requires_grad:
+        return module(tokens)
+    return _EmbeddingLookup.apply(module.weight, tokens, module.padding_idx)
+
+
+def _lstm_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor]:
+    """Scratch for the multi-CU LSTM kernels (step counters + the backward's exchange buffer); ``None``
+    when the library keeps one workgroup per row tile (batch large enough to fill the chip, or
+    PNMN_LSTM_CLUSTER=0).  A fresh allocation per launch: the caching allocator orders its reuse on
+    the launch stream."""
+    if os.environ.get("PNMN_LSTM_CLUSTER", "1") == "0":
+        return None
+    n = int(_hip.lib().pnmn_lstm_seq_workspace_bytes(batch, 1 if backward else 0))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
+def _decoder_workspace(batch: int, backward: bool, device) -> Optional[torch.Tensor]:
+    """Scratch of the multi-CU decoder kernels; ``None`` = use the one-workgroup-per-tile kernels
+    (PNMN_DECODER_CLUSTER=0, or a device too small for eight resident workgroups per tile)."""
+    if os.environ.get("PNMN_DECODER_CLUSTER", "1") == "0":
+        return None
+    n = int(_hip.lib().pnmn_attn_lstm_multi_workspace_bytes(batch, 1 if backward else 0))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
+class _LSTMLayerSeq(torch.autograd.Function):
+    """The recurrent half of one LSTM layer over a whole padded sequence, as ONE persistent kernel
+    launch (``pnmn_lstm_seq_fwd`` / ``_bwd``): (xp [B,T,4H] = input projection + biases, W_hh) -> all
+    hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states."""
+
+    @staticmethod
+    def forward(ctx, xp, w_hh):
+        if xp.device.type != "cuda":
+            raise _hip.HipLibraryError("LSTM layer on %s: the HIP path needs a ROCm device (no CPU fallback)" % xp.device)
+        xp, w = xp.contiguous(), w_hh.detach().contiguous()
+        B, T, H4 = xp.shape
+        Hd = H4 // 4
+        hs = torch.empty(B, T, Hd, dtype=xp.dtype, device=xp.device)
+        cs = torch.empty_like(hs)
+        act = torch.empty_like(xp)
+        wp = pack_fragments(w)
+        ws = _lstm_workspace(B, False, xp.device)
+        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), wp.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
+                                                B, T, Hd, ws.data_ptr() if ws is not None else None,
+                                                _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
+        ctx.save_for_backward(hs, cs, act, w)
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        hs, cs, act, w = ctx.saved_tensors
+        B, T, Hd = hs.shape
+        dhs = dhs.contiguous()
+        w_t = pack_fragments(w.t())  # W_hh^T [H][4H], fragment order
+        dgates = torch.empty_like(act)
+        ws = _lstm_workspace(B, True, hs.device)
+        _hip.check(_hip.lib().pnmn_lstm_seq_bwd(dhs.data_ptr(), act.data_ptr(), cs.data_ptr(), w_t.data_ptr(),
+                                                dgates.data_ptr(), B, T, Hd, ws.data_ptr() if ws is not None else None,
+                                                _hip.stream_ptr(hs.device)), "lstm_seq_bwd")
+        dw_hh = None
+        if ctx.needs_input_grad[1]:
+            hprev = torch.cat((hs.new_zeros(B, 1, Hd), hs[:, :-1]), 1).reshape(B * T, Hd)  # h_{t-1} per (row, step)
+            dw_hh = wgrad_gemm(dgates.reshape(B * T, 4 * Hd), hprev)
+        return dgates, dw_hh
+
+
+class _AttnLSTMDecoder(torch.autograd.Function):
+    """The decoding loop as one persistent kernel launch (``pnmn_attn_lstm_fwd`` / ``_bwd``).
+
+    inputs : xe [B,T,4H] (teacher forcing) or etable [V,4H] (free running), enc [B,S,H], mask [B,S] float,
+             h0 [B,H], W_c [4H,H], W_hh [4H,H], W_p [V,H], b_p [V]
+    outputs: hidden states [B,T,H], tokens [B,T] (free running only)
+    Weight gradients are batched GEMMs over what the kernels saved."""
+
+    @staticmethod
+    def forward(ctx, xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, mode, T, seed, row_offset, pad, unk, start):
+        dev = enc.device
+        if dev.type != "cuda":
+            raise _hip.HipLibraryError("decoder on %s: the HIP path needs a ROCm device (no CPU fallback)" % dev)
+        enc, mask, h0 = enc.contiguous(), mask.contiguous(), h0.contiguous()
+        w_c, w_hh = w_c.detach().contiguous(), w_hh.detach().contiguous()
+        w_c_p, w_hh_p = pack_fragments(w_c), pack_fragments(w_hh)
+        B, S, Hd = enc.shape
+        f = dict(dtype=torch.float32, device=dev)
+        hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
+        act = torch.empty(B, T, 4 * Hd, **f)
+        probs = torch.empty(B, T, S, **f)
+        tokens = None
+        V = 0
+        if mode != 0:
+            etable, w_p, b_p = etable.contiguous(), w_p.detach().contiguous(), b_p.detach().contiguous()
+            tokens = torch.empty(B, T, dtype=torch.long, device=dev)
+            V = w_p.size(0)
+        else:
+            xe = xe.contiguous()
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        args = (ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
+                h0.data_ptr(), w_c_p.data_ptr(), w_hh_p.data_ptr(), ptr(w_p if mode != 0 else None),
+                ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
+                probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset)
+        ws = _decoder_workspace(B, False, dev)
+        if ws is not None:
+            _hip.check(_hip.lib().pnmn_attn_lstm_fwd_multi(*args, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_fwd_multi")
+        else:
+            _hip.check(_hip.lib().pnmn_attn_lstm_fwd(*args, _hip.stream_ptr(dev)), "attn_lstm_fwd")
+        ctx.save_for_backward(hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh,
+                              tokens if tokens is not None else torch.empty(0, device=dev))
+        ctx.mode, ctx.start, ctx.vocab = mode, start, (etable.size(0) if mode != 0 else 0)
+        if tokens is not None:
+            ctx.mark_non_differentiable(tokens)
+            return hs, tokens
+        return hs, torch.empty(0, dtype=torch.long, device=dev)
+
+    @staticmethod
+    def backward(ctx, dhs, _):
+        hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, tokens = ctx.saved_tensors
+        B, T, Hd = hs.shape
+        S = enc.size(1)
+        dev = hs.device
+        dgates = torch.empty_like(act)
+        dh0 = torch.empty_like(h0)
+        # (named temporaries: a tensor that dies right after .data_ptr() may be recycled by the next allocation)
+        dhs_c, w_c_t, w_hh_t = dhs.contiguous(), pack_fragments(w_c.t()), pack_fragments(w_hh.t())
+        hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1)  # h_{t-1} of every (row, step)
+        ws = _decoder_workspace(B, True, dev)
+        if ws is not None:
+            dctx, dscore = torch.empty_like(hs), torch.empty_like(probs)
+            _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi(
+                dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), probs.data_ptr(), enc.data_ptr(),
+                mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(), dctx.data_ptr(),
+                dscore.data_ptr(), dh0.data_ptr(), B, T, S, Hd, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_bwd_multi")
+            # encoder-output gradient as two GEMMs per row over the T steps: enc_s enters step t through
+            # the context (weight w_ts) and through the score (gradient dscore_ts, times h_{t-1})
+            q = probs * mask.unsqueeze(1)
+            weights = q / (q.sum(-1, keepdim=True) + 1e-13)
+            denc = torch.baddbmm(torch.bmm(weights.transpose(1, 2), dctx), dscore.transpose(1, 2), hprev)
+        else:
+            denc = torch.zeros_like(enc)
+            _hip.check(_hip.lib().pnmn_attn_lstm_bwd(
+                dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), cx.data_ptr(), probs.data_ptr(),
+                enc.data_ptr(), mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(),
+                denc.data_ptr(), dh0.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)), "attn_lstm_bwd")
+        flat = dgates.reshape(B * T, 4 * Hd)
+        dw_c = wgrad_gemm(flat, cx.reshape(B * T, Hd))
+        dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
+        dxe = detable = None
+        if ctx.mode == 0:
+            dxe = dgates
+        else:
+            tok_in = torch.cat((tokens.new_full((B, 1), ctx.start), tokens[:, :-1]), 1).reshape(-1)
+            detable = torch.zeros(ctx.vocab, 4 * Hd, dtype=dgates.dtype, device=dev).index_add_(0, tok_in, flat)
+        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 9
+
+
+def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
+                  pad: int, unk: int, start: int):
+    """One decoding step's token choice on the device; returns (tokens int64 [B], logprob [B] no grad)."""
+    logits = logits.detach().contiguous()
+    B, V = logits.shape
+    tokens = torch.empty(B, dtype=torch.long, device=logits.device)
+    lp = torch.empty(B, dtype=torch.float32, device=logits.device)
+    _hip.check(_hip.lib().pnmn_sample_tokens(logits.data_ptr(), tokens.data_ptr(), lp.data_ptr(), B, V, int(greedy),
+                                             seed, row_offset, step, pad, unk, start,
+                                             _hip.stream_ptr(logits.device)), "sample_tokens")
+    return tokens, lp
+
+
+def add_sentence_boundary_token_ids(tokens: torch.Tensor, pad: int, bos: int, eos: int) -> torch.Tensor:
+    """(B,T) right-padded -> (B,T+2): @start@ first, @end@ right after the last real token
+    (allennlp.nn.util.add_sentence_boundary_token_ids, vectorised)."""
+    B, T = tokens.shape
+    lengths = (tokens != pad).sum(1)
+    out = tokens.new_zeros(B, T + 2)
+    out[:, 1:-1] = tokens
+    out[:, 0] = bos
+    out.scatter_(1, (lengths + 1).unsqueeze(1), eos)
+    return out
+
+
+def masked_softmax(vector: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """allennlp.nn.util.masked_softmax (memory_efficient=False), including its 1e-13."""
+    result = F.softmax(vector * mask, dim=-1) * mask
+    return result / (result.sum(dim=-1, keepdim=True) + 1e-13)
+
+
+def sequence_cross_entropy(logits, targets, weights, eps: float = 1e-13):
+    """Per-sequence masked-mean cross entropy (allennlp sequence_cross_entropy_with_logits,
+    average=None) with explicit weights -- plain torch ops (the kernels take a token mask, see
+    ``sequence_nll``)."""
+    weights = weights.float()
+    nll = -F.log_softmax(logits, dim=-1).gather(2, targets.unsqueeze(-1)).squeeze(-1) * weights
+    return nll.sum(1) / (weights.sum(1) + eps)
+
+
+class _SeqNLL(torch.autograd.Function):
+    """``pnmn_seq_nll_{fwd,bwd}``: one launch instead of log_softmax / gather / mask / sum / divide."""
+
+    @staticmethod
+    def forward(ctx, logits, tokens, mask_tokens, pad, eps):
+        B, T, V = logits.shape
+        if logits.stride(2) != 1 or logits.stride(1) != V:
+            logits = logits.contiguous()
+        if tokens.stride(1) != 1:
+            tokens = tokens.contiguous()
+        if mask_tokens.stride(1) != 1:
+            mask_tokens = mask_tokens.contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(B, T, dtype=torch.float32, device=logits.device)
+        _hip.check(_hip.lib().pnmn_seq_nll_fwd(logits.data_ptr(), logits.stride(0), tokens.data_ptr(), tokens.stride(0),
+                                               mask_tokens.data_ptr(), mask_tokens.stride(0), pad, loss.data_ptr(),
+                                               lse.data_ptr(), B, T, V, eps, _hip.stream_ptr(logits.device)), "seq_nll_fwd")
+        ctx.save_for_backward(logits, tokens, mask_tokens, lse)
+        ctx.pad, ctx.eps = pad, eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, tokens, mask_tokens, lse = ctx.saved_tensors
+        B, T, V = logits.shape
+        dlogits = torch.empty(B, T, V, dtype=torch.float32, device=logits.device)
+        dloss = dloss.contiguous()
+        _hip.check(_hip.lib().pnmn_seq_nll_bwd(logits.data_ptr(), logits.stride(0), tokens.data_ptr(), tokens.stride(0),
+                                               mask_tokens.data_ptr(), mask_tokens.stride(0), ctx.pad, lse.data_ptr(),
+                                               dloss.data_ptr(), dlogits.data_ptr(), T * V, B, T, V, ctx.eps,
+                                               _hip.stream_ptr(logits.device)), "seq_nll_bwd")
+        return dlogits, None, None, None, None
+
+
+def sequence_nll(logits: torch.Tensor, tokens: torch.Tensor, mask_tokens: torch.Tensor, pad: int, eps: float) -> torch.Tensor:
+    """loss[b] = sum_t w_t (-log_softmax(logits[b,t])[tokens[b,t]]) / (sum_t w_t + eps), w = mask_tokens != pad.
+    Covers both sequence losses of the reference: teacher-forced cross entropy (tokens = mask_tokens =
+    targets, eps 1e-13: allennlp's sequence_cross_entropy_with_logits) and the negative mean log-probability
+    of a sampled sequence (tokens = the raw samples, mask_tokens = the trimmed predictions, eps 1e-12:
+    seq2seq_base.py:235-244)."""
+    if logits.device.type != "cuda":
+        raise _hip.HipLibraryError("sequence loss input on %s: the HIP path needs a ROCm device" % logits.device)
+    return _SeqNLL.apply(logits, tokens, mask_tokens, pad, eps)
+
+
+def token_projection(embedding: nn.Embedding, tokens: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """``F.linear(embedding(tokens), weight, bias)`` for a small vocabulary: project the V < 100
+    embedding rows once (a [V, 4H] table) and gather table rows per token, instead of a GEMM over all
+    B x T rows; backward is the one-hot GEMM of ``_EmbeddingLookup`` into the table and a V-row GEMM
+    from there.  The padding row of ``embedding`` (all zeros, no gradient) keeps both properties."""
+    w = embedding.weight
+    if embedding.padding_idx is not None:
+        keep = torch.ones(w.size(0), 1, dtype=w.dtype, device=w.device)
+        keep[embedding.padding_idx] = 0.0
+        w = w * keep  # value unchanged (the row is zero); stops the gradient into the padding row
+    table = F.linear(w, weight, bias)
+    if tokens.device.type != "cuda" or not torch.is_grad_enabled():
+        return F.embedding(tokens, table)
+    return _EmbeddingLookup.apply(table, tokens, None)
+
+
+def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projection: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
+    length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
+    input GEMM batched over time and the recurrence in one persistent HIP kernel per layer.
+    ``first_projection``: the first layer's input projection when the caller already has it
+    (``token_projection``); ``x`` is then unused."""
+    B, T = mask.shape
+    inp = x
+    for layer in range(lstm.num_layers):
+        w_ih = getattr(lstm, "weight_ih_l%d" % layer)
+        w_hh = getattr(lstm, "weight_hh_l%d" % layer)
+        bias = getattr(lstm, "bias_ih_l%d" % layer) + getattr(lstm, "bias_hh_l%d" % layer)
+        if layer == 0 and first_projection is not None:
+            xp = first_projection
+        else:
+            xp = linear_rows(inp, w_ih, bias)  # (B,T,4H): one GEMM for all time steps
+        if lstm.hidden_size == 256:
+            inp = _LSTMLayerSeq.apply(xp, w_hh)  # one persistent launch for all T steps
+        else:  # other widths: step by step (GEMM per step + the cell kernel)
+            h = xp.new_zeros(B, lstm.hidden_size)
+            c = xp.new_zeros(B, lstm.hidden_size)
+            w_hh_t = w_hh.t()
+            outs = []
+            for t in range(T):
+                gates = torch.addmm(xp[:, t], h, w_hh_t)
+                h, c = lstm_cell_pointwise(gates, c)
+                outs.append(h)
+            inp = torch.stack(outs, 1)
+    return inp * mask.unsqueeze(-1).to(inp.dtype)
+
+
+class _TokenEmbedder(nn.Module):
+    """``BasicTextFieldEmbedder({"tokens": Embedding})`` as far as parameter naming goes."""
+
+    def __init__(self, key: str, num_embeddings: int, dim: int, padding_index: int):
+        super().__init__()
+        emb = nn.Embedding(num_embeddings, dim, padding_idx=padding_index)
+        nn.init.xavier_uniform_(emb.weight)  # AllenNLP Embedding init, then zero padding row
+        with torch.no_grad():
+            emb.weight[padding_index].fill_(0)
+        setattr(self, "token_embedder_" + key, emb)
+        self._key = "token_embedder_" + key
+
+    @property
+    def embedding(self) -> nn.Embedding:
+        return getattr(self, self._key)
+
+    def forward(self, tokens):
+        return embedding_lookup(self.embedding, tokens)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers, dropout):
+        super().__init__()
+        self._module = nn.LSTM(input_size, hidden_size, num_layers, dropout=dropout, batch_first=True)
+
+    def forward(self, x, mask):
+        return masked_lstm(self._module, x, mask)
+
+    def forward_tokens(self, embedding: nn.Embedding, tokens: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """``forward(embedding(tokens), mask)`` with the first layer's input projection taken from a
+        per-token table (``token_projection``)."""
+        lstm = self._module
+        xp = token_projection(embedding, tokens, lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
+        return masked_lstm(lstm, None, mask, first_projection=xp)
+
+
+class Seq2SeqBase(nn.Module):
+    def __init__(
+        self,
+        vocabulary,
+        source_namespace: str,
+        target_namespace: str,
+        input_size: int = 256,
+        hidden_size: int = 256,
+        num_layers: int = 2,
+        dropout: float = 0.0,
+        max_decoding_steps: int = 30,
+    ):
+        super().__init__()
+        self.vocabulary = vocabulary
+        # @@PADDING@@, @@UNKNOWN@@, @start@, @end@ have the same indices in all namespaces
+        self._pad_index = vocabulary.get_token_index("@@PADDING@@", namespace=source_namespace)
+        self._unk_index = vocabulary.get_token_index("@@UNKNOWN@@", namespace=source_namespace)
+        self._end_index = vocabulary.get_token_index("@end@", namespace=target_namespace)
+        self._start_index = vocabulary.get_token_index("@start@", namespace=target_namespace)
+        self._max_decoding_steps = max_decoding_steps
+        self._scheduled_sampling_ratio = 0.0
+        if dropout != 0.0:
+            raise NotImplementedError("dropout != 0 is not used by any reference config and not built")
+
+        v_src = vocabulary.get_vocab_size(namespace=source_namespace)
+        v_tgt = vocabulary.get_vocab_size(namespace=target_namespace)
+        self._source_embedder = _TokenEmbedder("tokens", v_src, input_size, self._pad_index)
+        self._encoder = _Encoder(input_size, hidden_size, num_layers, dropout)
+        # SimpleSeq2Seq: target embedding dim = source embedding dim; decoder dim = encoder dim
+        self._target_embedder = nn.Embedding(v_tgt, input_size)
+        nn.init.xavier_uniform_(self._target_embedder.weight)
+        self._decoder_cell = nn.LSTMCell(hidden_size + input_size, hidden_size)
+        self._output_projection_layer = nn.Linear(hidden_size, v_tgt)
+
+        self._log2_perplexity = Average()
+        self._sequence_accuracy = Average()
+        self._unigram_recall = Average()
+        # SimpleSeq2Seq(use_bleu=True): BLEU over evaluation predictions, special indices excluded
+        self._bleu = BLEU(exclude_indices={self._pad_index, self._end_index, self._start_index})
+        # row offset of this rank's shard in the global batch (keeps the sample stream shard-invariant)
+        self.sample_row_offset = 0
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(
+        self,
+        source_tokens: torch.LongTensor,
+        target_tokens: Optional[torch.LongTensor] = None,
+        decoding_strategy: str = "sampling",
+        need_predictions: bool = True,
+    ) -> Dict[str, torch.Tensor]:
+        return self.decode(self.encode(source_tokens), target_tokens, decoding_strategy, need_predictions)
+
+    def encode(self, source_tokens: torch.LongTensor) -> Dict[str, torch.Tensor]:
+        """Encoder half of ``forward`` (reference seq2seq_base.py ``_encode`` + ``_init_decoder_state``).
+        Rows are independent, so a trainer may encode one batch once and ``decode`` row subsets of
+        the state in different modes (``select_rows``)."""
+        if source_tokens.device.type != "cuda":
+            raise _hip.HipLibraryError("seq2seq input on %s: the HIP path needs a ROCm device" % source_tokens.device)
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        src = add_sentence_boundary_token_ids(source_tokens, pad, bos, eos)[:, 1:]  # @start@ is not encoded
+        src_mask = src != pad
+        enc = self._encoder.forward_tokens(self._source_embedder.embedding, src, src_mask)
+        rows = torch.arange(src.size(0), device=src.device)
+        return {"enc": enc, "h": enc[rows, src_mask.sum(1) - 1], "fmask": src_mask.float()}
+
+    @staticmethod
+    def select_rows(state: Dict[str, torch.Tensor], rows: torch.LongTensor) -> Dict[str, torch.Tensor]:
+        return {k: v.index_select(0, rows) for k, v in state.items()}
+
+    def decode(
+        self,
+        state: Dict[str, torch.Tensor],
+        target_tokens: Optional[torch.LongTensor] = None,
+        decoding_strategy: str = "sampling",
+        need_predictions: bool = True,
+    ) -> Dict[str, torch.Tensor]:
+        """``need_predictions=False`` (teacher forcing only): skip drawing the per-step predictions from the
+        teacher-forced distributions (reference :196-220) -- training iterations never read them."""
+        if decoding_strategy not in ("sampling", "greedy"):
+            raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        enc, h, fmask = state["enc"], state["h"], state["fmask"]
+        tgt = None
+        if target_tokens is not None:
+            tgt = add_sentence_boundary_token_ids(target_tokens, pad, bos, eos)
+        B = enc.size(0)
+        c = torch.zeros_like(h)
+
+        steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
+        greedy = decoding_strategy == "greedy"
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        Hd = h.size(1)
+        w_ih = self._decoder_cell.weight_ih
+        w_c, w_e = w_ih[:, :Hd], w_ih[:, Hd:]  # the cell's input is cat(attended, embedding)
+        bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
+        w_p, b_p = self._output_projection_layer.weight, self._output_projection_layer.bias
+        fused = Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128
+        if fused:
+            args = (pad, self._unk_index, bos)
+            if tgt is not None:  # teacher forcing: every step's input embedding is known up front
+                xe = token_projection(self._target_embedder, tgt[:, :steps], w_e, bias)
+                hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
+                                               0, steps, seed, self.sample_row_offset, *args)
+            else:  # free running: the kernel also picks each step's token
+                etable = F.linear(self._target_embedder.weight, w_e, bias)
+                hs, raw = _AttnLSTMDecoder.apply(None, etable, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p,
+                                                 b_p, 2 if greedy else 1, steps, seed, self.sample_row_offset, *args)
+            logits_all = self._output_projection_layer(hs)  # one GEMM for all steps
+            if tgt is not None:
+                output_dict = {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], pad, 1e-13)}
+                if need_predictions or not self.training:
+                    # predictions are drawn / arg-maxed from the teacher-forced distributions (reference :196-220)
+                    raw, _ = choose_tokens(logits_all.reshape(B * steps, -1), greedy, seed, self.sample_row_offset * steps,
+                                           0, pad, self._unk_index, bos)
+                    output_dict["predictions"] = self._trim_predictions(raw.view(B, steps))
+            else:
+                predictions = self._trim_predictions(raw)
+                output_dict = {"predictions": predictions, "loss": sequence_nll(logits_all, raw, predictions, pad, 1e-12)}
+            ce = output_dict["loss"]
+            predictions = output_dict.get("predictions")
+        else:
+            raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, c, tgt, steps, greedy, seed)
+            predictions = self._trim_predictions(raw)
+            pmask = (predictions != pad).float()
+            sequence_logprobs = (logprobs * pmask).sum(-1) / (pmask.sum(-1) + 1e-12)
+            output_dict = {"predictions": predictions, "loss": -sequence_logprobs}
+            if tgt is not None:
+                tmask = tgt != pad
+                ce = sequence_cross_entropy(logits_all, tgt[:, 1:], tmask[:, 1:])
+                output_dict["loss"] = ce
+        if tgt is not None:
+            if not self.training:
+                self._record_metrics(predictions, tgt[:, 1:], ce)
+                self._bleu(predictions, tgt)  # (reference :260: against the targets WITH their @start@, as allennlp)
+        return output_dict
+
+    def _decode_stepwise(self, enc, fmask, h, c, tgt, steps, greedy, seed):
+        """Step-by-step decoding for shapes the persistent kernel is not built for (hidden != 256,
+        more than 64 source positions or 128 target tokens): a GEMM per step + the cell kernel."""
+        B = enc.size(0)
+        pad, bos = self._pad_index, self._start_index
+        last = fmask.new_full((B,), bos, dtype=torch.long)
+        w_ih_t = self._decoder_cell.weight_ih.t()
+        w_hh_t = self._decoder_cell.weight_hh.t()
+        bias = self._decoder_cell.bias_ih + self._decoder_cell.bias_hh
+        step_logits, step_logprobs, step_predictions = [], [], []
+        for t in range(steps):
+            inputs = tgt[:, t] if tgt is not None else last
+            e = self._target_embedder(inputs)
+            scores = torch.bmm(enc, h.unsqueeze(-1)).squeeze(-1)
+            weights = masked_softmax(scores, fmask)
+            attended = torch.bmm(weights.unsqueeze(1), enc).squeeze(1)
+            x = torch.cat((attended, e), -1)
+            gates = torch.addmm(torch.addmm(bias, x, w_ih_t), h, w_hh_t)
+            h, c = lstm_cell_pointwise(gates, c)
+            logits = self._output_projection_layer(h)
+            last, _ = choose_tokens(logits, greedy, seed, self.sample_row_offset, t, pad, self._unk_index, bos)
+            step_predictions.append(last.unsqueeze(1))
+            step_logits.append(logits.unsqueeze(1))
+            step_logprobs.append(F.log_softmax(logits, dim=-1).gather(1, last.unsqueeze(1)))
+        return torch.cat(step_predictions, 1), torch.cat(step_logits, 1), torch.cat(step_logprobs, 1)
+
+    def _trim_predictions(self, predictions: torch.LongTensor) -> torch.LongTensor:
+        """Keep each row up to and including its first @end@; a row starting with @end@ becomes all
+        padding, a row without @end@ is kept whole (reference :278-293), without leaving the device."""
+        steps = predictions.size(1)
+        is_end = predictions == self._end_index
+        has_end = is_end.any(1, keepdim=True)
+        first = is_end.float().argmax(1, keepdim=True)  # first occurrence
+        pos = torch.arange(steps, device=predictions.device).unsqueeze(0)
+        keep = torch.where(has_end, (pos <= first) & (first > 0), torch.ones_like(is_end))
+        return predictions * keep
+
+    @torch.no_grad()
+    def _record_metrics(self, predictions, relevant_targets, ce) -> None:
+        n = relevant_targets.size(1)
+        pred = predictions[:, :n]
+        mask = relevant_targets != self._pad_index
+        correct = ((pred == relevant_targets) | ~mask).all(1).float().mean()
+        # unigram recall: fraction of gold tokens that appear anywhere in the prediction
+        hit = (relevant_targets.unsqueeze(2) == pred.unsqueeze(1)).any(2) & mask
+        recall = (hit.sum(1).float() / mask.sum(1).clamp(min=1).float()).mean()
+        self._log2_perplexity(ce.mean())
+        self._sequence_accuracy(correct)
+        self._unigram_recall(recall)
+
+    def get_metrics(self, reset: bool = True) -> Dict[str, float]:
+        if self.training:
+            return {}
+        return {
+            **self._bleu.get_metric(reset=True),  # (the reference resets BLEU unconditionally, :367)
+            "perplexity": 2 ** self._log2_perplexity.get_metric(reset=reset),
+            "sequence_accuracy": self._sequence_accuracy.get_metric(reset=reset),
+            "word_error_rate": 1 - self._unigram_recall.get_metric(reset=reset),
+        }

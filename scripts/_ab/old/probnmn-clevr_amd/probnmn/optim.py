@@ -1,0 +1,148 @@
+"""Fused gradient clamp + Adam over parameter arenas, as a ``torch.optim.Optimizer``.
+
+The reference clamps every gradient element to [-5, 5] in a Python loop and then calls one
+``torch.optim.Adam`` that spans all trainable models, driven by a ``ReduceLROnPlateau`` scheduler and
+saved / restored by the checkpoint manager (reference: probnmn/trainers/module_training_trainer.py:94-96,
+joint_training_trainer.py:182-188, _trainer.py:103-118,124-130,193).  On MI355X the whole update is one
+streaming kernel (``pnmn_clamp_adam``): 28 bytes of HBM traffic per parameter, one launch for the
+63 M-parameter trunk arena plus one item per loose tensor.  Arithmetic follows ``torch.optim.Adam``
+(no amsgrad).
+
+Optimizer surface: one parameter group holding every parameter in ``model.parameters()`` order (what
+``optim.Adam(all_parameters, ...)`` builds), so ``param_groups[0]["lr"]`` is what an lr scheduler
+changes and what the next fused step uses; ``state_dict()`` / ``load_state_dict()`` use
+``torch.optim.Adam``'s layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter index, logical
+parameter shapes), so optimizer state moves between this class and the reference's Adam in either
+direction.  The moments of arena parameters are views into two arena-shaped buffers.
+
+Deviation (documented, not hidden): ``step`` is one counter for all parameters.  ``torch.optim.Adam``
+starts a parameter's counter at its first non-None gradient; the engine hands every trunk parameter a
+(possibly all-zero) gradient from the first step on.  The two agree as soon as every module has been
+used once -- in the first iteration at the reference's batch sizes.
+"""
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from probnmn import _hip
+
+
+class ClampAdam(torch.optim.Optimizer):
+    def __init__(
+        self,
+        params: Iterable[nn.Parameter],
+        arenas: Sequence = (),
+        lr: float = 1e-4,
+        betas=(0.9, 0.999),
+        eps: float = 1e-8,
+        weight_decay: float = 0.0,
+        clamp: Optional[float] = 5.0,
+    ):
+        params = list(params)
+        if any(isinstance(p, dict) for p in params):
+            raise ValueError("ClampAdam takes one flat list of parameters (a single group, as the reference's Adam)")
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, clamp=clamp)
+        super().__init__(params, defaults)
+        self.arenas = list(arenas)
+        in_arena = set()
+        for a in self.arenas:
+            in_arena.update(id(a.param(n)) for n in a.names)
+        known = {id(p) for p in params}
+        for a in self.arenas:
+            missing = [n for n in a.names if id(a.param(n)) not in known]
+            if missing:
+                raise ValueError("arena parameters missing from the parameter list: %s ..." % missing[:3])
+        self.loose: List[nn.Parameter] = [p for p in params if id(p) not in in_arena and p.requires_grad]
+        self.step_count = 0
+        self._arena_state = [(torch.zeros_like(a.flat), torch.zeros_like(a.flat)) for a in self.arenas]
+        self._loose_state = [(torch.zeros_like(p, memory_format=torch.contiguous_format),
+                              torch.zeros_like(p, memory_format=torch.contiguous_format)) for p in self.loose]
+        self._bind_state()
+
+    # ---- torch.optim surface -------------------------------------------------------------------
+    def _bind_state(self) -> None:
+        """self.state in torch.optim.Adam's layout, aliasing the buffers the kernel updates."""
+        for a, (m, v) in zip(self.arenas, self._arena_state):
+            for n in a.names:
+                p = a.param(n)
+                self.state[p] = {"step": torch.tensor(float(self.step_count)), "exp_avg": a.view_of(m, n),
+                                 "exp_avg_sq": a.view_of(v, n)}
+        for p, (m, v) in zip(self.loose, self._loose_state):
+            self.state[p] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+
+    def add_param_group(self, param_group) -> None:
+        if getattr(self, "param_groups", None):
+            raise ValueError("ClampAdam updates all parameters with one fused launch: a single parameter group")
+        super().add_param_group(param_group)
+
+    def state_dict(self):
+        for st in self.state.values():
+            st["step"].fill_(float(self.step_count))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)  # casts to each parameter's device / dtype, replaces self.state
+        loaded = dict(self.state)
+        steps = [float(st["step"]) for st in loaded.values() if "step" in st]
+        if steps and max(steps) != min(steps):
+            raise ValueError("per-parameter step counts differ (%g..%g): ClampAdam keeps one counter"
+                             % (min(steps), max(steps)))
+        self.step_count = int(steps[0]) if steps else 0
+        with torch.no_grad():
+            for a, (m, v) in zip(self.arenas, self._arena_state):
+                for n in a.names:
+                    st = loaded.get(a.param(n))
+                    if st:
+                        a.view_of(m, n).copy_(st["exp_avg"])
+                        a.view_of(v, n).copy_(st["exp_avg_sq"])
+            for p, (m, v) in zip(self.loose, self._loose_state):
+                st = loaded.get(p)
+                if st:
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+        self.state.clear()
+        self._bind_state()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        # arena gradients are zeroed by the engine at the start of each backward
+        for p in self.loose:
+            p.grad = None
+
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @torch.no_grad()
+    def step(self, closure=None) -> None:
+        if closure is not None:
+            raise ValueError("ClampAdam.step takes no closure")
+        group = self.param_groups[0]
+        self.step_count += 1
+        items = []
+        for a, (m, v) in zip(self.arenas, self._arena_state):
+            if not a.intact():
+                raise _hip.HipLibraryError(
+                    "a parameter no longer aliases the arena this optimizer was built on (model.to() / .data = "
+                    "after the optimizer was constructed): build the optimizer after placing the model")
+            items.append((a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr(), a.total))
+        for p, (m, v) in zip(self.loose, self._loose_state):
+            if p.grad is None:
+                continue
+            if not p.is_contiguous() or not p.grad.is_contiguous():
+                raise _hip.HipLibraryError("ClampAdam needs contiguous loose parameters and gradients")
+            items.append((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+        if not items:
+            return
+        rec = np.zeros(len(items), _hip.ADAM_ITEM)
+        for i, it in enumerate(items):
+            rec[i]["param"], rec[i]["grad"], rec[i]["exp_avg"], rec[i]["exp_avg_sq"], rec[i]["n"] = it
+        device = (self.arenas[0].flat if self.arenas else self.loose[0]).device
+        buf = _hip.to_device(rec, device)
+        clamp = float(group["clamp"]) if group["clamp"] is not None else 0.0
+        _hip.check(
+            _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(items), float(group["lr"]), group["betas"][0],
+                                       group["betas"][1], group["eps"], group["weight_decay"], clamp,
+                                       self.step_count, _hip.stream_ptr(device)),
+            "clamp_adam")

@@ -1,0 +1,566 @@
+"""Execution engine of the Neural Module Network trunk on one MI355X.
+
+trunk = stem -> per-example module programs -> classifier conv1x1 + ReLU + max-pool + flatten
+(reference: probnmn/models/nmn.py:183-241 and :76-79).  One :class:`NMNEngine` belongs to one
+``NeuralModuleNetwork``; it owns the parameter arena, the transposed-weight arena used by the data
+gradients, the per-step activation / gradient arenas and the scheduler, and drives the kernels of
+``libprobnmn_hip.so`` on torch's current stream.  All device memory is torch-allocated and reused
+from step to step; the engine never synchronises with the host.
+
+Forward and backward are both explicit kernel schedules (no autograd inside): backward walks the
+forward levels in reverse; every weight gradient of the module convs is deferred into one big
+grouped launch at the end, where all (example, conv) pairs that share a weight are accumulated by
+the same workgroups.
+"""
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from probnmn import _hip
+from probnmn.runtime import program_compiler as pc
+from probnmn.runtime.arena import ParamArena
+from probnmn.runtime.schedule import BatchScheduler, Buffers, StepPlan, WeightTables
+
+C = _hip.CHANNELS
+
+_DT = {
+    "conv": _hip.CONV_ITEM,
+    "dot": _hip.DOT1_ITEM,
+    "same": _hip.SAME_ITEM,
+    "minmax": _hip.MINMAX_ITEM,
+    "maskbwd": _hip.MASKBWD_ITEM,
+    "wgrad_item": _hip.WGRAD_ITEM,
+    "wgrad_job": _hip.WGRAD_JOB,
+}
+
+
+class _Pack:
+    """Several numpy record arrays -> one device byte buffer (a single H2D copy per step)."""
+
+    def __init__(self):
+        self._chunks: List[np.ndarray] = []
+        self._offsets: Dict[str, int] = {}
+        self._itemsize: Dict[str, int] = {}
+        self._size = 0
+        self.device_buf: Optional[torch.Tensor] = None
+
+    def add(self, name: str, rec: np.ndarray) -> None:
+        raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1)
+        pad = (-self._size) % 64
+        if pad:
+            self._chunks.append(np.zeros(pad, np.uint8))
+            self._size += pad
+        self._offsets[name] = self._size
+        self._itemsize[name] = rec.dtype.itemsize
+        self._chunks.append(raw)
+        self._size += raw.size
+
+    def upload(self, device: torch.device) -> None:
+        host = np.concatenate(self._chunks) if self._chunks else np.zeros(64, np.uint8)
+        self.device_buf = _hip.to_device(host, device)
+
+    def ptr(self, name: str, index: int = 0) -> int:
+        return self.device_buf.data_ptr() + self._offsets[name] + index * self._itemsize[name]
+
+
+class _State:
+    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features")
+
+
+class NMNEngine:
+    def __init__(self, net, image_feature_size, module_channels: int, class_projection_channels: int):
+        cin, H, W = image_feature_size
+        if module_channels != C:
+            raise NotImplementedError(
+                "the gfx950 kernels are built for module_channels == 128 (got %d)" % module_channels)
+        if (H, W) not in ((14, 14), (28, 28)):
+            raise NotImplementedError("the gfx950 kernels are built for 14x14 and 28x28 feature maps (got %dx%d)" % (H, W))
+        if cin % C or class_projection_channels % C:
+            raise NotImplementedError("channel counts must be multiples of 128")
+        self.net = net
+        self.cin, self.H, self.W = cin, H, W
+        self.HW = H * W
+        # 28x28 maps: conv / weight-gradient workgroups cover one of four 7-row bands of an item, and a
+        # weight-gradient slab is 64 x 64 channels instead of 64 x 128 (csrc/conv_wgrad.hip)
+        self.banded = (H, W) != (14, 14)
+        self.cproj = class_projection_channels
+        self.arena: Optional[ParamArena] = None
+        self.direct_grads = False  # True: gradients stay in the arena, nothing is handed to autograd
+        self.generation = 0
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._fixed_cache: Dict[int, Dict[str, np.ndarray]] = {}
+        self.compiler = pc.ProgramCompiler(
+            net.vocabulary.get_index_to_token_vocabulary("programs"), module_channels)
+        self.last_plan: Optional[StepPlan] = None
+        # when a list, every conv / wgrad launch is bracketed by events on the launch stream and
+        # (kernel, algorithmic flops, start, end) is appended -- used by bench.py's roofline pass
+        self.event_log: Optional[list] = None
+        # True: weight gradients run on a second stream, concurrently with the level-by-level
+        # data-gradient chain.  Measured on MI355X (B=256): no gain -- a wgrad workgroup holds its CU
+        # (151 KiB LDS) for ~400 us and delays the chain's critical path as much as it fills its gaps --
+        # so the default is one stream, which also keeps per-kernel profiles clean.
+        self.overlap_wgrad = False
+        self._side_stream: Optional[torch.cuda.Stream] = None
+        # launches of a pass are collected and issued by ONE library call (pnmn_run_launches) unless they are
+        # being timed one by one (event_log) or spread over two streams (overlap_wgrad)
+        self._list: Optional[_hip.LaunchList] = None
+        self.launch_lists = os.environ.get("PNMN_LAUNCH_LISTS", "1") != "0"
+
+    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
+        log = self.event_log
+        if self._list is not None:  # (collected into one pnmn_run_launches call)
+            self._list.add(_hip.OP_CONV, n, ptr, p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
+            return
+        if log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _hip.check(_hip.lib().pnmn_conv_nhwc(ptr, n, self.H, self.W, cin_chunks, ntaps, in_stride, out_stride,
+                                             cout_blocks, relu, st), what)
+        if log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes: every item's input and
+            # output map once + one pass over the weights, kernel launches of this call)
+            log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
+                        4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C),
+                        _hip.lib().pnmn_conv_nhwc_launches(n, self.H, self.W, cin_chunks, ntaps, cout_blocks)))
+
+    def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
+        """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
+        log = self.event_log
+        st = stream.cuda_stream
+        if self._list is not None:
+            self._list.add(_hip.OP_WGRAD, n_jobs, items, jobs, p=(self.H, self.W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride))
+            return
+        if log is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        _hip.check(_hip.lib().pnmn_conv_wgrad(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
+                                              x_stride, dy_stride, st), what)
+        if log is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(stream)
+            log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1,
+                        4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C), 1))
+
+    def _op(self, op: int, name: str, n: int, a: int, st: int, what: str, b: int = 0, c: int = 0, p=()) -> None:
+        """One grouped launch of a non-conv kernel: into the pass's launch list, or directly."""
+        if self._list is not None:
+            self._list.add(op, n, a, b, c, p)
+            return
+        fn = getattr(_hip.lib(), name)
+        args = [x for x in (a, b, c) if x]
+        _hip.check(fn(*args, n, *p, st), what)
+
+    def _begin_list(self) -> None:
+        # (a list left over from a pass that raised is dropped here)
+        self._list = _hip.LaunchList() if (self.event_log is None and not self.overlap_wgrad and self.launch_lists) else None
+
+    def _flush_list(self, st: int, what: str, end: bool = False) -> None:
+        if self._list is not None:
+            self._list.run(st, what)
+            if end:
+                self._list = None
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def trunk_named_parameters(self):
+        return [(n, p) for n, p in self.net.named_parameters()
+                if not n.startswith(("classifier.4.", "classifier.6."))]
+
+    def ensure_arena(self) -> ParamArena:
+        device = self.net.stem[0].weight.device
+        if device.type != "cuda":
+            raise _hip.HipLibraryError(
+                "NeuralModuleNetwork parameters are on %s: the HIP path needs a ROCm device "
+                "(call .to('cuda')); there is no CPU fallback" % device)
+        _hip.lib()
+        if self.arena is None or self.arena.device != device or not self.arena.intact():
+            self.arena = ParamArena(self.trunk_named_parameters(), device)
+            self._build_tables()
+            self._ws.clear()
+            self._fixed_cache.clear()
+        return self.arena
+
+    def _build_tables(self) -> None:
+        a = self.arena
+        vocab = self.net.vocabulary.get_index_to_token_vocabulary("programs")
+        V = max(vocab) + 1
+        w3 = -np.ones((V, 6), np.int64)
+        b3 = -np.ones((V, 6), np.int64)
+        wt3 = -np.ones((V, 6), np.int64)
+        dotw = -np.ones(V, np.int64)
+        dotb = -np.ones(V, np.int64)
+        wt_items = []  # (src name, cout, cin, ntaps, wt offset)
+        wt_cursor = 0
+
+        def add_wt(name):
+            nonlocal wt_cursor
+            p = a.param(name)
+            co, ci, kh, kw = p.shape
+            off = wt_cursor
+            wt_cursor += p.numel()
+            wt_items.append((name, co, ci, kh * kw, off))
+            return off
+
+        for idx, tok in vocab.items():
+            kind = self.compiler.kinds[idx]
+            if kind in (pc.ATT, pc.QUERY, pc.REL, pc.CMP):
+                names = {pc.ATT: [None, "conv1", "conv2"], pc.QUERY: [None, "conv1", "conv2"],
+                         pc.REL: [None, "conv1", "conv2", "conv3", "conv4", "conv5"],
+                         pc.CMP: ["projection", "conv1", "conv2"]}[kind]
+                for j, nm in enumerate(names):
+                    if nm is None:
+                        continue
+                    w3[idx, j] = a.offsets["%s.%s.weight" % (tok, nm)]
+                    b3[idx, j] = a.offsets["%s.%s.bias" % (tok, nm)]
+                    wt3[idx, j] = add_wt("%s.%s.weight" % (tok, nm))
+            head = {pc.ATT: "conv3", pc.REL: "conv6", pc.SAME: "conv"}.get(kind)
+            if head:
+                dotw[idx] = a.offsets["%s.%s.weight" % (tok, head)]
+                dotb[idx] = a.offsets["%s.%s.bias" % (tok, head)]
+        self.wt_stem2 = add_wt("stem.2.weight")
+        self.wt_cls0 = add_wt("classifier.0.weight")
+        self.tables = WeightTables(w3, b3, wt3, dotw, dotb)
+        self.wt = torch.zeros(wt_cursor, dtype=torch.float32, device=a.device)
+        rec = np.zeros(len(wt_items), _hip.WTRANS_ITEM)
+        for i, (name, co, ci, nt, off) in enumerate(wt_items):
+            rec[i]["src"] = a.flat.data_ptr() + a.offsets[name] * 4
+            rec[i]["dst"] = self.wt.data_ptr() + off * 4
+            rec[i]["cout"], rec[i]["cin"], rec[i]["ntaps"] = co, ci, nt
+        self._wt_records = _hip.to_device(rec, a.device)
+        self._wt_count = len(wt_items)
+        self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
+        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT,
+                                        wgrad_chunk=int(os.environ.get("PNMN_WG_CHUNK", "2" if self.banded else "8")),
+                                        wgrad_groups=int(os.environ.get("PNMN_WG_GROUPS", "1")))
+
+    # ---- workspaces ---------------------------------------------------------------------------
+    def _buf(self, name: str, numel: int) -> torch.Tensor:
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel:
+            t = torch.empty(int(numel * 1.25) if t is not None else numel, dtype=torch.float32,
+                            device=self.arena.device)
+            self._ws[name] = t
+        return t
+
+    def _fixed_records(self, B: int, ws: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
+        """Work lists of the stem and classifier convs: depend only on B and buffer addresses."""
+        key = (B,) + tuple(ws[k].data_ptr() for k in sorted(ws))
+        hit = self._fixed_cache.get(key)
+        if hit is not None:
+            return hit
+        a = self.arena
+        HW = self.HW
+        e = np.arange(B, dtype=np.int64)
+        m128, mcin, mcls = HW * C * 4, HW * self.cin * 4, HW * self.cproj * 4
+        P = a.flat.data_ptr()
+        G = a.grad.data_ptr()
+
+        def po(name):
+            return P + a.offsets[name] * 4
+
+        def go(name):
+            return G + a.offsets[name] * 4
+
+        def conv(inp, w, b, out, gate=None):
+            r = np.zeros(B, _hip.CONV_ITEM)
+            r["in"], r["weight"], r["out"], r["dilation"] = inp, w, out, 1
+            if b is not None:
+                r["bias"] = b
+            if gate is not None:
+                r["gate"] = gate
+            return r
+
+        def wg(x, dy, gate=None):
+            r = np.zeros(B, _hip.WGRAD_ITEM)
+            r["x"], r["dy"], r["dilation"] = x, dy, 1
+            if gate is not None:
+                r["gate"] = gate
+            return r
+
+        def jobs(dw, db, yblocks):
+            # items per job: a launch of ceil(B / chunk) * yblocks workgroups costs ceil(. / 256) rounds of
+            # `chunk` items each (+ ~half an item for the atomic add of the job's slab into the shared
+            # weight gradient, which is also why a job never has fewer than 4 items); 260 workgroups cost
+            # two rounds, 208 one -- take the chunk with the shortest makespan
+            if self.banded:  # four bands per item, twice the slabs per weight
+                yblocks *= 2
+                sizes = range(1, 9)
+            else:
+                sizes = range(4, 33)
+            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // 256)) * (c + 0.5))
+            starts = np.arange(0, B, chunk)
+            j = np.zeros(starts.size, _hip.WGRAD_JOB)
+            j["dw"], j["dbias"] = dw, db
+            j["item_begin"], j["item_end"] = starts, np.minimum(starts + chunk, B)
+            return j
+
+        xin, s1, s2 = ws["xin"].data_ptr(), ws["stem1"].data_ptr(), ws["feat"].data_ptr()
+        gs1, gs2 = ws["gstem1"].data_ptr(), ws["gfeat"].data_ptr()
+        fin, gfin = ws["final"].data_ptr(), ws["gfinal"].data_ptr()
+        cls, gcls = ws["cls"].data_ptr(), ws["gcls"].data_ptr()
+        out = {
+            "stem1": conv(xin + e * mcin, po("stem.0.weight"), po("stem.0.bias"), s1 + e * m128),
+            "stem2": conv(s1 + e * m128, po("stem.2.weight"), po("stem.2.bias"), s2 + e * m128),
+            "cls": conv(fin + e * m128, po("classifier.0.weight"), po("classifier.0.bias"), cls + e * mcls),
+            "cls_dgrad": conv(gcls + e * mcls, self.wt.data_ptr() + self.wt_cls0 * 4, None, gfin + e * m128),
+            "stem2_dgrad": conv(gs2 + e * m128, self.wt.data_ptr() + self.wt_stem2 * 4, None, gs1 + e * m128,
+                                gate=s2 + e * m128),
+            "cls_wg": wg(fin + e * m128, gcls + e * mcls),
+            "cls_wg_jobs": jobs(go("classifier.0.weight"), go("classifier.0.bias"), 2 * self.cproj // C),
+            "stem2_wg": wg(s1 + e * m128, gs2 + e * m128, gate=s2 + e * m128),
+            "stem2_wg_jobs": jobs(go("stem.2.weight"), go("stem.2.bias"), 2),
+            "stem1_wg": wg(xin + e * mcin, gs1 + e * m128, gate=s1 + e * m128),
+            "stem1_wg_jobs": jobs(go("stem.0.weight"), go("stem.0.bias"), 2 * self.cin // C),
+        }
+        self._fixed_cache[key] = out
+        return out
+
+    # ---- forward --------------------------------------------------------------------------------
+    def begin_forward(self, features: torch.Tensor, need_backward: bool):
+        """The part of the forward pass that does not depend on the programs: layout change of the
+        input features and the two stem convolutions.  A trainer whose programs are still being
+        produced (joint training: sampled on the device, scheduled on the host) launches this first
+        and hands the returned token to ``run_forward`` -- the GPU then has ~3 ms more work queued
+        while the host compiles and schedules the sampled programs."""
+        a = self.ensure_arena()
+        lib = _hip.lib()
+        dev = a.device
+        if features.device != dev:
+            raise _hip.HipLibraryError("features on %s but the network is on %s" % (features.device, dev))
+        B = features.size(0)
+        if tuple(features.shape[1:]) != (self.cin, self.H, self.W):
+            raise ValueError("expected features (B,%d,%d,%d), got %s" % (self.cin, self.H, self.W, tuple(features.shape)))
+        # features already in the kernels' layout (a `channels_last` tensor, e.g. from
+        # probnmn.data.feature_store: the ingest kernel writes NHWC): used in place, no layout pass
+        nhwc = (features.dtype == torch.float32 and not features.is_contiguous()
+                and features.is_contiguous(memory_format=torch.channels_last))
+        if not nhwc:
+            features = features.contiguous().float()
+        HW = self.HW
+        st = _hip.stream_ptr(dev)
+        self.generation += 1
+
+        names = ["xin", "stem1", "feat", "final", "cls"]
+        sizes = [B * HW * self.cin, B * HW * C, B * HW * C, B * HW * C, B * HW * self.cproj]
+        if need_backward:
+            names += ["gstem1", "gfeat", "gfinal", "gcls"]
+            sizes += [B * HW * C, B * HW * C, B * HW * C, B * HW * self.cproj]
+        if nhwc:
+            names, sizes = names[1:], sizes[1:]
+        ws = {n: self._buf(n, s) for n, s in zip(names, sizes)}
+        if nhwc:
+            ws["xin"] = features.permute(0, 2, 3, 1).reshape(-1)  # a view of the caller's storage
+        if not need_backward:  # records still reference gradient buffers; point them somewhere valid
+            for n in ("gstem1", "gfeat", "gfinal", "gcls"):
+                ws[n] = ws["stem1"]
+        fixed = self._fixed_records(B, ws)
+        pack = _Pack()
+        for k in ("stem1", "stem2"):
+            pack.add(k, fixed[k])
+        pack.upload(dev)
+        self._begin_list()
+        if not nhwc:
+            self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc", B, features.data_ptr(), st, "nchw_to_nhwc",
+                     b=ws["xin"].data_ptr(), p=(self.cin, HW))
+        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
+        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
+        self._flush_list(st, "stem", end=True)
+        return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
+                "features": features, "pack": pack}
+
+    def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
+                    started=None):
+        if started is None:
+            started = self.begin_forward(features, need_backward)
+        elif (started["generation"] != self.generation or started["B"] != features.size(0)
+              or started["need_backward"] != need_backward):
+            raise ValueError("begin_forward token does not belong to this forward pass")
+        a = self.ensure_arena()
+        lib = _hip.lib()
+        dev = a.device
+        B, ws, fixed = started["B"], started["ws"], started["fixed"]
+        HW = self.HW
+        st = _hip.stream_ptr(dev)
+
+        floats = self.scheduler.arena_floats(compiled)
+        act = self._buf("act", max(floats, 1))
+        gact = self._buf("gact", max(floats, 1)) if need_backward else act
+        bufs = Buffers(
+            params=a.flat.data_ptr(), grads=a.grad.data_ptr(), wt=self.wt.data_ptr(),
+            act=act.data_ptr(), gact=gact.data_ptr(), feat=ws["feat"].data_ptr(),
+            gfeat=ws["gfeat"].data_ptr(), final=ws["final"].data_ptr(), gfinal=ws["gfinal"].data_ptr(),
+            ones=self.ones.data_ptr())
+        plan = self.scheduler.plan(compiled, bufs)
+        assert plan.arena_floats == floats, (plan.arena_floats, floats)
+        self.last_plan = plan
+
+        pack = _Pack()
+        for k, rec in fixed.items():
+            pack.add(k, rec)
+        for k, rec in plan.records.items():
+            pack.add(k, rec)
+        for k, rec in plan.wgrad_jobs.items():
+            pack.add(k + "_jobs", rec)
+        pack.upload(dev)
+
+        H, W = self.H, self.W
+        chk = _hip.check
+
+        final = ws["final"][: B * HW * C].view(B, HW * C)
+        feat = ws["feat"][: B * HW * C].view(B, HW * C)
+        valid = [p.valid for p in compiled]
+        if not all(valid):
+            inv = _hip.small_to_device([i for i, v in enumerate(valid) if not v], torch.long, dev)
+            final.index_fill_(0, inv, 0.0)  # reference: zeros_like(feat_input) for invalid programs
+        if plan.feat_result_examples.size:
+            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
+            final.index_copy_(0, idx, feat.index_select(0, idx))
+
+        pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
+        self._begin_list()
+        self._run_forward_launches(plan, pack, st)
+        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
+        self._op(_hip.OP_MAXPOOL_FWD, "pnmn_maxpool2_flatten_fwd", B, ws["cls"].data_ptr(), st, "maxpool",
+                 b=pooled.data_ptr(), p=(H, W, self.cproj))
+        self._flush_list(st, "module programs (forward)", end=True)
+
+        state = None
+        if need_backward:
+            state = _State()
+            state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
+            state.features = started["features"]  # (the stem's weight gradient reads the input again)
+            state.generation = self.generation
+        return pooled, state
+
+    def _run_forward_launches(self, plan: StepPlan, pack: _Pack, st: int) -> None:
+        lib, chk, H, W, HW = _hip.lib(), _hip.check, self.H, self.W, self.HW
+        for l in plan.forward:
+            n = l.end - l.begin
+            if l.kind == "conv":
+                self._conv(pack.ptr("conv", l.begin), n, 1, 9, C, C, 1, 1, st, "module conv")
+            elif l.kind == "proj":
+                self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection")
+            elif l.kind == "dot":
+                self._op(_hip.OP_DOT_FWD, "pnmn_dot1_sigmoid_fwd", n, pack.ptr("dot", l.begin), st, "dot1", p=(HW,))
+            elif l.kind == "same":
+                self._op(_hip.OP_SAME_FWD, "pnmn_same_fwd", n, pack.ptr("same", l.begin), st, "same", p=(HW,))
+            elif l.kind == "minmax":
+                self._op(_hip.OP_MINMAX_FWD, "pnmn_minmax_fwd", n, pack.ptr("minmax", l.begin), st, "minmax", p=(HW, C))
+            else:
+                raise AssertionError(l.kind)
+
+    # ---- backward -------------------------------------------------------------------------------
+    def run_backward(self, state: _State, dpooled: torch.Tensor):
+        if state.generation != self.generation:
+            raise RuntimeError(
+                "NeuralModuleNetwork.forward was called again before backward of the previous call: "
+                "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
+        a = self.arena
+        lib, chk = _hip.lib(), _hip.check
+        dev = a.device
+        st = _hip.stream_ptr(dev)
+        plan, pack, B = state.plan, state.pack, state.B
+        H, W, HW = self.H, self.W, self.HW
+        ws = self._ws
+        dpooled = dpooled.contiguous()
+
+        _hip.mark("trunk backward begins (dpooled ready)")
+        a.grad.zero_()
+        if plan.arena_floats:
+            ws["gact"][: plan.arena_floats].zero_()
+        ws["gfeat"][: B * HW * C].zero_()
+        _hip.mark("gradient buffers zeroed")
+        self._begin_list()
+        self._op(_hip.OP_TRANSPOSE_WEIGHTS, "pnmn_transpose_weights", self._wt_count, self._wt_records.data_ptr(), st,
+                 "transpose weights")
+
+        main = torch.cuda.current_stream(dev)
+        if self.overlap_wgrad:
+            if self._side_stream is None or self._side_stream.device != dev:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+        else:
+            side = main
+
+        def fork():
+            """work queued on `side` from here on may read everything `main` has produced so far"""
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+
+        # classifier conv
+        self._op(_hip.OP_MAXPOOL_BWD, "pnmn_maxpool2_flatten_bwd", B, ws["cls"].data_ptr(), st, "maxpool bwd",
+                 b=dpooled.data_ptr(), c=ws["gcls"].data_ptr(), p=(H, W, self.cproj))
+        fork()
+        nj = len(state.fixed["cls_wg_jobs"])
+        self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
+                    "classifier wgrad")
+        self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
+        if plan.feat_result_examples.size:
+            self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
+            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
+            gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
+            gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
+            gfeat.index_add_(0, idx, gfinal.index_select(0, idx))
+
+        # module programs, levels in reverse; each group of module-conv weight gradients is released
+        # to the side stream as soon as the data-gradient chain has passed its lowest level
+        groups = list(plan.wgrad_groups or [])
+        n_items3 = len(plan.records["wg3"])
+        n_jobs3 = max(1, len(plan.wgrad_jobs["wg3"]))
+        for phase in plan.backward:
+            for l in phase:
+                n = l.end - l.begin
+                if l.kind == "dot_bwd":
+                    self._op(_hip.OP_DOT_BWD, "pnmn_dot1_sigmoid_bwd", n, pack.ptr("dot", l.begin), st, "dot1 bwd", p=(HW,))
+                elif l.kind == "same_bwd":
+                    self._op(_hip.OP_SAME_BWD, "pnmn_same_bwd", n, pack.ptr("same", l.begin), st, "same bwd", p=(HW,))
+                elif l.kind == "minmax_bwd":
+                    self._op(_hip.OP_MINMAX_BWD, "pnmn_minmax_bwd", n, pack.ptr("minmax", l.begin), st, "minmax bwd", p=(HW, C))
+                elif l.kind == "dgrad":
+                    self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad")
+                elif l.kind == "pdgrad":
+                    self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad")
+                elif l.kind == "maskbwd":
+                    self._op(_hip.OP_MASK_BWD, "pnmn_mask_bwd", n, pack.ptr("maskbwd", l.begin), st, "mask bwd", p=(HW,))
+                else:
+                    raise AssertionError(l.kind)
+            level = phase[0].level
+            ready = [g for g in groups if g[0] >= level]
+            if ready:
+                groups = [g for g in groups if g[0] < level]
+                fork()
+                for _, jb, je in ready:
+                    self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3,
+                                9, 1, 1, C, C, side, "module wgrad")
+        fork()
+        for _, jb, je in groups:
+            self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3, 9, 1, 1,
+                        C, C, side, "module wgrad")
+        nj = len(plan.wgrad_jobs["wgp"])
+        if nj:
+            self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, side,
+                        "projection wgrad")
+
+        # stem: gfeat is complete here
+        nj = len(state.fixed["stem2_wg_jobs"])
+        self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, side, "stem conv2 wgrad")
+        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad")
+        fork()
+        nj = len(state.fixed["stem1_wg_jobs"])
+        self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, side,
+                    "stem conv1 wgrad")
+        if side is not main:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+        self._flush_list(st, "trunk backward", end=True)
+
+        if self.direct_grads:
+            a.attach_grads()
+            return [None] * len(a.names)
+        return [a.grad_view(n) for n in a.names]

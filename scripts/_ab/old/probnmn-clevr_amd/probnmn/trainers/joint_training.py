@@ -1,0 +1,286 @@
+"""Question-coding and joint-training iterations on one GPU / one DP rank (reference:
+probnmn/trainers/question_coding_trainer.py:109-168, joint_training_trainer.py:128-198,
+_trainer.py:135-151): split the batch into supervised / unsupervised examples, -ELBO (+ gamma *
+answer loss) on the unsupervised ones, alpha-weighted teacher-forced cross entropies on the
+supervised ones, backward, [gradient all-reduce], element-wise clamp to [-5, 5], one Adam over all
+trainable models.
+
+Data parallelism: every loss term is a mean over a data-dependent subset, so a mean of local means
+would weight shards wrongly; each local mean is rescaled by (n_local * world / n_global) before
+backward, which makes the averaged all-reduced gradient equal the single-process gradient
+(SURVEY.md 8e).
+"""
+import os
+import time
+from typing import Any, Dict
+
+import torch
+
+from probnmn import _hip, parallel
+from probnmn.modules.elbo import JointTrainingElbo, QuestionCodingElbo
+from probnmn.optim import ClampAdam
+from ._base import StepBase
+
+
+def _split_supervision(supervision: torch.Tensor):
+    """Index tensors of supervised / unsupervised examples.  The split sizes are data dependent, so
+    the host must know them; a CPU ``supervision`` tensor (what the data loader yields) costs no
+    device sync."""
+    sup_host = supervision.detach().cpu()
+    return sup_host.nonzero().flatten(), (1 - sup_host).nonzero().flatten()
+
+
+_dp_weight = parallel.mean_weight  # (n_local * world / n_global, see probnmn.parallel)
+
+
+def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
+    """Row-concatenate two token matrices, right-padding the narrower one."""
+    w = max(a.size(1), b.size(1))
+    if a.size(1) < w:
+        a = torch.nn.functional.pad(a, (0, w - a.size(1)), value=pad)
+    if b.size(1) < w:
+        b = torch.nn.functional.pad(b, (0, w - b.size(1)), value=pad)
+    return torch.cat((a, b), 0)
+
+
+class _TrainerBase(StepBase):
+    def _make_optimizer(self, models, lr, weight_decay):
+        arenas = []
+        params = []
+        for m in models:
+            if hasattr(m, "engine"):
+                arenas.append(m.engine.ensure_arena())
+                m.engine.direct_grads = True
+            params.extend(m.parameters())
+        optimizer = ClampAdam(params, arenas=arenas, lr=lr, weight_decay=weight_decay, clamp=5.0)
+        # data parallel: the NMN's fully connected layer (205 MB of gradient) is the first thing backward
+        # finishes -- its all-reduce starts from the gradient hook and runs beside the NMN trunk backward
+        # (plain grouped launches), well before the multi-CU recurrent kernels of the seq2seq backward,
+        # which want the whole chip to themselves
+        big = [p for p in optimizer.loose if p.numel() >= (1 << 20)]
+        self._early = parallel.EarlyReducer(big) if big else None
+        return optimizer
+
+    def _finish(self, loss: torch.Tensor) -> None:
+        if loss.requires_grad:  # (false only for a data-parallel shard without any row: it contributes zeros)
+            _hip.mark("backward begins")
+            loss.backward()
+            _hip.mark("backward issued")
+        side = getattr(self, "_side", None)
+        if side is not None:  # the NMN's backward ran on its own stream: gradients are used below on this one
+            torch.cuda.current_stream(side.device).wait_stream(side)
+        parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
+        self.optimizer.step()
+        self.iteration += 1
+
+    def _host_copy(self, tokens: torch.Tensor):
+        """Start the device -> host copy of the sampled programs into a (cached) pinned buffer and
+        return (host tensor, event).  Queued right behind the sampling decode, the copy completes
+        while the GPU works through the passes launched after it, so the host can compile and
+        schedule the NMN launches for the samples without the GPU ever waiting for it."""
+        cache = self.__dict__.setdefault("_pinned_programs", {})
+        key = tuple(tokens.shape)
+        if key not in cache:
+            cache[key] = torch.empty(key, dtype=tokens.dtype, pin_memory=True)
+        host = cache[key]
+        host.copy_(tokens, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return host, event
+
+    def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
+                        reconstruct: bool = True, host_programs: bool = False, after_sampling=None):
+        """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
+        rows of the reference's separate calls batched into as few recurrent launches as the data
+        dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
+        more rows costs the same time):
+
+          * one ProgramGenerator encoder pass over every question it will decode, then the
+            teacher-forced decode of the supervised rows and the sampling decode of the others;
+          * ONE QuestionReconstructor pass: both of the reference's calls are teacher-forced on the
+            question, with the sampled programs resp. the ground-truth programs as source.
+
+        Rows are independent in every model, so each row's loss equals the reference's separate
+        calls' (question_coding_trainer.py:128-160, joint_training_trainer.py:150-190).
+        ``reconstruct=False`` skips the reconstruction of the samples where the objective does not
+        use it (the reference's joint "baseline" objective evaluates and discards it, elbo.py:236-251)."""
+        dev = batch["question"].device
+        out = {}
+        n_sup, n_nosup = (sup_d.numel() if supervised else 0), (nosup_d.numel() if sampled else 0)
+        if n_sup == 0 and n_nosup == 0:
+            return out
+        question = batch["question"]
+        if n_sup:
+            program = batch["program"].to(dev)
+            prog_sup, ques_sup = program[sup_d], question[sup_d]
+        if n_sup and n_nosup:
+            state = self.pg.encode(question)
+            state_sup, state_nosup = self.pg.select_rows(state, sup_d), self.pg.select_rows(state, nosup_d)
+        elif n_sup:
+            state_sup = self.pg.encode(ques_sup)
+        else:
+            state_nosup = self.pg.encode(question[nosup_d])
+        if n_nosup:
+            ques_nosup = question[nosup_d]
+            out["pg"] = self.pg.decode(state_nosup, None, "sampling")
+            z = out["pg"]["predictions"]
+            out["programs"] = z
+            if host_programs:
+                out["programs_host"] = self._host_copy(z)
+            if after_sampling is not None:
+                out["after_sampling"] = after_sampling()
+        if n_sup:
+            out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"].mean()
+        if n_sup and n_nosup:
+            qr_loss = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
+            out["qr"], out["qr_sup"] = qr_loss[:n_nosup], qr_loss[n_nosup:].mean()
+        elif n_sup:
+            out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"].mean()
+        elif reconstruct:
+            out["qr"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
+        if n_nosup and prior:
+            with torch.no_grad():  # frozen model whose output only enters the detached reward
+                out["prior"] = self.prior(z, need_predictions=False)["loss"]
+        return out
+
+
+class QuestionCodingStep(_TrainerBase):
+    def __init__(self, program_generator, question_reconstructor, program_prior, objective: str = "ours",
+                 alpha: float = 100.0, beta: float = 0.1, delta: float = 0.99, lr: float = 1e-3,
+                 weight_decay: float = 0.0, lr_gamma: float = 0.5, lr_patience: int = 3):
+        if objective not in ("ours", "baseline"):
+            raise ValueError("objective must be 'ours' or 'baseline'")
+        self.pg, self.qr, self.prior = program_generator, question_reconstructor, program_prior
+        self.objective, self.alpha = objective, alpha
+        self.prior.eval()
+        self.elbo = QuestionCodingElbo(self.pg, self.qr, self.prior, beta=beta, baseline_decay=delta)
+        self.models = {"program_generator": self.pg, "question_reconstructor": self.qr}
+        self.optimizer = self._make_optimizer([self.pg, self.qr], lr, weight_decay)
+        self._init_schedule(lr_gamma, lr_patience)
+        self.iteration = 0
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        self.optimizer.zero_grad()
+        self.pg.train()
+        self.qr.train()
+        dev = batch["question"].device
+        sup, nosup = _split_supervision(batch["supervision"])
+        sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
+        ours = self.objective == "ours"
+        p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=True, sampled=ours, prior=True)
+        out: Dict[str, Any] = {}
+        loss = torch.zeros((), device=dev)
+        # Data parallel: both weights are computed (one collective each) and the REINFORCE baseline is
+        # synchronised on EVERY rank, whatever this rank's shard holds -- a rank without supervised (or
+        # without unsupervised) rows must issue the same sequence of collectives as the others.
+        w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
+        if "pg_sup" in p:
+            loss = loss + w_sup * (self.alpha if ours else 1.0) * (p["pg_sup"] + p["qr_sup"])
+            out["loss"] = {"program_generation_gt": p["pg_sup"].detach(), "question_reconstruction_gt": p["qr_sup"].detach()}
+        if "pg" in p:
+            elbo_out = self.elbo.combine(p["pg"]["loss"], p["qr"], p["prior"])
+            loss = loss - w_nosup * elbo_out["elbo"]
+            out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
+            out["programs"] = p["programs"]
+        elif ours and parallel.world() > 1:
+            self.elbo._reinforce.idle(dev)
+        self._finish(loss)
+        out["objective"] = loss.detach()
+        return out
+
+
+class JointTrainingStep(_TrainerBase):
+    def __init__(self, program_generator, question_reconstructor, program_prior, nmn, objective: str = "ours",
+                 alpha: float = 100.0, beta: float = 0.1, gamma: float = 1.0, delta: float = 0.99,
+                 lr: float = 1e-6, weight_decay: float = 0.0, lr_gamma: float = 0.5, lr_patience: int = 3):
+        if objective not in ("ours", "baseline"):
+            raise ValueError("objective must be 'ours' or 'baseline'")
+        self.pg, self.qr, self.prior, self.nmn = program_generator, question_reconstructor, program_prior, nmn
+        self.objective, self.alpha, self.gamma = objective, alpha, gamma
+        self.prior.eval()
+        self.elbo = JointTrainingElbo(self.pg, self.qr, self.prior, self.nmn, beta=beta, gamma=gamma,
+                                      baseline_decay=delta, objective=objective)
+        self.models = {"program_generator": self.pg, "question_reconstructor": self.qr, "nmn": self.nmn}
+        self.optimizer = self._make_optimizer([self.pg, self.qr, self.nmn], lr, weight_decay)
+        self._init_schedule(lr_gamma, lr_patience)
+        self.iteration = 0
+        self.blocked_seconds = 0.0  # host time spent waiting for the sampled programs (diagnostic, bench.py)
+        # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
+        self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
+        self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
+        self._side = None
+
+    def _nmn_stream(self, dev) -> "torch.cuda.Stream":
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        self.optimizer.zero_grad()
+        for m in (self.pg, self.qr, self.nmn):
+            m.train()
+        self.nmn.report_batch_metrics = False
+        dev = batch["question"].device
+        sup, nosup = _split_supervision(batch["supervision"])
+        sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
+        if nosup.numel() == 0 and parallel.world() == 1:
+            raise ValueError("joint training needs at least one example without program supervision in the batch")
+        ours = self.objective == "ours"
+        # Data parallel: every rank issues the same collectives in the same order (both loss weights, the
+        # REINFORCE baseline, the gradient all-reduces) whatever its shard holds; a shard without
+        # unsupervised rows contributes zeros to the terms it has no rows for.
+        w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
+        out: Dict[str, Any] = {"loss": {}}
+        if nosup.numel():
+            images, answers = batch["image"][nosup_d], batch["answer"][nosup_d]
+            main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            # (beyond ~320 sampled rows either side fills the chip on its own: sharing it gains < 1 % and
+            # only blurs per-kernel timings, so larger batches stay on one stream)
+            side = self._nmn_stream(dev) if (self.nmn_stream and main is not None
+                                             and nosup.numel() <= self.nmn_stream_max_rows) else None
+            if side is not None:
+                # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
+                # starts at once (next to the generator's encoder and sampling decode); its module programs
+                # and classifier run next to the reconstructor / prior / supervised passes, and autograd
+                # replays each side's backward on the stream its forward ran on, so the two backward passes
+                # overlap as well.  Only this build's trunk kernels go to the side stream -- none of them waits
+                # for another workgroup, so they always drain; the recurrent multi-CU kernels AND the library
+                # GEMMs (fully connected layers included) stay on the main stream, one after the other: two
+                # kernels that each wait for their own not-yet-resident workgroups can starve each other of
+                # CUs forever (that is what stalled the side-stream experiment of round 1).
+                side.wait_stream(main)  # images / answers / index tensors were produced on the main stream
+                with torch.cuda.stream(side):
+                    started = self.nmn.begin(images)
+                p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
+                                         reconstruct=ours, host_programs=True)
+            else:
+                # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
+                # (with the reconstructor / prior passes) while the host schedules the sampled programs
+                p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
+                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images))
+                started = p["after_sampling"]
+            programs_host, copied = p["programs_host"]
+            t0 = time.perf_counter()
+            copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
+            self.blocked_seconds += time.perf_counter() - t0
+            nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side)
+            elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
+            _hip.mark("elbo combined")
+            nmn_loss = elbo_out.pop("nmn_loss")
+            loss = w_nosup * (self.gamma * nmn_loss - elbo_out["elbo"])
+            out["loss"]["nmn"] = nmn_loss.detach()
+            out["elbo"] = {k: v.detach() for k, v in elbo_out.items()}
+            out["programs"] = p["programs"]
+        else:
+            p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=False, prior=False)
+            self.elbo._reinforce.idle(dev)
+            for a in self.optimizer.arenas:  # no NMN backward on this rank, which is what zeroes them
+                a.grad.zero_()
+            loss = torch.zeros((), device=dev)
+        if "pg_sup" in p:
+            loss = loss + w_sup * self.alpha * (p["pg_sup"] + p["qr_sup"])
+            out["loss"]["program_generation_gt"] = p["pg_sup"].detach()
+            out["loss"]["question_reconstruction_gt"] = p["qr_sup"].detach()
+        self._finish(loss)
+        out["objective"] = loss.detach()
+        return out
