@@ -46,13 +46,16 @@ __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows][128], the last rows are zero
     constexpr int NB = H / TH;
-    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (XCD = linear id % 8), each with
-    // its own L2.  The KSPLIT workgroups of a unit all stage the same input region, so they are given ids
-    // that are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
+    // XCD-aware mapping: the hardware deals workgroups round-robin over the 8 XCDs (XCD = linear id % 8), each
+    // with its own L2.  XCD x takes the CONTIGUOUS range [x per_xcd, (x+1) per_xcd) of the launch's units: the
+    // host sorts a launch's items by weight, so an XCD streams one or two 590 KB weights through its 4 MB L2
+    // instead of all ~15 of the level (dealing units round-robin fetched 380-700 KB per item, ranges 130-160;
+    // scripts/pmc_conv.sh).  The KSPLIT workgroups of a unit all stage the same input region and get ids that
+    // are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
     const int slot = blockIdx.x >> 3;
     const int j = slot / KSPLIT;
-    const int unit = per_xcd ? (blockIdx.x & 7) * per_xcd + j : j * 8 + (blockIdx.x & 7);
-    if (unit >= n_units || (per_xcd && j >= per_xcd)) return;
+    const int unit = (blockIdx.x & 7) * per_xcd + j;
+    if (unit >= n_units || j >= per_xcd) return;
     const int u = unit0 + unit;
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
@@ -77,9 +80,8 @@ int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_c
         configured = true;
     }
     dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT, cout_blocks);
-    static const bool ranges = getenv("PNMN_CONV_XCD_RANGES") != nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
-                       out_stride, relu, ranges ? (n_units + 7) / 8 : 0);
+                       out_stride, relu, (n_units + 7) / 8);
     return (int)hipGetLastError();
 }
 

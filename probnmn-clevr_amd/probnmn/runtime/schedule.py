@@ -333,9 +333,12 @@ class BatchScheduler:
         records: Dict[str, np.ndarray] = {}
         launches: Dict[str, List[Tuple[int, int, int]]] = {}
 
-        def finish(name, mat, lv, dtype_key):
-            """sort by level, view as records, cut launches"""
-            idx = np.argsort(lv, kind="stable")
+        def finish(name, mat, lv, dtype_key, wcol=None):
+            """sort by level (and, inside a level, by weight: the conv kernels deal contiguous ranges of a
+            launch's items to the XCDs, so each XCD's L2 holds the one or two weights its items use instead of
+            every weight of the level -- 3x less HBM read traffic, scripts/pmc_conv.sh), view as records, cut
+            launches"""
+            idx = np.argsort(lv, kind="stable") if wcol is None else np.lexsort((mat[:, wcol], lv))
             records[name] = np.ascontiguousarray(mat[idx]).view(self.dt[dtype_key]).reshape(-1)
             launches[name] = _cut(lv[idx])
             return idx
@@ -376,8 +379,8 @@ class BatchScheduler:
                 dg[:, 7] = dil[m]
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 2], wg[:, 3], wg[:, 4], wg[:, 5] = a_f[m], mask_ptr, o_g[m], o_f[m], dil[m]
-            idx = finish("conv", fw, lv, "conv")
-            finish("dgrad", dg, lv, "conv")
+            idx = finish("conv", fw, lv, "conv", wcol=4)
+            finish("dgrad", dg, lv, "conv", wcol=4)
             # mask backward for the masked convs (same level order as the dgrads)
             mm = masked[idx]
             if mm.any() and not self.fuse_mask_bwd:
@@ -410,14 +413,14 @@ class BatchScheduler:
             fw[:, 0], fw[:, 1] = a_f[m], b_f[m]
             fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
             fw[:, 7] = 1
-            finish("proj", fw, lv, "conv")
+            finish("proj", fw, lv, "conv", wcol=4)
             # two dgrads (one per operand), accumulate flag set; the halves never share a launch
             pd = np.zeros((2 * n, 12), u64)
             pd[:, 0], pd[:, 3] = np.tile(o_g[m], 2), np.tile(o_f[m], 2)
             pd[:n, 4], pd[n:, 4] = buf.wt + wt_off * 4, buf.wt + (wt_off + C * C) * 4
             pd[:n, 6], pd[n:, 6] = a_g[m], b_g[m]
             pd[:, 7] = 1 | (1 << 32)
-            finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + 1)), "conv")
+            finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + 1)), "conv", wcol=4)
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 1], wg[:, 3], wg[:, 4] = a_f[m], b_f[m], o_g[m], o_f[m]
             records["wgp"], jobsp, _ = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4)
