@@ -108,7 +108,25 @@ class NMNEngine:
         self._list: Optional[_hip.LaunchList] = None
         self.launch_lists = os.environ.get("PNMN_LAUNCH_LISTS", "1") != "0"
 
-    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what):
+    def _conv_bytes(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
+        """Algorithmic HBM bytes of one grouped conv call (roofline accounting only): every map an item must
+        read (input chunks, the ReLU gate of a data gradient, the attention mask, the forward features and the
+        accumulated gradient of the fused mask backward, the previous contents of an accumulating output) and
+        write once, plus ONE pass over each distinct weight of the call."""
+        m = self.HW * C * 4.0
+        wbytes = cout_blocks * C * ntaps * cin_chunks * C * 4.0
+        if rec is None:
+            return n * m * (cin_chunks + cout_blocks) + wbytes
+        r = rec
+        maps = np.full(n, float(cin_chunks + cout_blocks))
+        maps += (r["gate"] != 0) * cin_chunks
+        maps += ((r["flags"] & _hip.CONV_ACCUMULATE) != 0) * cout_blocks
+        mb = (r["flags"] & _hip.CONV_MASKBWD) != 0
+        maps += mb * (1.0 + (r["mb_attn"] != 0))  # dFEAT read-modify-write (+ FEAT when an attention multiplies it)
+        extra = self.HW * 4.0 * ((r["mask"] != 0).sum() + 2 * (mb & (r["mb_attn"] != 0)).sum())
+        return float(maps.sum()) * m + extra + np.unique(r["weight"]).size * wbytes
+
+    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what, rec=None):
         log = self.event_log
         if self._list is not None:  # (collected into one pnmn_run_launches call)
             self._list.add(_hip.OP_CONV, n, ptr, p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
@@ -121,10 +139,9 @@ class NMNEngine:
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes: every item's input and
-            # output map once + one pass over the weights, kernel launches of this call)
+            # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes, kernel launches of this call)
             log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
-                        4.0 * (n * self.HW * (cin_chunks + cout_blocks) * C + cout_blocks * C * ntaps * cin_chunks * C),
+                        self._conv_bytes(rec, n, cin_chunks, ntaps, cout_blocks),
                         _hip.lib().pnmn_conv_nhwc_launches(n, self.H, self.W, cin_chunks, ntaps, cout_blocks)))
 
     def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
@@ -365,8 +382,8 @@ class NMNEngine:
         if not nhwc:
             self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc", B, features.data_ptr(), st, "nchw_to_nhwc",
                      b=ws["xin"].data_ptr(), p=(self.cin, HW))
-        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1")
-        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2")
+        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1", rec=fixed["stem1"])
+        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2", rec=fixed["stem2"])
         self._flush_list(st, "stem", end=True)
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
                 "features": features, "pack": pack}
@@ -422,7 +439,7 @@ class NMNEngine:
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
         self._begin_list()
         self._run_forward_launches(plan, pack, st)
-        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv")
+        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv", rec=fixed["cls"])
         self._op(_hip.OP_MAXPOOL_FWD, "pnmn_maxpool2_flatten_fwd", B, ws["cls"].data_ptr(), st, "maxpool",
                  b=pooled.data_ptr(), p=(H, W, self.cproj))
         self._flush_list(st, "module programs (forward)", end=True)
@@ -440,9 +457,9 @@ class NMNEngine:
         for l in plan.forward:
             n = l.end - l.begin
             if l.kind == "conv":
-                self._conv(pack.ptr("conv", l.begin), n, 1, 9, C, C, 1, 1, st, "module conv")
+                self._conv(pack.ptr("conv", l.begin), n, 1, 9, C, C, 1, 1, st, "module conv", rec=plan.records["conv"][l.begin:l.end])
             elif l.kind == "proj":
-                self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection")
+                self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection", rec=plan.records["proj"][l.begin:l.end])
             elif l.kind == "dot":
                 self._op(_hip.OP_DOT_FWD, "pnmn_dot1_sigmoid_fwd", n, pack.ptr("dot", l.begin), st, "dot1", p=(HW,))
             elif l.kind == "same":
@@ -499,7 +516,7 @@ class NMNEngine:
         nj = len(state.fixed["cls_wg_jobs"])
         self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
                     "classifier wgrad")
-        self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad")
+        self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad", rec=state.fixed["cls_dgrad"])
         if plan.feat_result_examples.size:
             self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
             idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
@@ -522,9 +539,9 @@ class NMNEngine:
                 elif l.kind == "minmax_bwd":
                     self._op(_hip.OP_MINMAX_BWD, "pnmn_minmax_bwd", n, pack.ptr("minmax", l.begin), st, "minmax bwd", p=(HW, C))
                 elif l.kind == "dgrad":
-                    self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad")
+                    self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad", rec=plan.records["dgrad"][l.begin:l.end])
                 elif l.kind == "pdgrad":
-                    self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad")
+                    self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad", rec=plan.records["pdgrad"][l.begin:l.end])
                 elif l.kind == "maskbwd":
                     self._op(_hip.OP_MASK_BWD, "pnmn_mask_bwd", n, pack.ptr("maskbwd", l.begin), st, "mask bwd", p=(HW,))
                 else:
@@ -549,7 +566,7 @@ class NMNEngine:
         # stem: gfeat is complete here
         nj = len(state.fixed["stem2_wg_jobs"])
         self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, side, "stem conv2 wgrad")
-        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad")
+        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad", rec=state.fixed["stem2_dgrad"])
         fork()
         nj = len(state.fixed["stem1_wg_jobs"])
         self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, side,
