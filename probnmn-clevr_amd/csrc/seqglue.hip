@@ -112,34 +112,64 @@ __global__ __launch_bounds__(256) void mask_last_bwd_kernel(const float* __restr
 
 // ---- embedding gradient for a small vocabulary ------------------------------------------------------------
 //   dw[v][c] += sum over rows r with tokens[r] == v of dy[r][c]          (dw zeroed by the caller, V <= 128)
-// grid (C / 64, row splits); a workgroup sums its rows into an LDS table [V][64] (ds_add_f32), then adds the
-// table into dw.  `shift` = 1: row (b, t) takes the token of (b, t - 1) and `start` for t = 0 (the input
-// token of decoding step t), tokens being [B][T].
+// grid (C / (64 VEC), row splits); a workgroup sums its rows into an LDS table [V][64 VEC] (ds_add_f32), then
+// adds the table into dw.  A wave reads 256 VEC contiguous bytes of one row; the four waves take different rows,
+// eight rows in flight each (the loop is bound by the latency of its loads, not by their bytes).  `shift` = 1:
+// row (b, t) takes the token of (b, t - 1) and `start` for t = 0 (the input token of decoding step t),
+// tokens being [B][T].
+template <int VEC>
 __global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ dy, const int64_t* __restrict__ tokens,
                                                              int64_t tok_bstride, int B, int T, int C, int V, int shift,
                                                              int start, int skip, float* __restrict__ dw) {
-    extern __shared__ float table[];  // [V][64]
-    for (int i = threadIdx.x; i < V * 64; i += 256) table[i] = 0.f;
+    extern __shared__ float table[];  // [V][64 * VEC]
+    constexpr int W = 64 * VEC;
+    constexpr int UN = 8;
+    for (int i = threadIdx.x; i < V * W; i += 256) table[i] = 0.f;
     __syncthreads();
-    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + col;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * W + lane * VEC;
     const int R = B * T;
     const int per = (R + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
-    for (int r = r0 + sub; r < r1; r += 4) {
-        const int b = r / T, t = r - b * T;
-        int64_t v;
-        if (shift)
-            v = t == 0 ? start : tokens[(size_t)b * tok_bstride + t - 1];
-        else
-            v = tokens[(size_t)b * tok_bstride + t];
-        if (v == skip || v < 0 || v >= V) continue;
-        unsafeAtomicAdd(&table[(int)v * 64 + col], dy[(size_t)r * C + c]);
+    for (int rb = r0 + sub; rb < r1; rb += 4 * UN) {
+        float val[UN][VEC];
+        int tok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int r = rb + 4 * u;
+            tok[u] = -1;
+            if (r < r1) {
+                const int b = r / T, t = r - b * T;
+                int64_t v;
+                if (shift)
+                    v = t == 0 ? start : tokens[(size_t)b * tok_bstride + t - 1];
+                else
+                    v = tokens[(size_t)b * tok_bstride + t];
+                tok[u] = (v == skip || v < 0 || v >= V) ? -1 : (int)v;
+                const float* src = dy + (size_t)r * C + c;
+                if (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    val[u][0] = q.x, val[u][1 % VEC] = q.y, val[u][2 % VEC] = q.z, val[u][3 % VEC] = q.w;
+                } else if (VEC == 2) {
+                    const float2 q = *reinterpret_cast<const float2*>(src);
+                    val[u][0] = q.x, val[u][1 % VEC] = q.y;
+                } else {
+                    val[u][0] = *src;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (tok[u] < 0) continue;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                if (val[u][k] != 0.f) unsafeAtomicAdd(&table[tok[u] * W + lane * VEC + k], val[u][k]);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < V * 64; i += 256) {
+    for (int i = threadIdx.x; i < V * W; i += 256) {
         const float s = table[i];
-        if (s != 0.f) unsafeAtomicAdd(dw + (size_t)(i >> 6) * C + blockIdx.x * 64 + (i & 63), s);
+        if (s != 0.f) unsafeAtomicAdd(dw + (size_t)(i / W) * C + blockIdx.x * W + (i % W), s);
     }
 }
 
@@ -218,12 +248,33 @@ extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64
     if (B <= 0 || T <= 0) return 0;
     if (!dy || !tokens || !dw || (C & 63) || V < 1 || V > 128) return PNMN_EINVAL;
     const long rows = (long)B * T;
-    int splits = (int)((rows + 255) / 256);  // >= 256 rows per workgroup
-    const int cap = 1024 / (C / 64) > 1 ? 1024 / (C / 64) : 1;
+    // widest row segment per wave (1 KiB; the table then takes up to 128 KiB of the CU's LDS: one workgroup per
+    // CU, eight loads in flight per lane)
+    const int vec = (C % 256 == 0) ? 4 : (C % 128 == 0) ? 2 : 1;
+    const int blocks = C / (64 * vec);
+    int splits = (int)((rows + 127) / 128);  // >= 128 rows per workgroup
+    const int cap = 512 / blocks > 1 ? 512 / blocks : 1;
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
-    hipLaunchKernelGGL(embedding_grad_kernel, dim3(C / 64, splits), dim3(256), (size_t)V * 64 * sizeof(float),
-                       static_cast<hipStream_t>(stream), dy, tokens, token_row_stride, B, T, C, V, shift, start, skip, dw);
+    const size_t lds = (size_t)V * 64 * vec * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(blocks, splits);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embedding_grad_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    if (vec == 4)
+        hipLaunchKernelGGL(embedding_grad_kernel<4>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
+                           start, skip, dw);
+    else if (vec == 2)
+        hipLaunchKernelGGL(embedding_grad_kernel<2>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
+                           start, skip, dw);
+    else
+        hipLaunchKernelGGL(embedding_grad_kernel<1>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
+                           start, skip, dw);
     return (int)hipGetLastError();
 }
 
