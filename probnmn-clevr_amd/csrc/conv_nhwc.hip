@@ -54,8 +54,8 @@ __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     // are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
     const int slot = blockIdx.x >> 3;
     const int j = slot / KSPLIT;
-    const int unit = (blockIdx.x & 7) * per_xcd + j;
-    if (unit >= n_units || j >= per_xcd) return;
+    const int unit = per_xcd ? (blockIdx.x & 7) * per_xcd + j : j * 8 + (blockIdx.x & 7);
+    if (unit >= n_units || (per_xcd && j >= per_xcd)) return;
     const int u = unit0 + unit;
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
@@ -80,8 +80,9 @@ int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_c
         configured = true;
     }
     dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT, cout_blocks);
+    static const bool round_robin = getenv("PNMN_CONV_XCD_ROUNDROBIN") != nullptr;  // (tuning hook: the former mapping)
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
-                       out_stride, relu, (n_units + 7) / 8);
+                       out_stride, relu, round_robin ? 0 : (n_units + 7) / 8);
     return (int)hipGetLastError();
 }
 

@@ -338,7 +338,10 @@ class BatchScheduler:
             launch's items to the XCDs, so each XCD's L2 holds the one or two weights its items use instead of
             every weight of the level -- 3x less HBM read traffic, scripts/pmc_conv.sh), view as records, cut
             launches"""
-            idx = np.argsort(lv, kind="stable") if wcol is None else np.lexsort((mat[:, wcol], lv))
+            if wcol is None or os.environ.get("PNMN_NO_WEIGHT_SORT"):  # (the variable: a tuning hook)
+                idx = np.argsort(lv, kind="stable")
+            else:
+                idx = np.lexsort((mat[:, wcol], lv))
             records[name] = np.ascontiguousarray(mat[idx]).view(self.dt[dtype_key]).reshape(-1)
             launches[name] = _cut(lv[idx])
             return idx

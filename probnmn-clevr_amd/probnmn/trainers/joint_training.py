@@ -232,7 +232,7 @@ class JointTrainingStep(_TrainerBase):
         w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
         out: Dict[str, Any] = {"loss": {}}
         if nosup.numel():
-            images, answers = batch["image"][nosup_d], batch["answer"][nosup_d]
+            answers = batch["answer"][nosup_d]
             main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
             # (beyond ~320 sampled rows either side fills the chip on its own: sharing it gains < 1 % and
             # only blurs per-kernel timings, so larger batches stay on one stream)
@@ -248,12 +248,17 @@ class JointTrainingStep(_TrainerBase):
                 # GEMMs (fully connected layers included) stay on the main stream, one after the other: two
                 # kernels that each wait for their own not-yet-resident workgroups can starve each other of
                 # CUs forever (that is what stalled the side-stream experiment of round 1).
-                side.wait_stream(main)  # images / answers / index tensors were produced on the main stream
+                side.wait_stream(main)  # the batch and the index tensors were produced on the main stream
                 with torch.cuda.stream(side):
+                    # (the gather of the unsupervised examples' features -- 0.8 MB each -- belongs to the NMN's
+                    # lane: on the main stream it sat in front of the generator's encoder for as long as the
+                    # stem convolutions held the CUs)
+                    images = batch["image"][nosup_d]
                     started = self.nmn.begin(images)
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True)
             else:
+                images = batch["image"][nosup_d]
                 # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
                 # (with the reconstructor / prior passes) while the host schedules the sampled programs
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
