@@ -79,7 +79,11 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     const int g = lane >> 4;
 
     // (Measured and rejected: a static s_setprio 1 for waves 4-7 -- MI355X_MICROARCH.md, two waves per SIMD,
-    // item 4 -- changes no launch size by more than 1 %.)
+    // item 4 -- changes no launch size by more than 1 %.  Also rejected: requesting the NEXT stage's region
+    // into registers at the start of a stage's taps, to hide the staging round trips of multi-chunk and
+    // three-pass convolutions behind the MFMAs -- 13-16 more live 16-byte registers push the kernel from 128
+    // VGPRs to 256 + 60-90 spilled, and every launch size lost 5-10 %: full launches 115 -> 108 TFLOP/s,
+    // stem conv1 106 -> 104.)
     const int nt = wave % NT;
     const int ks = wave / NT;  // which slice of the input channels this wave contracts
     const int n0 = cout_block * CB + (nsub * NT + nt) * 16;  // this wave's 16 out channels
