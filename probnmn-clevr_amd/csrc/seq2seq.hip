@@ -416,6 +416,10 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
 // show up), one agent-scope acquire, barrier.  The counter is monotonic (S per step), so no reset race.
 // blockIdx -> (tile, p) keeps a tile's workgroups on one XCD (round-robin dispatch: XCD = blockIdx % 8),
 // which makes the exchange an L2 hit; correctness does not depend on that.
+// (Measured and rejected, round 2: two row tiles per workgroup, alternating, so that one tile's hand-off
+// completes behind the other tile's step -- 1024 rows as 32 pairs x 8 members instead of 64 tiles x 4.  The
+// hand-off is not what a step waits for: 13.4 us per step against 8.7, the two tiles' chains of wait -> load
+// h -> MFMA -> LDS -> cell -> store simply add up in one instruction stream.)
 // The operand order of every accumulation is the single-workgroup kernels'; results differ from theirs
 // only by the compiler's fma contraction of the cell update (last ulps), and are run-to-run identical.
 // -----------------------------------------------------------------------------------------------------
