@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of two checkouts of the python package in ONE gpurun call (box-to-box variance of the host-bound side
-# objects is larger than most changes): scripts/_ab/old (git archive of the baseline commit) vs the tree.
+# objects is larger than most changes): scripts/_ab/old (the baseline commit, git-ignored; make it here with
+#   mkdir -p scripts/_ab/old && git archive <commit> probnmn-clevr_amd/probnmn | tar -x -C scripts/_ab/old
+# -- it runs against the tree's library, so the baseline must not need symbols the tree dropped) vs the tree.
 #   usage: bash scripts/ab.sh [rounds]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
