@@ -449,6 +449,43 @@ typedef struct pnmn_launch {
 int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Host-side batch planner (no device work)                    replaces the per-example interpreter loop of
+ * nmn.py:191-238 together with probnmn.runtime.schedule.BatchScheduler (csrc/host_plan.hip)
+ *   in:   the template bank ([n_templates][pmax][18] int64 primitive tables, see schedule.py), per valid
+ *         example its template id, batch index, first float of its arena block and the token of each call
+ *         ([nv][cmax]); per-token weight offset tables (floats into the parameter / gradient / transposed-weight
+ *         arenas); device base addresses in bytes
+ *   out:  out_words = the record matrices back to back (uint64 words, bit-identical to the structs above):
+ *         0 conv, 1 dgrad, 2 wgrad items (3x3), 3 wgrad jobs (3x3), 4 proj, 5 pdgrad, 6 wgrad items (proj),
+ *         7 wgrad jobs (proj), 8 dot, 9 same, 10 minmax, 11 maskbwd -- each sorted by (level, weight)
+ *         meta[0] = primitives, meta[1] = deepest level, meta[2 + 3k ..] = (first word, rows, words per row) of
+ *         record kind k, meta[38] = number of cuts
+ *         cuts[i] = (kind, level, begin, end): runs of one level in a sorted record array (kinds 0 conv, 1 proj,
+ *         2 dot, 3 same, 4 minmax, 5 dgrad, 6 maskbwd, 7 pdgrad -- pdgrad levels are 2*level + operand), and
+ *         kind 8 = a group of 3x3 weight-gradient jobs (lowest forward level of the group, first job, one past)
+ *   returns PNMN_EINVAL when a capacity is too small (out_capacity words, cuts_capacity rows of 4 int32)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const int64_t* tables;
+    const int64_t* nprims;
+    const int64_t* tids;
+    const int64_t* examples;
+    const int64_t* base;
+    const int64_t* tokens;
+    const int64_t* w3;
+    const int64_t* b3;
+    const int64_t* wt3;
+    const int64_t* dotw;
+    const int64_t* dotb;
+    uint64_t params, grads, wt, act, gact, feat, gfeat, final_, gfinal, ones;
+    int32_t n_templates, pmax, nv, cmax;
+    int32_t hw, channels, wgrad_chunk, wgrad_groups;
+    int32_t fuse_mask_bwd, sole_writer, sort_by_weight, reserved;
+} pnmn_plan_in;   /* 216 bytes */
+int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int64_t out_capacity, int64_t* meta, int32_t* cuts,
+                    int32_t cuts_capacity);
+
+/* ---------------------------------------------------------------------------------------------
  * Host-side batch program compiler (no device work)        nmn.py:191-238, SURVEY App. C
  *   tokens [n_programs][length] int64 prefix programs; kinds[token] = module class of each
  *   vocabulary entry (0 skip, 1 scene, 2 and, 3 or, 4 comparison, 5 attention, 6 query, 7 relate,

@@ -76,6 +76,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_bwd_multi": (_P,) * 14 + (_I,) * 4 + (_P, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_run_launches": (_P, _I, _P),
+    "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
@@ -184,6 +185,11 @@ MINMAX_ITEM = np.dtype(
 MASKBWD_ITEM = np.dtype([("dx", _u64), ("feats", _u64), ("attn", _u64), ("dfeats", _u64), ("dattn", _u64)])
 AXPY_ITEM = np.dtype([("src", _u64), ("dst", _u64), ("n", np.int64)])
 DERIVE_JOB = np.dtype([("src", _u64), ("src2", _u64), ("dst", _u64), ("n", _i32), ("k", _i32), ("ld", _i32), ("kind", _i32)])
+PLAN_IN = np.dtype([(n, _u64) for n in ("tables", "nprims", "tids", "examples", "base", "tokens", "w3", "b3", "wt3",
+                                         "dotw", "dotb", "params", "grads", "wt", "act", "gact", "feat", "gfeat",
+                                         "final_", "gfinal", "ones")]
+                   + [(n, _i32) for n in ("n_templates", "pmax", "nv", "cmax", "hw", "channels", "wgrad_chunk",
+                                          "wgrad_groups", "fuse_mask_bwd", "sole_writer", "sort_by_weight", "reserved")])
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
@@ -227,6 +233,7 @@ ITEM_SIZES = {
     "pnmn_axpy_item": (AXPY_ITEM, 24),
     "pnmn_adam_item": (ADAM_ITEM, 40),
     "pnmn_derive_job": (DERIVE_JOB, 40),
+    "pnmn_plan_in": (PLAN_IN, 216),
 }
 
 

@@ -65,7 +65,7 @@ class CompiledProgram:
     first use when the program came out of the batch compiler as an int32 table ``[n_calls, 7]``
     (kind, token, a, b, a_channels, b_channels, out_channels) -- the scheduler only needs the table."""
 
-    __slots__ = ("valid", "result", "_raw", "_calls", "_template_id", "_template_owner", "_tokens")
+    __slots__ = ("valid", "result", "_raw", "_calls", "_template_id", "_template_owner", "_tokens", "_tokens_row")
 
     def __init__(self, valid: bool, calls: Tuple[ModuleCall, ...] = (), result: int = FEAT, raw=None):
         self.valid = valid
@@ -75,6 +75,7 @@ class CompiledProgram:
         self._template_id = None
         self._template_owner = None
         self._tokens = None
+        self._tokens_row = None
 
     @property
     def calls(self) -> Tuple[ModuleCall, ...]:

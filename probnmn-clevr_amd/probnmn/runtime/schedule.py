@@ -22,13 +22,14 @@ placed directly in the classifier's input row (``FINAL``).
 """
 import os
 from dataclasses import dataclass
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, NamedTuple, Sequence, Tuple
 
 import numpy as np
 
 from . import program_compiler as pc
 
 HW_ALIGN = 64  # floats; keeps every slot 256-byte aligned
+TOKEN_ROW = 48  # calls per program of the fixed-width token rows (longer programs: a per-example copy loop)
 
 # operand location kinds
 L_SLOT, L_FEAT, L_ONES, L_FINAL = 0, 1, 2, 3
@@ -181,8 +182,7 @@ class Buffers:
     ones: int  # [HW] of 1.0
 
 
-@dataclass
-class Launch:
+class Launch(NamedTuple):
     kind: str
     level: int
     begin: int
@@ -224,6 +224,9 @@ class BatchScheduler:
         self.wgrad_groups = wgrad_groups
         self.fuse_mask_bwd = True  # masked convs' data-gradients do the `feats * attn` backward in their epilogue
         self.sole_writer_rmw = os.environ.get("PNMN_MB_SOLE", "1") != "0"
+        self._tables64 = tuple(np.ascontiguousarray(a, dtype=np.int64)
+                               for a in (tables.w3, tables.b3, tables.wt3, tables.dotw, tables.dotb))
+        self._tables64_ptrs = tuple(a.ctypes.data for a in self._tables64)
         self._ids: Dict[Tuple, int] = {}
         self._templates: List[Template] = []
         self._bank = None  # (tables [T, Pmax, NCOLS], nprims [T], sizes [T])
@@ -243,6 +246,10 @@ class BatchScheduler:
         prog._template_id = tid
         prog._template_owner = self
         prog._tokens = prog.table()[:, 1].astype(np.int64)
+        if prog._tokens.size <= TOKEN_ROW:  # fixed-width copy: a batch's token matrix is then one np.array() call
+            row = np.zeros(TOKEN_ROW, np.int64)
+            row[: prog._tokens.size] = prog._tokens
+            prog._tokens_row = row
         return tid
 
     def template(self, prog: pc.CompiledProgram) -> Template:
@@ -262,10 +269,28 @@ class BatchScheduler:
 
     def arena_floats(self, programs: Sequence[pc.CompiledProgram]) -> int:
         """Activation-arena size (floats) the batch needs; the gradient arena mirrors it."""
-        return int(sum(self.template(p).size for p in programs if p.valid))
+        return self._prepare(programs)[5]
+
+    def _prepare(self, programs: Sequence[pc.CompiledProgram]):
+        """Per-batch index arrays shared by ``arena_floats`` and ``plan`` (the engine sizes its buffers with the
+        first and plans with the second): valid examples, their template ids, arena block bases."""
+        hit = self.__dict__.get("_prepared")
+        if hit is not None and hit[0] is programs:
+            return hit
+        ex_valid = [e for e, p in enumerate(programs) if p.valid]
+        nv = len(ex_valid)
+        tids = np.fromiter((self.template_id(programs[e]) for e in ex_valid), dtype=np.int64, count=nv)
+        sizes = self._get_bank()[2]
+        blk = sizes[tids] if nv else np.zeros(0, np.int64)
+        base = np.cumsum(blk) - blk  # first float of each example's arena block
+        self._prepared = (programs, ex_valid, tids, np.asarray(ex_valid, dtype=np.int64), base, int(blk.sum()))
+        return self._prepared
 
     # --------------------------------------------------------------------------------------------
-    def plan(self, programs: Sequence[pc.CompiledProgram], buf: Buffers) -> StepPlan:
+    def plan_numpy(self, programs: Sequence[pc.CompiledProgram], buf: Buffers) -> StepPlan:
+        """The planner as whole-array numpy arithmetic: the specification ``plan`` (the library's
+        ``pnmn_plan_batch``) is checked against, record for record (tests/test_schedule.py).  Not used by the
+        engine: ~250 numpy calls cost 0.75 ms per 65 programs, on the critical path of a small-batch step."""
         hw, C = self.hw, self.channels
         map_bytes = hw * C * 4
         tb = self.tables
@@ -370,8 +395,6 @@ class BatchScheduler:
                 _, inv, cnt = np.unique(lv.astype(np.int64) * (1 << 48) + (a_g[m] >> 4).astype(np.int64) * masked,
                                         return_inverse=True, return_counts=True)
                 sole = masked & (cnt[inv] == 1) & self.sole_writer_rmw
-                if os.environ.get("PNMN_MB_SOLE") == "2":  # timing experiment only (wrong gradients)
-                    sole = masked
                 dg[:, 7] = dil[m] + np.where(masked, 4 << 32, 0) + np.where(sole, 8 << 32, 0)
                 dg[:, 8] = np.where(masked, a_f[m], 0)
                 dg[:, 9] = mask_ptr
@@ -468,8 +491,13 @@ class BatchScheduler:
         for k, v in empty.items():
             records.setdefault(k, v)
 
-        # ---- launch order ------------------------------------------------------------------------
-        depth = int(level.max()) if N else 0
+        fwd, bwd = self._order(launches, int(level.max()) if N else 0)
+        return StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N, wgroups)
+
+    @staticmethod
+    def _order(launches: Dict[str, List[Tuple[int, int, int]]], depth: int):
+        """Forward launch list (by level; within a level And/Or, Same, heads, projections, convs) and the backward
+        phases (levels in reverse) from the per-kind (level, begin, end) cuts."""
         at: Dict[int, Dict[str, Tuple[int, int]]] = {}
         for k in ("conv", "proj", "dot", "same", "minmax", "dgrad", "maskbwd"):
             for lv, b, e in launches.get(k, []):
@@ -498,8 +526,73 @@ class BatchScheduler:
                     phase.append(Launch(k, lv, *here[k]))
             if phase:
                 bwd.append(phase)
+        return fwd, bwd
 
-        return StepPlan(records, fwd, bwd, {"wg3": jobs3, "wgp": jobsp}, arena, feat_result, N, wgroups)
+    # --------------------------------------------------------------------------------------------
+    _RECORD_KINDS = (("conv", "conv"), ("dgrad", "conv"), ("wg3", "wgrad_item"), ("jobs3", "wgrad_job"), ("proj", "conv"),
+                     ("pdgrad", "conv"), ("wgp", "wgrad_item"), ("jobsp", "wgrad_job"), ("dot", "dot"), ("same", "same"),
+                     ("minmax", "minmax"), ("maskbwd", "maskbwd"))
+    _CUT_KINDS = ("conv", "proj", "dot", "same", "minmax", "dgrad", "maskbwd", "pdgrad", "wgroup")
+
+    def plan(self, programs: Sequence[pc.CompiledProgram], buf: Buffers) -> StepPlan:
+        """Work lists of one batch: ONE call of the library's host routine ``pnmn_plan_batch`` (csrc/host_plan.hip)
+        over the template bank; see ``plan_numpy`` for the arithmetic."""
+        from probnmn import _hip
+
+        _, ex_valid, tids, E, base, arena = self._prepare(programs)
+        self._prepared = None  # (one batch, one plan: do not keep the batch's programs alive)
+        nv = len(ex_valid)
+        dt = self.dt
+        records = {name: np.zeros(0, dt[key]) for name, key in self._RECORD_KINDS if not name.startswith("jobs")}
+        if nv == 0:
+            return StepPlan(records, [], [], {"wg3": np.zeros(0, dt["wgrad_job"]), "wgp": np.zeros(0, dt["wgrad_job"])},
+                            0, np.zeros(0, np.int64), 0, [])
+        tables, nprims, sizes, isfeat = self._get_bank()
+        feat_result = E[isfeat[tids]]
+        rows = [programs[e]._tokens_row for e in ex_valid]
+        if all(r is not None for r in rows):
+            cmax = TOKEN_ROW
+            tokens = np.array(rows)
+        else:
+            cmax = max(1, max(programs[e]._tokens.size for e in ex_valid))
+            tokens = np.zeros((nv, cmax), np.int64)
+            for i, e in enumerate(ex_valid):
+                t = programs[e]._tokens
+                tokens[i, : t.size] = t
+        n_total = int(nprims[tids].sum())
+        words = np.empty(n_total * 48 + 64, np.uint64)  # (a projection: 12 + 24 + 6 + 3 words; a masked conv: 38)
+        meta = np.zeros(40, np.int64)
+        cuts = np.empty((4096, 4), np.int32)
+        tb = self._tables64
+        rec = np.zeros(1, _hip.PLAN_IN)
+        rec[0] = (tables.ctypes.data, nprims.ctypes.data, tids.ctypes.data, E.ctypes.data, base.ctypes.data,
+                  tokens.ctypes.data) + self._tables64_ptrs + (
+            buf.params, buf.grads, buf.wt, buf.act, buf.gact, buf.feat, buf.gfeat, buf.final, buf.gfinal, buf.ones,
+            tables.shape[0], tables.shape[1], nv, cmax, self.hw, self.channels, self.wgrad_chunk, self.wgrad_groups,
+            int(self.fuse_mask_bwd), int(self.sole_writer_rmw),
+            int(not os.environ.get("PNMN_NO_WEIGHT_SORT")), 0)  # (PNMN_NO_WEIGHT_SORT: a tuning hook)
+        _hip.check(_hip.lib().pnmn_plan_batch(rec.ctypes.data, words.ctypes.data, words.size, meta.ctypes.data,
+                                              cuts.ctypes.data, cuts.shape[0]), "plan_batch")
+        jobs = {}
+        for k, (name, key) in enumerate(self._RECORD_KINDS):
+            off, rows, cols = (int(v) for v in meta[2 + 3 * k: 5 + 3 * k])
+            if rows == 0:
+                arr = np.zeros(0, dt[key])
+            else:
+                arr = words[off: off + rows * cols].view(dt[key])
+            if name.startswith("jobs"):
+                jobs["wg3" if name == "jobs3" else "wgp"] = arr
+            else:
+                records[name] = arr
+        launches: Dict[str, List[Tuple[int, int, int]]] = {}
+        wgroups = []
+        for kind, lv, b, e in cuts[: int(meta[38])].tolist():
+            if kind == 8:
+                wgroups.append((lv, b, e))
+            else:
+                launches.setdefault(self._CUT_KINDS[kind], []).append((lv, b, e))
+        fwd, bwd = self._order(launches, int(meta[1]))
+        return StepPlan(records, fwd, bwd, jobs, arena, feat_result, int(meta[0]), wgroups)
 
     def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray, group=None):
         """Sort weight-gradient items by (group,) weight and cut each run into jobs of at most

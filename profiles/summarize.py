@@ -47,6 +47,35 @@ def pmc(path):
         print("%-72s %-12s %8d %14.1f %12.2f" % (name.replace(".kd", "")[:72], ctr, n, tot, avg))
 
 
+def mfma(path):
+    """MFMA utilisation per kernel from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass:
+    busy cycles summed over the chip's SIMDs / (GPU-active cycles x 256 CUs x 4 SIMDs).  (ROCm 7.2 ships no gfx950
+    derived metrics; this is the gfx94x MfmaUtil formula.  A v_mfma_f32_16x16x4_f32 occupies its SIMD's matrix
+    pipe for 32 cycles, so the figure can be checked against the algorithmic MFMA count.)"""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
+    suffix = tab.replace("rocpd_kernel_dispatch", "")
+    q = f"""select s.kernel_name, i.name, count(*), sum(e.value)
+            from rocpd_pmc_event{suffix} e
+            join rocpd_kernel_dispatch{suffix} d on d.event_id = e.event_id
+            join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
+            join rocpd_info_pmc{suffix} i on i.id = e.pmc_id
+            group by s.kernel_name, i.name"""
+    agg = {}
+    for name, ctr, n, tot in cur.execute(q):
+        a = agg.setdefault(name.replace(".kd", ""), {})
+        a[ctr] = tot
+        a["calls"] = n
+    print("# MFMA utilisation of %s" % path)
+    print("%-88s %8s %16s %16s %8s" % ("kernel", "calls", "MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "util"))
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
+        busy, act = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
+        if busy <= 0:
+            continue
+        print("%-88s %8d %16.0f %16.0f %7.1f%%" % (name[:88], a["calls"], busy, act, 100.0 * busy / (act * 1024) if act else 0.0))
+
+
 def steady(path, nsteps):
     """Per-STEP kernel table of the last `nsteps` training iterations of the trace (an iteration ends with its
     clamp_adam_kernel dispatch): what the timed region of bench.py looks like without the set-up work."""
@@ -102,7 +131,9 @@ def timeline(path):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--timeline":
+    if sys.argv[1] == "--mfma":
+        mfma(sys.argv[2])
+    elif sys.argv[1] == "--timeline":
         timeline(sys.argv[2])
     elif sys.argv[1] == "--pmc":
         pmc(sys.argv[2])

@@ -15,4 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_$C.log 2>&1
   python profiles/summarize.py --pmc $(find /tmp/pmc_$C -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_$C.txt 2>&1
 done
+# 3) MFMA utilisation (SQ + GRBM counters share a pass)
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_MFMA.log 2>&1
+python profiles/summarize.py --mfma $(find /tmp/pmc_mfma -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_MFMA.txt 2>&1
 cut -c1-400 gpurun_out/${TAG}_prof_bench.json

@@ -108,3 +108,45 @@ def test_invalid_batch_is_empty_plan():
     progs = encode_programs(["scene", "count"], v.get_token_to_index_vocabulary("programs")).numpy()
     plan = s.plan(comp.compile_batch(progs), BUF)
     assert plan.n_prims == 0 and plan.arena_floats == 0 and not plan.forward and not plan.backward
+
+
+def _same_plan(a, b):
+    assert a.n_prims == b.n_prims and a.arena_floats == b.arena_floats
+    assert np.array_equal(a.feat_result_examples, b.feat_result_examples)
+    assert set(a.records) == set(b.records)
+    for k in a.records:
+        assert a.records[k].dtype == b.records[k].dtype and a.records[k].shape == b.records[k].shape, k
+        assert a.records[k].tobytes() == b.records[k].tobytes(), k
+    for k in ("wg3", "wgp"):
+        assert a.wgrad_jobs[k].tobytes() == b.wgrad_jobs[k].tobytes(), k
+    assert a.forward == b.forward and a.backward == b.backward
+    assert [tuple(int(x) for x in g) for g in (a.wgrad_groups or [])] == [tuple(int(x) for x in g) for g in (b.wgrad_groups or [])]
+
+
+def test_library_planner_equals_the_numpy_planner(monkeypatch):
+    """``pnmn_plan_batch`` (csrc/host_plan.hip) against the whole-array numpy formulation: every record of every
+    launch bit for bit, the launch order, the weight-gradient jobs and groups -- on the validity cases (ragged,
+    invalid, placeholder-only programs), on synthetic CLEVR batches incl. the deep 40-token shapes, with and
+    without the fused mask backward, several weight-gradient groups, and without the weight sort."""
+    from probnmn.data.synthetic import deep_template_program  # noqa: F401  (the deep shapes are part of deep=True batches)
+
+    v, comp, s = _scheduler()
+    t2i = v.get_token_to_index_vocabulary("programs")
+    batches = [comp.compile_batch(encode_programs(VALIDITY_CASES, t2i).numpy())]
+    for seed, n, deep in ((1, 1, False), (2, 65, False), (3, 300, False), (4, 64, True)):
+        kw = {"deep": True, "program_length": 40} if deep else {}
+        b = synthetic_batch(v, n, seed=seed, with_image=False, **kw)
+        batches.append(comp.compile_batch(b["program"].numpy()))
+    for compiled in batches:
+        _same_plan(s.plan(compiled, BUF), s.plan_numpy(compiled, BUF))
+    mixed = batches[2]
+    s.fuse_mask_bwd = False
+    _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
+    s.fuse_mask_bwd = True
+    s.sole_writer_rmw = False
+    _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
+    s.sole_writer_rmw = True
+    s.wgrad_groups, s.wgrad_chunk = 3, 2
+    _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
+    monkeypatch.setenv("PNMN_NO_WEIGHT_SORT", "1")
+    _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
