@@ -238,7 +238,12 @@ ITEM_SIZES = {
 
 
 def stream_ptr(device: torch.device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw handle of torch's current stream on ``device`` (every kernel call needs it: the raw query costs a
+    fraction of building a ``torch.cuda.Stream`` object, ~6 us x 80 calls per step)."""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 class _PinnedRing:

@@ -9,7 +9,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from probnmn import _hip
-from probnmn.modules.seq2seq_base import (DerivedParams, _Encoder, _TokenEmbedder, _TokenPrep, lstm_derived_specs,
+from probnmn.modules.seq2seq_base import (DerivedParams, _Encoder, _TokenEmbedder, _TokenPrep, lstm_derived_params,
+                                          lstm_derived_specs,
                                           sequence_nll)
 from probnmn.running_metrics import Average
 
@@ -36,7 +37,7 @@ class ProgramPrior(nn.Module):
         lstm = self._encoder._module
         if lstm.hidden_size != 256 or lstm.weight_hh_l0.device.type != "cuda":
             return None
-        return self._derived_cache.get(lstm_derived_specs(lstm))
+        return self._derived_cache.get(lstm_derived_params(lstm), lambda: lstm_derived_specs(lstm))
 
     @classmethod
     def from_config(cls, config):

@@ -102,16 +102,18 @@ class DerivedParams:
         self._key = None
         self._out: Dict[str, torch.Tensor] = {}
 
-    def get(self, specs) -> Dict[str, torch.Tensor]:
-        """``specs``: list of (name, kind, a, b) -- kind "pack" (fragment order of the [N][K] matrix ``a``),
-        "packT" (of its transpose), "sum" (a + b)."""
+    def get(self, params, make_specs) -> Dict[str, torch.Tensor]:
+        """``params``: the parameters everything is derived from (the cache key is their storage, version
+        counters and the fused optimiser's step count -- a dozen attribute reads per call);
+        ``make_specs()``: list of (name, kind, a, b) -- kind "pack" (fragment order of the [N][K] matrix ``a``),
+        "packT" (of its transpose), "sum" (a + b) -- built only when the cache misses."""
         from probnmn.optim import parameter_epoch
 
-        dev = specs[0][2].device
-        key = (parameter_epoch(), dev, tuple((t.data_ptr(), t._version, None if u is None else (u.data_ptr(), u._version))
-                                             for _, _, t, u in specs))
+        key = (parameter_epoch(),) + tuple((p._version, p.data_ptr()) for p in params)
         if key == self._key:
             return self._out
+        specs = make_specs()
+        dev = specs[0][2].device
         import numpy as np
 
         total = sum(a.numel() for _, _, a, _ in specs)
@@ -574,6 +576,12 @@ def lstm_derived_specs(lstm: nn.LSTM, prefix: str = "l"):
     return specs
 
 
+def lstm_derived_params(lstm: nn.LSTM):
+    """The parameters ``lstm_derived_specs`` reads (cache key of ``DerivedParams.get``)."""
+    return [getattr(lstm, "%s_l%d" % (n, layer)) for layer in range(lstm.num_layers)
+            for n in ("weight_hh", "bias_ih", "bias_hh")]
+
+
 def lstm_bias(lstm: nn.LSTM, layer: int, derived: Optional[Dict[str, torch.Tensor]], prefix: str = "l") -> torch.Tensor:
     b_ih, b_hh = getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)
     if derived is None:
@@ -707,12 +715,15 @@ class Seq2SeqBase(nn.Module):
         Hd = cell.hidden_size
         if lstm.hidden_size != 256 or Hd != 256 or lstm.weight_hh_l0.device.type != "cuda":
             return None
-        w_c = cell.weight_ih[:, :Hd]
-        specs = lstm_derived_specs(lstm) + [
-            ("d.c", "pack", w_c, None), ("d.hh", "pack", cell.weight_hh, None),
-            ("d.cT", "packT", w_c, None), ("d.hhT", "packT", cell.weight_hh, None),
-            ("d.b", "sum", cell.bias_ih, cell.bias_hh)]
-        return self._derived_cache.get(specs)
+        def specs():
+            w_c = cell.weight_ih[:, :Hd]
+            return lstm_derived_specs(lstm) + [
+                ("d.c", "pack", w_c, None), ("d.hh", "pack", cell.weight_hh, None),
+                ("d.cT", "packT", w_c, None), ("d.hhT", "packT", cell.weight_hh, None),
+                ("d.b", "sum", cell.bias_ih, cell.bias_hh)]
+
+        return self._derived_cache.get(lstm_derived_params(lstm) + [cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh],
+                                       specs)
 
     # ---------------------------------------------------------------------------------------------
     def forward(

@@ -147,9 +147,7 @@ class ClampAdam(torch.optim.Optimizer):
             items.append((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
         if not items:
             return
-        rec = np.zeros(len(items), _hip.ADAM_ITEM)
-        for i, it in enumerate(items):
-            rec[i]["param"], rec[i]["grad"], rec[i]["exp_avg"], rec[i]["exp_avg_sq"], rec[i]["n"] = it
+        rec = np.array(items, dtype=np.uint64).view(_hip.ADAM_ITEM).reshape(-1)  # (five 8-byte fields per item)
         device = (self.arenas[0].flat if self.arenas else self.loose[0]).device
         buf = _hip.to_device(rec, device)
         clamp = float(group["clamp"]) if group["clamp"] is not None else 0.0

@@ -161,8 +161,9 @@ class QuestionCodingStep(_TrainerBase):
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         self.optimizer.zero_grad()
-        self.pg.train()
-        self.qr.train()
+        for m in (self.pg, self.qr):
+            if not m.training:  # (Module.train() walks every submodule: 0.2-0.5 ms per model and step)
+                m.train()
         dev = batch["question"].device
         sup, nosup = _split_supervision(batch["supervision"])
         sup_d, nosup_d = sup.to(dev, non_blocking=True), nosup.to(dev, non_blocking=True)
@@ -218,7 +219,8 @@ class JointTrainingStep(_TrainerBase):
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         self.optimizer.zero_grad()
         for m in (self.pg, self.qr, self.nmn):
-            m.train()
+            if not m.training:  # (Module.train() walks every submodule: 0.2-0.5 ms per model and step)
+                m.train()
         self.nmn.report_batch_metrics = False
         dev = batch["question"].device
         sup, nosup = _split_supervision(batch["supervision"])
