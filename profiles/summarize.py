@@ -56,24 +56,27 @@ def mfma(path):
     cur = db.cursor()
     tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
     suffix = tab.replace("rocpd_kernel_dispatch", "")
-    q = f"""select s.kernel_name, i.name, count(*), sum(e.value)
+    q = f"""select s.kernel_name, i.name, count(*), sum(e.value), count(distinct d.id)
             from rocpd_pmc_event{suffix} e
             join rocpd_kernel_dispatch{suffix} d on d.event_id = e.event_id
             join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
             join rocpd_info_pmc{suffix} i on i.id = e.pmc_id
             group by s.kernel_name, i.name"""
     agg = {}
-    for name, ctr, n, tot in cur.execute(q):
+    for name, ctr, n, tot, disp in cur.execute(q):
         a = agg.setdefault(name.replace(".kd", ""), {})
         a[ctr] = tot
-        a["calls"] = n
+        a[ctr + "#"] = n / max(disp, 1)  # instances the counter is reported in per dispatch (XCDs / shader engines)
+        a["calls"] = disp
     print("# MFMA utilisation of %s" % path)
-    print("%-88s %8s %16s %16s %8s" % ("kernel", "calls", "MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "util"))
+    print("# util = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip) / (GPU-active cycles x 1024 SIMDs); GRBM_GUI_ACTIVE")
+    print("# is reported once per XCD, so active cycles = its sum / its instances per dispatch")
+    print("%-88s %8s %16s %14s %8s" % ("kernel", "calls", "MFMA_BUSY_CYCLES", "active cycles", "util"))
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
-        busy, act = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0)
+        busy, act = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("GRBM_GUI_ACTIVE", 0.0) / max(a.get("GRBM_GUI_ACTIVE#", 1.0), 1.0)
         if busy <= 0:
             continue
-        print("%-88s %8d %16.0f %16.0f %7.1f%%" % (name[:88], a["calls"], busy, act, 100.0 * busy / (act * 1024) if act else 0.0))
+        print("%-88s %8d %16.0f %14.0f %7.1f%%" % (name[:88], a["calls"], busy, act, 100.0 * busy / (act * 1024) if act else 0.0))
 
 
 def steady(path, nsteps):
