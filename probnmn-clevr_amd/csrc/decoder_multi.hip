@@ -181,23 +181,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             acc[r] = v;
         }
         {
-            const float* cp = a.ctx + ((size_t)arow * T + t) * H + 4 * g;
-            const float* hp = (t > 0 ? a.hs + ((size_t)arow * T + (t - 1)) * H : a.h0 + (size_t)arow * H) + 4 * g;
-            // A operands in four batches of 4 + 4 fragments, each requested in full before its MFMAs (the
-            // compiler otherwise waits for every 16-byte fragment separately; larger batches do not fit
-            // beside the 128 weight registers).  This wave owns ONE output tile, so a single accumulator
-            // would make its 128 MFMAs one dependent chain (each waits out the previous one's full
-            // latency, ~3x the issue time): four partial sums -- context / hidden state, even / odd
-            // k-block -- keep four chains in flight and are added at the end.
+            // A operands (the tile's 16 x 256 context and hidden vectors) go through LDS in four parts of 64
+            // columns, double buffered in the 16 KB that the attention phase's partial contexts and the token
+            // phase's logits leave idle here: one coalesced 16-byte load per thread and part -- requested
+            // while the previous part's MFMAs run -- instead of 32 scattered loads per lane in four batches
+            // that each waited out a full L2 round trip in front of their MFMAs (5 400 of the phase's 13 600
+            // cycles).  Slot s of row r sits at slot s ^ r: the 16 lanes of an MFMA operand read hit 16 banks
+            // groups.  This wave owns ONE output tile, so a single accumulator would make its 128 MFMAs one
+            // dependent chain (each waits out the previous one's full latency, ~3x the issue time): four
+            // partial sums -- context / hidden state, even / odd k-block -- keep four chains in flight.
             constexpr int NB = 4;
+            float* stage = &cpart[0][0][0];  // [2 buffers][2 tensors][16 rows][64]
+            const int s_tensor = tid >> 8, s_row = (tid >> 4) & 15, s_slot = tid & 15;
+            const int s_rowc = min(row0 + s_row, a.B - 1);
+            const float* s_src = (s_tensor == 0 ? a.ctx + ((size_t)s_rowc * T + t) * H
+                                                : (t > 0 ? a.hs + ((size_t)s_rowc * T + (t - 1)) * H : a.h0 + (size_t)s_rowc * H)) + 4 * s_slot;
+            float* s_dst = stage + (s_tensor * ROWS + s_row) * 64 + 4 * (s_slot ^ s_row);
+            f32x4 sv = *reinterpret_cast<const f32x4*>(s_src);
+            *reinterpret_cast<f32x4*>(s_dst) = sv;
+            __syncthreads();
             f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0, ph0 = pc0, ph1 = pc0;
 #pragma unroll
             for (int part = 0; part < (H / 16) / NB; ++part) {
+                if (part + 1 < (H / 16) / NB) sv = *reinterpret_cast<const f32x4*>(s_src + (part + 1) * 64);
+                const float* buf = stage + (part & 1) * (2 * ROWS * 64);
                 f32x4 ac[NB], ah[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    ac[j] = *reinterpret_cast<const f32x4*>(cp + (part * NB + j) * 16);
-                    ah[j] = *reinterpret_cast<const f32x4*>(hp + (part * NB + j) * 16);
+                    const int slot = (4 * j + g) ^ li;
+                    ac[j] = *reinterpret_cast<const f32x4*>(buf + li * 64 + 4 * slot);
+                    ah[j] = *reinterpret_cast<const f32x4*>(buf + (ROWS + li) * 64 + 4 * slot);
                 }
 #pragma unroll
                 for (int j = 0; j < NB; j += 2) {
@@ -218,6 +231,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].w, wh[kb].w, ph0, 0, 0, 0);
                     pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].w, wc[kb + 1].w, pc1, 0, 0, 0);
                     ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].w, wh[kb + 1].w, ph1, 0, 0, 0);
+                }
+                if (part + 1 < (H / 16) / NB) {
+                    *reinterpret_cast<f32x4*>(s_dst + ((part + 1) & 1) * (2 * ROWS * 64)) = sv;
+                    __syncthreads();
                 }
             }
             acc += (pc0 + pc1) + (ph0 + ph1);

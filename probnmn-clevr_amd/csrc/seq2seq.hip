@@ -435,6 +435,11 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
     constexpr int J = UW * 16 / 512;    // (row, unit) pairs per thread in the cell update
     constexpr int GLD = UW + 4;
     __shared__ float gl[4][LROWS][GLD];
+    // h_{t-1} of the tile, staged ONCE per step by the whole workgroup (two coalesced 16-byte loads per thread)
+    // and read back as MFMA operands from LDS: every wave needs all 16 x 256 values, and 16 scattered 16-byte
+    // loads per lane straight from L2 kept the matrix pipe waiting ~4 000 cycles per step (cycle stamps)
+    constexpr int HLD = LH + 4;
+    __shared__ __attribute__((aligned(16))) float hl[LROWS][HLD];
     int tile, part;
     pnmn::cluster_coords<S>(tile, part);
     if (tile >= tiles) return;
@@ -455,7 +460,6 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
     float creg[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) creg[j] = 0.f;
-    const int arow = min(row0 + li, B - 1);  // A-operand row of this lane (clamped: the padding rows' results are dropped)
 
     for (int t = 0; t < T; ++t) {
         f32x4_ acc[UB];
@@ -469,10 +473,17 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
             }
         if (t > 0) {
             cl.wait();
-            const float* hrow = hs + ((size_t)arow * T + (t - 1)) * LH + 4 * g;
+#pragma unroll
+            for (int i = tid; i < LROWS * LH / 4; i += 512) {
+                const int rl = i / (LH / 4), c4 = i % (LH / 4);
+                const int row = min(row0 + rl, B - 1);
+                *reinterpret_cast<f32x4_*>(&hl[rl][4 * c4]) =
+                    *reinterpret_cast<const f32x4_*>(hs + ((size_t)row * T + (t - 1)) * LH + 4 * c4);
+            }
+            __syncthreads();
             f32x4_ a[LH / 16];
 #pragma unroll
-            for (int kb = 0; kb < LH / 16; ++kb) a[kb] = *reinterpret_cast<const f32x4_*>(hrow + kb * 16);
+            for (int kb = 0; kb < LH / 16; ++kb) a[kb] = *reinterpret_cast<const f32x4_*>(&hl[li][kb * 16 + 4 * g]);
 #pragma unroll
             for (int kb = 0; kb < LH / 16; ++kb)
 #pragma unroll
