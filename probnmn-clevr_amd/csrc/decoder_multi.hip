@@ -387,21 +387,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float row_mask = lane < S ? a.mask[(size_t)min(myrow0 + (wave >> 2), a.B - 1) * S + lane] : 0.f;
     __syncthreads();
 
+    // What a step reads of the forward pass (activated gates, cell states, the incoming d h, the attention
+    // probabilities) does not depend on the recurrence: step t - 1's values are requested before the last
+    // hand-off of step t and arrive while it completes, instead of costing an HBM round trip at the top of
+    // every step.
+    struct Saved {
+        float ig, fg, gg, og, c, cp, dhs, p;
+    };
+    const int c_rl = tid >> 5, c_ul = tid & 31;
+    const int c_row = row0 + c_rl, c_u = u0 + c_ul;
+    const int p_row = min(myrow0 + (wave >> 2), a.B - 1);
+    auto load_saved = [&](int t) {
+        Saved v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c_row < a.B) {
+            const size_t o = ((size_t)c_row * T + t) * H + c_u;
+            const float* ar = a.act + ((size_t)c_row * T + t) * G4;
+            v.ig = ar[c_u], v.fg = ar[H + c_u], v.gg = ar[2 * H + c_u], v.og = ar[3 * H + c_u];
+            v.c = a.cs[o];
+            v.cp = t > 0 ? a.cs[o - H] : 0.f;
+            v.dhs = a.dhs[o];
+        }
+        if ((wave & 3) == 0 && lane < S) v.p = a.probs[((size_t)p_row * T + t) * S + lane];
+        return v;
+    };
+    Saved sv = load_saved(T - 1);
+
     for (int t = T - 1; t >= 0; --t) {
+        const Saved cur = sv;
         // ---------------- cell backward of my units: thread -> (row, unit) ----------------
         {
-            const int rl = tid >> 5, ul = tid & 31;
-            const int row = row0 + rl, u = u0 + ul;
+            const int rl = c_rl, ul = c_ul;
+            const int row = c_row, u = c_u;
             float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
             if (row < a.B) {
-                const size_t o = ((size_t)row * T + t) * H + u;
-                const float* ar = a.act + ((size_t)row * T + t) * G4;
-                const float ig = ar[u], fg = ar[H + u], gg = ar[2 * H + u], og = ar[3 * H + u];
-                const float c = a.cs[o];
-                const float cp = t > 0 ? a.cs[o - H] : 0.f;
+                const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og;
+                const float c = cur.c;
+                const float cp = cur.cp;
                 const float tc = tanhf(c);
                 const float dhp = t < T - 1 ? x2t[((size_t)((t + 1) & 1) * ROWS + rl) * H + u] : 0.f;
-                const float dh = a.dhs[o] + dhp;
+                const float dh = cur.dhs + dhp;
                 const float dc = dc_rec + dh * og * (1.f - tc * tc);
                 di = dc * gg * ig * (1.f - ig);
                 df = dc * cp * fg * (1.f - fg);
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         {
             const int rl = wave >> 2, q = wave & 3;
-            const int row = myrow0 + rl, rowc = min(row, a.B - 1);
+            const int row = myrow0 + rl;
             const float* er = encl + (size_t)rl * S * H + 4 * lane;
             const f32x4 dc4 = *reinterpret_cast<const f32x4*>(&dctxl[rl][4 * lane]);
             {   // (all partial products first, then the wave reductions interleaved -- as in the forward)
@@ -497,7 +521,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (q == 0) {
                 // forward quantities of this (row, step): p (softmax before masking), mask, q, Z
                 const float m = row_mask;
-                const float p = lane < S ? a.probs[((size_t)rowc * T + t) * S + lane] : 0.f;
+                const float p = lane < S ? cur.p : 0.f;
                 const float qv = p * m;
                 const float Z = wsum(qv) + 1e-13f;
                 const float dw = lane < S ? dwl[rl][lane] : 0.f;
@@ -526,6 +550,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 a.dh0[(size_t)(myrow0 + rl2) * H + k] = v;
         }
         if (t == 0) break;
+        sv = load_saved(t - 1);
         cl.signal();
         cl.wait();
     }
