@@ -95,8 +95,11 @@ class DerivedParams:
     of W_hh / W_c (and of their transposes, for the backward kernels) and the bias sums b_ih + b_hh.  All of
     them are produced by ONE ``pnmn_derive_params`` launch per model and optimiser step, where the straight-line
     code issued a permute + copy per weight and pass and an add per bias and pass (~25 launches per step).
-    The cache is keyed on the parameters' version counters and on ``probnmn.optim.parameter_epoch()`` (the
-    fused optimiser updates parameters through their pointers, which bumps no version counter)."""
+    The cache is keyed on the parameters' storage, their version counters and ``probnmn.optim.parameter_epoch()``
+    (the fused optimiser updates parameters through their pointers, which bumps no version counter).  Anything
+    that changes a parameter behind autograd's back the same way -- writes through ``p.data`` or a raw pointer --
+    must call ``probnmn.optim.parameters_changed()``; ``load_state_dict``, ``torch.optim`` steps, ``copy_`` /
+    in-place ops under ``no_grad`` and ``.to(device)`` are all seen through the version counters / storage."""
 
     def __init__(self):
         self._key = None

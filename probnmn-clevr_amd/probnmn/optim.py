@@ -39,6 +39,13 @@ def parameter_epoch() -> int:
     return _PARAMETER_EPOCH
 
 
+def parameters_changed() -> None:
+    """Tell the derived-parameter caches that parameter VALUES were changed without touching a version counter
+    (a write through ``p.data`` or a raw device pointer).  ``ClampAdam.step`` calls it itself."""
+    global _PARAMETER_EPOCH
+    _PARAMETER_EPOCH += 1
+
+
 class ClampAdam(torch.optim.Optimizer):
     def __init__(
         self,
@@ -128,8 +135,7 @@ class ClampAdam(torch.optim.Optimizer):
     def step(self, closure=None) -> None:
         if closure is not None:
             raise ValueError("ClampAdam.step takes no closure")
-        global _PARAMETER_EPOCH
-        _PARAMETER_EPOCH += 1
+        parameters_changed()
         group = self.param_groups[0]
         self.step_count += 1
         items = []
