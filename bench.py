@@ -274,6 +274,63 @@ def recurrent_kernel_report(dev):
     return out
 
 
+def hbm_kernel_report(dev, optimizer=None):
+    """The HBM-bound kernels of the step at the headline shapes: algorithmic bytes / launch time as a
+    fraction of the 8.0 TB/s HBM peak -- the layout change of the input features, the ReLU-gated max-pool (forward
+    and backward), the one-channel attention head, And / Or, and the fused clamp + Adam over every trainable
+    parameter of the joint step (28 bytes per parameter: gradient, parameter and both moments read, parameter
+    and both moments written)."""
+    import numpy as np
+
+    from probnmn import _hip
+
+    lib, st = _hip.lib(), _hip.stream_ptr(dev)
+    out = {}
+
+    def clock(fn, reps=5):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def entry(name, ms, nbytes, what):
+        out[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 3),
+                     "algorithmic_bytes": int(nbytes), "what": what}
+
+    B, HW, Cin, Cp, Cm = 512, 196, 1024, 1024, 128
+    x = torch.randn(B, Cin, HW, device=dev)
+    y = torch.empty(B, HW, Cin, device=dev)
+    entry("nchw_to_nhwc", clock(lambda: _hip.check(lib.pnmn_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cin, HW, st), "layout")),
+          2.0 * x.numel() * 4, "input features, %d examples of 1024 x 14 x 14" % B)
+    cls = torch.randn(B, HW, Cp, device=dev)
+    pooled = torch.empty(B, Cp * 49, device=dev)
+    dcls = torch.empty_like(cls)
+    entry("maxpool_fwd", clock(lambda: _hip.check(lib.pnmn_maxpool2_flatten_fwd(cls.data_ptr(), pooled.data_ptr(), B, 14, 14, Cp, st), "pool")),
+          (cls.numel() + pooled.numel()) * 4.0, "ReLU-gated 2x2 max-pool + flatten of the classifier conv, %d examples" % B)
+    entry("maxpool_bwd", clock(lambda: _hip.check(lib.pnmn_maxpool2_flatten_bwd(cls.data_ptr(), pooled.data_ptr(), dcls.data_ptr(), B, 14, 14, Cp, st), "pool bwd")),
+          (2 * cls.numel() + pooled.numel()) * 4.0, "its backward (input re-read for the arg-max, gradient map written)")
+    n = 4096
+    a, b2, o = torch.rand(n, HW, Cm, device=dev), torch.rand(n, HW, device=dev), torch.empty(n, HW, Cm, device=dev)
+    rec = np.zeros(n, _hip.MINMAX_ITEM)
+    e = np.arange(n, dtype=np.int64)
+    rec["a"], rec["b"], rec["out"] = a.data_ptr() + e * HW * Cm * 4, b2.data_ptr() + e * HW * 4, o.data_ptr() + e * HW * Cm * 4
+    rec["a_channels"], rec["b_channels"], rec["is_max"] = Cm, 1, 1
+    items = _hip.to_device(rec, dev)
+    entry("minmax_fwd", clock(lambda: _hip.check(lib.pnmn_minmax_fwd(items.data_ptr(), n, HW, Cm, st), "minmax")),
+          n * HW * (2 * Cm + 1) * 4.0, "And / Or of a 128-channel map with a 1-channel map, %d items" % n)
+    if optimizer is not None:
+        params = sum(a.total for a in optimizer.arenas) + sum(p.numel() for p in optimizer.loose if p.grad is not None)
+        entry("clamp_adam", clock(lambda: optimizer.step(), reps=3), 28.0 * params,
+              "element-wise clamp + Adam over the %d trainable parameters of the step" % params)
+    out["note"] = "HBM peak %.1f TB/s (MI355X_MICROARCH.md; measured copy peak 6.29 TB/s)" % (PEAK_HBM_GBS / 1e3)
+    return out
+
+
 def timed(step_fn, steps, warmup, dev, world, trainer=None):
     """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both
     sides; returns (max-over-ranks seconds, host seconds to enqueue, host seconds blocked on the GPU:
@@ -520,6 +577,12 @@ def main():
             recurrent = recurrent_kernel_report(dev)
         except Exception as exc:  # a side report must not take the headline line down
             recurrent = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    hbm_kernels = None
+    if rank == 0 and not args.no_roofline:
+        try:  # (after every timed run of the headline: the optimiser steps below move its parameters)
+            hbm_kernels = hbm_kernel_report(dev, trainer.optimizer)
+        except Exception as exc:
+            hbm_kernels = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     extras = {}
     if not args.no_extras:
@@ -591,6 +654,7 @@ def main():
             "cpu_baseline": cpu,
             "module_training_cpu_b32": cpu1,
             "recurrent_kernels": recurrent,
+            "hbm_bound_kernels": hbm_kernels,
         }
         line.update(extras)
         if cpu:
