@@ -5,6 +5,7 @@
 // for a whole batch in one call: in joint training every step samples a few hundred programs the
 // compiler has not seen before, and the Python loop over them (~10 us each) sat on the critical path
 // between the sampling decode and the first NMN launch.
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
