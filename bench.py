@@ -580,7 +580,8 @@ def main():
     hbm_kernels = None
     if rank == 0 and not args.no_roofline:
         try:  # (after every timed run of the headline: the optimiser steps below move its parameters)
-            hbm_kernels = hbm_kernel_report(dev, trainer.optimizer)
+            # (the optimiser is timed at N = 1 only: stepping rank 0 alone would let its replica drift from the others)
+            hbm_kernels = hbm_kernel_report(dev, trainer.optimizer if world == 1 else None)
         except Exception as exc:
             hbm_kernels = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
