@@ -136,9 +136,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), hv) : 0.f;
                     }
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                        for (int k = 0; k < NP; ++k) part[k] += __shfl_xor(part[k], o);
+                    for (int k = 0; k < NP; ++k) part[k] = wsum(part[k]);  // (DPP chains: independent, the scheduler interleaves them)
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
                         if (lane == 0 && q + 4 * (k0 + k) < S) scl[rl][q + 4 * (k0 + k)] = part[k];
@@ -509,9 +507,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4) : 0.f;
                     }
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                        for (int k = 0; k < NP; ++k) part[k] += __shfl_xor(part[k], o);
+                    for (int k = 0; k < NP; ++k) part[k] = wsum(part[k]);  // (DPP chains: independent, the scheduler interleaves them)
 #pragma unroll
                     for (int k = 0; k < NP; ++k)
                         if (lane == 0 && q + 4 * (k0 + k) < S) dwl[rl][q + 4 * (k0 + k)] = part[k];

@@ -7,19 +7,12 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "sampling.h"
 
 namespace {
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return pnmn::wmax(v); }  // (DPP reductions, sampling.h)
+__device__ __forceinline__ float wave_sum(float v) { return pnmn::wsum(v); }
 
 // log-sum-exp of one row of V logits, computed by one wave (every lane gets the result)
 __device__ __forceinline__ float row_lse(const float* __restrict__ z, int V, int lane) {

@@ -8,15 +8,30 @@
 namespace pnmn {
 
 __device__ __forceinline__ float sigm(float z) { return 1.f / (1.f + expf(-z)); }
+// Wave-wide sum / max on the VALU's data-parallel primitives (DPP): four steps inside each row of 16 lanes
+// (quad swaps, half-row and row mirrors), two row broadcasts, one v_readlane -- every lane gets the result.  The
+// __shfl_xor butterfly these replace compiles to six ds_bpermute_b32, i.e. six dependent trips through the LDS
+// crossbar (~60 cycles each) per reduction; the decoder kernels do ~25 reductions per time step.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {  // lanes without a source keep `identity`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xF, false));
+}
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, float identity, Op op) {
+    v = op(v, dpp_move<0xB1, 0xF>(identity, v));   // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E, 0xF>(identity, v));   // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141, 0xF>(identity, v));  // row_half_mirror
+    v = op(v, dpp_move<0x140, 0xF>(identity, v));  // row_mirror: every lane = its row of 16
+    v = op(v, dpp_move<0x142, 0xA>(identity, v));  // row_bcast:15 into rows 1, 3
+    v = op(v, dpp_move<0x143, 0xC>(identity, v));  // row_bcast:31 into rows 2, 3: lane 63 = the wave
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return wave_reduce(v, 0.f, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    return wave_reduce(v, -INFINITY, [](float a, float b) { return fmaxf(a, b); });
 }
 
 __device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {

@@ -12,6 +12,7 @@
 
 #include "../../include/probnmn_hip.h"
 #include "cluster.h"
+#include "sampling.h"
 
 namespace {
 
@@ -88,16 +89,8 @@ __device__ float philox_uniform(uint64_t seed, uint64_t row, uint32_t step) {
     return (float)(ctr[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return pnmn::wmax(v); }  // (the decoder kernels' DPP reductions:
+__device__ __forceinline__ float wave_sum(float v) { return pnmn::wsum(v); }  //  same summation order, same tokens)
 
 // one wave per row; V up to 64*MAXV
 constexpr int MAXV = 8;
