@@ -232,15 +232,16 @@ def recurrent_kernel_report(dev):
     r = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dev)  # noqa: E731
 
     def clock(fn, reps=5):
+        # median of per-call timings: one call in a few hundred lands on an allocator refill (tens of ms)
         for _ in range(2):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
             fn()
-        e1.record()
+            ev[i + 1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
 
     out = {}
     Hd = 256
@@ -288,15 +289,16 @@ def hbm_kernel_report(dev, optimizer=None):
     out = {}
 
     def clock(fn, reps=5):
+        # median of per-call timings: one call in a few hundred lands on an allocator refill (tens of ms)
         for _ in range(2):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
             fn()
-        e1.record()
+            ev[i + 1].record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
 
     def entry(name, ms, nbytes, what):
         out[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 3),

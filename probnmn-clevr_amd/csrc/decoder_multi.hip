@@ -453,26 +453,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const f32x4 av = *reinterpret_cast<const f32x4*>(&dgl[li][kl * 16 + 4 * g]);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[nt][kl].x, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[nt][kl].y, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[nt][kl].z, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[nt][kl].w, accc[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wh[nt][kl].x, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wh[nt][kl].y, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wh[nt][kl].z, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wh[nt][kl].w, acch[nt], 0, 0, 0);
+                    // (weights as the A operand: the product comes out transposed, each lane holding FOUR
+                    // CONSECUTIVE UNITS of one row -- one 16-byte store per tile below instead of four 4-byte ones)
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].x, av.x, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].y, av.y, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].z, av.z, accc[nt], 0, 0, 0);
+                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].w, av.w, accc[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].x, av.x, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].y, av.y, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].z, av.z, acch[nt], 0, 0, 0);
+                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].w, av.w, acch[nt], 0, 0, 0);
                 }
             }
             float* pc = x1t + (((size_t)(t & 1) * MEMBERS + part) * 2 + 0) * ROWS * H;
             float* ph = pc + ROWS * H;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t o = (size_t)(4 * g + r) * H + 16 * (2 * wave + nt) + li;
-                    pc[o] = accc[nt][r];
-                    ph[o] = acch[nt][r];
-                }
+            {
+                const size_t o = (size_t)li * H + 16 * (2 * wave + nt) + 4 * g;  // row li, units 16 (2 wave + nt) + 4 g ..
+                *reinterpret_cast<f32x4*>(pc + o) = accc[nt];
+                *reinterpret_cast<f32x4*>(ph + o) = acch[nt];
+            }
         }
         cl.signal();
         cl.wait();

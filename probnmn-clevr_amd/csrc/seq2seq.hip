@@ -625,17 +625,18 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
             const f32x4_ a = *reinterpret_cast<const f32x4_*>(&dgl[li][kl * 16 + 4 * g]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wreg[nt][kl].x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wreg[nt][kl].y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wreg[nt][kl].z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wreg[nt][kl].w, acc[nt], 0, 0, 0);
+                // (weights as the A operand: the product comes out transposed, each lane holding four
+                // consecutive units of one row -- one 16-byte store per tile instead of four 4-byte ones)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][kl].x, a.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][kl].y, a.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][kl].z, a.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][kl].w, a.w, acc[nt], 0, 0, 0);
             }
         }
         float* po = ptile + ((size_t)(t & 1) * S + part) * LROWS * LH;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) po[(size_t)(4 * g + r) * LH + 16 * (2 * wave + nt) + li] = acc[nt][r];
+            *reinterpret_cast<f32x4_*>(po + (size_t)li * LH + 16 * (2 * wave + nt) + 4 * g) = acc[nt];
         cl.signal();  // also: everyone is done reading dgl
     }
 }
