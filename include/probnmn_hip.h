@@ -198,6 +198,8 @@ int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream);
  * Layout changes at the boundary: the reference hands NCHW features (datasets.py:137-142).
  * ------------------------------------------------------------------------------------------- */
 int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int C, int HW, void* stream);
+/* the same for a subset of a batch: example i of dst is example rows[i] of src (no gathered copy of the 0.8 MB maps) */
+int pnmn_nchw_to_nhwc_rows(const float* src, float* dst, const int64_t* rows, int n, int C, int HW, void* stream);
 int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* stream);
 
 /* Feature ingest: replaces the per-item h5 read + float cast + collate + .to(device) of

@@ -57,8 +57,10 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
                                                static_cast<float*>(const_cast<void*>(l.c)), l.n, p[0], p[1], p[2], stream);
                 break;
             case PNMN_OP_NCHW_TO_NHWC:
-                rc = pnmn_nchw_to_nhwc(static_cast<const float*>(l.a), static_cast<float*>(const_cast<void*>(l.b)), l.n, p[0],
-                                       p[1], stream);
+                rc = l.c ? pnmn_nchw_to_nhwc_rows(static_cast<const float*>(l.a), static_cast<float*>(const_cast<void*>(l.b)),
+                                                  static_cast<const int64_t*>(l.c), l.n, p[0], p[1], stream)
+                         : pnmn_nchw_to_nhwc(static_cast<const float*>(l.a), static_cast<float*>(const_cast<void*>(l.b)), l.n,
+                                             p[0], p[1], stream);
                 break;
             default:
                 return PNMN_EINVAL;

@@ -429,10 +429,12 @@ __device__ __forceinline__ void copy_batched4(int n, Load load, Store store) {
 // NCHW <-> NHWC
 // ------------------------------------------------------------------------------------------------
 template <bool TO_NHWC>
-__global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                     int Cn, int HW, int PT) {
+__global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ src_base, float* __restrict__ dst,
+                                                     int Cn, int HW, int PT, const int64_t* __restrict__ rows) {
     extern __shared__ float tile[];  // [64][PT+1]: 64 channels x one chunk of PT pixels (blockIdx.z)
     const int n = blockIdx.y;
+    // (rows: example n of the output is example rows[n] of the source -- a batch subset without a gathered copy)
+    const float* src = rows ? src_base + ((size_t)rows[n] - (size_t)n) * Cn * HW : src_base;
     const int c0 = blockIdx.x * 64;
     const int p0 = blockIdx.z * PT;
     const int np = (HW - p0) < PT ? (HW - p0) : PT;
@@ -643,7 +645,7 @@ static int layout_chunk(int HW) {
 }
 
 template <bool TO_NHWC>
-static int launch_layout(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
+static int launch_layout(const float* src, float* dst, int n, int Cn, int HW, void* stream, const int64_t* rows) {
     if (n <= 0) return 0;
     if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
     const int PT = layout_chunk(HW);
@@ -655,7 +657,7 @@ static int launch_layout(const float* src, float* dst, int n, int Cn, int HW, vo
         cfg = true;
     }
     hipLaunchKernelGGL(layout_kernel<TO_NHWC>, dim3((Cn + 63) / 64, n, (HW + PT - 1) / PT), dim3(256), lds,
-                       STREAM(stream), src, dst, Cn, HW, PT);
+                       STREAM(stream), src, dst, Cn, HW, PT, rows);
     return last_error();
 }
 
@@ -756,11 +758,16 @@ int pnmn_transpose_weights(const pnmn_wtrans_item* items, int n_items, void* str
 }
 
 int pnmn_nchw_to_nhwc(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
-    return launch_layout<true>(src, dst, n, Cn, HW, stream);
+    return launch_layout<true>(src, dst, n, Cn, HW, stream, nullptr);
+}
+
+int pnmn_nchw_to_nhwc_rows(const float* src, float* dst, const int64_t* rows, int n, int Cn, int HW, void* stream) {
+    if (!rows) return PNMN_EINVAL;
+    return launch_layout<true>(src, dst, n, Cn, HW, stream, rows);
 }
 
 int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int Cn, int HW, void* stream) {
-    return launch_layout<false>(src, dst, n, Cn, HW, stream);
+    return launch_layout<false>(src, dst, n, Cn, HW, stream, nullptr);
 }
 
 int pnmn_maxpool2_flatten_fwd(const float* in, float* out, int n, int H, int W, int Cn, void* stream) {

@@ -48,6 +48,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_mask_bwd": (_P, _I, _I, _P),
     "pnmn_accumulate": (_P, _I, _P),
     "pnmn_nchw_to_nhwc": (_P, _P, _I, _I, _I, _P),
+    "pnmn_nchw_to_nhwc_rows": (_P, _P, _P, _I, _I, _I, _P),
     "pnmn_nhwc_to_nchw": (_P, _P, _I, _I, _I, _P),
     "pnmn_gather_features": (_P, _P, _P, _I, ctypes.c_int64, _I, _I, _P),
     "pnmn_maxpool2_flatten_fwd": (_P, _P, _I, _I, _I, _I, _P),

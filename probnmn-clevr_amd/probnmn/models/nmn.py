@@ -157,14 +157,17 @@ class NeuralModuleNetwork(nn.Module):
         return self._engine
 
     def forward(self, features: torch.Tensor, programs: torch.Tensor, answers: Optional[torch.Tensor] = None,
-                started=None, trunk_stream=None):
+                started=None, trunk_stream=None, rows: Optional[torch.Tensor] = None):
         # ``started``: token of ``begin(features)`` when the caller already launched the stem (optional)
+        # ``rows``: run on ``features[rows]`` (programs / answers belong to those examples) without the gathered copy
         # ``trunk_stream``: run the trunk (stem, module programs, classifier conv + pool -- this build's own
         # kernels, none of which waits for another workgroup) on that stream, forward and backward, beside
         # whatever the caller queues on the current stream; the fully connected layers and the loss stay on
         # the current stream (see DESIGN 6 for why the library GEMMs must not leave it)
         engine = self._engine
         arena = engine.ensure_arena()
+        if rows is not None and started is None:
+            started = self.begin(features, rows)
         # the programs decide the launch schedule, so they are needed on the host (the reference
         # also reads them back, once per example: nmn.py:203)
         # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
@@ -209,11 +212,13 @@ class NeuralModuleNetwork(nn.Module):
             output_dict["metrics"] = self.get_metrics(reset=True)
         return output_dict
 
-    def begin(self, features: torch.Tensor):
+    def begin(self, features: torch.Tensor, rows: Optional[torch.Tensor] = None):
         """Launch the program-independent part of ``forward`` (feature layout + stem) ahead of time;
-        pass the returned token as ``forward(..., started=token)`` with the same ``features``."""
+        pass the returned token as ``forward(..., started=token)`` with the same ``features``.  ``rows`` (int64
+        device tensor): the pass runs on ``features[rows]`` -- programs / answers of ``forward`` then belong to
+        those examples -- without the gathered copy of the feature maps."""
         trains = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        return self._engine.begin_forward(features, trains)
+        return self._engine.begin_forward(features, trains, rows)
 
     def get_metrics(self, reset: bool = True) -> Dict[str, float]:
         return {

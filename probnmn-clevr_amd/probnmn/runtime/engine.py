@@ -336,24 +336,31 @@ class NMNEngine:
         return out
 
     # ---- forward --------------------------------------------------------------------------------
-    def begin_forward(self, features: torch.Tensor, need_backward: bool):
+    def begin_forward(self, features: torch.Tensor, need_backward: bool, rows: Optional[torch.Tensor] = None):
         """The part of the forward pass that does not depend on the programs: layout change of the
         input features and the two stem convolutions.  A trainer whose programs are still being
         produced (joint training: sampled on the device, scheduled on the host) launches this first
         and hands the returned token to ``run_forward`` -- the GPU then has ~3 ms more work queued
-        while the host compiles and schedules the sampled programs."""
+        while the host compiles and schedules the sampled programs.  ``rows`` (int64, on the device): run on
+        examples ``features[rows]`` without materialising that gather (0.8 MB per example): the layout kernel reads
+        through the index."""
         a = self.ensure_arena()
         lib = _hip.lib()
         dev = a.device
         if features.device != dev:
             raise _hip.HipLibraryError("features on %s but the network is on %s" % (features.device, dev))
-        B = features.size(0)
+        B = features.size(0) if rows is None else int(rows.numel())
+        if rows is not None and (rows.dtype != torch.long or rows.device != dev or not rows.is_contiguous()):
+            raise ValueError("rows must be a contiguous int64 tensor on the network's device")
         if tuple(features.shape[1:]) != (self.cin, self.H, self.W):
             raise ValueError("expected features (B,%d,%d,%d), got %s" % (self.cin, self.H, self.W, tuple(features.shape)))
         # features already in the kernels' layout (a `channels_last` tensor, e.g. from
         # probnmn.data.feature_store: the ingest kernel writes NHWC): used in place, no layout pass
         nhwc = (features.dtype == torch.float32 and not features.is_contiguous()
                 and features.is_contiguous(memory_format=torch.channels_last))
+        if nhwc and rows is not None:  # (a row subset of an NHWC batch: gather it, the layout pass is what reads through rows)
+            features, rows = features[rows], None
+            nhwc = (not features.is_contiguous()) and features.is_contiguous(memory_format=torch.channels_last)
         if not nhwc:
             features = features.contiguous().float()
         HW = self.HW
@@ -380,20 +387,21 @@ class NMNEngine:
         pack.upload(dev)
         self._begin_list()
         if not nhwc:
-            self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc", B, features.data_ptr(), st, "nchw_to_nhwc",
-                     b=ws["xin"].data_ptr(), p=(self.cin, HW))
+            self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc" if rows is None else "pnmn_nchw_to_nhwc_rows", B,
+                     features.data_ptr(), st, "nchw_to_nhwc", b=ws["xin"].data_ptr(),
+                     c=0 if rows is None else rows.data_ptr(), p=(self.cin, HW))
         self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1", rec=fixed["stem1"])
         self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2", rec=fixed["stem2"])
         self._flush_list(st, "stem", end=True)
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
-                "features": features, "pack": pack}
+                "features": features, "pack": pack, "rows": rows}
 
     def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
                     started=None):
         if started is None:
             started = self.begin_forward(features, need_backward)
-        elif (started["generation"] != self.generation or started["B"] != features.size(0)
-              or started["need_backward"] != need_backward):
+        elif (started["generation"] != self.generation or started["need_backward"] != need_backward
+              or (started["rows"] is None and started["B"] != features.size(0))):
             raise ValueError("begin_forward token does not belong to this forward pass")
         a = self.ensure_arena()
         lib = _hip.lib()

@@ -252,25 +252,24 @@ class JointTrainingStep(_TrainerBase):
                 # CUs forever (that is what stalled the side-stream experiment of round 1).
                 side.wait_stream(main)  # the batch and the index tensors were produced on the main stream
                 with torch.cuda.stream(side):
-                    # (the gather of the unsupervised examples' features -- 0.8 MB each -- belongs to the NMN's
-                    # lane: on the main stream it sat in front of the generator's encoder for as long as the
-                    # stem convolutions held the CUs)
-                    images = batch["image"][nosup_d]
-                    started = self.nmn.begin(images)
+                    # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
+                    # layout kernel: no gathered copy)
+                    images = batch["image"]
+                    started = self.nmn.begin(images, rows=nosup_d)
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True)
             else:
-                images = batch["image"][nosup_d]
+                images = batch["image"]
                 # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
                 # (with the reconstructor / prior passes) while the host schedules the sampled programs
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
-                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images))
+                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images, rows=nosup_d))
                 started = p["after_sampling"]
             programs_host, copied = p["programs_host"]
             t0 = time.perf_counter()
             copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
             self.blocked_seconds += time.perf_counter() - t0
-            nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side)
+            nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
             elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
             _hip.mark("elbo combined")
             nmn_loss = elbo_out.pop("nmn_loss")

@@ -191,3 +191,33 @@ def test_cpu_tensors_fail_loudly():
     vocab, net, programs, features, answers = _setup(cases=VALIDITY_CASES[:2])
     with pytest.raises(_hip.HipLibraryError):
         net(features, programs, answers)
+
+
+@pytest.mark.parametrize("size", [14, 28])
+def test_row_subset_equals_the_gathered_batch(size):
+    """``forward(features, ..., rows=idx)`` (the layout kernel reads through the index) against
+    ``forward(features[idx], ...)``: same kernels on the same values -- losses and predictions bit for bit, the stem's
+    weight gradient (the only gradient that reads the input features) to summation order."""
+    cases = VALIDITY_CASES if size == 14 else LONG_CASES
+    vocab, net, programs, features, answers = _setup(seed=3, cases=cases, size=size, length=26 if size == 14 else 40)
+    dev = torch.device("cuda:0")
+    net.to(dev)
+    B = programs.size(0)
+    g = torch.Generator().manual_seed(11)
+    big = torch.relu(torch.randn(B + 5, 1024, size, size, generator=g)).to(dev)
+    idx = torch.randperm(B + 5, generator=g)[:B].to(dev)
+    outs = []
+    for use_rows in (False, True):
+        net.zero_grad()
+        net.train()
+        if use_rows:
+            out = net(big, programs, answers.to(dev), rows=idx)
+        else:
+            out = net(big[idx], programs, answers.to(dev))
+        out["loss"].mean().backward()
+        outs.append((out["loss"].detach().clone(), out["predictions"].clone(), net.stem[0].weight.grad.clone(),
+                     net.classifier[6].weight.grad.clone()))
+    (loss_a, pred_a, gs_a, gc_a), (loss_b, pred_b, gs_b, gc_b) = outs
+    assert torch.equal(loss_a, loss_b) and torch.equal(pred_a, pred_b)
+    for a, b in ((gs_a, gs_b), (gc_a, gc_b)):  # (weight gradients are summed with fp32 atomics: order varies run to run)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
