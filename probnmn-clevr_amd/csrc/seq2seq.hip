@@ -410,6 +410,10 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
 // show up), one agent-scope acquire, barrier.  The counter is monotonic (S per step), so no reset race.
 // blockIdx -> (tile, p) keeps a tile's workgroups on one XCD (round-robin dispatch: XCD = blockIdx % 8),
 // which makes the exchange an L2 hit; correctness does not depend on that.
+// (Measured and rejected, round 2: SIXTEEN members per tile for batches of at most 256 rows -- one 16-column tile
+// per gate and member, the eight waves being four gates x two halves of the contraction: an LSTM layer alone runs
+// 4.4 -> 3.5 us per step, but the joint step, where the NMN's convolutions share the chip on their own stream, gets
+// slower (8.0 -> 8.2 ms at 128 questions): twice the workgroups have to find a free CU at once.)
 // (Measured and rejected, round 2: two row tiles per workgroup, alternating, so that one tile's hand-off
 // completes behind the other tile's step -- 1024 rows as 32 pairs x 8 members instead of 64 tiles x 4.  The
 // hand-off is not what a step waits for: 13.4 us per step against 8.7, the two tiles' chains of wait -> load
