@@ -7,7 +7,6 @@
 // All are bandwidth/latency-bound: one thread per (row, hidden unit) reading the four gate
 // pre-activations (coalesced across units), one wave per sampled row with shuffle reductions.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -527,95 +526,6 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
     }
 }
 
-// Sixteen members per tile, for batches of at most 256 rows (16 tiles x 16 = 256 workgroups): a member owns 16
-// hidden units, i.e. ONE 16-column tile per gate, and its eight waves are four gates x two halves of the
-// contraction (k-blocks 0-7 / 8-15 of h_{t-1}); the halves meet in LDS, where the cell update adds them.  The
-// matrix pipe's share of a step -- two waves per SIMD x 64 dependent MFMAs at eight members -- halves.
-__global__ __launch_bounds__(512) void lstm_seq_fwd_cluster16_kernel(const float* __restrict__ xp,
-                                                                     const float* __restrict__ w_hh,
-                                                                     float* hs, float* __restrict__ cs,
-                                                                     float* __restrict__ act, int* sync, int B, int T,
-                                                                     int tiles) {
-    constexpr int S = 16, UW = LH / S, GLD = UW + 4, HLD = LH + 4, KH = LH / 32;  // KH: k-blocks per half
-    __shared__ float gl[2][4][LROWS][GLD];
-    __shared__ __attribute__((aligned(16))) float hl[LROWS][HLD];
-    int tile, part;
-    pnmn::cluster_coords<S>(tile, part);
-    if (tile >= tiles) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int row0 = tile * LROWS, u0 = part * UW;
-    const int gate = wave >> 1, kh = wave & 1;
-    pnmn::Cluster cl;
-    cl.start(sync + tile * pnmn::CLUSTER_COUNTER_STRIDE, S);
-
-    f32x4_ wreg[KH];
-#pragma unroll
-    for (int k = 0; k < KH; ++k) {
-        const int ntile = gate * (LH / 16) + u0 / 16;
-        wreg[k] = *reinterpret_cast<const f32x4_*>(w_hh + ((size_t)(ntile * (LH / 16) + kh * KH + k) * 64 + lane) * 4);
-    }
-    float creg = 0.f;                      // cell state of (row tid / 16, unit u0 + tid % 16), threads 0-255
-    const int rl = (tid >> 4) & 15, ul = tid & 15;
-
-    for (int t = 0; t < T; ++t) {
-        f32x4_ acc = f32x4_{0.f, 0.f, 0.f, 0.f};
-        if (kh == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                acc[r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + gate * LH + u0 + li] : 0.f;
-            }
-        }
-        if (t > 0) {
-            cl.wait();
-#pragma unroll
-            for (int i = tid; i < LROWS * LH / 4; i += 512) {
-                const int r2 = i / (LH / 4), c4 = i % (LH / 4);
-                const int row = min(row0 + r2, B - 1);
-                *reinterpret_cast<f32x4_*>(&hl[r2][4 * c4]) =
-                    *reinterpret_cast<const f32x4_*>(hs + ((size_t)row * T + (t - 1)) * LH + 4 * c4);
-            }
-            __syncthreads();
-            f32x4_ a[KH];
-#pragma unroll
-            for (int k = 0; k < KH; ++k) a[k] = *reinterpret_cast<const f32x4_*>(&hl[li][(kh * KH + k) * 16 + 4 * g]);
-#pragma unroll
-            for (int k = 0; k < KH; ++k) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k].x, wreg[k].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k].y, wreg[k].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k].z, wreg[k].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k].w, wreg[k].w, acc, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gl[kh][gate][4 * g + r][li] = acc[r];
-        __syncthreads();
-        if (tid < 256) {
-            const int row = row0 + rl, u = u0 + ul;
-            const float ig = sigm(gl[0][0][rl][ul] + gl[1][0][rl][ul]);
-            const float fg = sigm(gl[0][1][rl][ul] + gl[1][1][rl][ul]);
-            const float gg = tanhf(gl[0][2][rl][ul] + gl[1][2][rl][ul]);
-            const float og = sigm(gl[0][3][rl][ul] + gl[1][3][rl][ul]);
-            const float c = fg * creg + ig * gg;
-            const float h = og * tanhf(c);
-            creg = c;
-            if (row < B) {
-                const size_t o = ((size_t)row * T + t) * LH + u;
-                hs[o] = h;
-                cs[o] = c;
-                if (act) {
-                    float* ar = act + ((size_t)row * T + t) * (4 * LH);
-                    ar[u] = ig;
-                    ar[LH + u] = fg;
-                    ar[2 * LH + u] = gg;
-                    ar[3 * LH + u] = og;
-                }
-            }
-        }
-        if (t + 1 < T) cl.signal();  // also the barrier that protects gl for the next step
-    }
-}
-
 template <int S>
 __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* __restrict__ dhs,
                                                                    const float* __restrict__ act,
@@ -625,8 +535,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
                                                                    int B, int T, int tiles) {
     constexpr int UW = LH / S;
     constexpr int KB = 4 * UW / 16;     // k blocks of this workgroup's gate columns
-    constexpr int J = (UW * 16 + 511) / 512;  // (row, unit) pairs per thread; sixteen members: threads 0-255 take one
-    constexpr int PAIRS = UW * 16;
+    constexpr int J = UW * 16 / 512;
     constexpr int DLD = 4 * UW + 4;
     __shared__ __attribute__((aligned(16))) float dgl[LROWS][DLD];
     int tile, part;
@@ -661,7 +570,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
             const int rl = idx / UW, ul = idx % UW;
             const int row = row0 + rl, u = u0 + ul;
             ig[j] = fg[j] = gg[j] = og[j] = cc[j] = cp[j] = dho[j] = 0.f;
-            if (idx < PAIRS && row < B) {
+            if (row < B) {
                 const size_t o = ((size_t)row * T + t) * LH + u;
                 const float* ar = act + ((size_t)row * T + t) * (4 * LH);
                 ig[j] = ar[u], fg[j] = ar[LH + u], gg[j] = ar[2 * LH + u], og[j] = ar[3 * LH + u];
@@ -678,10 +587,8 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
                 const int idx = tid + 512 * j;
                 const int rl = idx / UW, ul = idx % UW;
                 float sum = 0.f;
-                if (idx < PAIRS) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) sum += pp[((size_t)s * LROWS + rl) * LH + u0 + ul];
-                }
+                for (int s = 0; s < S; ++s) sum += pp[((size_t)s * LROWS + rl) * LH + u0 + ul];
                 dh_rec[j] = sum;
             }
         }
@@ -691,7 +598,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
             const int rl = idx / UW, ul = idx % UW;
             const int row = row0 + rl, u = u0 + ul;
             float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
-            if (idx < PAIRS && row < B) {
+            if (row < B) {
                 const float tc = tanhf(cc[j]);
                 const float dh = dho[j] + dh_rec[j];
                 const float dc = dc_rec[j] + dh * og[j] * (1.f - tc * tc);
@@ -707,12 +614,10 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
                 dr[3 * LH + u] = dout;
             }
             dc_rec[j] = dcp;
-            if (idx < PAIRS) {
-                dgl[rl][ul] = di;
-                dgl[rl][UW + ul] = df;
-                dgl[rl][2 * UW + ul] = dg;
-                dgl[rl][3 * UW + ul] = dout;
-            }
+            dgl[rl][ul] = di;
+            dgl[rl][UW + ul] = df;
+            dgl[rl][2 * UW + ul] = dg;
+            dgl[rl][3 * UW + ul] = dout;
         }
         if (t == 0) break;
         __syncthreads();
@@ -747,17 +652,9 @@ constexpr size_t SYNC_BYTES = pnmn::CLUSTER_SYNC_BYTES;
 
 extern "C" {
 
-// members per tile of the LSTM layer kernels: sixteen while the grid still fits (at most 256 rows), else 8 / 4
-static int lstm_members(int tiles) {
-    static const bool no16 = getenv("PNMN_LSTM_MEMBERS16") && atoi(getenv("PNMN_LSTM_MEMBERS16")) == 0;  // (tuning hook)
-    const int S = cluster_split(tiles);
-    if (S == 8 && !no16 && 8 * 16 * ((tiles + 7) / 8) <= pnmn::device_cus()) return 16;
-    return S;
-}
-
 int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward) {
     const int tiles = (B + LROWS - 1) / LROWS;
-    const int S = lstm_members(tiles);
+    const int S = cluster_split(tiles);
     if (S == 0) return 0;
     return (int64_t)SYNC_BYTES + (backward ? (int64_t)tiles * 2 * S * LROWS * LH * sizeof(float) : 0);
 }
@@ -769,14 +666,7 @@ int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, 
     if (hidden != LH) return PNMN_ESHAPE;
     const int tiles = (B + LROWS - 1) / LROWS;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int S = workspace ? lstm_members(tiles) : 0;
-    if (S == 16) {  // few tiles: sixteen members each
-        hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(lstm_seq_fwd_cluster16_kernel, dim3(8 * 16 * ((tiles + 7) / 8)), dim3(512), 0, st, xp, w_hh, hs, cs,
-                           act, static_cast<int*>(workspace), B, T, tiles);
-        return (int)hipGetLastError();
-    }
+    const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
         hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
@@ -799,16 +689,14 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
     if (hidden != LH) return PNMN_ESHAPE;
     const int tiles = (B + LROWS - 1) / LROWS;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int S = workspace ? lstm_members(tiles) : 0;
+    const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
         hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(8 * S * ((tiles + 7) / 8));
         int* sync = static_cast<int*>(workspace);
         float* px = reinterpret_cast<float*>(static_cast<char*>(workspace) + SYNC_BYTES);
-        if (S == 16)
-            hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<16>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
-        else if (S == 8)
+        if (S == 8)
             hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<8>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
         else
             hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<4>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
