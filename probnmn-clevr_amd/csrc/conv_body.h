@@ -59,14 +59,18 @@ struct MaskBwd {
     float* dattn;        // [HW], += (ignored when attn == nullptr)
 };
 
-template <int H, int W, int TH, int KSPLIT>
+// MSPLIT = 2 (launches of a handful of items only): the band's 13 m-tiles are shared by two workgroups, `msub`
+// 0 / 1 taking m-tiles [0, 7) / [7, 14) -- the 14th lies outside the band and is masked.  Both stage the whole
+// region (the halo rows are needed anyway); what halves is the matrix time of a launch that is pure latency.
+template <int H, int W, int TH, int KSPLIT, int MSPLIT = 1>
 __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, int nsub, int cout_block, int cin_chunks,
                                           int ntaps, int in_stride, int out_stride, int relu, float* lds,
-                                          const MaskBwd* mb) {
+                                          const MaskBwd* mb, int msub = 0) {
     constexpr bool WHOLE = (TH == H);   // the band is the whole map: one pass per chunk, compile-time region
     constexpr int HW = TH * W;          // output pixels of this workgroup
     constexpr int ZB = zero_base(region_pixels<H, W, TH>());  // first zero row of the LDS image
-    constexpr int MT = (HW + 15) / 16;
+    constexpr int MT = ((HW + 15) / 16 + MSPLIT - 1) / MSPLIT;  // m-tiles of this workgroup
+    const int mbase = (MSPLIT == 1) ? 0 : msub * MT;             // its first m-tile
     constexpr int NT = 8 / KSPLIT;   // 16-channel output tiles per workgroup
     constexpr int KB = 8 / KSPLIT;   // 16-channel input blocks per wave and tap
     constexpr int NTHREADS = 512;
@@ -96,7 +100,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int p = mt * 16 + li;
+        const int p = (mbase + mt) * 16 + li;
         py[mt] = (p < HW) ? y0 + p / W : -100000;
         px[mt] = p % W;
     }
@@ -309,7 +313,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
 #pragma unroll
             for (int j = 0; j < EG; ++j) {
                 const int mt = m0 + j;
-                const int p = mt * 16 + li;
+                const int p = (mbase + mt) * 16 + li;
                 old[j] = (mt < MT && accumulate && p < HW)
                              ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
                              : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -317,7 +321,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
 #pragma unroll
             for (int j = 0; j < EG; ++j) {
                 const int mt = m0 + j;
-                const int p = mt * 16 + li;
+                const int p = (mbase + mt) * 16 + li;
                 if (mt < MT && p < HW) {
                     f32x4 v = acc[mt < MT ? mt : 0] + bias4;
                     if (relu) {
@@ -349,7 +353,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
 #pragma unroll
             for (int j = 0; j < EG; ++j) {
                 const int mt = m0 + j;
-                const int p = mt * 16 + li;
+                const int p = (mbase + mt) * 16 + li;
                 const bool ok = mt < MT && p < HW;
                 am[j] = (ok && attn) ? attn[p_img + p] : 1.f;
                 fv[j] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -359,7 +363,7 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
             for (int j = 0; j < EG; ++j) {
                 const int mt = m0 + j;
                 if (mt >= MT) continue;
-                const int p = mt * 16 + li;
+                const int p = (mbase + mt) * 16 + li;
                 const bool ok = p < HW;
                 const f32x4 v = acc[mt < MT ? mt : 0];
                 float part = v.x * fv[j].x + v.y * fv[j].y + v.z * fv[j].z + v.w * fv[j].w;

@@ -39,7 +39,7 @@ using pnmn::CB;
 // item).  WPS = minimum waves per SIMD the register allocation must leave room for: 2 = one workgroup per
 // CU (the 98 KiB tile allows no more), 4 = two (half-map tiles of 68 KiB: one workgroup stages or stores
 // while the other one's MFMAs run).
-template <int H, int W, int TH, int KSPLIT, int WPS>
+template <int H, int W, int TH, int KSPLIT, int WPS, int MSPLIT = 1>
 __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     const pnmn_conv_item* __restrict__ items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
     int out_stride, int relu, int per_xcd) {
@@ -53,17 +53,18 @@ __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     // scripts/pmc_conv.sh).  The KSPLIT workgroups of a unit all stage the same input region and get ids that
     // are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
     const int slot = blockIdx.x >> 3;
-    const int j = slot / KSPLIT;
+    const int j = slot / (KSPLIT * MSPLIT);
+    const int sub = slot % (KSPLIT * MSPLIT);
     const int unit = per_xcd ? (blockIdx.x & 7) * per_xcd + j : j * 8 + (blockIdx.x & 7);
     if (unit >= n_units || (per_xcd && j >= per_xcd)) return;
     const int u = unit0 + unit;
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
-    pnmn::conv_body<H, W, TH, KSPLIT>(it, u % NB, slot % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
-                                      relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr);
+    pnmn::conv_body<H, W, TH, KSPLIT, MSPLIT>(it, u % NB, sub % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
+                                              relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr, sub / KSPLIT);
 }
 
-template <int H, int W, int TH, int KSPLIT>
+template <int H, int W, int TH, int KSPLIT, int MSPLIT = 1>
 int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
                   int out_stride, int cout_blocks, int relu, hipStream_t stream) {
     constexpr size_t lds_bytes = (size_t)pnmn::lds_rows<H, W, TH>() * CB * sizeof(float);
@@ -72,14 +73,14 @@ int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_c
     static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((TH * W + 15) / 16) * 64 * 16 <= lds_bytes,
                   "reduction scratch must fit in the input image");
     static bool configured = false;
-    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT, WPS>;
+    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT, WPS, MSPLIT>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT, cout_blocks);
+    dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT * MSPLIT, cout_blocks);
     static const bool round_robin = getenv("PNMN_CONV_XCD_ROUNDROBIN") != nullptr;  // (tuning hook: the former mapping)
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
                        out_stride, relu, round_robin ? 0 : (n_units + 7) / 8);
@@ -103,10 +104,12 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
         return e ? atof(e) : 0.5;
     }();
     const double overhead = stage_cost * cin_chunks + 0.25;
-    auto round_cost = [&](int s) { return work / s + overhead; };
+    // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
+    auto round_cost = [&](int s) { return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead; };
+    static const int s_max = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
     LaunchPlan best{1, 0, 1};
     double best_t = 1e30;
-    for (int s = 1; s <= 8; s *= 2) {
+    for (int s = 1; s <= s_max; s *= 2) {
         const long per_item = (long)cout_blocks * s;
         const long full_rounds = (long)n_items * per_item / 256;
         long n_main = full_rounds * 256 / per_item;
@@ -117,7 +120,7 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
             if (t_main < best_t * 0.97) best_t = t_main, best = LaunchPlan{s, n_items, s};
             continue;
         }
-        for (int st = s; st <= 8; st *= 2) {
+        for (int st = s; st <= s_max; st *= 2) {
             const long tail_rounds = (n_tail * cout_blocks * st + 255) / 256;
             const double t = t_main + (double)tail_rounds * round_cost(st) + (n_main > 0 ? 0.3 : 0.0);
             if (t < best_t * 0.97) {  // prefer the smaller splits unless the gain is real
@@ -133,6 +136,9 @@ template <int H, int W, int TH>
 int launch_conv_split(int split, const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps,
                       int in_stride, int out_stride, int cout_blocks, int relu, hipStream_t stream) {
     switch (split) {
+        case 16:
+            return launch_conv_k<H, W, TH, 8, 2>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
+                                                 cout_blocks, relu, stream);
         case 8:
             return launch_conv_k<H, W, TH, 8>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
                                               cout_blocks, relu, stream);

@@ -97,7 +97,7 @@ def test_conv3x3_masked_relu(hip, dilation):
     torch.testing.assert_close(from_nhwc(out, n, C), ref, rtol=RT, atol=AT)
 
 
-@pytest.mark.parametrize("n", [41, 129, 300, 520, 777])
+@pytest.mark.parametrize("n", [5, 17, 41, 129, 300, 520, 777])
 def test_conv_many_items_every_launch_shape(hip, n):
     """Item counts around and beyond one round of 256 workgroups: the library cuts such launches into
     whole rounds with one K-split plus a remainder with a larger one, and maps the splits of an item to
