@@ -261,10 +261,10 @@ def recurrent_kernel_report(dev):
         mask = torch.ones(B, S, device=dev)
         w_c, w_hh = r(4 * Hd, Hd, scale=0.05), r(4 * Hd, Hd, scale=0.05)
         w_p, b_p = r(V, Hd, scale=0.3), r(V)
-        xe = r(B, T, 4 * Hd, scale=0.5) if mode == 0 else None
-        etable = r(V, 4 * Hd, scale=0.5) if mode != 0 else None
+        etable = r(V, 4 * Hd, scale=0.5)
+        teacher = torch.randint(0, V, (B, T), device=dev) if mode == 0 else None  # (inputs = rows of etable, as the models run it)
         dh = r(B, T, Hd)
-        run = lambda e: _AttnLSTMDecoder.apply(xe, etable, e, mask, h0, w_c, w_hh, w_p, b_p, mode, T, 5, 0, 0, 1, 2)[0]  # noqa: E731
+        run = lambda e: _AttnLSTMDecoder.apply(None, etable, e, mask, h0, w_c, w_hh, w_p, b_p, mode, T, 5, 0, 0, 1, 2, None, teacher)[0]  # noqa: E731
         fwd = clock(lambda: run(enc.detach()))
         both = clock(lambda: run(enc).backward(dh))
         flops = B * T * (2.0 * 2 * Hd * 4 * Hd + 4.0 * S * Hd + (2.0 * V * Hd if mode else 0.0))

@@ -344,9 +344,14 @@ int pnmn_lstm_cell_bwd(const float* act, const float* c_prev, const float* c, co
  * packed in MFMA-fragment order: for W [N][K] row-major,
  *     packed[N/16][K/16][64][4], packed[nt][kb][16*g + li][j] = W[16*nt + li][16*kb + 4*g + j]
  * (one wave-wide operand load = 1 KiB contiguous).
+ * `tokens` (pnmn_lstm_seq_fwd; NULL = xp as above): the layer's input is an embedding, xp is the [V][4H]
+ * table Emb W_ih^T + b_ih + b_hh and step t of row b uses its row tokens[b * token_stride + t] -- the per-token
+ * projection is never materialised per (row, step); dgates is then scattered into the table's gradient with
+ * pnmn_embedding_grad.
  * ------------------------------------------------------------------------------------------- */
-int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B,
-                      int T, int hidden, void* workspace, void* stream);
+int pnmn_lstm_seq_fwd(const float* xp, const int64_t* tokens, int64_t token_stride, const float* w_hh,
+                      float* hs, float* cs, float* act, int B, int T, int hidden, void* workspace,
+                      void* stream);
 int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const float* w_hh_t,
                       float* dgates, int B, int T, int hidden, void* workspace, void* stream);
 /* Multi-CU variants: with a `workspace` of pnmn_lstm_seq_workspace_bytes(B, backward) bytes (device
@@ -364,7 +369,8 @@ int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward);
  *   per step: w = masked_softmax(enc . h, mask); ctx = w . enc; gates = xe_t + ctx W_c^T + h W_hh^T;
  *             LSTM cell; [sample != 0: logits = h W_p^T + b_p, token choice, next xe from etable]
  *   W_ih of the reference's LSTMCell is [W_c | W_e] (input = cat(ctx, embedding)); xe / etable carry
- *   the embedding half plus both biases.  sample: 0 teacher forced (xe), 1 sample, 2 greedy.
+ *   the embedding half plus both biases.  sample: 0 teacher forced (xe; or xe == NULL and step t's
+ *   input taken as row in_tokens[b * in_token_stride + t] of etable), 1 sample, 2 greedy.
  *   saved for backward: act, cs, hs, ctx, probs (softmax before masking).
  * backward: dhs (gradient wrt every h_t) -> dgates (= d xe), denc (+=, zero on entry), dh0.
  * S <= 64 encoder positions, V <= 128 sampled vocabulary.
@@ -374,7 +380,8 @@ int pnmn_attn_lstm_fwd(const float* xe, const float* etable, const float* enc, c
                        const float* b_p, float* hs, float* cs, float* act, float* ctx, float* probs,
                        int64_t* tokens, int B, int T, int S, int V, int hidden, int sample,
                        int pad_index, int unk_index, int start_index, uint64_t seed,
-                       uint64_t row_offset, void* stream);
+                       uint64_t row_offset, const int64_t* in_tokens, int64_t in_token_stride,
+                       void* stream);
 int pnmn_attn_lstm_bwd(const float* dhs, const float* act, const float* cs, const float* hs,
                        const float* ctx, const float* probs, const float* enc, const float* mask,
                        const float* h0, const float* w_c_t, const float* w_hh_t, float* dgates,
@@ -396,7 +403,8 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
                              const float* b_p, float* hs, float* cs, float* act, float* ctx,
                              float* probs, int64_t* tokens, int B, int T, int S, int V, int hidden,
                              int sample, int pad_index, int unk_index, int start_index,
-                             uint64_t seed, uint64_t row_offset, void* workspace, void* stream);
+                             uint64_t seed, uint64_t row_offset, const int64_t* in_tokens,
+                             int64_t in_token_stride, void* workspace, void* stream);
 int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs, const float* hs,
                              const float* probs, const float* enc, const float* mask,
                              const float* h0, const float* w_c_t, const float* w_hh_t,

@@ -13,6 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace pnmn {
 
 // Hand-off state of one workgroup.  `fast` is decided once per launch (see start()): when every member
@@ -22,7 +26,7 @@ namespace pnmn {
 // the agent-scope pair costs 6-9 us per hand-off with 256 workgroups resident (every release writes
 // back all of the XCD's dirty output lines); the same-XCD pair costs a fraction of that.
 struct Cluster {
-    int* counter;   // [0] arrivals (monotonic), [1] OR of (1 << XCC id) over the members
+    int* counter;   // [0] arrivals (monotonic), [1] OR of (1 << XCC id) over the members, [2] members that finished
     int handoffs;
     int members;
     bool fast;
@@ -52,6 +56,22 @@ struct Cluster {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+    }
+
+    // Last act of a member.  The member that finishes last puts the tile's three words back to zero, so the
+    // next launch on the stream finds the block as the library created it and no zeroing dispatch has to go
+    // in front of every launch (16 per training step).  Every member has passed its last wait() when it gets
+    // here, so nobody polls the words any more; vmcnt(0) first: this member's last signal() has been performed.
+    __device__ __forceinline__ void finish() {
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int before = __hip_atomic_fetch_add(counter + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before == members - 1) {
+                __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counter + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counter + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 
     // First hand-off of a launch (always with full agent-scope ordering): the members publish the XCD
@@ -101,23 +121,48 @@ inline int cluster_split(int tiles, bool allow4 = true) {
     return 0;
 }
 
-// one counter per tile, each on its own 256-byte line: the members of up to 64 tiles poll and increment
-// concurrently, and counters sharing a line would serialise all of them on one L2 channel
-// The hand-off counters are zeroed by a KERNEL in front of every multi-CU launch, not by hipMemsetAsync:
-// when the launch sequence is captured into a hipGraph (torch.cuda.make_graphed_callables over a whole
-// seq2seq pass), a memset node was seen to run out of order with the kernel nodes around it -- zeroing
-// the counters of a multi-CU kernel that was still running (the workspace of the next launch reuses the
-// freed block) and trapping it.  Kernel nodes keep stream order.
+// One counter line per tile, each on its own 256-byte line: the members of up to 128 tiles poll and increment
+// concurrently, and counters sharing a line would serialise all of them on one L2 channel.
+//
+// The lines live in a block the LIBRARY owns, one per (device, stream), zeroed once when it is created; the
+// kernels leave it zeroed (Cluster::finish), and launches on one stream run one after the other.  Only while
+// the stream is being captured into a hipGraph do the counters go into the caller's workspace behind a
+// zeroing KERNEL (a replayed graph may run next to eager launches of the stream it was captured on; and a
+// memset node was seen to run out of order with the kernel nodes around it -- kernel nodes keep stream order).
 static __global__ void cluster_zero_kernel(int* words, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) words[i] = 0;
 }
 
-inline hipError_t cluster_zero(void* workspace, size_t bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(cluster_zero_kernel, dim3(8), dim3(256), 0, stream, static_cast<int*>(workspace), (int)(bytes / sizeof(int)));
-    return hipGetLastError();
-}
-
 constexpr int CLUSTER_COUNTER_STRIDE = 64;                                     // ints
 constexpr size_t CLUSTER_SYNC_BYTES = 128 * CLUSTER_COUNTER_STRIDE * sizeof(int);  // up to 128 tiles
+
+// The counter block a launch on `stream` uses; `workspace` = the caller's (>= CLUSTER_SYNC_BYTES), used under capture.
+inline hipError_t cluster_sync_block(void* workspace, hipStream_t stream, int** out) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    hipError_t e = hipStreamIsCapturing(stream, &cap);
+    if (e != hipSuccess) return e;
+    if (cap != hipStreamCaptureStatusNone) {
+        *out = static_cast<int*>(workspace);
+        hipLaunchKernelGGL(cluster_zero_kernel, dim3(8), dim3(256), 0, stream, *out, (int)(CLUSTER_SYNC_BYTES / sizeof(int)));
+        return hipGetLastError();
+    }
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int*> blocks;
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    int*& b = blocks[{dev, stream}];
+    if (!b) {
+        void* p = nullptr;
+        if ((e = hipMalloc(&p, CLUSTER_SYNC_BYTES)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(p, 0, CLUSTER_SYNC_BYTES, stream)) != hipSuccess) {
+            (void)hipFree(p);
+            return e;
+        }
+        b = static_cast<int*>(p);
+    }
+    *out = b;
+    return hipSuccess;
+}
 
 }  // namespace pnmn

@@ -59,6 +59,8 @@ struct FwdArgs {
     float* ctx;             // [B][T][H]
     float* probs;           // [B][T][S]  softmax before masking
     int64_t* tokens;        // [B][T] sampled / arg-max tokens (sampling mode)
+    const int64_t* in_tokens;  // teacher forcing without xe: step t's input is row in_tokens[row][t] of etable
+    long in_stride;
     int B, T, S, V;
     int sample;             // 0: teacher forced, 1: sample, 2: greedy
     int pad, unk, start;
@@ -159,7 +161,9 @@ __global__ __launch_bounds__(512) void attn_lstm_fwd_kernel(const FwdArgs a) {
                     const int n = gate * H + 32 * wave + 16 * ut + li;
                     float v = 0.f;
                     if (row < a.B) {
-                        v = a.sample ? a.etable[(size_t)tokl[rl] * G4 + n] : a.xe[((size_t)row * T + t) * G4 + n];
+                        v = a.sample ? a.etable[(size_t)tokl[rl] * G4 + n]
+                                     : (a.xe ? a.xe[((size_t)row * T + t) * G4 + n]
+                                             : a.etable[(size_t)a.in_tokens[(size_t)row * a.in_stride + t] * G4 + n]);
                     }
                     acc[gate][ut][r] = v;
                 }
@@ -429,13 +433,13 @@ int pnmn_attn_lstm_fwd(const float* xe, const float* etable, const float* enc, c
                        const float* w_c, const float* w_hh, const float* w_p, const float* b_p, float* hs, float* cs,
                        float* act, float* ctx, float* probs, int64_t* tokens, int B, int T, int S, int V, int hidden,
                        int sample, int pad_index, int unk_index, int start_index, uint64_t seed, uint64_t row_offset,
-                       void* stream) {
+                       const int64_t* in_tokens, int64_t in_token_stride, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!enc || !mask || !h0 || !w_c || !w_hh || !hs || !cs || !act || !ctx || !probs) return PNMN_EINVAL;
-    if (sample ? (!etable || !w_p || !b_p || !tokens) : !xe) return PNMN_EINVAL;
+    if (sample ? (!etable || !w_p || !b_p || !tokens) : (!xe && !(etable && in_tokens))) return PNMN_EINVAL;
     if (hidden != H || S < 1 || S > MAXS || (sample && (V < 1 || V > MAXV))) return PNMN_ESHAPE;
-    FwdArgs a{xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, hs, cs, act, ctx, probs, tokens, B, T, S, V,
-              sample, pad_index, unk_index, start_index, seed, row_offset};
+    FwdArgs a{xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, hs, cs, act, ctx, probs, tokens, (!sample && !xe) ? in_tokens : nullptr,
+              (long)in_token_stride, B, T, S, V, sample, pad_index, unk_index, start_index, seed, row_offset};
     hipLaunchKernelGGL(attn_lstm_fwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(512), 0,
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();

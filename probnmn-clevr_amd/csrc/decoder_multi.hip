@@ -65,6 +65,8 @@ struct MFwdArgs {
     float* ctx;
     float* probs;
     int64_t* tokens;
+    const int64_t* in_tokens;  // teacher forcing without xe: step t's input is row in_tokens[row][t] of etable
+    long in_stride;
     int* sync;
     int B, T, S, V, tiles;
     int sample;
@@ -74,15 +76,18 @@ struct MFwdArgs {
 
 constexpr size_t FWD_FIXED_LDS = sizeof(float) * (4 * ROWS * GLD + RW * 4 * H + ROWS * MAXV + RW * MAXS) + sizeof(int) * ROWS;
 
+// ALLPARTS: 16 KB more LDS behind `logl` (the launch adds them when S leaves room: S <= 59), so that the gates
+// phase can hold all four parts of its A operands at once.
+template <bool ALLPARTS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_multi_kernel(const MFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char raw[];
     const int T = a.T, S = a.S;
     float* encl = reinterpret_cast<float*>(raw);                                       // [RW][S][H]
     float (*gl)[ROWS][GLD] = reinterpret_cast<float (*)[ROWS][GLD]>(encl + RW * S * H);  // [4][16][36]
-    float (*cpart)[4][H] = reinterpret_cast<float (*)[4][H]>(&gl[4][0][0]);            // [RW][4][H]
-    float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]
-    float (*scl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&logl[ROWS][0]);            // [RW][64]
+    float (*scl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&gl[4][0][0]);              // [RW][64]
     int* tokl = reinterpret_cast<int*>(&scl[RW][0]);                                   // [16]
+    float (*cpart)[4][H] = reinterpret_cast<float (*)[4][H]>(tokl + ROWS);             // [RW][4][H]
+    float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]  (+ 16 KB: ALLPARTS)
 
     int tile, part;
     pnmn::cluster_coords<MEMBERS>(tile, part);
@@ -115,6 +120,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float row_mask = lane < S ? a.mask[(size_t)min(myrow0 + (wave >> 2), a.B - 1) * S + lane] : 0.f;
     float creg = 0.f;                       // cell state of (row tid / 32, unit u0 + tid % 32)
     const int arow = min(row0 + li, a.B - 1);  // A-operand row (padding rows read a real row; results dropped)
+    // teacher forcing from the table: tokl holds the step's input tokens as in the sampling modes; thread r < 16
+    // fetches row r's next one a step ahead
+    const int64_t* tf_row = (a.in_tokens && tid < ROWS) ? a.in_tokens + (size_t)min(row0 + tid, a.B - 1) * a.in_stride : nullptr;
+    if (tf_row) tokl[tid] = (int)tf_row[0];
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
@@ -175,34 +184,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int rl = 4 * g + r, row = row0 + rl;
             const int n = gate * H + u0 + 16 * ub + li;
             float v = 0.f;
-            if (row < a.B) v = a.sample ? a.etable[(size_t)tokl[rl] * G4 + n] : a.xe[((size_t)row * T + t) * G4 + n];
+            if (row < a.B) v = a.xe ? a.xe[((size_t)row * T + t) * G4 + n] : a.etable[(size_t)tokl[rl] * G4 + n];
             acc[r] = v;
         }
+        const int tf_next = tf_row ? (int)tf_row[min(t + 1, T - 1)] : 0;  // (stored into tokl behind the cell phase)
         {
             // A operands (the tile's 16 x 256 context and hidden vectors) go through LDS in four parts of 64
-            // columns, double buffered in the 16 KB that the attention phase's partial contexts and the token
-            // phase's logits leave idle here: one coalesced 16-byte load per thread and part -- requested
-            // while the previous part's MFMAs run -- instead of 32 scattered loads per lane in four batches
-            // that each waited out a full L2 round trip in front of their MFMAs (5 400 of the phase's 13 600
-            // cycles).  Slot s of row r sits at slot s ^ r: the 16 lanes of an MFMA operand read hit 16 banks
-            // groups.  This wave owns ONE output tile, so a single accumulator would make its 128 MFMAs one
-            // dependent chain (each waits out the previous one's full latency, ~3x the issue time): four
-            // partial sums -- context / hidden state, even / odd k-block -- keep four chains in flight.
-            constexpr int NB = 4;
-            float* stage = &cpart[0][0][0];  // [2 buffers][2 tensors][16 rows][64]
+            // columns: one coalesced 16-byte load per thread and part instead of 32 scattered loads per lane in
+            // four batches that each waited out a full L2 round trip in front of their MFMAs (5 400 of the phase's
+            // 13 600 cycles).  ALLPARTS: all four parts are requested at once and stored side by side -- one L2
+            // round trip and one barrier for the lot.  Otherwise (S > 59) they are double buffered in the 16 KB
+            // that the attention phase's partial contexts and the token phase's logits leave idle here, part
+            // p + 1 requested while part p's MFMAs run (32 MFMAs are shorter than that round trip; and holding
+            // all four in registers instead spills -- kernels with scratch memory were seen to cost the HOST
+            // milliseconds per step once a second stream runs beside them).  Slot s of row r sits at slot s ^ r:
+            // the 16 lanes of an MFMA operand read hit 16 bank groups.  This wave owns ONE output tile, so a
+            // single accumulator would make its 128 MFMAs one dependent chain (each waits out the previous one's
+            // full latency, ~3x the issue time): four partial sums -- context / hidden state, even / odd k-block
+            // -- keep four chains in flight.
+            constexpr int NB = 4, NPARTS = (H / 16) / NB, PART = 2 * ROWS * 64;
+            float* stage = &cpart[0][0][0];  // [2 buffers | 4 parts][2 tensors][16 rows][64]
             const int s_tensor = tid >> 8, s_row = (tid >> 4) & 15, s_slot = tid & 15;
             const int s_rowc = min(row0 + s_row, a.B - 1);
             const float* s_src = (s_tensor == 0 ? a.ctx + ((size_t)s_rowc * T + t) * H
                                                 : (t > 0 ? a.hs + ((size_t)s_rowc * T + (t - 1)) * H : a.h0 + (size_t)s_rowc * H)) + 4 * s_slot;
             float* s_dst = stage + (s_tensor * ROWS + s_row) * 64 + 4 * (s_slot ^ s_row);
-            f32x4 sv = *reinterpret_cast<const f32x4*>(s_src);
-            *reinterpret_cast<f32x4*>(s_dst) = sv;
+            f32x4 sv;
+            if constexpr (ALLPARTS) {
+                f32x4 all[NPARTS];
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) all[part] = *reinterpret_cast<const f32x4*>(s_src + part * 64);
+#pragma unroll
+                for (int part = 0; part < NPARTS; ++part) *reinterpret_cast<f32x4*>(s_dst + part * PART) = all[part];
+            } else {
+                sv = *reinterpret_cast<const f32x4*>(s_src);
+                *reinterpret_cast<f32x4*>(s_dst) = sv;
+            }
             __syncthreads();
             f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0, ph0 = pc0, ph1 = pc0;
 #pragma unroll
-            for (int part = 0; part < (H / 16) / NB; ++part) {
-                if (part + 1 < (H / 16) / NB) sv = *reinterpret_cast<const f32x4*>(s_src + (part + 1) * 64);
-                const float* buf = stage + (part & 1) * (2 * ROWS * 64);
+            for (int part = 0; part < NPARTS; ++part) {
+                if (!ALLPARTS && part + 1 < NPARTS) sv = *reinterpret_cast<const f32x4*>(s_src + (part + 1) * 64);
+                const float* buf = stage + (ALLPARTS ? part : (part & 1)) * PART;
                 f32x4 ac[NB], ah[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -230,8 +253,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].w, wc[kb + 1].w, pc1, 0, 0, 0);
                     ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].w, wh[kb + 1].w, ph1, 0, 0, 0);
                 }
-                if (part + 1 < (H / 16) / NB) {
-                    *reinterpret_cast<f32x4*>(s_dst + ((part + 1) & 1) * (2 * ROWS * 64)) = sv;
+                if (!ALLPARTS && part + 1 < NPARTS) {
+                    *reinterpret_cast<f32x4*>(s_dst + ((part + 1) & 1) * PART) = sv;
                     __syncthreads();
                 }
             }
@@ -260,6 +283,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 ar[3 * H + u] = og;
             }
         }
+        if (tf_row) tokl[tid] = tf_next;       // (read again behind the hand-off's barriers)
         if (t + 1 == T && !a.sample) break;  // nobody needs h_T
         cl.signal();
         cl.wait();
@@ -316,6 +340,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
         }
     }
+    cl.finish();
 }
 
 struct MBwdArgs {
@@ -551,6 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         cl.signal();
         cl.wait();
     }
+    cl.finish();
 }
 
 // rows one launch can take: all tiles x 8 members resident, one workgroup per CU
@@ -581,32 +607,38 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
                              const float* w_c, const float* w_hh, const float* w_p, const float* b_p, float* hs, float* cs,
                              float* act, float* ctx, float* probs, int64_t* tokens, int B, int T, int S, int V, int hidden,
                              int sample, int pad_index, int unk_index, int start_index, uint64_t seed, uint64_t row_offset,
-                             void* workspace, void* stream) {
+                             const int64_t* in_tokens, int64_t in_token_stride, void* workspace, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!enc || !mask || !h0 || !w_c || !w_hh || !hs || !cs || !act || !ctx || !probs || !workspace) return PNMN_EINVAL;
-    if (sample ? (!etable || !w_p || !b_p || !tokens) : !xe) return PNMN_EINVAL;
+    if (sample ? (!etable || !w_p || !b_p || !tokens) : (!xe && !(etable && in_tokens))) return PNMN_EINVAL;
     if (hidden != H || S < 1 || S > MAXS || (sample && (V < 1 || V > MAXV))) return PNMN_ESHAPE;
     const int chunk = rows_per_launch();
     if (chunk <= 0) return PNMN_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H;
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        hipError_t e = allow_lds(attn_lstm_fwd_multi_kernel, lds);
+    constexpr size_t ALL_PARTS_LDS = sizeof(float) * 2 * 2 * ROWS * 64;  // parts 2 and 3 of the gates phase's operands
+    constexpr size_t LDS_LIMIT = 160 * 1024;
+    const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * S * H + ALL_PARTS_LDS <= LDS_LIMIT;
+    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H + (all_parts ? ALL_PARTS_LDS : 0);
+    static size_t allowed[2] = {0, 0};
+    if (lds > allowed[all_parts]) {
+        hipError_t e = all_parts ? allow_lds(attn_lstm_fwd_multi_kernel<true>, lds) : allow_lds(attn_lstm_fwd_multi_kernel<false>, lds);
         if (e != hipSuccess) return (int)e;
-        allowed = lds;
+        allowed[all_parts] = lds;
     }
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
         const int tiles = (rows + ROWS - 1) / ROWS;
-        hipError_t e = pnmn::cluster_zero(workspace, pnmn::CLUSTER_SYNC_BYTES, st);
+        int* sync = nullptr;
+        hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
         const size_t r = (size_t)r0;
         MFwdArgs a{xe ? xe + r * T * G4 : nullptr, etable, enc + r * S * H, mask + r * S, h0 + r * H, w_c, w_hh, w_p, b_p,
                    hs + r * T * H, cs + r * T * H, act + r * T * G4, ctx + r * T * H, probs + r * T * S,
-                   tokens ? tokens + r * T : nullptr, static_cast<int*>(workspace), rows, T, S, V, tiles, sample,
+                   tokens ? tokens + r * T : nullptr, (!sample && !xe) ? in_tokens + r * in_token_stride : nullptr,
+                   (long)in_token_stride, sync, rows, T, S, V, tiles, sample,
                    pad_index, unk_index, start_index, seed, row_offset + r};
-        hipLaunchKernelGGL(attn_lstm_fwd_multi_kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(all_parts ? attn_lstm_fwd_multi_kernel<true> : attn_lstm_fwd_multi_kernel<false>,
+                           dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -639,12 +671,13 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
         const int tiles = (rows + ROWS - 1) / ROWS;
-        hipError_t e = pnmn::cluster_zero(workspace, pnmn::CLUSTER_SYNC_BYTES, st);
+        int* sync = nullptr;
+        hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
         const size_t r = (size_t)r0;
         MBwdArgs a{dhs + r * T * H, act + r * T * G4, cs + r * T * H, hs + r * T * H, probs + r * T * S, enc + r * S * H,
                    mask + r * S, h0 + r * H, w_c_t, w_hh_t, dgates + r * T * G4, dctx + r * T * H, dscore + r * T * S,
-                   dh0 + r * H, x1, x2, static_cast<int*>(workspace), rows, T, S, tiles};
+                   dh0 + r * H, x1, x2, sync, rows, T, S, tiles};
         hipLaunchKernelGGL(attn_lstm_bwd_multi_kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

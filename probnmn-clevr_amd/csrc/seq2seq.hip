@@ -237,7 +237,15 @@ constexpr int LH = 256;        // hidden size the kernel is built for
 constexpr int LROWS = 16;      // batch rows per workgroup
 constexpr int LLD = LH + 4;    // LDS row stride (floats): 16-byte aligned, breaks the 1 KiB bank period
 
-__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ w_hh,
+// The input projection of (row, t): row (row, t) of xp [B][T][4H], or -- `tokens` given -- row tokens[row][t] of the
+// [V][4H] table xp then is (first layers, whose input is an embedding: the per-token projection is never
+// materialised per (row, step); the token of step t + 1 is fetched during step t).
+__device__ __forceinline__ const float* xp_row(const float* xp, const int64_t* tokens, long tstride, int row, int T, int t) {
+    return xp + (tokens ? (size_t)tokens[(size_t)row * tstride + t] : (size_t)row * T + t) * (4 * 256);
+}
+
+__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restrict__ xp, const int64_t* __restrict__ tokens,
+                                                           long tstride, const float* __restrict__ w_hh,
                                                            float* __restrict__ hs, float* __restrict__ cs,
                                                            float* __restrict__ act, int B, int T) {
     __shared__ __attribute__((aligned(16))) float hl[2][LROWS][LLD];
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restri
                 for (int r = 0; r < 4; ++r) {
                     const int row = row0 + 4 * g + r;
                     const int n = gate * LH + 32 * wave + 16 * ut + li;
-                    acc[gate][ut][r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + n] : 0.f;
+                    acc[gate][ut][r] = row < B ? xp_row(xp, tokens, tstride, row, T, t)[n] : 0.f;
                 }
         if (t > 0) {
 #pragma unroll 4
@@ -421,8 +429,9 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(const float* __restri
 // only by the compiler's fma contraction of the cell update (last ulps), and are run-to-run identical.
 // -----------------------------------------------------------------------------------------------------
 
-template <int S>
+template <int S, bool TOK>
 __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* __restrict__ xp,
+                                                                   const int64_t* __restrict__ tokens, long tstride,
                                                                    const float* __restrict__ w_hh,
                                                                    float* hs, float* __restrict__ cs,
                                                                    float* __restrict__ act, int* sync, int B, int T,
@@ -458,24 +467,47 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
 #pragma unroll
     for (int j = 0; j < J; ++j) creg[j] = 0.f;
 
+    // this lane's four rows of xp at step t (rows past the batch read the last row; their results are never
+    // stored -- a `row < B ?` around each load makes the compiler issue them one after the other, each behind a
+    // vmcnt(0)).  TOK: the row index is fetched one step ahead and only turned into an address at the top of the
+    // step that uses it (a use right behind the load would make the wave wait for it -- and, the memory counter
+    // being in order, for the xp loads in front of it -- BEFORE it starts polling the hand-off counter: +2.5 us
+    // per step, measured)
+    int64_t xrow[4];
+    const int64_t* trow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + 4 * g + r, B - 1);
+        trow[r] = TOK ? tokens + (size_t)row * tstride : nullptr;
+        xrow[r] = TOK ? trow[r][0] : (int64_t)row * T;
+    }
+
     for (int t = 0; t < T; ++t) {
         f32x4_ acc[UB];
 #pragma unroll
         for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                const int n = gate * LH + u0 + 16 * (ub0 + ub) + li;
-                acc[ub][r] = row < B ? xp[((size_t)row * T + t) * (4 * LH) + n] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r)
+                acc[ub][r] = xp[(size_t)xrow[r] * (4 * LH) + gate * LH + u0 + 16 * (ub0 + ub) + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xrow[r] = TOK ? trow[r][min(t + 1, T - 1)] : xrow[r] + 1;
         if (t > 0) {
             cl.wait();
+            {   // both loads in flight before the first LDS store (written as a loop the compiler issues load,
+                // vmcnt(0), store, load, vmcnt(0), store: two L2 round trips on the step's critical path)
+                static_assert(LROWS * LH / 4 == 2 * 512, "two 16-byte pieces per thread");
+                f32x4_ piece[2];
 #pragma unroll
-            for (int i = tid; i < LROWS * LH / 4; i += 512) {
-                const int rl = i / (LH / 4), c4 = i % (LH / 4);
-                const int row = min(row0 + rl, B - 1);
-                *reinterpret_cast<f32x4_*>(&hl[rl][4 * c4]) =
-                    *reinterpret_cast<const f32x4_*>(hs + ((size_t)row * T + (t - 1)) * LH + 4 * c4);
+                for (int k = 0; k < 2; ++k) {
+                    const int i = tid + 512 * k, rl = i / (LH / 4), c4 = i % (LH / 4);
+                    const int row = min(row0 + rl, B - 1);
+                    piece[k] = *reinterpret_cast<const f32x4_*>(hs + ((size_t)row * T + (t - 1)) * LH + 4 * c4);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int i = tid + 512 * k, rl = i / (LH / 4), c4 = i % (LH / 4);
+                    *reinterpret_cast<f32x4_*>(&hl[rl][4 * c4]) = piece[k];
+                }
             }
             __syncthreads();
             f32x4_ a[LH / 16];
@@ -524,6 +556,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_cluster_kernel(const float* 
         }
         if (t + 1 < T) cl.signal();  // also the barrier that protects gl for the next step
     }
+    cl.finish();
 }
 
 template <int S>
@@ -643,6 +676,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_cluster_kernel(const float* 
             *reinterpret_cast<f32x4_*>(po + (size_t)li * LH + 16 * (2 * wave + nt) + 4 * g) = acc[nt];
         cl.signal();  // also: everyone is done reading dgl
     }
+    cl.finish();
 }
 
 using pnmn::cluster_split;
@@ -659,26 +693,26 @@ int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward) {
     return (int64_t)SYNC_BYTES + (backward ? (int64_t)tiles * 2 * S * LROWS * LH * sizeof(float) : 0);
 }
 
-int pnmn_lstm_seq_fwd(const float* xp, const float* w_hh, float* hs, float* cs, float* act, int B, int T, int hidden,
-                      void* workspace, void* stream) {
+int pnmn_lstm_seq_fwd(const float* xp, const int64_t* tokens, int64_t token_stride, const float* w_hh, float* hs,
+                      float* cs, float* act, int B, int T, int hidden, void* workspace, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!xp || !w_hh || !hs || !cs) return PNMN_EINVAL;
+    const long tstride = (long)token_stride;
     if (hidden != LH) return PNMN_ESHAPE;
     const int tiles = (B + LROWS - 1) / LROWS;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
-        hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
+        int* sync = nullptr;
+        hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(8 * S * ((tiles + 7) / 8));
-        int* sync = static_cast<int*>(workspace);
-        if (S == 8)
-            hipLaunchKernelGGL(lstm_seq_fwd_cluster_kernel<8>, grid, dim3(512), 0, st, xp, w_hh, hs, cs, act, sync, B, T, tiles);
-        else
-            hipLaunchKernelGGL(lstm_seq_fwd_cluster_kernel<4>, grid, dim3(512), 0, st, xp, w_hh, hs, cs, act, sync, B, T, tiles);
+        auto kern = S == 8 ? (tokens ? lstm_seq_fwd_cluster_kernel<8, true> : lstm_seq_fwd_cluster_kernel<8, false>)
+                           : (tokens ? lstm_seq_fwd_cluster_kernel<4, true> : lstm_seq_fwd_cluster_kernel<4, false>);
+        hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, xp, tokens, tstride, w_hh, hs, cs, act, sync, B, T, tiles);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(tiles), dim3(512), 0, st, xp, w_hh, hs, cs, act, B, T);
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(tiles), dim3(512), 0, st, xp, tokens, tstride, w_hh, hs, cs, act, B, T);
     return (int)hipGetLastError();
 }
 
@@ -691,10 +725,10 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int S = workspace ? cluster_split(tiles) : 0;
     if (S) {
-        hipError_t e = pnmn::cluster_zero(workspace, SYNC_BYTES, st);
+        int* sync = nullptr;
+        hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
         const dim3 grid(8 * S * ((tiles + 7) / 8));
-        int* sync = static_cast<int*>(workspace);
         float* px = reinterpret_cast<float*>(static_cast<char*>(workspace) + SYNC_BYTES);
         if (S == 8)
             hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<8>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);

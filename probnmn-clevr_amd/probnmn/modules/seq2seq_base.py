@@ -161,6 +161,27 @@ class _Alias(torch.autograd.Function):
         return g, g, None
 
 
+class _SplitColumns(torch.autograd.Function):
+    """``(w[:, :k], w[:, k:])`` whose backward is ONE concatenation: two slices of a parameter otherwise cost two
+    zero-filled full-size gradients, two copies into them and an addition per use."""
+
+    @staticmethod
+    def forward(ctx, w, k):
+        ctx.k, ctx.n = k, w.size(1)
+        return w[:, :k], w[:, k:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None and db is None:
+            return None, None
+        ref = da if da is not None else db
+        if da is None:
+            da = ref.new_zeros(ref.size(0), ctx.k)
+        if db is None:
+            db = ref.new_zeros(ref.size(0), ctx.n - ctx.k)
+        return torch.cat((da, db), 1), None
+
+
 class _TokenTable(torch.autograd.Function):
     """``F.linear(embedding.weight, weight, bias)`` ([V, 4H]) where the embedding's padding row receives no
     gradient (nn.Embedding(padding_idx=...) never updates it; its value is zero, so the table row is the bias)."""
@@ -293,16 +314,7 @@ class _EmbeddingLookup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (tokens,) = ctx.saved_tensors
-        if ctx.vocab <= 128 and dy.size(-1) % 64 == 0 and tokens.dim() == 2:
-            skip = ctx.padding_idx if ctx.padding_idx is not None else -1
-            return embedding_grad(dy, tokens, ctx.vocab, skip=skip), None, None
-        flat = tokens.reshape(-1)
-        onehot = torch.zeros(flat.numel(), ctx.vocab, dtype=dy.dtype, device=dy.device)
-        onehot.scatter_(1, flat.unsqueeze(1), 1.0)
-        dw = wgrad_gemm(onehot, dy.reshape(flat.numel(), -1).contiguous())
-        if ctx.padding_idx is not None:
-            dw[ctx.padding_idx].zero_()
-        return dw, None, None
+        return _table_grad(dy, tokens, ctx.vocab, ctx.padding_idx), None, None
 
 
 def embedding_lookup(module: nn.Embedding, tokens: torch.Tensor) -> torch.Tensor:
@@ -334,23 +346,34 @@ def _decoder_workspace(batch: int, backward: bool, device) -> Optional[torch.Ten
 class _LSTMLayerSeq(torch.autograd.Function):
     """The recurrent half of one LSTM layer over a whole padded sequence, as ONE persistent kernel
     launch (``pnmn_lstm_seq_fwd`` / ``_bwd``): (xp [B,T,4H] = input projection + biases, W_hh) -> all
-    hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states."""
+    hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states.
+    With ``tokens`` ([B,T] int64): ``xp`` is the [V,4H] per-token table of ``_TokenTable`` and the kernel reads
+    row ``tokens[b,t]`` of it -- ``F.embedding(tokens, table)`` is never written out; its gradient is the
+    LDS-table sum of ``pnmn_embedding_grad`` over the gate gradients."""
 
     @staticmethod
-    def forward(ctx, xp, w_hh, wp=None, w_t=None):
+    def forward(ctx, xp, w_hh, wp=None, w_t=None, tokens=None):
         if xp.device.type != "cuda":
             raise _hip.HipLibraryError("LSTM layer on %s: the HIP path needs a ROCm device (no CPU fallback)" % xp.device)
         xp, w = xp.contiguous(), w_hh.detach()
-        B, T, H4 = xp.shape
+        if tokens is not None:
+            if tokens.dtype != torch.long or tokens.stride(1) != 1:
+                tokens = tokens.long().contiguous()
+            (B, T), H4 = tokens.shape, xp.size(1)
+        else:
+            B, T, H4 = xp.shape
         Hd = H4 // 4
         hs = torch.empty(B, T, Hd, dtype=xp.dtype, device=xp.device)
         cs = torch.empty_like(hs)
-        act = torch.empty_like(xp)
+        act = torch.empty(B, T, H4, dtype=xp.dtype, device=xp.device)
         if wp is None:
             wp = pack_fragments(w)
         ctx.w_t = w_t  # (fragment order of W_hh^T from the model's DerivedParams, else packed in backward)
+        ctx.tokens, ctx.vocab = tokens, xp.size(0)
         ws = _lstm_workspace(B, False, xp.device)
-        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), wp.data_ptr(), hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
+        _hip.check(_hip.lib().pnmn_lstm_seq_fwd(xp.data_ptr(), tokens.data_ptr() if tokens is not None else None,
+                                                tokens.stride(0) if tokens is not None else 0, wp.data_ptr(),
+                                                hs.data_ptr(), cs.data_ptr(), act.data_ptr(),
                                                 B, T, Hd, ws.data_ptr() if ws is not None else None,
                                                 _hip.stream_ptr(xp.device)), "lstm_seq_fwd")
         ctx.save_for_backward(hs, cs, act, w)
@@ -371,7 +394,23 @@ class _LSTMLayerSeq(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             hprev = torch.cat((hs.new_zeros(B, 1, Hd), hs[:, :-1]), 1).reshape(B * T, Hd)  # h_{t-1} per (row, step)
             dw_hh = wgrad_gemm(dgates.reshape(B * T, 4 * Hd), hprev)
-        return dgates, dw_hh, None, None
+        dxp = dgates
+        if ctx.tokens is not None:
+            dxp = _table_grad(dgates, ctx.tokens, ctx.vocab) if ctx.needs_input_grad[0] else None
+        return dxp, dw_hh, None, None, None
+
+
+def _table_grad(dy: torch.Tensor, tokens: torch.Tensor, vocab: int, padding_idx: Optional[int] = None) -> torch.Tensor:
+    """Gradient of ``F.embedding(tokens, table)`` wrt the table, from the gradient ``dy`` [B,T,C] of its output."""
+    if vocab <= 128 and dy.size(-1) % 64 == 0 and tokens.dim() == 2:
+        return embedding_grad(dy, tokens, vocab, skip=padding_idx if padding_idx is not None else -1)
+    flat = tokens.reshape(-1)
+    onehot = torch.zeros(flat.numel(), vocab, dtype=dy.dtype, device=dy.device)
+    onehot.scatter_(1, flat.unsqueeze(1), 1.0)
+    dw = wgrad_gemm(onehot, dy.reshape(flat.numel(), -1).contiguous())
+    if padding_idx is not None:
+        dw[padding_idx].zero_()
+    return dw
 
 
 class _AttnLSTMDecoder(torch.autograd.Function):
@@ -384,7 +423,7 @@ class _AttnLSTMDecoder(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xe, etable, enc, mask, h0, w_c, w_hh, w_p, b_p, mode, T, seed, row_offset, pad, unk, start,
-                packs=None):
+                packs=None, in_tokens=None):
         dev = enc.device
         if dev.type != "cuda":
             raise _hip.HipLibraryError("decoder on %s: the HIP path needs a ROCm device (no CPU fallback)" % dev)
@@ -407,13 +446,20 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             etable, w_p, b_p = etable.contiguous(), w_p.detach().contiguous(), b_p.detach().contiguous()
             tokens = torch.empty(B, T, dtype=torch.long, device=dev)
             V = w_p.size(0)
+        elif in_tokens is not None:  # teacher forcing from the [V,4H] table: step t's input is row in_tokens[b,t]
+            etable = etable.contiguous()
+            if in_tokens.dtype != torch.long or in_tokens.stride(1) != 1:
+                in_tokens = in_tokens.long().contiguous()
+            xe = None
         else:
             xe = xe.contiguous()
         ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        args = (ptr(xe if mode == 0 else None), ptr(etable if mode != 0 else None), enc.data_ptr(), mask.data_ptr(),
+        args = (ptr(xe if mode == 0 else None), ptr(etable if (mode != 0 or in_tokens is not None) else None),
+                enc.data_ptr(), mask.data_ptr(),
                 h0.data_ptr(), w_c_p.data_ptr(), w_hh_p.data_ptr(), ptr(w_p if mode != 0 else None),
                 ptr(b_p if mode != 0 else None), hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(),
-                probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset)
+                probs.data_ptr(), ptr(tokens), B, T, S, V, Hd, mode, pad, unk, start, seed, row_offset,
+                ptr(in_tokens) if mode == 0 else None, in_tokens.stride(0) if (mode == 0 and in_tokens is not None) else 0)
         ws = _decoder_workspace(B, False, dev)
         if ws is not None:
             _hip.check(_hip.lib().pnmn_attn_lstm_fwd_multi(*args, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_fwd_multi")
@@ -421,7 +467,8 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             _hip.check(_hip.lib().pnmn_attn_lstm_fwd(*args, _hip.stream_ptr(dev)), "attn_lstm_fwd")
         ctx.save_for_backward(hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh,
                               tokens if tokens is not None else torch.empty(0, device=dev))
-        ctx.mode, ctx.start, ctx.vocab = mode, start, (etable.size(0) if mode != 0 else 0)
+        ctx.mode, ctx.start, ctx.vocab = mode, start, (etable.size(0) if etable is not None else 0)
+        ctx.in_tokens = in_tokens if mode == 0 else None
         if tokens is not None:
             ctx.mark_non_differentiable(tokens)
             return hs, tokens
@@ -461,7 +508,9 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         dw_c = wgrad_gemm(flat, cx.reshape(B * T, Hd))
         dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
         dxe = detable = None
-        if ctx.mode == 0:
+        if ctx.mode == 0 and ctx.in_tokens is not None:
+            detable = _table_grad(dgates, ctx.in_tokens, ctx.vocab) if ctx.needs_input_grad[1] else None
+        elif ctx.mode == 0:
             dxe = dgates
         else:
             if ctx.vocab <= 128:  # step t's input is the token chosen at step t - 1 (@start@ first)
@@ -469,7 +518,7 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             else:
                 tok_in = torch.cat((tokens.new_full((B, 1), ctx.start), tokens[:, :-1]), 1).reshape(-1)
                 detable = torch.zeros(ctx.vocab, 4 * Hd, dtype=dgates.dtype, device=dev).index_add_(0, tok_in, flat)
-        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 10
+        return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 11
 
 
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
@@ -557,17 +606,6 @@ def sequence_nll(logits: torch.Tensor, tokens: torch.Tensor, mask_tokens: torch.
     return _SeqNLL.apply(logits, tokens, mask_tokens, pad, eps)
 
 
-def token_projection(embedding: nn.Embedding, tokens: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """``F.linear(embedding(tokens), weight, bias)`` for a small vocabulary: project the V < 100
-    embedding rows once (a [V, 4H] table) and gather table rows per token, instead of a GEMM over all
-    B x T rows; backward is the one-hot GEMM of ``_EmbeddingLookup`` into the table and a V-row GEMM
-    from there.  The padding row of ``embedding`` (all zeros, no gradient) keeps both properties."""
-    if tokens.device.type != "cuda" or not torch.is_grad_enabled():
-        return F.embedding(tokens, F.linear(embedding.weight, weight, bias))
-    table = _TokenTable.apply(embedding.weight, weight, bias, embedding.padding_idx)
-    return _EmbeddingLookup.apply(table, tokens, None)
-
-
 def lstm_derived_specs(lstm: nn.LSTM, prefix: str = "l"):
     """DerivedParams specs of an ``nn.LSTM``: per layer the fragment-order W_hh, its transpose and b_ih + b_hh."""
     specs = []
@@ -593,12 +631,14 @@ def lstm_bias(lstm: nn.LSTM, layer: int, derived: Optional[Dict[str, torch.Tenso
 
 
 def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projection: Optional[torch.Tensor] = None,
-                derived: Optional[Dict[str, torch.Tensor]] = None, last: Optional[torch.Tensor] = None):
+                derived: Optional[Dict[str, torch.Tensor]] = None, last: Optional[torch.Tensor] = None,
+                first_tokens: Optional[torch.Tensor] = None):
     """``PytorchSeq2SeqWrapper(nn.LSTM)(x, mask)``: zero initial state, outputs zero past each row's
     length.  Rows are run over all T steps (a unidirectional state never sees later steps) with the
     input GEMM batched over time and the recurrence in one persistent HIP kernel per layer.
     ``first_projection``: the first layer's input projection when the caller already has it
-    (``token_projection``); ``x`` is then unused.  ``derived``: the model's ``DerivedParams`` output (packed
+    ; ``x`` is then unused -- with ``first_tokens`` it is the [V,4H] per-token TABLE and the
+    layer kernel looks the rows up itself.  ``derived``: the model's ``DerivedParams`` output (packed
     weights, bias sums).  ``last`` ([B] int32, ``mask`` then being the float mask): also return each row's
     state at that step -- (outputs, last states) from one launch."""
     B, T = mask.shape
@@ -606,16 +646,22 @@ def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projec
     for layer in range(lstm.num_layers):
         w_ih = getattr(lstm, "weight_ih_l%d" % layer)
         w_hh = getattr(lstm, "weight_hh_l%d" % layer)
+        tokens = None
         if layer == 0 and first_projection is not None:
             xp = first_projection
+            if first_tokens is not None:
+                if lstm.hidden_size == 256:
+                    tokens = first_tokens
+                else:
+                    xp = _EmbeddingLookup.apply(xp, first_tokens, None)
         else:
             xp = linear_rows(inp, w_ih, lstm_bias(lstm, layer, derived))  # (B,T,4H): one GEMM for all time steps
         if lstm.hidden_size == 256:
             # one persistent launch for all T steps
             if derived is not None:
-                inp = _LSTMLayerSeq.apply(xp, w_hh, derived["l%d.hh" % layer], derived["l%d.hhT" % layer])
+                inp = _LSTMLayerSeq.apply(xp, w_hh, derived["l%d.hh" % layer], derived["l%d.hhT" % layer], tokens)
             else:
-                inp = _LSTMLayerSeq.apply(xp, w_hh)
+                inp = _LSTMLayerSeq.apply(xp, w_hh, None, None, tokens)
         else:  # other widths: step by step (GEMM per step + the cell kernel)
             h = xp.new_zeros(B, lstm.hidden_size)
             c = xp.new_zeros(B, lstm.hidden_size)
@@ -662,10 +708,10 @@ class _Encoder(nn.Module):
     def forward_tokens(self, embedding: nn.Embedding, tokens: torch.Tensor, mask: torch.Tensor,
                        derived: Optional[Dict[str, torch.Tensor]] = None, last: Optional[torch.Tensor] = None):
         """``forward(embedding(tokens), mask)`` with the first layer's input projection taken from a
-        per-token table (``token_projection``); with ``last`` also each row's state at that step."""
+        per-token table (``_TokenTable``: V < 100 projected rows instead of a GEMM over all B x T); with ``last`` also each row's state at that step."""
         lstm = self._module
-        xp = token_projection(embedding, tokens, lstm.weight_ih_l0, lstm_bias(lstm, 0, derived))
-        return masked_lstm(lstm, None, mask, first_projection=xp, derived=derived, last=last)
+        table = _TokenTable.apply(embedding.weight, lstm.weight_ih_l0, lstm_bias(lstm, 0, derived), embedding.padding_idx)
+        return masked_lstm(lstm, None, mask, first_projection=table, derived=derived, last=last, first_tokens=tokens)
 
 
 class Seq2SeqBase(nn.Module):
@@ -777,7 +823,8 @@ class Seq2SeqBase(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
         Hd = h.size(1)
         w_ih = self._decoder_cell.weight_ih
-        w_c, w_e = w_ih[:, :Hd], w_ih[:, Hd:]  # the cell's input is cat(attended, embedding)
+        # the cell's input is cat(attended, embedding)
+        w_c, w_e = _SplitColumns.apply(w_ih, Hd) if w_ih.requires_grad and torch.is_grad_enabled() else (w_ih[:, :Hd], w_ih[:, Hd:])
         w_p, b_p = self._output_projection_layer.weight, self._output_projection_layer.bias
         fused = Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128
         derived = self._derived() if fused else None
@@ -790,9 +837,10 @@ class Seq2SeqBase(nn.Module):
         if fused:
             args = (pad, self._unk_index, bos, packs)
             if tgt is not None:  # teacher forcing: every step's input embedding is known up front
-                xe = token_projection(self._target_embedder, tgt[:, :steps], w_e, bias)
-                hs, _ = _AttnLSTMDecoder.apply(xe, None, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
-                                               0, steps, seed, self.sample_row_offset, *args)
+                emb = self._target_embedder
+                etable = _TokenTable.apply(emb.weight, w_e, bias, emb.padding_idx)
+                hs, _ = _AttnLSTMDecoder.apply(None, etable, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p, b_p,
+                                               0, steps, seed, self.sample_row_offset, *args, tgt[:, :steps])
             else:  # free running: the kernel also picks each step's token
                 etable = F.linear(self._target_embedder.weight, w_e, bias)
                 hs, raw = _AttnLSTMDecoder.apply(None, etable, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p,

@@ -296,6 +296,103 @@ def test_multi_cu_lstm_layer_matches_one_workgroup_per_tile(batch, monkeypatch):
             assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
 
 
+@pytest.mark.parametrize("batch,cluster", [(5, "1"), (128, "1"), (1000, "1"), (130, "0")])
+def test_lstm_layer_reads_its_input_projection_from_the_token_table(batch, cluster, monkeypatch):
+    """pnmn_lstm_seq_fwd with `tokens`: row tokens[b, t] of the [V, 4H] table instead of xp[b, t] -- same states
+    bit for bit as with F.embedding(tokens, table) written out, and the table's gradient = the scatter-add of
+    the gate gradients (tokens as a strided view, as the models pass them)."""
+    from probnmn.modules.seq2seq_base import _LSTMLayerSeq
+
+    monkeypatch.setenv("PNMN_LSTM_CLUSTER", cluster)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(batch)
+    T, H, V = 21, 256, 93
+    table = (torch.randn(V, 4 * H, generator=g) * 0.7).to(dev)
+    w = (torch.randn(4 * H, H, generator=g) * 0.06).to(dev)
+    tokens = torch.randint(0, V, (batch, T + 3), generator=g).to(dev)[:, 1 : T + 1]
+    dhs = torch.randn(batch, T, H, generator=g).to(dev)
+    ta, wa = table.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ha = _LSTMLayerSeq.apply(F.embedding(tokens, ta), wa)
+    ha.backward(dhs)
+    tb, wb = table.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    hb = _LSTMLayerSeq.apply(tb, wb, None, None, tokens)
+    hb.backward(dhs)
+    assert torch.equal(ha, hb)
+    assert torch.equal(wa.grad, wb.grad)
+    torch.testing.assert_close(tb.grad, ta.grad, rtol=1e-5, atol=1e-5 * float(ta.grad.abs().max()))
+
+
+@pytest.mark.parametrize("batch,multi", [(7, "1"), (128, "1"), (530, "1"), (40, "0")])
+def test_decoder_teacher_forcing_from_the_token_table(batch, multi, monkeypatch):
+    """pnmn_attn_lstm_fwd(_multi) with in_tokens: the teacher-forced inputs as rows of etable."""
+    from probnmn.modules.seq2seq_base import _AttnLSTMDecoder
+
+    monkeypatch.setenv("PNMN_DECODER_CLUSTER", multi)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(batch + 1)
+    T, S, H, V = 12, 27, 256, 44
+    etable = (torch.randn(V, 4 * H, generator=g) * 0.5).to(dev)
+    enc = torch.randn(batch, S, H, generator=g).to(dev)
+    mask = (torch.rand(batch, S, generator=g) < 0.8).float().to(dev)
+    mask[:, 0] = 1.0
+    h0 = torch.randn(batch, H, generator=g).to(dev)
+    w_c = (torch.randn(4 * H, H, generator=g) * 0.05).to(dev)
+    w_hh = (torch.randn(4 * H, H, generator=g) * 0.05).to(dev)
+    tokens = torch.randint(0, V, (batch, T + 2), generator=g).to(dev)[:, :T]
+    dhs = torch.randn(batch, T, H, generator=g).to(dev)
+    outs = []
+    for fused in (False, True):
+        et, e, h = etable.clone().requires_grad_(True), enc.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        if fused:
+            hs, _ = _AttnLSTMDecoder.apply(None, et, e, mask, h, w_c, w_hh, None, None, 0, T, 5, 0, 0, 1, 2, None, tokens)
+        else:
+            hs, _ = _AttnLSTMDecoder.apply(F.embedding(tokens, et), None, e, mask, h, w_c, w_hh, None, None, 0, T, 5, 0, 0, 1, 2)
+        hs.backward(dhs)
+        outs.append((hs.detach(), e.grad, h.grad, et.grad))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    torch.testing.assert_close(outs[1][3], outs[0][3], rtol=1e-5, atol=1e-5 * float(outs[0][3].abs().max()))
+
+
+def test_multi_cu_hand_off_counters_per_stream_and_under_capture():
+    """The hand-off counters live in a block the library keeps per stream and the kernels leave zeroed
+    (cluster.h): launches on two streams at once must not share one, and a launch captured into a graph
+    (counters in the caller's workspace, zeroed by a kernel node) must replay correctly -- also next to
+    eager launches on the stream it was captured on."""
+    from probnmn.modules.seq2seq_base import _LSTMLayerSeq
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77)
+    B, T, H = 128, 19, 256
+    xs = [(torch.randn(B, T, 4 * H, generator=g) * 0.7).to(dev) for _ in range(2)]
+    w = (torch.randn(4 * H, H, generator=g) * 0.06).to(dev)
+    with torch.no_grad():
+        ref = [_LSTMLayerSeq.apply(x, w).clone() for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        for _ in range(3):
+            outs = []
+            for x, st in zip(xs, streams):
+                with torch.cuda.stream(st):
+                    for _ in range(4):
+                        out = _LSTMLayerSeq.apply(x, w)
+                    outs.append(out)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            _LSTMLayerSeq.apply(xs[0], w)  # allocations of the pass are in the pool before the capture
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                captured = _LSTMLayerSeq.apply(xs[0], w)
+            for _ in range(3):
+                graph.replay()
+                eager = _LSTMLayerSeq.apply(xs[1], w)
+            side.synchronize()
+        assert torch.equal(captured, ref[0]) and torch.equal(eager, ref[1])
+
+
 @pytest.mark.parametrize("batch,steps,positions", [(7, 5, 3), (128, 27, 46), (530, 9, 27), (1024, 12, 64)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_multi_cu_decoder_matches_one_workgroup_per_tile(batch, steps, positions, mode, monkeypatch):
