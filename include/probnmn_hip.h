@@ -270,6 +270,19 @@ int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_ro
                         int V, int shift, int start, int skip, float* dw, void* stream);
 int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int max_quads, void* stream);
 
+/* Per-token projection table of an embedding layer (V <= 128 rows; K, N multiples of 16 / 64):
+ *   table[v][n] = bias[n] + sum_k emb[v][k] weight[n][k]
+ * = F.linear(embedding.weight, W_ih, b_ih + b_hh) of the first encoder layers and of the decoder cell's embedding
+ * half (reference modules/seq2seq_base.py:101-141 embeds and projects every (row, step); here the V rows are
+ * projected once and pnmn_lstm_seq_fwd / pnmn_attn_lstm_fwd look their step inputs up by token).
+ * weight rows are weight_row_stride floats apart (a column slice of the cell's W_ih).  Backward: dtable [V][N] ->
+ * demb [V][K] (row padding_idx zeroed; -1 = none), dweight [N][K] (contiguous), dbias [N]; each may be NULL. */
+int pnmn_token_table_fwd(const float* emb, const float* weight, int64_t weight_row_stride,
+                         const float* bias, int V, int K, int N, float* table, void* stream);
+int pnmn_token_table_bwd(const float* dtable, const float* emb, const float* weight,
+                         int64_t weight_row_stride, int V, int K, int N, int padding_idx, float* demb,
+                         float* dweight, float* dbias, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-sequence masked-mean negative log-likelihood            seq2seq_base.py:235-254 (sampled programs:
  * -sum_t logprob_t mask_t / (sum mask + 1e-12)), :334-341 -> allennlp sequence_cross_entropy_with_logits

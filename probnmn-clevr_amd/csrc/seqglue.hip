@@ -204,6 +204,107 @@ __global__ __launch_bounds__(256) void derive_params_kernel(const pnmn_derive_jo
     reinterpret_cast<float4*>(jb.dst)[q] = v;
 }
 
+
+// ---- per-token projection table ---------------------------------------------------------------------------
+// table[v][n] = bias[n] + sum_k emb[v][k] W[n][k]   (V <= 128 vocabulary rows, K = embedding size, N = 4H): the
+// input projection of an embedding layer's V rows, from which the recurrent kernels take their step inputs.  The
+// three GEMMs of it (forward; backward: d emb = d table W, d W = d table^T emb, d bias) have V x N x K = 26 MFLOP
+// apiece -- as library calls they cost the host ~30 us each, fifteen per training step.  Here: one launch forward,
+// one backward, fp32 MFMA 16x16x4 with both operands read straight from the row-major matrices (lane (li, g)
+// holds row li, columns 16 kb + 4 g .. + 3: the four MFMAs of a k-block consume them in turn).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+// grid N / 16: workgroup -> 16 table columns, wave w -> vocabulary tiles w, w + 4
+__global__ __launch_bounds__(256) void token_table_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ w, long ldw,
+                                                              const float* __restrict__ bias, int V, int K, int N,
+                                                              float* __restrict__ table) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int n0 = 16 * blockIdx.x;
+    const float* wrow = w + (size_t)(n0 + li) * ldw + 4 * g;
+    const float b = bias ? bias[n0 + li] : 0.f;
+    for (int mt = wave; 16 * mt < V; mt += 4) {
+        const float* arow = emb + (size_t)min(16 * mt + li, V - 1) * K + 4 * g;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < K / 16; ++kb)
+            acc = mfma4(*reinterpret_cast<const f32x4*>(arow + 16 * kb), *reinterpret_cast<const f32x4*>(wrow + 16 * kb), acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = 16 * mt + 4 * g + r;
+            if (v < V) table[(size_t)v * N + n0 + li] = acc[r] + b;
+        }
+    }
+}
+
+// blocks [0, N / 16): d W rows n0 .. n0 + 15 (all K columns) and d bias of them -- contraction over the V rows;
+// blocks behind: one 16 x 16 tile of d emb each -- contraction over the N columns, split over the four waves.
+__global__ __launch_bounds__(256) void token_table_bwd_kernel(const float* __restrict__ dtable, const float* __restrict__ emb,
+                                                              const float* __restrict__ w, long ldw, int V, int K, int N,
+                                                              int padding_idx, float* __restrict__ demb,
+                                                              float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ float lds[128 * 17];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int V16 = (V + 15) & ~15;
+    if ((int)blockIdx.x < N / 16) {
+        const int n0 = 16 * blockIdx.x;
+        for (int i = tid; i < V16 * 16; i += 256) {
+            const int v = i >> 4, c = i & 15;
+            lds[v * 17 + c] = v < V ? dtable[(size_t)v * N + n0 + c] : 0.f;
+        }
+        __syncthreads();
+        if (dbias && tid < 16) {
+            float sum = 0.f;
+            for (int v = 0; v < V; ++v) sum += lds[v * 17 + tid];
+            dbias[n0 + tid] = sum;
+        }
+        if (!dw) return;
+        for (int kt = wave; kt < K / 16; kt += 4) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int vb = 0; vb < V16 / 16; ++vb) {
+                f32x4 a, b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = 16 * vb + 4 * g + j;
+                    a[j] = lds[v * 17 + li];
+                    b[j] = v < V ? emb[(size_t)v * K + 16 * kt + li] : 0.f;
+                }
+                acc = mfma4(a, b, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dw[(size_t)(n0 + 4 * g + r) * K + 16 * kt + li] = acc[r];
+        }
+        return;
+    }
+    if (!demb) return;
+    const int tile = blockIdx.x - N / 16, mt = tile / (K / 16), kt = tile % (K / 16);
+    const float* arow = dtable + (size_t)min(16 * mt + li, V - 1) * N + 4 * g;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int per = N / 4;  // columns of this wave (N % 64 == 0)
+    for (int n = wave * per; n < (wave + 1) * per; n += 16) {
+        f32x4 b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = w[(size_t)(n + 4 * g + j) * ldw + 16 * kt + li];
+        acc = mfma4(*reinterpret_cast<const f32x4*>(arow + n), b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lds[(wave * 16 + 4 * g + r) * 17 + li] = acc[r];
+    __syncthreads();
+    {
+        const int r = tid >> 4, c = tid & 15, v = 16 * mt + r;
+        if (v < V) {
+            const float sum = (lds[r * 17 + c] + lds[(16 + r) * 17 + c]) + (lds[(32 + r) * 17 + c] + lds[(48 + r) * 17 + c]);
+            demb[(size_t)v * K + 16 * kt + c] = v == padding_idx ? 0.f : sum;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pnmn_token_prep(const int64_t* tokens, int64_t token_row_stride, int B, int T, int pad, int bos, int eos,
@@ -283,5 +384,26 @@ extern "C" int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int m
     if (!jobs || max_quads <= 0) return PNMN_EINVAL;
     hipLaunchKernelGGL(derive_params_kernel, dim3((max_quads + 255) / 256, n_jobs), dim3(256), 0,
                        static_cast<hipStream_t>(stream), jobs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_token_table_fwd(const float* emb, const float* weight, int64_t weight_row_stride, const float* bias, int V,
+                                    int K, int N, float* table, void* stream) {
+    if (V <= 0) return 0;
+    if (!emb || !weight || !table) return PNMN_EINVAL;
+    if (V > 128 || K < 16 || K % 16 || N < 64 || N % 64 || weight_row_stride % 4) return PNMN_ESHAPE;
+    hipLaunchKernelGGL(token_table_fwd_kernel, dim3(N / 16), dim3(256), 0, static_cast<hipStream_t>(stream), emb, weight,
+                       (long)weight_row_stride, bias, V, K, N, table);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_token_table_bwd(const float* dtable, const float* emb, const float* weight, int64_t weight_row_stride, int V,
+                                    int K, int N, int padding_idx, float* demb, float* dweight, float* dbias, void* stream) {
+    if (V <= 0) return 0;
+    if (!dtable || !emb || !weight) return PNMN_EINVAL;
+    if (V > 128 || K < 16 || K % 16 || N < 64 || N % 64) return PNMN_ESHAPE;
+    const int blocks = N / 16 + (demb ? ((V + 15) / 16) * (K / 16) : 0);
+    hipLaunchKernelGGL(token_table_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dtable, emb, weight,
+                       (long)weight_row_stride, V, K, N, padding_idx, demb, dweight, dbias);
     return (int)hipGetLastError();
 }

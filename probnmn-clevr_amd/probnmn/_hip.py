@@ -69,6 +69,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_seq_fwd": (_P, _P, ctypes.c_int64, _P, _P, _P, _P, _I, _I, _I, _P, _P),
     "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P, _P),
+    "pnmn_token_table_fwd": (_P, _P, ctypes.c_int64, _P, _I, _I, _I, _P, _P),
+    "pnmn_token_table_bwd": (_P, _P, _P, ctypes.c_int64, _I, _I, _I, _I, _P, _P, _P, _P),
     "pnmn_lstm_seq_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P),
     "pnmn_attn_lstm_bwd": (_P,) * 14 + (_I,) * 4 + (_P,),
@@ -266,6 +268,7 @@ class _PinnedRing:
         self._events = [None] * slots
         self._next = 0
         self._small = None
+        self._big = 0
         self._small_events = [None] * self.SMALL_SLOTS
         self._small_next = 0
         self.wait_seconds = 0.0  # time the host spent blocked on the GPU (diagnostic)
@@ -290,8 +293,15 @@ class _PinnedRing:
             events, buf = self._events, self._bufs[i]
         self._wait(events[i])
         if buf is None or buf.numel() < n:
-            buf = torch.empty(max(n * 2, 1 << 16), dtype=torch.uint8).pin_memory()
-            self._bufs[i] = buf
+            # a hipHostMalloc costs milliseconds (19 ms seen for 0.5 MB): all growable slots share one size (4 MB
+            # to begin with) and are replaced together, so a longer work list than any before stalls ONE step --
+            # not one step per slot, whenever the list happens to land in a slot that has not met its like yet
+            # (sampled programs differ from step to step: that was a 4 ms tail on 1 step in 5 at 128 questions)
+            self._big = max(2 * self._big, 2 * n, 4 << 20)
+            for j in range(len(self._bufs)):
+                self._wait(self._events[j])
+                self._bufs[j] = torch.empty(self._big, dtype=torch.uint8).pin_memory()
+            buf = self._bufs[i]
         buf.numpy()[:n] = raw
         out = buf[:n].to(device, non_blocking=True)
         if events[i] is None:

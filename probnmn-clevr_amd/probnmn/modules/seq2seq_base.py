@@ -103,6 +103,7 @@ class DerivedParams:
 
     def __init__(self):
         self._key = None
+        self._where = None
         self._out: Dict[str, torch.Tensor] = {}
 
     def get(self, params, make_specs) -> Dict[str, torch.Tensor]:
@@ -112,8 +113,20 @@ class DerivedParams:
         "packT" (of its transpose), "sum" (a + b) -- built only when the cache misses."""
         from probnmn.optim import parameter_epoch
 
-        key = (parameter_epoch(),) + tuple((p._version, p.data_ptr()) for p in params)
+        flat = [parameter_epoch()]
+        for p in params:
+            flat.append(p._version)
+            flat.append(p.data_ptr())
+        key = tuple(flat)
         if key == self._key:
+            return self._out
+        where = key[2::2]
+        if where == self._where:
+            # same storage, new values (every optimiser step): the job list still describes the work -- run it
+            # again into the same buffer (launches on this stream that read the old copies are ordered before it)
+            _hip.check(_hip.lib().pnmn_derive_params(self._jobs.data_ptr(), self._n_jobs, self._max_quads,
+                                                     _hip.stream_ptr(self._device)), "derive_params")
+            self._key = key
             return self._out
         specs = make_specs()
         dev = specs[0][2].device
@@ -146,6 +159,7 @@ class DerivedParams:
         jobs = _hip.to_device(rec, dev)
         _hip.check(_hip.lib().pnmn_derive_params(jobs.data_ptr(), len(specs), max_quads, _hip.stream_ptr(dev)), "derive_params")
         self._key, self._out, self._jobs = key, out, jobs
+        self._where, self._n_jobs, self._max_quads, self._device, self._buf = where, len(specs), max_quads, dev, buf
         return out
 
 
@@ -184,25 +198,54 @@ class _SplitColumns(torch.autograd.Function):
 
 class _TokenTable(torch.autograd.Function):
     """``F.linear(embedding.weight, weight, bias)`` ([V, 4H]) where the embedding's padding row receives no
-    gradient (nn.Embedding(padding_idx=...) never updates it; its value is zero, so the table row is the bias)."""
+    gradient (nn.Embedding(padding_idx=...) never updates it; its value is zero, so the table row is the bias).
+    One launch each way for the vocabularies here (``pnmn_token_table_fwd`` / ``_bwd``); library GEMMs otherwise."""
+
+    @staticmethod
+    def _fused(emb, weight):
+        return (emb.device.type == "cuda" and emb.size(0) <= 128 and emb.size(1) % 16 == 0 and weight.size(0) % 64 == 0
+                and emb.is_contiguous() and weight.stride(1) == 1 and weight.stride(0) % 4 == 0)
 
     @staticmethod
     def forward(ctx, emb, weight, bias, padding_idx):
         ctx.save_for_backward(emb, weight)
         ctx.padding_idx = padding_idx
-        return torch.addmm(bias, emb, weight.t())
+        emb_d, weight_d = emb.detach(), weight.detach()
+        if not _TokenTable._fused(emb_d, weight_d) or not bias.is_contiguous():
+            return torch.addmm(bias, emb_d, weight_d.t())
+        V, K = emb_d.shape
+        N = weight_d.size(0)
+        table = torch.empty(V, N, dtype=emb_d.dtype, device=emb_d.device)
+        _hip.check(_hip.lib().pnmn_token_table_fwd(emb_d.data_ptr(), weight_d.data_ptr(), weight_d.stride(0), bias.data_ptr(),
+                                                   V, K, N, table.data_ptr(), _hip.stream_ptr(emb_d.device)), "token_table_fwd")
+        return table
 
     @staticmethod
     def backward(ctx, dtable):
         emb, weight = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if _TokenTable._fused(emb, weight):
+            dtable = dtable.contiguous()
+            V, K = emb.shape
+            N = weight.size(0)
+            f = dict(dtype=emb.dtype, device=emb.device)
+            demb = torch.empty(V, K, **f) if need[0] else None
+            dweight = torch.empty(N, K, **f) if need[1] else None
+            dbias = torch.empty(N, **f) if need[2] else None
+            ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            _hip.check(_hip.lib().pnmn_token_table_bwd(dtable.data_ptr(), emb.data_ptr(), weight.data_ptr(), weight.stride(0),
+                                                       V, K, N, -1 if ctx.padding_idx is None else ctx.padding_idx,
+                                                       ptr(demb), ptr(dweight), ptr(dbias), _hip.stream_ptr(emb.device)),
+                       "token_table_bwd")
+            return demb, dweight, dbias, None
         demb = dweight = dbias = None
-        if ctx.needs_input_grad[0]:
+        if need[0]:
             demb = dtable @ weight
             if ctx.padding_idx is not None:
                 demb[ctx.padding_idx].zero_()
-        if ctx.needs_input_grad[1]:
+        if need[1]:
             dweight = dtable.t() @ emb
-        if ctx.needs_input_grad[2]:
+        if need[2]:
             dbias = dtable.sum(0)
         return demb, dweight, dbias, None
 

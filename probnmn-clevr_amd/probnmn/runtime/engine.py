@@ -101,7 +101,7 @@ class NMNEngine:
         # data-gradient chain.  Measured on MI355X (B=256): no gain -- a wgrad workgroup holds its CU
         # (151 KiB LDS) for ~400 us and delays the chain's critical path as much as it fills its gaps --
         # so the default is one stream, which also keeps per-kernel profiles clean.
-        self.overlap_wgrad = False
+        self.overlap_wgrad = os.environ.get("PNMN_OVERLAP_WGRAD", "0") == "1"
         self._side_stream: Optional[torch.cuda.Stream] = None
         # launches of a pass are collected and issued by ONE library call (pnmn_run_launches) unless they are
         # being timed one by one (event_log) or spread over two streams (overlap_wgrad)

@@ -38,6 +38,10 @@ wrap(eng.scheduler, "arena_floats")
 for n in ("compile", "begin_forward", "run_forward", "run_backward", "_run_forward_launches", "_flush_list", "_fixed_records"):
     if hasattr(eng, n): wrap(eng, n, "engine." + n)
 wrap(E._Pack, "upload", "pack.upload")
+wrap(eng.compiler, "compile_batch", "compiler.compile_batch")
+wrap(eng.scheduler, "template_id", "scheduler.template_id")
+wrap(_hip, "to_device", "_hip.to_device")
+wrap(_hip, "small_to_device", "_hip.small_to_device")
 wrap(nmn, "forward", "nmn.forward")
 wrap(nmn, "begin", "nmn.begin")
 for _ in range(6): step.step(batch)

@@ -121,7 +121,8 @@ def test_embedding_grad(B, T, C, V):
 
 def test_derived_params_follow_the_parameters():
     """Fragment-order copies and bias sums from one launch equal the per-tensor formulation, are reused while the
-    parameters are unchanged and rebuilt after an in-place update or a fused optimiser step."""
+    parameters are unchanged and brought up to date (in place, by re-running the cached job list) after an in-place
+    update or a fused optimiser step; parameters that moved to other storage get a new job list."""
     from probnmn.models import ProgramGenerator
     from probnmn.modules.seq2seq_base import pack_fragments
     from probnmn.optim import ClampAdam
@@ -151,12 +152,45 @@ def test_derived_params_follow_the_parameters():
     with torch.no_grad():
         cell.weight_hh.mul_(1.5)  # an in-place update bumps the version counter
     d2 = pg._derived()
-    assert d2 is not d1
     check(d2)
     opt = ClampAdam(list(pg.parameters()), lr=1e-2)
     for p in pg.parameters():
         p.grad = torch.ones_like(p)
     opt.step()  # the fused step writes through pointers: the epoch counter invalidates the cache
     d3 = pg._derived()
-    assert d3 is not d2
     check(d3)
+    assert pg._derived() is d3
+    with torch.no_grad():  # new storage: the cached job list no longer describes the work
+        cell.weight_hh.data = cell.weight_hh.data.clone() * 0.5
+    check(pg._derived())
+
+
+@pytest.mark.parametrize("V,K,N,sliced,pad", [(93, 256, 1024, False, 0), (44, 256, 1024, True, None), (128, 64, 128, False, 3), (5, 16, 64, True, None)])
+def test_token_table_matches_linear(V, K, N, sliced, pad):
+    """pnmn_token_table_fwd / _bwd against F.linear(embedding.weight, W, b) and autograd (weight as a column slice of
+    a wider matrix, as the decoder cell's embedding half is; padding row without gradient)."""
+    from probnmn.modules.seq2seq_base import _TokenTable
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(V + K)
+    emb = torch.randn(V, K, generator=g).to(dev)
+    if pad is not None:
+        emb[pad] = 0.0
+    wide = (torch.randn(N, 2 * K, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    dtable = torch.randn(V, N, generator=g).to(dev)
+    e1, w1, b1 = emb.clone().requires_grad_(True), wide.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = torch.nn.functional.linear(e1, w1[:, K:] if sliced else w1[:, :K].contiguous(), b1)
+    ref.backward(dtable)
+    e2, w2, b2 = emb.clone().requires_grad_(True), wide.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    weight = w2[:, K:] if sliced else w2[:, :K].contiguous()
+    got = _TokenTable.apply(e2, weight, b2, pad)
+    got.backward(dtable)
+    tol = dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got, ref, **tol)
+    torch.testing.assert_close(b2.grad, b1.grad, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(w2.grad, w1.grad, rtol=1e-5, atol=1e-4)
+    want = e1.grad.clone()
+    if pad is not None:
+        want[pad] = 0.0
+    torch.testing.assert_close(e2.grad, want, rtol=1e-5, atol=1e-4)
