@@ -244,9 +244,10 @@ int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t*
  * pnmn_mask_last_fwd/bwd   PytorchSeq2SeqWrapper's zeroed padded steps + get_final_encoder_states:
  *     enc = hs * fmask[..., None],  hlast[b] = enc[b][last[b]]  (negative index: from the end)
  *     dhs = (denc + [t == last[b]] dhlast[b]) * fmask        (denc, dhlast may be null)
- * pnmn_embedding_grad      dw[v] += sum_{rows with token v} dy[row]   (V <= 128, C % 64 == 0, dw zeroed by
- *                          the caller; rows = (b, t) of tokens [B][T]; shift = 1: row (b, t) takes token
- *                          (b, t-1) and `start` at t = 0; token `skip` contributes nothing)
+ * pnmn_embedding_grad      dw[v] = sum_{rows with token v} dy[row]   (V <= 128, C % 4 == 0; dw is written whole;
+ *                          rows = (b, t) of tokens [B][T]; shift = 1: row (b, t) takes token (b, t-1) and
+ *                          `start` at t = 0; token `skip` contributes nothing; workspace: device memory of
+ *                          pnmn_embedding_grad_workspace_bytes(B, T, V) bytes, any contents)
  * pnmn_derive_params       once per optimiser step and model: MFMA-fragment copies of the recurrent weights
  *                          (kind 0: of src [n][k]; kind 1: of its transpose, src stored [k][n]; ld = row
  *                          stride of src) and bias sums (kind 2: dst = src + src2, n floats).
@@ -266,8 +267,9 @@ int pnmn_mask_last_fwd(const float* hs, const float* fmask, const int* last, int
                        float* hlast, void* stream);
 int pnmn_mask_last_bwd(const float* denc, const float* dhlast, const float* fmask, const int* last, int B, int T,
                        int H, float* dhs, void* stream);
+int64_t pnmn_embedding_grad_workspace_bytes(int B, int T, int V);
 int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
-                        int V, int shift, int start, int skip, float* dw, void* stream);
+                        int V, int shift, int start, int skip, float* dw, void* workspace, void* stream);
 int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int max_quads, void* stream);
 
 /* Per-token projection table of an embedding layer (V <= 128 rows; K, N multiples of 16 / 64):

@@ -5,6 +5,7 @@
 // bound by the NUMBER of launches (host time and ~5 us of GPU time apiece), not by their work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/probnmn_hip.h"
 
@@ -111,66 +112,118 @@ __global__ __launch_bounds__(256) void mask_last_bwd_kernel(const float* __restr
 }
 
 // ---- embedding gradient for a small vocabulary ------------------------------------------------------------
-//   dw[v][c] += sum over rows r with tokens[r] == v of dy[r][c]          (dw zeroed by the caller, V <= 128)
-// grid (C / (64 VEC), row splits); a workgroup sums its rows into an LDS table [V][64 VEC] (ds_add_f32), then
-// adds the table into dw.  A wave reads 256 VEC contiguous bytes of one row; the four waves take different rows,
-// eight rows in flight each (the loop is bound by the latency of its loads, not by their bytes).  `shift` = 1:
-// row (b, t) takes the token of (b, t - 1) and `start` for t = 0 (the input token of decoding step t),
-// tokens being [B][T].
-template <int VEC>
-__global__ __launch_bounds__(256) void embedding_grad_kernel(const float* __restrict__ dy, const int64_t* __restrict__ tokens,
-                                                             int64_t tok_bstride, int B, int T, int C, int V, int shift,
-                                                             int start, int skip, float* __restrict__ dw) {
-    extern __shared__ float table[];  // [V][64 * VEC]
-    constexpr int W = 64 * VEC;
+//   dw[v][c] = sum over rows r with token(r) == v of dy[r][c]                       (V <= 128; dw need not be zeroed)
+// rows = (b, t) of tokens [B][T]; `shift` = 1: row (b, t) takes the token of (b, t - 1) and `start` for t = 0 (the
+// input token of decoding step t); token `skip` and tokens outside [0, V) contribute nothing.
+// Two launches.  (1) one workgroup buckets the row indices by token (LDS histogram, prefix sums, scatter), cuts
+// every bucket into chunks of 64 rows and zeroes dw; (2) one workgroup per (chunk, 1024 columns) adds its rows up
+// in registers -- whole 4 KiB rows, eight in flight per thread -- and adds the result into dw with 16 bytes of
+// global atomics per thread.  (Round 2's first version summed into an LDS table with ds_add_f32: 0.7 TB/s on dense
+// gradients -- LDS float atomics retire a few lanes per cycle -- and 12 M global atomics for the table flushes.)
+constexpr int EG_CHUNK = 64;
+
+// (b, t) of row r by a multiply instead of a division: the bucketing kernel is ONE workgroup walking every row
+// twice, ~40 instructions of integer division per row were most of its time.  magic = ceil(2^32 / T); exact
+// for r T < 2^32 (the launcher checks).
+__device__ __forceinline__ int eg_token(const int64_t* __restrict__ tokens, int64_t tok_bstride, int T, unsigned magic, int shift,
+                                        int start, int skip, int V, int r) {
+    int b = magic ? (int)__umulhi((unsigned)r, magic) : r;  // (magic == 0: T == 1)
+    b -= (b * T > r);
+    const int t = r - b * T;
+    const int64_t raw = tokens[(size_t)b * tok_bstride + (shift ? max(t - 1, 0) : t)];  // (unconditional: loads of a batch overlap)
+    const int64_t v = (shift && t == 0) ? (int64_t)start : raw;
+    return (v == skip || v < 0 || v >= V) ? -1 : (int)v;
+}
+
+// workspace: order[R] | chunks[slices][3 * max_per] | count[slices]
+__global__ __launch_bounds__(1024) void embedding_rows_kernel(const int64_t* __restrict__ tokens, int64_t tok_bstride, int B,
+                                                              int T, unsigned magic, int V, int shift, int start, int skip, int C,
+                                                              int* __restrict__ order, int* __restrict__ chunks, int max_per,
+                                                              int* __restrict__ count, float* __restrict__ dw) {
+    // one histogram per wave: 47 k rows through 93 shared counters would queue up behind each other
+    __shared__ int whist[16][128], hist[128], rowbase[128], chbase[128];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // workgroup g buckets its own slice of the rows [lo, R) into its own part of `order` / `chunks`: no exchange
+    // between workgroups, at the price of a few more partly filled chunks
+    const int per = (B * T + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, R = min(B * T, lo + per);
+    chunks += 3 * (size_t)blockIdx.x * max_per;
+    count += blockIdx.x;
+    for (int i = tid; i < 16 * 128; i += 1024) (&whist[0][0])[i] = 0;
+    __syncthreads();
+    constexpr int UN = 8;  // token loads in flight per thread (one at a time, a pass is 46 L2 round trips at 47 k rows)
+    for (int r0 = lo + tid; r0 < R; r0 += 1024 * UN) {
+        int v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = eg_token(tokens, tok_bstride, T, magic, shift, start, skip, V, min(r0 + 1024 * u, R - 1));
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (r0 + 1024 * u < R && v[u] >= 0) atomicAdd(&whist[wave][v[u]], 1);
+    }
+    for (size_t i = blockIdx.x * 1024 + tid; i < (size_t)V * C / 4; i += 1024 * gridDim.x)
+        reinterpret_cast<float4*>(dw)[i] = float4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (tid < 128) {  // counts -> this wave's first position inside the token's bucket
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int n = whist[w][tid];
+            whist[w][tid] = run;
+            run += n;
+        }
+        hist[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int rows = lo, ch = 0;
+        for (int v = 0; v < V; ++v) {
+            rowbase[v] = rows, chbase[v] = ch;
+            rows += hist[v];
+            ch += (hist[v] + EG_CHUNK - 1) / EG_CHUNK;
+        }
+        *count = ch;
+    }
+    __syncthreads();
+    for (int r0 = lo + tid; r0 < R; r0 += 1024 * UN) {
+        int v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = eg_token(tokens, tok_bstride, T, magic, shift, start, skip, V, min(r0 + 1024 * u, R - 1));
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (r0 + 1024 * u < R && v[u] >= 0) order[rowbase[v[u]] + atomicAdd(&whist[wave][v[u]], 1)] = r0 + 1024 * u;
+    }
+    for (int v = tid; v < V; v += 1024) {
+        const int n = hist[v];
+        for (int j = 0; j * EG_CHUNK < n; ++j) {
+            int* c = chunks + 3 * (chbase[v] + j);
+            c[0] = v, c[1] = rowbase[v] + j * EG_CHUNK, c[2] = rowbase[v] + min(n, (j + 1) * EG_CHUNK);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_sum_kernel(const float* __restrict__ dy, const int* __restrict__ order,
+                                                            const int* __restrict__ chunks, int max_per,
+                                                            const int* __restrict__ count, int C, float* __restrict__ dw) {
+    const int slice = blockIdx.x / max_per, j = blockIdx.x % max_per;
+    if (j >= count[slice]) return;
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const int* ch = chunks + 3 * ((size_t)slice * max_per + j);
+    const int v = ch[0], b = ch[1], e = ch[2];
     constexpr int UN = 8;
-    for (int i = threadIdx.x; i < V * W; i += 256) table[i] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = blockIdx.x * W + lane * VEC;
-    const int R = B * T;
-    const int per = (R + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
-    for (int rb = r0 + sub; rb < r1; rb += 4 * UN) {
-        float val[UN][VEC];
-        int tok[UN];
+    float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+    for (int i = b; i < e; i += UN) {
+        float4 q[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int r = rb + 4 * u;
-            tok[u] = -1;
-            if (r < r1) {
-                const int b = r / T, t = r - b * T;
-                int64_t v;
-                if (shift)
-                    v = t == 0 ? start : tokens[(size_t)b * tok_bstride + t - 1];
-                else
-                    v = tokens[(size_t)b * tok_bstride + t];
-                tok[u] = (v == skip || v < 0 || v >= V) ? -1 : (int)v;
-                const float* src = dy + (size_t)r * C + c;
-                if (VEC == 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(src);
-                    val[u][0] = q.x, val[u][1 % VEC] = q.y, val[u][2 % VEC] = q.z, val[u][3 % VEC] = q.w;
-                } else if (VEC == 2) {
-                    const float2 q = *reinterpret_cast<const float2*>(src);
-                    val[u][0] = q.x, val[u][1 % VEC] = q.y;
-                } else {
-                    val[u][0] = *src;
-                }
-            }
-        }
+        for (int u = 0; u < UN; ++u) q[u] = *reinterpret_cast<const float4*>(dy + (size_t)order[min(i + u, e - 1)] * C + c);
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            if (tok[u] < 0) continue;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                if (val[u][k] != 0.f) unsafeAtomicAdd(&table[tok[u] * W + lane * VEC + k], val[u][k]);
-        }
+        for (int u = 0; u < UN; ++u)
+            if (i + u < e) acc.x += q[u].x, acc.y += q[u].y, acc.z += q[u].z, acc.w += q[u].w;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < V * W; i += 256) {
-        const float s = table[i];
-        if (s != 0.f) unsafeAtomicAdd(dw + (size_t)(i / W) * C + blockIdx.x * W + (i % W), s);
-    }
+    float* dst = dw + (size_t)v * C + c;
+    unsafeAtomicAdd(dst, acc.x);
+    unsafeAtomicAdd(dst + 1, acc.y);
+    unsafeAtomicAdd(dst + 2, acc.z);
+    unsafeAtomicAdd(dst + 3, acc.w);
 }
 
 // ---- derived parameters of the recurrent kernels, one launch for a whole model ------------------------------
@@ -344,38 +397,35 @@ extern "C" int pnmn_mask_last_bwd(const float* denc, const float* dhlast, const 
     return (int)hipGetLastError();
 }
 
-extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
-                                   int V, int shift, int start, int skip, float* dw, void* stream) {
-    if (B <= 0 || T <= 0) return 0;
-    if (!dy || !tokens || !dw || (C & 63) || V < 1 || V > 128) return PNMN_EINVAL;
+namespace {
+constexpr int EG_SLICES = 8;
+inline int eg_max_per(long rows, int V) { return (int)(((rows + EG_SLICES - 1) / EG_SLICES) / EG_CHUNK) + V; }
+}  // namespace
+
+extern "C" int64_t pnmn_embedding_grad_workspace_bytes(int B, int T, int V) {
+    if (B <= 0 || T <= 0 || V <= 0) return 0;
     const long rows = (long)B * T;
-    // widest row segment per wave (1 KiB; the table then takes up to 128 KiB of the CU's LDS: one workgroup per
-    // CU, eight loads in flight per lane)
-    const int vec = (C % 256 == 0) ? 4 : (C % 128 == 0) ? 2 : 1;
-    const int blocks = C / (64 * vec);
-    int splits = (int)((rows + 127) / 128);  // >= 128 rows per workgroup
-    const int cap = 512 / blocks > 1 ? 512 / blocks : 1;
-    if (splits > cap) splits = cap;
-    if (splits < 1) splits = 1;
-    const size_t lds = (size_t)V * 64 * vec * sizeof(float);
+    return (int64_t)sizeof(int) * (rows + (long)EG_SLICES * (3 * eg_max_per(rows, V) + 1));
+}
+
+extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
+                                   int V, int shift, int start, int skip, float* dw, void* workspace, void* stream) {
+    if (V <= 0 || C <= 0) return 0;
+    if (!dw || (C & 3) || V > 128) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(blocks, splits);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embedding_grad_kernel<4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 256 * 4);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    if (vec == 4)
-        hipLaunchKernelGGL(embedding_grad_kernel<4>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
-                           start, skip, dw);
-    else if (vec == 2)
-        hipLaunchKernelGGL(embedding_grad_kernel<2>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
-                           start, skip, dw);
-    else
-        hipLaunchKernelGGL(embedding_grad_kernel<1>, grid, dim3(256), lds, s, dy, tokens, token_row_stride, B, T, C, V, shift,
-                           start, skip, dw);
+    if (B <= 0 || T <= 0) return (int)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)V * C, s);
+    if (!dy || !tokens || !workspace) return PNMN_EINVAL;
+    const long rows = (long)B * T;
+    if (rows * T >= (1L << 32)) return PNMN_ESHAPE;
+    const unsigned magic = T == 1 ? 0u : (unsigned)(((1ULL << 32) + T - 1) / T);
+    const int max_per = eg_max_per(rows, V);
+    int* order = static_cast<int*>(workspace);
+    int* chunks = order + rows;
+    int* count = chunks + 3 * (size_t)EG_SLICES * max_per;
+    hipLaunchKernelGGL(embedding_rows_kernel, dim3(EG_SLICES), dim3(1024), 0, s, tokens, token_row_stride, B, T, magic, V, shift,
+                       start, skip, C, order, chunks, max_per, count, dw);
+    hipLaunchKernelGGL(embedding_sum_kernel, dim3(EG_SLICES * max_per, (C + 1023) / 1024), dim3(256), 0, s, dy, order, chunks,
+                       max_per, count, C, dw);
     return (int)hipGetLastError();
 }
 

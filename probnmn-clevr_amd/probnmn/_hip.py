@@ -61,7 +61,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_trim_predictions": (_P, _I, _I, _I, _P, _P),
     "pnmn_mask_last_fwd": (_P, _P, _P, _I, _I, _I, _P, _P, _P),
     "pnmn_mask_last_bwd": (_P, _P, _P, _P, _I, _I, _I, _P, _P),
-    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _P, _P),
+    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P),
+    "pnmn_embedding_grad_workspace_bytes": (_I, _I, _I),
     "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),

@@ -312,9 +312,11 @@ def embedding_grad(dy: torch.Tensor, tokens: torch.Tensor, vocab: int, shift: bo
     dy = dy.contiguous()
     if tokens.stride(1) != 1:
         tokens = tokens.contiguous()
-    dw = torch.zeros(vocab, C, dtype=dy.dtype, device=dy.device)
+    dw = torch.empty(vocab, C, dtype=dy.dtype, device=dy.device)
+    ws = torch.empty(int(_hip.lib().pnmn_embedding_grad_workspace_bytes(B, T, vocab)), dtype=torch.uint8, device=dy.device)
     _hip.check(_hip.lib().pnmn_embedding_grad(dy.data_ptr(), tokens.data_ptr(), tokens.stride(0), B, T, C, vocab, int(shift),
-                                              start, skip, dw.data_ptr(), _hip.stream_ptr(dy.device)), "embedding_grad")
+                                              start, skip, dw.data_ptr(), ws.data_ptr(), _hip.stream_ptr(dy.device)),
+               "embedding_grad")
     return dw
 
 

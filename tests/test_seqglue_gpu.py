@@ -93,7 +93,8 @@ def test_mask_and_last(B, T, H):
     assert torch.equal(hs3.grad, ref * fmask.unsqueeze(-1))
 
 
-@pytest.mark.parametrize("B,T,C,V", [(1, 1, 64, 5), (130, 46, 1024, 96), (1024, 28, 1024, 44), (7, 30, 256, 128)])
+@pytest.mark.parametrize("B,T,C,V", [(1, 1, 64, 5), (130, 46, 1024, 96), (1024, 28, 1024, 44), (7, 30, 256, 128), (3, 70, 68, 9),
+                                     (600, 1, 2052, 3)])
 def test_embedding_grad(B, T, C, V):
     from probnmn.modules.seq2seq_base import embedding_grad
 
