@@ -237,13 +237,6 @@ constexpr int LH = 256;        // hidden size the kernel is built for
 constexpr int LROWS = 16;      // batch rows per workgroup
 constexpr int LLD = LH + 4;    // LDS row stride (floats): 16-byte aligned, breaks the 1 KiB bank period
 
-// The input projection of (row, t): row (row, t) of xp [B][T][4H], or -- `tokens` given -- row tokens[row][t] of the
-// [V][4H] table xp then is (first layers, whose input is an embedding: the per-token projection is never
-// materialised per (row, step); the token of step t + 1 is fetched during step t).
-__device__ __forceinline__ const float* xp_row(const float* xp, const int64_t* tokens, long tstride, int row, int T, int t) {
-    return xp + (tokens ? (size_t)tokens[(size_t)row * tstride + t] : (size_t)row * T + t) * (4 * 256);
-}
-
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restrict__ xp, const int64_t* __restrict__ tokens,
                                                            long tstride, const float* __restrict__ w_hh,
                                                            float* __restrict__ hs, float* __restrict__ cs,
@@ -257,6 +250,15 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) creg[ut][r] = 0.f;
 
+    // this lane's four rows of xp (rows past the batch re-read the last one; never stored); with tokens the row of
+    // step t + 1 is fetched during step t (see the multi-CU kernel below)
+    int64_t xrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = min(row0 + 4 * g + r, B - 1);
+        xrow[r] = tokens ? tokens[(size_t)row * tstride] : (int64_t)row * T;
+    }
+
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         f32x4_ acc[4][2];
@@ -266,11 +268,13 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(const float* __restri
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + 4 * g + r;
-                    const int n = gate * LH + 32 * wave + 16 * ut + li;
-                    acc[gate][ut][r] = row < B ? xp_row(xp, tokens, tstride, row, T, t)[n] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r)
+                    acc[gate][ut][r] = xp[(size_t)xrow[r] * (4 * LH) + gate * LH + 32 * wave + 16 * ut + li];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(row0 + 4 * g + r, B - 1);
+            xrow[r] = tokens ? tokens[(size_t)row * tstride + min(t + 1, T - 1)] : xrow[r] + 1;
+        }
         if (t > 0) {
 #pragma unroll 4
             for (int kb = 0; kb < LH / 16; ++kb) {
