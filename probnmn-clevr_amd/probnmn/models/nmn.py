@@ -164,6 +164,13 @@ class NeuralModuleNetwork(nn.Module):
         # kernels, none of which waits for another workgroup) on that stream, forward and backward, beside
         # whatever the caller queues on the current stream; the fully connected layers and the loss stay on
         # the current stream (see DESIGN 6 for why the library GEMMs must not leave it)
+        return self.forward_head(self.forward_trunk(features, programs, started, trunk_stream, rows), answers)
+
+    def forward_trunk(self, features: torch.Tensor, programs: torch.Tensor, started=None, trunk_stream=None,
+                      rows: Optional[torch.Tensor] = None):
+        """First half of ``forward``: compile and schedule the programs, launch the trunk (on ``trunk_stream`` when
+        given).  Nothing is queued on the current stream, so a caller that runs the trunk on its own stream can
+        keep feeding the current one before ``forward_head`` makes it wait for the trunk."""
         engine = self._engine
         arena = engine.ensure_arena()
         if rows is not None and started is None:
@@ -172,9 +179,6 @@ class NeuralModuleNetwork(nn.Module):
         # also reads them back, once per example: nmn.py:203)
         # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
         compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
-        from probnmn import _hip
-
-        valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, features.device)
 
         # the trunk's parameters as inputs of its autograd node -- all of them when autograd is to receive
         # their gradients; ONE anchor when a trainer reads the gradients straight from the arena
@@ -184,13 +188,24 @@ class NeuralModuleNetwork(nn.Module):
         if engine.direct_grads:
             params = params[:1]
         if trunk_stream is not None:
-            current = torch.cuda.current_stream(features.device)
             with torch.cuda.stream(trunk_stream):
                 pooled = _Trunk.apply(features, engine, compiled, started, *params)
-            current.wait_stream(trunk_stream)
-            pooled.record_stream(current)
         else:
             pooled = _Trunk.apply(features, engine, compiled, started, *params)
+        return pooled, compiled, trunk_stream
+
+    def forward_head(self, trunk, answers: Optional[torch.Tensor] = None):
+        """Second half of ``forward``: the fully connected layers and the loss, on the current stream."""
+        from probnmn import _hip
+
+        pooled, compiled, trunk_stream = trunk
+        # (staged here, not in forward_trunk: the host's time between the sampled programs' arrival and the trunk's
+        # launch is on the critical path of a small-batch step)
+        valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, pooled.device)
+        if trunk_stream is not None:
+            current = torch.cuda.current_stream(pooled.device)
+            current.wait_stream(trunk_stream)
+            pooled.record_stream(current)
         hidden = F.relu(self.classifier[4](pooled))
         answer_logits = self.classifier[6](hidden)
         _hip.mark("classifier FC forward done")

@@ -60,12 +60,15 @@ class ModuleCall:
     out_channels: int
 
 
+TOKEN_ROW = 48  # calls per program of the fixed-width token rows the scheduler stacks (longer programs: a copy loop)
+
+
 class CompiledProgram:
     """valid / calls / result of one program.  ``calls`` (a tuple of :class:`ModuleCall`) is built on
     first use when the program came out of the batch compiler as an int32 table ``[n_calls, 7]``
     (kind, token, a, b, a_channels, b_channels, out_channels) -- the scheduler only needs the table."""
 
-    __slots__ = ("valid", "result", "_raw", "_calls", "_template_id", "_template_owner", "_tokens", "_tokens_row")
+    __slots__ = ("valid", "result", "_raw", "_calls", "_template_id", "_template_owner", "_tokens", "_tokens_row", "_skey")
 
     def __init__(self, valid: bool, calls: Tuple[ModuleCall, ...] = (), result: int = FEAT, raw=None):
         self.valid = valid
@@ -76,6 +79,7 @@ class CompiledProgram:
         self._template_owner = None
         self._tokens = None
         self._tokens_row = None
+        self._skey = None  # bytes of the call table with the token column zeroed (the scheduler's template key)
 
     @property
     def calls(self) -> Tuple[ModuleCall, ...]:
@@ -150,11 +154,28 @@ class ProgramCompiler:
                 sub.ctypes.data, n, length, self._kinds_array.ctypes.data, self._kinds_array.size, self.module_channels,
                 valid.ctypes.data, n_calls.ctypes.data, calls.ctypes.data, result.ctypes.data), "compile_programs")
             valid_l, n_l, res_l = valid.tolist(), n_calls.tolist(), result.tolist()
+            # what the scheduler wants of a new program, for the whole batch at once: the structure key (call table
+            # without the tokens) and the tokens as a zero-padded int64 row -- per program these were a fancy-indexed
+            # copy, an astype and a zeros() each, 4 us x ~35 new programs per step on the way to the first launch
+            width = max(length, TOKEN_ROW)
+            used = np.arange(max(length, 1))[None, :] < n_calls[:, None]
+            struct = np.where(used[:, :, None], calls, 0)
+            rows = np.zeros((n, width), np.int64)
+            rows[:, : struct.shape[1]] = struct[:, :, 1]
+            struct[:, :, 1] = 0
             for j, i in enumerate(miss):
                 key = keys[i]
                 hit = cache.get(key)  # (the same new program may occur several times in the batch)
                 if hit is None:
-                    hit = CompiledProgram(True, result=res_l[j], raw=calls[j, : n_l[j]].copy()) if valid_l[j] else self._invalid
+                    if valid_l[j]:
+                        nj = n_l[j]
+                        hit = CompiledProgram(True, result=res_l[j], raw=calls[j, :nj].copy())
+                        hit._skey = struct[j, :nj].tobytes()
+                        hit._tokens = rows[j, :nj]
+                        if nj <= TOKEN_ROW:
+                            hit._tokens_row = rows[j, :TOKEN_ROW]
+                    else:
+                        hit = self._invalid
                     cache[key] = hit
                 out[i] = hit
         return out

@@ -29,7 +29,7 @@ import numpy as np
 from . import program_compiler as pc
 
 HW_ALIGN = 64  # floats; keeps every slot 256-byte aligned
-TOKEN_ROW = 48  # calls per program of the fixed-width token rows (longer programs: a per-example copy loop)
+TOKEN_ROW = pc.TOKEN_ROW  # calls per program of the fixed-width token rows (longer programs: a per-example copy loop)
 
 # operand location kinds
 L_SLOT, L_FEAT, L_ONES, L_FINAL = 0, 1, 2, 3
@@ -62,8 +62,12 @@ class Template:
 
 
 def structure_key(prog: pc.CompiledProgram) -> Tuple:
-    """Kinds and wiring of the calls (tokens ignored) + the result value."""
-    return (prog.table()[:, (0, 2, 3)].tobytes(), prog.result)
+    """Kinds, wiring and channel counts of the calls (tokens ignored) + the result value."""
+    if prog._skey is None:  # (programs out of the batch compiler carry it)
+        t = prog.table().copy()
+        t[:, 1] = 0
+        prog._skey = t.tobytes()
+    return (prog._skey, prog.result)
 
 
 def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template:
@@ -245,11 +249,12 @@ class BatchScheduler:
             self._bank = None
         prog._template_id = tid
         prog._template_owner = self
-        prog._tokens = prog.table()[:, 1].astype(np.int64)
-        if prog._tokens.size <= TOKEN_ROW:  # fixed-width copy: a batch's token matrix is then one np.array() call
-            row = np.zeros(TOKEN_ROW, np.int64)
-            row[: prog._tokens.size] = prog._tokens
-            prog._tokens_row = row
+        if prog._tokens is None:  # (programs out of the batch compiler carry both)
+            prog._tokens = prog.table()[:, 1].astype(np.int64)
+            if prog._tokens.size <= TOKEN_ROW:  # fixed-width copy: a batch's token matrix is then one np.array() call
+                row = np.zeros(TOKEN_ROW, np.int64)
+                row[: prog._tokens.size] = prog._tokens
+                prog._tokens_row = row
         return tid
 
     def template(self, prog: pc.CompiledProgram) -> Template:
@@ -277,9 +282,13 @@ class BatchScheduler:
         hit = self.__dict__.get("_prepared")
         if hit is not None and hit[0] is programs:
             return hit
-        ex_valid = [e for e, p in enumerate(programs) if p.valid]
+        ex_valid, ids = [], []
+        for e, p in enumerate(programs):
+            if p.valid:
+                ex_valid.append(e)
+                ids.append(p._template_id if p._template_owner is self else self.template_id(p))
         nv = len(ex_valid)
-        tids = np.fromiter((self.template_id(programs[e]) for e in ex_valid), dtype=np.int64, count=nv)
+        tids = np.asarray(ids, dtype=np.int64)
         sizes = self._get_bank()[2]
         blk = sizes[tids] if nv else np.zeros(0, np.int64)
         base = np.cumsum(blk) - blk  # first float of each example's arena block

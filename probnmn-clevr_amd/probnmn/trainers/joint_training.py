@@ -89,7 +89,8 @@ class _TrainerBase(StepBase):
         return host, event
 
     def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
-                        reconstruct: bool = True, host_programs: bool = False, after_sampling=None):
+                        reconstruct: bool = True, host_programs: bool = False, after_sampling=None,
+                        before_prior=None):
         """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
         rows of the reference's separate calls batched into as few recurrent launches as the data
         dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
@@ -138,6 +139,8 @@ class _TrainerBase(StepBase):
             out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"].mean()
         elif reconstruct:
             out["qr"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
+        if before_prior is not None and n_nosup:
+            out["before_prior"] = before_prior(out["programs_host"])
         if n_nosup and prior:
             with torch.no_grad():  # frozen model whose output only enters the detached reward
                 out["prior"] = self.prior(z, need_predictions=False)["loss"]
@@ -209,6 +212,7 @@ class JointTrainingStep(_TrainerBase):
         # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
+        self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
@@ -256,8 +260,20 @@ class JointTrainingStep(_TrainerBase):
                     # layout kernel: no gathered copy)
                     images = batch["image"]
                     started = self.nmn.begin(images, rows=nosup_d)
+                def launch_trunk(programs_host):
+                    # Between the reconstructor pass and the prior pass: by now the sampled programs are on the
+                    # host, and the main stream has the reconstructor to work on while the host compiles and
+                    # schedules them (~1 ms) and launches the trunk; the prior pass, issued afterwards, and the
+                    # trunk then run side by side instead of one after the other.
+                    host, copied = programs_host
+                    t0 = time.perf_counter()
+                    copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
+                    self.blocked_seconds += time.perf_counter() - t0
+                    return self.nmn.forward_trunk(images, host, started=started, trunk_stream=side, rows=nosup_d)
+
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
-                                         reconstruct=ours, host_programs=True)
+                                         reconstruct=ours, host_programs=True,
+                                         before_prior=launch_trunk if self.trunk_before_prior else None)
             else:
                 images = batch["image"]
                 # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
@@ -265,11 +281,14 @@ class JointTrainingStep(_TrainerBase):
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images, rows=nosup_d))
                 started = p["after_sampling"]
-            programs_host, copied = p["programs_host"]
-            t0 = time.perf_counter()
-            copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
-            self.blocked_seconds += time.perf_counter() - t0
-            nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
+            if "before_prior" in p:
+                nmn_out = self.nmn.forward_head(p["before_prior"], answers)
+            else:
+                programs_host, copied = p["programs_host"]
+                t0 = time.perf_counter()
+                copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
+                self.blocked_seconds += time.perf_counter() - t0
+                nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
             elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
             _hip.mark("elbo combined")
             nmn_loss = elbo_out.pop("nmn_loss")
