@@ -66,7 +66,7 @@ class _Pack:
 
 
 class _State:
-    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features")
+    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows")
 
 
 class NMNEngine:
@@ -458,6 +458,15 @@ class NMNEngine:
             state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
             state.features = started["features"]  # (the stem's weight gradient reads the input again)
             state.generation = self.generation
+            state.backward_rows = None
+            if self.event_log is None and not self.overlap_wgrad and self.launch_lists:
+                # the backward pass's launch list, put together now: the forward launches are out and the GPU is busy
+                # with them, whereas in run_backward nothing runs on this stream until the list is complete
+                # (0.4 ms of host time per step on the critical path of a small batch)
+                self._begin_list()
+                cut, where = self._queue_backward(state, 0, st, live=False)
+                state.backward_rows = (np.array(self._list._rows, dtype=np.uint64), cut, where)
+                self._list = None
         return pooled, state
 
     def _run_forward_launches(self, plan: StepPlan, pack: _Pack, st: int) -> None:
@@ -478,27 +487,25 @@ class NMNEngine:
                 raise AssertionError(l.kind)
 
     # ---- backward -------------------------------------------------------------------------------
-    def run_backward(self, state: _State, dpooled: torch.Tensor):
-        if state.generation != self.generation:
-            raise RuntimeError(
-                "NeuralModuleNetwork.forward was called again before backward of the previous call: "
-                "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
+    def _feat_result_backward(self, plan, ws, B, dev) -> None:
+        """Programs whose result is the stem's feature map itself: d(final) goes straight to d(features)."""
+        HW = self.HW
+        idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
+        gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
+        gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
+        gfeat.index_add_(0, idx, gfinal.index_select(0, idx))
+
+    def _queue_backward(self, state: _State, dpooled_ptr: int, st: int, live: bool):
+        """The trunk's backward launches, appended to the current launch list (or issued one by one when there is
+        none).  ``live``: called from run_backward -- the list is flushed where a torch op has to go in between;
+        otherwise (run_forward putting the list together ahead of time) returns (rows before that op, index of the
+        row that carries d(pooled))."""
         a = self.arena
-        lib, chk = _hip.lib(), _hip.check
         dev = a.device
-        st = _hip.stream_ptr(dev)
         plan, pack, B = state.plan, state.pack, state.B
         H, W, HW = self.H, self.W, self.HW
         ws = self._ws
-        dpooled = dpooled.contiguous()
-
-        _hip.mark("trunk backward begins (dpooled ready)")
-        a.grad.zero_()
-        if plan.arena_floats:
-            ws["gact"][: plan.arena_floats].zero_()
-        ws["gfeat"][: B * HW * C].zero_()
-        _hip.mark("gradient buffers zeroed")
-        self._begin_list()
+        cut = 0
         self._op(_hip.OP_TRANSPOSE_WEIGHTS, "pnmn_transpose_weights", self._wt_count, self._wt_records.data_ptr(), st,
                  "transpose weights")
 
@@ -518,19 +525,20 @@ class NMNEngine:
                 side.wait_event(ev)
 
         # classifier conv
+        where = len(self._list) if self._list is not None else -1
         self._op(_hip.OP_MAXPOOL_BWD, "pnmn_maxpool2_flatten_bwd", B, ws["cls"].data_ptr(), st, "maxpool bwd",
-                 b=dpooled.data_ptr(), c=ws["gcls"].data_ptr(), p=(H, W, self.cproj))
+                 b=dpooled_ptr, c=ws["gcls"].data_ptr(), p=(H, W, self.cproj))
         fork()
         nj = len(state.fixed["cls_wg_jobs"])
         self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
                     "classifier wgrad")
         self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad", rec=state.fixed["cls_dgrad"])
         if plan.feat_result_examples.size:
-            self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
-            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
-            gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
-            gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
-            gfeat.index_add_(0, idx, gfinal.index_select(0, idx))
+            if live:
+                self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
+                self._feat_result_backward(plan, ws, B, dev)
+            else:
+                cut = len(self._list)
 
         # module programs, levels in reverse; each group of module-conv weight gradients is released
         # to the side stream as soon as the data-gradient chain has passed its lowest level
@@ -583,7 +591,44 @@ class NMNEngine:
             ev = torch.cuda.Event()
             ev.record(side)
             main.wait_event(ev)
-        self._flush_list(st, "trunk backward", end=True)
+        return cut, where
+
+
+    def run_backward(self, state: _State, dpooled: torch.Tensor):
+        if state.generation != self.generation:
+            raise RuntimeError(
+                "NeuralModuleNetwork.forward was called again before backward of the previous call: "
+                "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
+        a = self.arena
+        lib, chk = _hip.lib(), _hip.check
+        dev = a.device
+        st = _hip.stream_ptr(dev)
+        plan, pack, B = state.plan, state.pack, state.B
+        H, W, HW = self.H, self.W, self.HW
+        ws = self._ws
+        dpooled = dpooled.contiguous()
+
+        _hip.mark("trunk backward begins (dpooled ready)")
+        a.grad.zero_()
+        if plan.arena_floats:
+            ws["gact"][: plan.arena_floats].zero_()
+        ws["gfeat"][: B * HW * C].zero_()
+        _hip.mark("gradient buffers zeroed")
+        pre = state.backward_rows
+        if pre is not None and self.event_log is None and not self.overlap_wgrad and self.launch_lists:
+            # the launch list was put together behind the forward pass (run_forward): only d(pooled) is new
+            rows, cut, where = pre
+            rows[where, 1] = dpooled.data_ptr()
+            lib_run = _hip.lib().pnmn_run_launches
+            if cut:
+                chk(lib_run(rows.ctypes.data, cut, st), "classifier backward")
+                self._feat_result_backward(plan, ws, B, dev)
+            if rows.shape[0] > cut:
+                chk(lib_run(rows[cut:].ctypes.data, rows.shape[0] - cut, st), "trunk backward")
+        else:
+            self._begin_list()
+            cut, _ = self._queue_backward(state, dpooled.data_ptr(), st, live=True)
+            self._flush_list(st, "trunk backward", end=True)
 
         if self.direct_grads:
             a.attach_grads()
