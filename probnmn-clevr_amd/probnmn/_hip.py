@@ -86,6 +86,9 @@ SIGNATURES: Dict[str, tuple] = {
 }
 
 
+ABI_VERSION = 3  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -100,6 +103,9 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = ctypes.c_int64 if name.endswith("_bytes") else ctypes.c_int
             fn.argtypes = list(argtypes)
+        if handle.pnmn_abi_version() != ABI_VERSION:  # (same symbol names, other argument lists: never call into it)
+            raise HipLibraryError("%s has ABI version %d, this package binds version %d -- rebuild the library"
+                                  % (LIB_PATH, handle.pnmn_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
