@@ -275,7 +275,7 @@ class _PinnedRing:
         self._events = [None] * slots
         self._next = 0
         self._small = None
-        self._big = 0
+        self._big = 16 << 20
         self._small_events = [None] * self.SMALL_SLOTS
         self._small_next = 0
         self.wait_seconds = 0.0  # time the host spent blocked on the GPU (diagnostic)
@@ -300,15 +300,15 @@ class _PinnedRing:
             events, buf = self._events, self._bufs[i]
         self._wait(events[i])
         if buf is None or buf.numel() < n:
-            # a hipHostMalloc costs milliseconds (19 ms seen for 0.5 MB): all growable slots share one size (4 MB
-            # to begin with) and are replaced together, so a longer work list than any before stalls ONE step --
-            # not one step per slot, whenever the list happens to land in a slot that has not met its like yet
-            # (sampled programs differ from step to step: that was a 4 ms tail on 1 step in 5 at 128 questions)
-            self._big = max(2 * self._big, 2 * n, 4 << 20)
-            for j in range(len(self._bufs)):
-                self._wait(self._events[j])
-                self._bufs[j] = torch.empty(self._big, dtype=torch.uint8).pin_memory()
-            buf = self._bufs[i]
+            # a hipHostMalloc costs milliseconds (19 ms seen for 0.5 MB): the growable slots share one size, 16 MB to
+            # begin with -- several times the longest work list of any configuration measured (3 MB: 28x28 maps,
+            # 40-token programs) -- that doubles when a list outgrows it; a slot is replaced when it is next used.
+            # (Sized to the list at hand, every slot regrew whenever a step's sampled programs made a longer list than
+            # that slot had seen: a 4 ms tail on one step in five at 128 questions.)
+            while self._big < n:
+                self._big *= 2
+            buf = torch.empty(self._big, dtype=torch.uint8).pin_memory()
+            self._bufs[i] = buf
         buf.numpy()[:n] = raw
         out = buf[:n].to(device, non_blocking=True)
         if events[i] is None:
