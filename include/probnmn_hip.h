@@ -374,7 +374,10 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
  * 16-row tile, each holding its slice of W_hh in registers and exchanging the recurrent vector through
  * L2 once per step.  Every accumulation keeps the operand order of the workspace == NULL kernels (one
  * workgroup per tile); results agree to the last few ulps (fma contraction of the cell update).  The
- * kernel needs every workgroup resident at once; the library sizes the grid for that. */
+ * kernel needs every workgroup resident at once; the library sizes the grid for that.  The hand-off
+ * counters of the multi-CU kernels (these and the decoder's) live in a block the library keeps per stream
+ * (hipMalloc on a stream's first launch; the kernels leave it zeroed); while the stream is being captured
+ * into a graph they go to the head of `workspace` behind a zeroing kernel node instead. */
 int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward);
 
 /* ---------------------------------------------------------------------------------------------

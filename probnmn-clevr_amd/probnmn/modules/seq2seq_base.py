@@ -348,7 +348,8 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> to
 class _EmbeddingLookup(torch.autograd.Function):
     """``F.embedding`` whose weight gradient is one kernel: the vocabularies here have < 100 entries, so the
     scatter-add of B x T rows into them that torch's backward does (sort + segmented reduction, ~0.4 ms per
-    call) is a sum into an LDS-resident table (``pnmn_embedding_grad``; larger vocabularies: a one-hot GEMM)."""
+    call) is ``pnmn_embedding_grad`` (rows bucketed by token, summed chunk by chunk; larger vocabularies: a
+    one-hot GEMM)."""
 
     @staticmethod
     def forward(ctx, weight, tokens, padding_idx):
@@ -394,7 +395,7 @@ class _LSTMLayerSeq(torch.autograd.Function):
     hidden states [B,T,H].  The weight gradient of W_hh is one GEMM over the saved states.
     With ``tokens`` ([B,T] int64): ``xp`` is the [V,4H] per-token table of ``_TokenTable`` and the kernel reads
     row ``tokens[b,t]`` of it -- ``F.embedding(tokens, table)`` is never written out; its gradient is the
-    LDS-table sum of ``pnmn_embedding_grad`` over the gate gradients."""
+    per-token sum of ``pnmn_embedding_grad`` over the gate gradients."""
 
     @staticmethod
     def forward(ctx, xp, w_hh, wp=None, w_t=None, tokens=None):
