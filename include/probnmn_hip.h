@@ -412,7 +412,8 @@ int pnmn_attn_lstm_bwd(const float* dhs, const float* act, const float* cs, cons
  * above).  Batches beyond what fits the chip at once (512 rows on 256 CUs) run as successive launches.
  * The backward emits dctx [B,T,H] (gradient wrt every context vector) and dscore [B,T,S] (gradient
  * wrt the attention scores) instead of accumulating denc; the caller forms
- *     denc = w^T dctx + dscore^T h_prev      (two GEMMs per row over the T steps, w = masked softmax)
+ *     denc = w^T dctx + dscore^T h_prev      (two GEMMs per row over the T steps; w = the masked, renormalised
+ *                                             attention weights, which the kernel writes to `weights` [B,T,S])
  * Sums over source positions / gate columns are associated differently from the one-workgroup
  * kernels: results agree to fp32 round-off, not bit for bit. */
 int64_t pnmn_attn_lstm_multi_workspace_bytes(int B, int backward);
@@ -426,8 +427,8 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
 int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs, const float* hs,
                              const float* probs, const float* enc, const float* mask,
                              const float* h0, const float* w_c_t, const float* w_hh_t,
-                             float* dgates, float* dctx, float* dscore, float* dh0, int B, int T,
-                             int S, int hidden, void* workspace, void* stream);
+                             float* dgates, float* dctx, float* dscore, float* weights, float* dh0,
+                             int B, int T, int S, int hidden, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One decoding step's token choice                                   seq2seq_base.py:203-220

@@ -357,6 +357,7 @@ struct MBwdArgs {
     float* dgates;        // [B][T][4H]
     float* dctx;          // [B][T][H]
     float* dscore;        // [B][T][S]
+    float* weights;       // [B][T][S]  masked, renormalised attention weights w (what the caller's dctx GEMM needs)
     float* dh0;           // [B][H]
     float* x1;            // [tiles][2][MEMBERS][2][16][H]   partial dctx / dh of every member
     float* x2;            // [tiles][2][16][H]               complete dh_{t-1} rows
@@ -554,7 +555,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float dscore = dv * m;
                 if (lane < S) {
                     dwl[rl][lane] = dscore;
-                    if (row < a.B) a.dscore[((size_t)row * T + t) * S + lane] = dscore;
+                    if (row < a.B) {
+                        a.dscore[((size_t)row * T + t) * S + lane] = dscore;
+                        a.weights[((size_t)row * T + t) * S + lane] = qv / Z;
+                    }
                 }
             }
             __syncthreads();
@@ -647,11 +651,12 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
 
 int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs, const float* hs, const float* probs,
                              const float* enc, const float* mask, const float* h0, const float* w_c_t,
-                             const float* w_hh_t, float* dgates, float* dctx, float* dscore, float* dh0, int B, int T,
+                             const float* w_hh_t, float* dgates, float* dctx, float* dscore, float* weights, float* dh0, int B,
+                             int T,
                              int S, int hidden, void* workspace, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (!dhs || !act || !cs || !hs || !probs || !enc || !mask || !h0 || !w_c_t || !w_hh_t || !dgates || !dctx ||
-        !dscore || !dh0 || !workspace)
+        !dscore || !weights || !dh0 || !workspace)
         return PNMN_EINVAL;
     if (hidden != H || S < 1 || S > MAXS) return PNMN_ESHAPE;
     const int chunk = rows_per_launch();
@@ -677,6 +682,7 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
         const size_t r = (size_t)r0;
         MBwdArgs a{dhs + r * T * H, act + r * T * G4, cs + r * T * H, hs + r * T * H, probs + r * T * S, enc + r * S * H,
                    mask + r * S, h0 + r * H, w_c_t, w_hh_t, dgates + r * T * G4, dctx + r * T * H, dscore + r * T * S,
+                   weights + r * T * S,
                    dh0 + r * H, x1, x2, sync, rows, T, S, tiles};
         hipLaunchKernelGGL(attn_lstm_bwd_multi_kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
         e = hipGetLastError();

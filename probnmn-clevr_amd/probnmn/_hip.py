@@ -77,7 +77,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_bwd": (_P,) * 14 + (_I,) * 4 + (_P,),
     "pnmn_attn_lstm_multi_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P, _P),
-    "pnmn_attn_lstm_bwd_multi": (_P,) * 14 + (_I,) * 4 + (_P, _P),
+    "pnmn_attn_lstm_bwd_multi": (_P,) * 15 + (_I,) * 4 + (_P, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_run_launches": (_P, _I, _P),
     "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),

@@ -534,15 +534,15 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1)  # h_{t-1} of every (row, step)
         ws = _decoder_workspace(B, True, dev)
         if ws is not None:
-            dctx, dscore = torch.empty_like(hs), torch.empty_like(probs)
+            dctx, dscore, weights = torch.empty_like(hs), torch.empty_like(probs), torch.empty_like(probs)
             _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi(
                 dhs_c.data_ptr(), act.data_ptr(), cs.data_ptr(), hs.data_ptr(), probs.data_ptr(), enc.data_ptr(),
                 mask.data_ptr(), h0.data_ptr(), w_c_t.data_ptr(), w_hh_t.data_ptr(), dgates.data_ptr(), dctx.data_ptr(),
-                dscore.data_ptr(), dh0.data_ptr(), B, T, S, Hd, ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_bwd_multi")
+                dscore.data_ptr(), weights.data_ptr(), dh0.data_ptr(), B, T, S, Hd, ws.data_ptr(), _hip.stream_ptr(dev)),
+                "attn_lstm_bwd_multi")
             # encoder-output gradient as two GEMMs per row over the T steps: enc_s enters step t through
-            # the context (weight w_ts) and through the score (gradient dscore_ts, times h_{t-1})
-            q = probs * mask.unsqueeze(1)
-            weights = q / (q.sum(-1, keepdim=True) + 1e-13)
+            # the context (weight w_ts = masked, renormalised attention, written out by the kernel) and through the
+            # score (gradient dscore_ts, times h_{t-1})
             denc = torch.baddbmm(torch.bmm(weights.transpose(1, 2), dctx), dscore.transpose(1, 2), hprev)
         else:
             denc = torch.zeros_like(enc)
