@@ -286,8 +286,14 @@ class _PinnedRing:
             ev.synchronize()  # the host is far ahead of the GPU: wait for the slot
             self.wait_seconds += time.perf_counter() - t0
 
-    def stage(self, raw: np.ndarray, device: torch.device) -> torch.Tensor:
-        n = raw.size
+    def stage(self, raw, device: torch.device, total: int = -1) -> torch.Tensor:
+        """``raw``: a uint8 array, or (with ``total`` = their summed size) a list of (offset, uint8 array) pieces that
+        are copied straight into the pinned slot (no concatenated host copy first)."""
+        pieces = None
+        if total >= 0:
+            pieces, n = raw, total
+        else:
+            n = raw.size
         if n <= self.SMALL:
             if self._small is None:
                 self._small = torch.empty(self.SMALL * self.SMALL_SLOTS, dtype=torch.uint8).pin_memory()
@@ -309,7 +315,12 @@ class _PinnedRing:
                 self._big *= 2
             buf = torch.empty(self._big, dtype=torch.uint8).pin_memory()
             self._bufs[i] = buf
-        buf.numpy()[:n] = raw
+        if pieces is None:
+            buf.numpy()[:n] = raw
+        else:
+            view = buf.numpy()
+            for off, piece in pieces:
+                view[off:off + piece.size] = piece
         out = buf[:n].to(device, non_blocking=True)
         if events[i] is None:
             events[i] = torch.cuda.Event()
@@ -341,6 +352,14 @@ def to_device(records: np.ndarray, device: torch.device) -> torch.Tensor:
         raise HipLibraryError("probnmn HIP kernels need a cuda (ROCm) device, got %s" % device)
     raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
     return _ring(device).stage(raw, device)
+
+
+def pieces_to_device(pieces, total: int, device: torch.device) -> torch.Tensor:
+    """``to_device`` of the concatenation of (offset, uint8 array) pieces laid out in ``total`` bytes (gaps between
+    pieces carry whatever the staging slot held)."""
+    if device.type != "cuda":
+        raise HipLibraryError("probnmn HIP kernels need a cuda (ROCm) device, got %s" % device)
+    return _ring(device).stage(pieces, device, total)
 
 
 def small_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.Tensor:

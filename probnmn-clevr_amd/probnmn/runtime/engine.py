@@ -13,7 +13,7 @@ grouped launch at the end, where all (example, conv) pairs that share a weight a
 the same workgroups.
 """
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -40,7 +40,7 @@ class _Pack:
     """Several numpy record arrays -> one device byte buffer (a single H2D copy per step)."""
 
     def __init__(self):
-        self._chunks: List[np.ndarray] = []
+        self._chunks: List[Tuple[int, np.ndarray]] = []
         self._offsets: Dict[str, int] = {}
         self._itemsize: Dict[str, int] = {}
         self._size = 0
@@ -48,18 +48,16 @@ class _Pack:
 
     def add(self, name: str, rec: np.ndarray) -> None:
         raw = np.ascontiguousarray(rec).view(np.uint8).reshape(-1)
-        pad = (-self._size) % 64
-        if pad:
-            self._chunks.append(np.zeros(pad, np.uint8))
-            self._size += pad
+        self._size += (-self._size) % 64  # (the padding bytes are never read)
         self._offsets[name] = self._size
         self._itemsize[name] = rec.dtype.itemsize
-        self._chunks.append(raw)
+        if raw.size:
+            self._chunks.append((self._size, raw))
         self._size += raw.size
 
     def upload(self, device: torch.device) -> None:
-        host = np.concatenate(self._chunks) if self._chunks else np.zeros(64, np.uint8)
-        self.device_buf = _hip.to_device(host, device)
+        # (the pieces go straight into the pinned staging slot: no concatenated host copy in between)
+        self.device_buf = _hip.pieces_to_device(self._chunks, max(self._size, 64), device)
 
     def ptr(self, name: str, index: int = 0) -> int:
         return self.device_buf.data_ptr() + self._offsets[name] + index * self._itemsize[name]

@@ -552,8 +552,9 @@ class BatchScheduler:
         self._prepared = None  # (one batch, one plan: do not keep the batch's programs alive)
         nv = len(ex_valid)
         dt = self.dt
-        records = {name: np.zeros(0, dt[key]) for name, key in self._RECORD_KINDS if not name.startswith("jobs")}
+        records = {}
         if nv == 0:
+            records = {name: np.zeros(0, dt[key]) for name, key in self._RECORD_KINDS if not name.startswith("jobs")}
             return StepPlan(records, [], [], {"wg3": np.zeros(0, dt["wgrad_job"]), "wgp": np.zeros(0, dt["wgrad_job"])},
                             0, np.zeros(0, np.int64), 0, [])
         tables, nprims, sizes, isfeat = self._get_bank()
@@ -571,8 +572,9 @@ class BatchScheduler:
         n_total = int(nprims[tids].sum())
         words = np.empty(n_total * 48 + 64, np.uint64)  # (a projection: 12 + 24 + 6 + 3 words; a masked conv: 38)
         meta = np.zeros(40, np.int64)
-        cuts = np.empty((4096, 4), np.int32)
-        tb = self._tables64
+        cuts = self.__dict__.get("_cuts")
+        if cuts is None:  # (64 KB of scratch the library fills; copied out below)
+            cuts = self._cuts = np.empty((4096, 4), np.int32)
         rec = np.zeros(1, _hip.PLAN_IN)
         rec[0] = (tables.ctypes.data, nprims.ctypes.data, tids.ctypes.data, E.ctypes.data, base.ctypes.data,
                   tokens.ctypes.data) + self._tables64_ptrs + (
