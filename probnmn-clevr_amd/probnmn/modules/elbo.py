@@ -56,7 +56,9 @@ class _FusedElbo(torch.autograd.Function):
     def forward(ctx, pg_loss, qr_loss, prior_loss, nmn_loss, baseline, beta, gamma):
         n = pg_loss.numel()
         dev = pg_loss.device
-        sums = torch.empty(6, dtype=torch.float32, device=dev)
+        # (zeros, not empty: with no sampled rows the kernel returns without writing, and the means and the
+        # baseline update below must then see zeros, not whatever the allocator handed out)
+        sums = torch.zeros(6, dtype=torch.float32, device=dev)
         dpg = torch.empty(n, dtype=torch.float32, device=dev)
         from probnmn import _hip
 
@@ -108,7 +110,7 @@ class _ElboWithReinforce(nn.Module):
             stats = torch.stack((sums[5], torch.full_like(sums[5], float(n))))
             stats = parallel.all_reduce_scalars(stats)
             r._baseline = r._baseline + r._baseline_decay * stats[0] / stats[1].clamp(min=1.0)
-        means = sums / n
+        means = sums / max(n, 1)
         out = {"reconstruction_likelihood": means[0], "kl_divergence": means[1], "elbo": means[2],
                "reinforce_reward": means[3]}
         if nmn_loss is not None:

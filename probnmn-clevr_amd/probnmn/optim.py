@@ -73,6 +73,7 @@ class ClampAdam(torch.optim.Optimizer):
                 raise ValueError("arena parameters missing from the parameter list: %s ..." % missing[:3])
         self.loose: List[nn.Parameter] = [p for p in params if id(p) not in in_arena and p.requires_grad]
         self.step_count = 0
+        self._check_full = True  # first step (and the first after load_state_dict): every parameter checked
         self._arena_state = [(torch.zeros_like(a.flat), torch.zeros_like(a.flat)) for a in self.arenas]
         self._loose_state = [(torch.zeros_like(p, memory_format=torch.contiguous_format),
                               torch.zeros_like(p, memory_format=torch.contiguous_format)) for p in self.loose]
@@ -101,6 +102,16 @@ class ClampAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)  # casts to each parameter's device / dtype, replaces self.state
+        # torch REPLACES param_groups with the saved ones: a checkpoint written by the reference's torch.optim.Adam
+        # has no 'clamp' entry (the reference clamps in a Python loop, _trainer.py:145-150) and carries options this
+        # fused update does not implement -- restore the former, refuse the latter instead of ignoring them
+        for g in self.param_groups:
+            for flag in ("amsgrad", "maximize"):
+                if g.get(flag):
+                    raise ValueError("ClampAdam has no %s: the loaded optimizer state was written with %s=True" % (flag, flag))
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+        self._check_full = True  # (the next step re-verifies that every parameter still aliases its arena)
         loaded = dict(self.state)
         steps = [float(st["step"]) for st in loaded.values() if "step" in st]
         if steps and max(steps) != min(steps):
@@ -140,7 +151,9 @@ class ClampAdam(torch.optim.Optimizer):
         self.step_count += 1
         items = []
         for a, (m, v) in zip(self.arenas, self._arena_state):
-            if not a.intact():
+            # every parameter on the first step, after load_state_dict and every 64th step; a rotating sample
+            # otherwise (a re-pointed parameter would train on while the fused update writes the arena slice)
+            if not a.intact(full=self._check_full or self.step_count % 64 == 0):
                 raise _hip.HipLibraryError(
                     "a parameter no longer aliases the arena this optimizer was built on (model.to() / .data = "
                     "after the optimizer was constructed): build the optimizer after placing the model")
@@ -151,6 +164,7 @@ class ClampAdam(torch.optim.Optimizer):
             if not p.is_contiguous() or not p.grad.is_contiguous():
                 raise _hip.HipLibraryError("ClampAdam needs contiguous loose parameters and gradients")
             items.append((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+        self._check_full = False
         if not items:
             return
         rec = np.array(items, dtype=np.uint64).view(_hip.ADAM_ITEM).reshape(-1)  # (five 8-byte fields per item)

@@ -4,9 +4,11 @@ The reference wraps models in ``nn.DataParallel`` (single process, parameter bro
 gradient reduce through device 0 every step -- reference: probnmn/trainers/_trainer.py:94-100).
 Here every rank owns a replica and a shard of the batch; after backward the gradient *arenas*
 (one contiguous buffer per model, ``probnmn.runtime.arena``) are summed with a single
-``all_reduce`` each -- for the NMN that is one 257 MB collective instead of ~110 small ones,
-which is what a point-to-point xGMI fabric wants (per-link bound; few, large messages) -- then
-scaled by 1/world so that equal-sized shards reproduce the single-process mean loss gradient.
+``all_reduce`` each -- for the NMN trunk that is one 52 MB collective instead of ~110 small ones (the
+205 MB gradient of the fully connected layer is a loose tensor, reduced early from its gradient hook:
+``EarlyReducer``), which is what a point-to-point xGMI fabric wants (per-link bound; few, large
+messages) -- then scaled by 1/world so that equal-sized shards reproduce the single-process mean loss
+gradient.
 The element-wise clamp happens AFTER the reduce, as in the reference, where the clamp sees the
 whole-batch gradient (joint_training_trainer.py:181-188).
 """
@@ -55,8 +57,15 @@ class EarlyReducer:
         self.params = [q for q in self.params if q is not p]
         self.reset()
 
+    def arm(self) -> None:
+        """The trainer that owns this reducer is about to run backward: its hooks may start collectives.  A hook
+        that fires while its reducer is NOT armed (another trainer over the same parameter stepping: its
+        ``all_reduce_gradients`` reduces that gradient itself) does nothing -- otherwise the gradient would be
+        summed twice and an orphan collective would be left in ``_pending``."""
+        self.armed = True
+
     def _fire(self, p: torch.nn.Parameter) -> None:
-        if world() == 1 or p.grad is None:
+        if world() == 1 or p.grad is None or not getattr(self, "armed", False):
             return
         # autograd may finish the hooked gradients in a different order on different ranks (their graphs
         # differ when a loss term has no rows in a shard): a collective is started only once every
@@ -109,6 +118,7 @@ def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Param
                 started = (dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True), p.grad)
             handles.append(started)
         early.reset()
+        early.armed = False
     for a in arenas:
         handles.append((dist.all_reduce(a.grad, op=dist.ReduceOp.SUM, async_op=True), a.grad))
     small = []  # the seq2seq models have ~40 tensors of a few hundred KB: one bucket, one collective
@@ -158,3 +168,8 @@ def broadcast_parameters(arenas: Sequence, loose_params: Iterable[torch.nn.Param
         dist.broadcast(a.flat, src)
     for p in loose_params:
         dist.broadcast(p.data, src)
+    # written through .data / the arena: no version counter moved, so tell the caches of derived parameters
+    # (fragment-packed recurrent weights, bias sums) that the values changed
+    from probnmn.optim import parameters_changed
+
+    parameters_changed()

@@ -62,6 +62,9 @@ class _TrainerBase(StepBase):
         return optimizer
 
     def _finish(self, loss: torch.Tensor) -> None:
+        early = getattr(self, "_early", None)
+        if early is not None:
+            early.arm()
         if loss.requires_grad:  # (false only for a data-parallel shard without any row: it contributes zeros)
             _hip.mark("backward begins")
             loss.backward()

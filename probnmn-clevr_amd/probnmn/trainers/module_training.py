@@ -41,6 +41,8 @@ class ModuleTrainingStep(StepBase):
         loss = out["loss"].mean()
         # data parallel: the reference's loss is the mean over the whole batch (module_training_trainer.py:91);
         # weighting the local mean by n_local * world / n_global keeps that exact for unequal shards
+        if self._early is not None:
+            self._early.arm()
         (loss * parallel.mean_weight(out["loss"].numel(), out["loss"].device)).backward()
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=self._early)
         self.optimizer.step()

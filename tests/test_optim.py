@@ -138,3 +138,46 @@ def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
     net.stem[0].weight.data = net.stem[0].weight.data.clone()
     with pytest.raises(Exception, match="arena"):
         opt2.step()
+
+
+def test_loading_a_torch_adam_state_keeps_the_group_options():
+    """torch's load_state_dict REPLACES param_groups with the saved ones; a reference checkpoint's
+    Adam group has no 'clamp' key (step() would raise KeyError) and may carry options the fused update does not
+    implement -- those are refused, not silently ignored."""
+    m = _model()
+    adam = torch.optim.Adam(m.parameters(), lr=2e-3)
+    m(torch.randn(4, 6)).pow(2).sum().backward()
+    adam.step()
+    opt = ClampAdam(copy.deepcopy(m).parameters(), lr=1.0, clamp=5.0)
+    opt.load_state_dict(copy.deepcopy(adam.state_dict()))
+    g = opt.param_groups[0]
+    assert g["clamp"] == 5.0 and g["lr"] == 2e-3 and g["betas"] == (0.9, 0.999) and opt._check_full
+    for flag in ("amsgrad", "maximize"):
+        sd = copy.deepcopy(adam.state_dict())
+        sd["param_groups"][0][flag] = True
+        with pytest.raises(ValueError, match=flag):
+            ClampAdam(copy.deepcopy(m).parameters(), lr=1.0).load_state_dict(sd)
+
+
+@pytest.mark.gpu
+def test_steps_after_loading_a_reference_adam_state():
+    """The resume path _base.load_state_dict advertises: optimizer state written by torch.optim.Adam (a reference
+    checkpoint) -> ClampAdam -> ONE fused step == clamp + torch Adam's next step."""
+    dev = torch.device("cuda:0")
+    m = _model()
+    adam = torch.optim.Adam(m.parameters(), lr=2e-3)
+    for _ in range(2):
+        adam.zero_grad()
+        m(torch.randn(4, 6)).pow(2).sum().backward()
+        adam.step()
+    m_dev = copy.deepcopy(m).to(dev)
+    opt = ClampAdam(m_dev.parameters(), lr=1.0, clamp=5.0)
+    opt.load_state_dict(copy.deepcopy(adam.state_dict()))
+    grads = [torch.randn(p.shape) * 4 for p in m.parameters()]
+    for p, q, gr in zip(m.parameters(), m_dev.parameters(), grads):
+        p.grad, q.grad = gr.clamp(-5, 5), gr.to(dev)
+    adam.step()
+    opt.step()
+    assert opt.step_count == 3
+    for p, q in zip(m.parameters(), m_dev.parameters()):
+        torch.testing.assert_close(q.detach().cpu(), p.detach(), rtol=1e-5, atol=2e-6)

@@ -52,9 +52,10 @@ def _worker(rank, world, port, out_path):
     early2 = parallel.EarlyReducer([loose])    # the loose parameter's all-reduce starts inside backward
     shard = slice(rank * 4, rank * 4 + 4)
     loss = (((X[shard] @ w.T + loose) * scale + shift - Y[shard]) ** 2).sum(1).mean()
+    early2.arm()  # (what a trainer does right before its backward)
     loss.backward()
     arena.grad.copy_(w.grad.reshape(-1))
-    assert early.take(loose) is not None or True  # (the hook fired during backward; taken below)
+    assert id(loose) in early2._pending  # the hook fired during backward; taken by all_reduce_gradients below
     parallel.all_reduce_gradients([arena], [loose, scale, shift], early=early2)
     sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
     # loss terms are means over data-dependent subsets: shard sizes 3 and 5 here.  The trainers weight

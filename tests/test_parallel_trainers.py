@@ -152,3 +152,33 @@ def test_second_trainer_takes_over_the_early_hook():
     assert len(p._post_accumulate_grad_hooks) == 1
     second.remove()
     assert not p._post_accumulate_grad_hooks
+
+
+def test_unarmed_reducer_starts_no_collective(monkeypatch):
+    """the hook's owner starts collectives only while ITS trainer runs backward.  The older trainer
+    stepping again (its optimizer still lists the parameter) must not leave an orphan all-reduce in the newer
+    reducer, nor have the gradient summed twice."""
+    sys.path.insert(0, os.path.join(ROOT, "probnmn-clevr_amd"))
+    from probnmn import parallel
+
+    calls = []
+
+    class _Done:
+        def wait(self):
+            pass
+
+    monkeypatch.setattr(parallel, "world", lambda: 2)
+    monkeypatch.setattr(parallel.dist, "all_reduce", lambda t, op=None, async_op=False: (calls.append(t), _Done())[1])
+    p = torch.nn.Parameter(torch.ones(3))
+    old, new = parallel.EarlyReducer([p]), parallel.EarlyReducer([p])  # `new` took the hook over
+    (p * 2.0).sum().backward()  # the OLD trainer's backward: nobody armed
+    assert calls == [] and not new._pending
+    parallel.all_reduce_gradients([], [p], early=old, average=False)  # old has no early parameters left
+    assert len(calls) == 1  # reduced exactly once, as an ordinary loose tensor
+    calls.clear()
+    p.grad = None
+    new.arm()
+    (p * 2.0).sum().backward()
+    assert len(calls) == 1 and id(p) in new._pending  # started from the hook
+    parallel.all_reduce_gradients([], [p], early=new, average=False)
+    assert len(calls) == 1 and not new._pending and not new.armed
