@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: CLEVR questions/sec of one joint_training step on MI355X (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[3] on one GPU): configs/joint_training_ours.yml (alpha 100, beta 0.1,
-gamma 1, delta 0.99, lr 1e-6), 1024 questions per GPU (weak scaling: global batch 1024 x N; `--scaling
-strong` keeps the global batch at 1024 and gives every rank 1024 / N -- configs[3] as written), 14x14x1024
+(N > 1: one process per GPU over RCCL -- under torch.distributed.run as the driver starts it, or on its own: without
+WORLD_SIZE in the environment the script launches its N ranks itself.)
+
+Workload (BASELINE.json configs[3]): configs/joint_training_ours.yml (alpha 100, beta 0.1, gamma 1, delta
+0.99, lr 1e-6), GLOBAL batch 1024 questions split evenly over the N ranks ("scaling": "strong" -- configs[3]
+as written is 1024 questions over 8 GPUs; N = 1 runs all 1024 on one GPU).  `--scaling weak` gives every rank
+1024 questions instead; for N > 1 that run rides along as the side object `weak_scaling`.  14x14x1024
 features, synthetic CLEVR-shaped batch (probnmn.data.synthetic: programs from the eight template
 shapes, half of the examples with program supervision -- what the reference's
 SupervisionWeightedRandomSampler yields, data/samplers.py:5-27).  A step is the reference's
@@ -29,10 +33,16 @@ Besides the contract fields the JSON line carries
                  the 157.3 TFLOP/s fp32 matrix peak of gfx950
   cpu_baseline   the CPU oracle's identical step (same weights), timed on this host's cores on a
                  bounded sample of the same workload (N=1 only)
-  module_training / question_coding / joint_training_b128 / joint_training_28x28
+  module_training / question_coding / joint_training_b128 / joint_training_28x28   (N = 1)
                  side measurements of BASELINE.json configs[1], configs[2], of configs[3] read as
                  1024 questions over 8 GPUs (128 per GPU) and of configs[4] (28x28 maps, programs of up
                  to 40 tokens, 128 per GPU); never `value`
+  joint_training_ingest
+                 the headline step with its features gathered every step from a pinned host store over PCIe
+                 (PrefetchingLoader beside the step): questions/s, PCIe GB/s, slowdown vs resident features
+  collectives / rccl_ranks / allreduce_ms_per_step / allreduce_hidden_frac   (N > 1)
+                 the step's gradient all-reduces alone on an idle chip, what the step's stream actually waits
+                 for them, and the fraction hidden behind backward
 """
 import argparse
 import json
@@ -131,77 +141,132 @@ def cpu_config1(vocab, nmn_sd, threads, steps=3, batch=32):
             "workload": "module_training.yml, batch 32, CPU oracle (configs[0])"}
 
 
+def source_sha():
+    """Hash of everything a kernel's HBM traffic depends on (kernel sources, the C ABI, the launch planner): a PMC
+    summary is only quoted beside a bench line taken on the same sources.  (The GPU box has no .git; profiles
+    written in the build container also carry the commit, see profiles/summarize.py.)"""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        from summarize import source_sha as f
+    finally:
+        sys.path.pop(0)
+    return f(ROOT)
+
+
 def kernel_rooflines(engine, step_fn, passes, trainer=None):
     """Instrumented steps: events around every conv / wgrad launch on the launch stream.  ONE stream, so
     that each kernel's duration is its own and not that of two kernels sharing the chip: a trainer that
     runs the NMN beside the seq2seq passes (small batches) is switched to its single-stream schedule for
-    these passes."""
+    these passes.
+
+    Every pass is aggregated on its own and the MEDIAN pass is reported (per kernel family: the pass with the
+    median FLOP/s; per call site: the median over passes) -- a stalled event interval or an allocator refill in
+    one pass then moves nothing.  Each pass's whole step is timed on the same stream; a kernel family whose summed
+    launch time exceeds the single-stream step it ran in cannot be right, and the result is marked suspect."""
     overlap, engine.overlap_wgrad = engine.overlap_wgrad, False
     side_stream = getattr(trainer, "nmn_stream", None)
     if side_stream is not None:
         trainer.nmn_stream = False
-    engine.event_log = []
-    for _ in range(passes):
-        step_fn()
-    torch.cuda.synchronize()
-    events, engine.event_log = engine.event_log, None
-    engine.overlap_wgrad = overlap
-    if side_stream is not None:
-        trainer.nmn_stream = side_stream
-    agg = {}
+    per_pass, step_ms = [], []
     table = os.environ.get("PNMN_LAUNCH_TABLE")  # debugging aid: one line per conv / wgrad call of the instrumented steps
-    if table:
-        with open(table, "a") as f:
+    try:
+        step_fn()  # (the single-stream schedule's first step allocates)
+        for _ in range(passes):
+            engine.event_log = []
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            step_fn()
+            s1.record()
+            torch.cuda.synchronize()
+            events, engine.event_log = engine.event_log, None
+            step_ms.append(s0.elapsed_time(s1))
+            agg = {}
             for kern, what, flops, e0, e1, nbytes, launches in events:
                 ms = e0.elapsed_time(e1)
-                f.write("%-11s %-20s %9.3f GFLOP %8.4f ms %7.1f TF  %d launches\n" % (kern, what, flops / 1e9, ms, flops / ms / 1e9, launches))
-            f.write("\n")
-    for kern, what, flops, e0, e1, nbytes, launches in events:
-        a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
-        ms = e0.elapsed_time(e1)
-        a["flops"] += flops
-        a["bytes"] += nbytes
-        a["ms"] += ms
-        a["launches"] += launches  # (a call with a remainder is two kernel launches)
-        b = a["by"].setdefault(what, [0.0, 0.0, 0])
-        b[0] += flops
-        b[1] += ms
-        b[2] += 1
-    return agg
+                a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
+                a["flops"] += flops
+                a["bytes"] += nbytes
+                a["ms"] += ms
+                a["launches"] += launches  # (a call with a remainder is two kernel launches)
+                b = a["by"].setdefault(what, [0.0, 0.0, 0])
+                b[0] += flops
+                b[1] += ms
+                b[2] += 1
+                if table:
+                    with open(table, "a") as f:
+                        f.write("%-11s %-20s %9.3f GFLOP %8.4f ms %7.1f TF  %d launches\n" % (kern, what, flops / 1e9, ms, flops / ms / 1e9, launches))
+            per_pass.append(agg)
+    finally:
+        engine.event_log = None
+        engine.overlap_wgrad = overlap
+        if side_stream is not None:
+            trainer.nmn_stream = side_stream
+
+    def median(xs):
+        xs = sorted(xs)
+        return xs[(len(xs) - 1) // 2]
+
+    out = {}
+    for kern in sorted({k for p in per_pass for k in p}):
+        runs = [p[kern] for p in per_pass if kern in p and p[kern]["ms"] > 0]
+        mid = median([(r["flops"] / r["ms"], i) for i, r in enumerate(runs)])[1]
+        chosen = dict(runs[mid])
+        by = {}
+        for what in sorted({w for r in runs for w in r["by"]}):
+            site = [r["by"][what] for r in runs if what in r["by"] and r["by"][what][1] > 0]
+            tf = median([x[0] / x[1] for x in site])
+            ms = median([x[1] for x in site])
+            by[what] = [tf * ms, ms, median([x[2] for x in site])]
+        chosen["by"] = by
+        chosen["tflops_per_pass"] = [round(r["flops"] / r["ms"] / 1e9, 2) for r in runs]
+        out[kern] = chosen
+    out["_step_ms"] = median(step_ms)
+    out["_passes"] = len(per_pass)
+    return out
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summaries (profiles/
     rNN_pmc_{FETCH,WRITE}_SIZE.txt: separate `rocprofv3 --pmc` passes of this same command, see
     scripts/profile_round.sh).  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950
-    counts 128-byte read requests at 64 bytes, MI355X_MICROARCH.md, HBM).  None without summaries."""
+    counts 128-byte read requests at 64 bytes, MI355X_MICROARCH.md, HBM).  Counters cannot be collected inside
+    this process, so the figure is quoted ONLY when the summaries were taken on these very sources (their
+    `# source_sha` header equals source_sha()); None otherwise."""
     import glob
     import re
 
     tags = sorted({os.path.basename(f).split("_pmc_")[0] for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_FETCH_SIZE.txt"))})
     if not tags:
         return None
+    want = source_sha()
     tag, total, calls = tags[-1], 0.0, 0
     for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.txt" % (tag, counter))
         if not os.path.exists(path):
             return None
-        n = 0
+        n, sha = 0, None
         for line in open(path):
+            m = re.match(r"#\s*source_sha:\s*(\w+)", line)
+            if m:
+                sha = m.group(1)
             m = re.match(r"(\S+)\s+%s\s+(\d+)\s+([0-9.]+)" % counter, line)
             if m and kernel in m.group(1):
                 n += int(m.group(2))
                 total += factor * 1024.0 * float(m.group(3))
+        if sha != want:
+            return None
         calls = max(calls, n)
-    return {"bytes_per_launch": round(total / calls), "source": "profiles/%s_pmc_*_SIZE.txt" % tag} if calls else None
+    return {"bytes_per_launch": round(total / calls), "source": "profiles/%s_pmc_*_SIZE.txt (source_sha %s)" % (tag, want)} if calls else None
 
 
-def roofline_object(agg, passes):
-    dom = max(agg, key=lambda k: agg[k]["ms"])
-    a = agg[dom]
+def roofline_object(agg, kernel=None):
+    kerns = {k: v for k, v in agg.items() if not k.startswith("_")}
+    dom = kernel or max(kerns, key=lambda k: kerns[k]["ms"])
+    a = kerns[dom]
     achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
     pmc = pmc_traffic(dom)
-    return {
+    total_ms = sum(v["ms"] for v in kerns.values())
+    out = {
         "kernel": dom,
         "bound": "mfma",
         "achieved": round(achieved, 2),
@@ -212,14 +277,23 @@ def roofline_object(agg, passes):
         "traffic_unit": "HBM bytes per launch (PMC, %s)" % pmc["source"] if pmc else None,
         "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
-        "launches_per_step": a["launches"] // passes,
+        "launches_per_step": a["launches"],
+        "passes": agg["_passes"],
+        "tflops_per_pass": a["tflops_per_pass"],
+        "single_stream_step_ms": round(agg["_step_ms"], 3),
         "kernels": {
-            k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / passes, 3),
-                "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1] / passes, 3)}
+            k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"], 3),
+                "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1], 3)}
                                  for w, b in v["by"].items()}}
-            for k, v in agg.items()
+            for k, v in kerns.items()
         },
     }
+    if total_ms > 1.02 * agg["_step_ms"]:
+        # the instrumented kernels cannot take longer than the single-stream step they ran in: the timing is broken
+        # (a stalled event interval in most passes) -- say so instead of reporting a fraction
+        out.update({"suspect": True, "achieved": None, "frac": None,
+                    "why": "sum of instrumented kernel time %.2f ms > single-stream step %.2f ms" % (total_ms, agg["_step_ms"])})
+    return out
 
 
 def recurrent_kernel_report(dev):
@@ -435,11 +509,12 @@ def config5_side(vocab, prior, dev, rank, world, args):
         trainer.step(batch)
     torch.cuda.synchronize()
     elapsed, host, blocked = timed(lambda: trainer.step(batch), 10, 4, dev, world, trainer)
-    agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2, trainer=trainer)
+    agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=4, trainer=trainer)
     out = None
     if rank == 0:
-        conv = agg["conv_nhwc"]
-        tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        roof = roofline_object(agg, "conv_nhwc")
+        for k in ("traffic", "traffic_unit"):  # (the committed PMC summaries are of the 14x14 headline)
+            roof[k] = None
         out = {
             "metric": "CLEVR questions/sec (joint_training step)",
             "value": round(n * world * 10 / elapsed, 1), "unit": "questions/s", "ms_per_step": round(elapsed / 10 * 1e3, 3),
@@ -452,20 +527,143 @@ def config5_side(vocab, prior, dev, rank, world, args):
             "module_primitives_per_step": nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None,
             "host_busy_ms_per_step": round((host - blocked) / 10 * 1e3, 3),
             "host_blocked_ms_per_step": round(blocked / 10 * 1e3, 3),
-            "roofline": {
-                "kernel": "conv_nhwc", "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                "kernels": {
-                    k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"] / 2, 3),
-                        "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1] / 2, 3)}
-                                         for w, b in v["by"].items()}}
-                    for k, v in agg.items()},
-            },
+            "roofline": roof,
         }
     trainer.close()
     del trainer, nmn, pg, qr, batch
     torch.cuda.empty_cache()
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per GPU,
+    rendezvous on 127.0.0.1) with the same arguments, pass their output through and exit with their status."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd[2:])))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def collective_report(trainer, step_fn, dev, world, passes=4):
+    """What the gradient all-reduces cost the step (N > 1): `exposed` = time the step's stream is held at the
+    waits in all_reduce_gradients (events on that stream around them, instrumented steps); `standalone` = the same
+    sequence of collectives (same sizes: the early-reduced tensors, the arena pieces, the small-tensor bucket)
+    issued back to back on an otherwise idle GPU; hidden = 1 - exposed / standalone."""
+    from probnmn import parallel
+
+    parallel.TIMING = []
+    for _ in range(passes):
+        step_fn()
+    torch.cuda.synchronize()
+    timing, parallel.TIMING = parallel.TIMING, None
+    exposed = sorted(e0.elapsed_time(e1) for e0, e1 in timing)
+    exposed = exposed[(len(exposed) - 1) // 2] if exposed else 0.0
+    opt = trainer.optimizer
+    early = getattr(trainer, "_early", None)
+    sizes = []
+    covered = {}
+    if early is not None:
+        sizes += [p.numel() for p in early.params] + [hi - lo for _, lo, hi in early.pieces]
+        for a in opt.arenas:
+            covered[id(a)] = sum(hi - lo for lo, hi in early.covers(a))
+    sizes += [a.total - covered.get(id(a), 0) for a in opt.arenas if a.total > covered.get(id(a), 0)]
+    first = {id(p) for p in early.params} if early is not None else set()
+    rest = [p.numel() for p in opt.loose if id(p) not in first]
+    small = sum(n for n in rest if n * 4 < parallel.SMALL_BUCKET_BYTES)
+    sizes += [n for n in rest if n * 4 >= parallel.SMALL_BUCKET_BYTES] + ([small] if small else [])
+    bufs = [torch.zeros(n, dtype=torch.float32, device=dev) for n in sizes]
+    times = []
+    for _ in range(5):
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for h in [dist.all_reduce(b, async_op=True) for b in bufs]:
+            h.wait()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    standalone = sorted(times)[2]
+    t = torch.tensor([exposed, standalone], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    exposed, standalone = float(t[0]), float(t[1])
+    nbytes = 4 * sum(sizes)
+    return {
+        "rccl_ranks": dist.get_world_size(),  # (after real all-reduces on this process group)
+        "backend": dist.get_backend(),
+        "allreduce_bytes_per_step": nbytes,
+        "collectives_per_step": len(sizes),
+        "allreduce_ms_per_step": round(standalone, 3),
+        "allreduce_exposed_ms_per_step": round(exposed, 3),
+        "allreduce_hidden_frac": round(max(0.0, 1.0 - exposed / standalone), 3) if standalone > 0 else None,
+        "allreduce_algbw_GBs": round(nbytes / standalone / 1e6, 1) if standalone > 0 else None,
+        "cluster_cus": int(__import__("probnmn._hip", fromlist=["lib"]).lib().pnmn_cluster_reserve_cus(-1)),
+        "note": "allreduce_ms_per_step: the step's collectives alone on an idle chip; exposed: what the step's stream "
+                "waits for them behind backward (median of %d instrumented steps, max over ranks)" % passes,
+    }
+
+
+def ingest_side(vocab, trainer, dev, rank, world, args, resident_ms):
+    """The same joint step fed by its ingest (reference data/readers.py:63-108, datasets.py:137-142,
+    _trainer.py:272-287): a pinned host store of `--ingest-rows` feature rows, fresh random rows every step through
+    PrefetchingLoader -- the gather kernel reads them over PCIe on its own stream while the previous step runs."""
+    from probnmn.data.feature_store import PinnedFeatureStore, PrefetchingLoader
+    from probnmn.data.synthetic import synthetic_batch
+
+    n, rows, k, w = args.batch, args.ingest_rows, args.steps, 4
+    g = torch.Generator().manual_seed(77 + rank)
+    store = PinnedFeatureStore.__new__(PinnedFeatureStore)  # (filled in place: no second host copy of 6.6 GB)
+    store.shape = (rows, 1024, 14, 14)
+    store.store = torch.empty(store.shape, dtype=torch.float32, pin_memory=True)
+    blk = torch.randn(256, 1024, 14, 14, generator=g).relu_()
+    for lo in range(0, rows, 256):
+        store.store[lo:lo + 256] = blk[: min(256, rows - lo)]
+    host = synthetic_batch(vocab, n, seed=1000 + rank)
+    del host["image"]
+
+    def batches(count):
+        for _ in range(count):
+            b = dict(host)
+            b["image_index"] = torch.randint(0, rows, (n,), generator=g)
+            yield b
+
+    it = iter(PrefetchingLoader(batches(w + k + 1), store, dev))
+    for _ in range(w):
+        trainer.step(next(it))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        trainer.step(next(it))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / k * 1e3
+    feat_bytes = n * 1024 * 196 * 4
+    del it, store
+    return {"metric": "CLEVR questions/sec (joint_training step, features ingested from a pinned host store)",
+            "value": round(n * world / (elapsed / k), 1), "unit": "questions/s", "ms_per_step": round(ms, 3),
+            "steps": k, "warmup": w, "store_rows": rows, "pcie_GBs_per_gpu": round(feat_bytes / (ms * 1e-3) / 1e9, 2),
+            "slowdown_vs_resident": round(ms / resident_ms, 4),
+            "workload": "the headline step with batch['image'] gathered every step from %d pinned fp32 rows (%.1f GB) by "
+                        "pnmn_gather_features on the loader's stream (PrefetchingLoader, one batch ahead); NHWC batch "
+                        "used in place by the stem" % (rows, rows * 1024 * 196 * 4 / 1e9)}
 
 
 def main():
@@ -479,33 +677,42 @@ def main():
     ap.add_argument("--warmup", type=int, default=10,
                     help="untimed steps first: allocator pools, GEMM heuristics and the program / template caches settle")
     ap.add_argument("--batch", type=int, default=1024,
-                    help="questions of the joint_training step: per GPU (--scaling weak) or in total (--scaling strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --batch questions per GPU (global batch grows with N); strong: --batch questions in "
-                         "total, split evenly over the N ranks (BASELINE configs[3] as written: 1024 over 8 GPUs)")
+                    help="questions of the joint_training step: in total (--scaling strong, the default) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): --batch questions in total, split evenly over the N ranks -- BASELINE "
+                         "configs[3] as written, 1024 over 8 GPUs; weak: --batch questions per GPU (global batch "
+                         "grows with N).  N = 1 is the same run either way")
     ap.add_argument("--batch28", type=int, default=128, help="questions per GPU of the 28x28 / 40-token side measurement")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--settle", type=int, default=8, help="set-up iterations before the warm-up (see main)")
     ap.add_argument("--fit-iters", type=int, default=1500, help="cap on the generator's pre-fit iterations")
     ap.add_argument("--fit-target", type=float, default=0.95)
+    ap.add_argument("--ingest-rows", type=int, default=8192, help="rows of the pinned host feature store of the ingest side measurement")
+    ap.add_argument("--roofline-passes", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the module_training / question_coding / b128 side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--extras", action="store_true", help="N > 1: run the single-GPU side measurements too (default: N = 1 only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the measured path)")
-    global_batch = args.batch * world if args.scaling == "weak" else args.batch
+    total = args.batch  # as given on the command line
     if args.scaling == "strong":
         if args.batch % world:
             raise SystemExit("--scaling strong needs --batch divisible by the number of ranks")
-        args.batch //= world  # from here on: questions per rank
+        global_batch, per_rank = args.batch, args.batch // world
+    else:
+        global_batch, per_rank = args.batch * world, args.batch
+    args.batch = per_rank  # from here on: questions per rank
     # test hooks for boxes with fewer GPUs than ranks (the multi-rank logic of this file can then be
     # exercised with several processes on ONE device over gloo): never set by the driver
     backend = os.environ.get("PNMN_BENCH_BACKEND", "nccl")
@@ -535,7 +742,7 @@ def main():
     for m in (pg, qr):
         m.sample_row_offset = rank * args.batch  # distinct sampler streams per rank
 
-    # weak scaling: every rank gets its own batch of --batch questions
+    # every rank its own shard of the global batch
     batch = device_batch(vocab, args.batch, 1000 + rank, dev)
     valid_fraction, fit_iters = fit_program_generator(pg, vocab, batch, dev, args.fit_iters, args.fit_target)
 
@@ -556,12 +763,19 @@ def main():
     log("timed region: %.3f s for %d steps" % (elapsed, args.steps))
     prims = nmn.engine.last_plan.n_prims if nmn.engine.last_plan else None
 
+    collectives = None
+    if world > 1:
+        try:  # every rank takes part
+            collectives = collective_report(trainer, lambda: trainer.step(batch), dev, world)
+        except Exception as exc:
+            collectives = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     roof = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the step's collectives); rank 0 reports
-        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=2, trainer=trainer)
+        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=args.roofline_passes, trainer=trainer)
         if rank == 0:
-            roof = roofline_object(agg, 2)
+            roof = roofline_object(agg)
         log("roofline pass done")
 
     cpu = cpu1 = None
@@ -588,22 +802,37 @@ def main():
             hbm_kernels = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     extras = {}
-    if not args.no_extras:
-        def side(name, metric, workload, n, make, k=10):
-            try:
-                b = device_batch(vocab, n, 3000 + rank, dev)
-                step = make()
-                if name == "module_training":
-                    b["program"] = b["program"].cpu()
-                e, h, bl = timed(lambda: step.step(b), k, 6, dev, world, step)
-                extras[name] = {"metric": metric, "value": round(n * world * k / e, 1), "unit": "questions/s",
-                                "ms_per_step": round(e / k * 1e3, 3), "global_batch": n * world, "steps": k,
-                                "warmup": 6, "host_busy_ms_per_step": round((h - bl) / k * 1e3, 3),
-                                "host_blocked_ms_per_step": round(bl / k * 1e3, 3), "workload": workload}
-                log("%s: %.1f questions/s" % (name, extras[name]["value"]))
-            except Exception as exc:  # the headline line must survive a failure of a side measurement
-                extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    want_extras = not args.no_extras and (world == 1 or args.extras)
 
+    def side(name, metric, workload, n, make, k=10):
+        try:
+            b = device_batch(vocab, n, 3000 + rank, dev)
+            step = make()
+            if name == "module_training":
+                b["program"] = b["program"].cpu()
+            e, h, bl = timed(lambda: step.step(b), k, 6, dev, world, step)
+            extras[name] = {"metric": metric, "value": round(n * world * k / e, 1), "unit": "questions/s",
+                            "ms_per_step": round(e / k * 1e3, 3), "global_batch": n * world, "steps": k,
+                            "warmup": 6, "host_busy_ms_per_step": round((h - bl) / k * 1e3, 3),
+                            "host_blocked_ms_per_step": round(bl / k * 1e3, 3), "workload": workload}
+            log("%s: %.1f questions/s" % (name, extras[name]["value"]))
+        except Exception as exc:  # the headline line must survive a failure of a side measurement
+            extras[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    if not args.no_extras and world > 1 and args.scaling == "strong":
+        # weak scaling beside the strong-scaling headline: the one-GPU workload (all of --batch) on EVERY rank
+        side("weak_scaling", "CLEVR questions/sec (joint_training step)",
+             "joint_training_ours.yml, %d questions per GPU (global batch %d): per-GPU work fixed as N grows" % (total, total * world),
+             total, lambda: trainer, k=args.steps)
+        if "value" in extras.get("weak_scaling", {}):
+            extras["weak_scaling"]["scaling"] = "weak"
+    if not args.no_extras and args.ingest_rows > 0:
+        try:
+            extras["joint_training_ingest"] = ingest_side(vocab, trainer, dev, rank, world, args, elapsed / args.steps * 1e3)
+            log("joint_training_ingest: %.1f questions/s" % extras["joint_training_ingest"]["value"])
+        except Exception as exc:
+            extras["joint_training_ingest"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if want_extras:
         side("joint_training_b128", "CLEVR questions/sec (joint_training step)",
              "joint_training_ours.yml, 128 questions per GPU (configs[3] read as 1024 over 8 GPUs)", 128,
              lambda: trainer, k=40)  # (8 ms steps whose sampled programs differ: 10 of them scatter by +-4 %)
@@ -615,8 +844,6 @@ def main():
         side("module_training", "CLEVR questions/sec (module_training step)",
              "module_training.yml, 256 questions per GPU, ground-truth programs, NMN fwd+bwd+clamp+Adam (configs[1])", 256,
              lambda: ModuleTrainingStep(nmn, lr=1e-4, weight_decay=0.0, report_metrics=False))
-
-    if not args.no_extras:
         try:
             extras["joint_training_28x28"] = config5_side(vocab, prior, dev, rank, world, args)
             if rank == 0:
@@ -645,9 +872,12 @@ def main():
             "data": "synthetic (random-init weights; ProgramGenerator pre-fitted on the synthetic batch so that "
                     "sampled programs are valid)",
             "config": {
-                "workload": "joint_training_ours.yml (NMN + seq2seq + REINFORCE), batch %d per GPU, 14x14x1024 "
-                            "features, half of the batch with program supervision, fwd+bwd+clamp+Adam" % args.batch,
+                "workload": "joint_training_ours.yml (NMN + seq2seq + REINFORCE), global batch %d = %d questions per GPU "
+                            "x %d (BASELINE configs[3]%s), 14x14x1024 features, half of the batch with program "
+                            "supervision, fwd+bwd+[all-reduce]+clamp+Adam"
+                            % (global_batch, args.batch, world, "" if (global_batch == 1024 and args.scaling == "strong") else "; non-default batch/scaling"),
                 "global_batch": global_batch,
+                "per_gpu_batch": args.batch,
                 "parallelism": "dp%d" % world,
                 "valid_program_fraction": round(valid_fraction, 4),
                 "program_generator_fit_iterations": fit_iters,
@@ -659,10 +889,14 @@ def main():
             "recurrent_kernels": recurrent,
             "hbm_bound_kernels": hbm_kernels,
         }
+        if collectives is not None:
+            line["collectives"] = collectives
+            for k in ("rccl_ranks", "allreduce_ms_per_step", "allreduce_hidden_frac"):
+                line[k] = collectives.get(k)
         line.update(extras)
         if cpu:
             line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -379,6 +379,13 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
  * (hipMalloc on a stream's first launch; the kernels leave it zeroed); while the stream is being captured
  * into a graph they go to the head of `workspace` behind a zeroing kernel node instead. */
 int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward);
+/* Data parallel (replaces nothing in the reference, whose nn.DataParallel is one process:
+ * trainers/_trainer.py:94-100): keep `cus` compute units out of the grids of the multi-CU recurrent kernels
+ * (these and the decoder's), so that RCCL's workgroups -- resident for a whole collective, waiting for their
+ * peers -- never have to share the chip with a grid that needs every CU at once.  A batch whose tiles no longer
+ * fit one launch runs as several launches over row ranges.  cus < 0 only queries.  Returns the CU count the
+ * multi-CU launches are sized for (<= 0 without a device).  Also settable as PNMN_CLUSTER_RESERVE_CUS. */
+int pnmn_cluster_reserve_cus(int cus);
 
 /* ---------------------------------------------------------------------------------------------
  * Persistent attention-LSTM decoder (hidden = 256): the whole decoding loop of
@@ -528,7 +535,7 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
-/* Library self-description (no GPU needed).  2 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* Library self-description (no GPU needed).  4 = round 3: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -100,7 +101,20 @@ __device__ __forceinline__ void cluster_coords(int& tile, int& member) {
     member = slot % S;
 }
 
-inline int device_cus() {
+// CUs the multi-CU kernels leave alone.  A data-parallel run keeps RCCL's workgroups (one per channel, resident
+// for the whole collective, waiting for their PEERS) off the CUs these kernels size their grids for: a grid that
+// needs every CU while part of the chip is held by a kernel that itself waits is what stalled round 1.
+// Set by pnmn_cluster_reserve_cus() or PNMN_CLUSTER_RESERVE_CUS; one instance per library (inline, C++17).
+inline int& cluster_reserved_cus() {
+    static int reserved = [] {
+        const char* e = getenv("PNMN_CLUSTER_RESERVE_CUS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 0;
+    }();
+    return reserved;
+}
+
+inline int physical_cus() {
     // cached per device: the design is one process per GPU, but a process that drives several devices must
     // not size a grid for device 1 from device 0's CU count
     static int cus[64] = {0};
@@ -109,6 +123,20 @@ inline int device_cus() {
     if (!cus[dev] && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus[dev] = -1;
     return cus[dev];
+}
+
+// CUs a multi-CU launch may count on (physical minus the reserve, never fewer than 32 of a real device)
+inline int device_cus() {
+    const int cus = physical_cus();
+    if (cus <= 0) return cus;
+    const int left = cus - cluster_reserved_cus();
+    return left >= 32 ? left : (cus < 32 ? cus : 32);
+}
+
+// Largest number of 16-row tiles ONE multi-CU launch can take (four members per tile); 0 = none.
+inline int cluster_max_tiles() {
+    const int cus = device_cus();
+    return cus >= 32 ? 8 * (cus / 32) : 0;
 }
 
 // Members per tile such that the whole grid is resident with one workgroup per CU; 0 = does not fit.

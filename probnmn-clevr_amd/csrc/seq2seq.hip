@@ -690,11 +690,26 @@ constexpr size_t SYNC_BYTES = pnmn::CLUSTER_SYNC_BYTES;
 
 extern "C" {
 
+// Rows one multi-CU launch covers: the whole batch when its tiles fit the chip, else (a large batch on a chip
+// with CUs reserved for RCCL, pnmn_cluster_reserve_cus) as many whole groups of 8 tiles as fit with four members
+// per tile -- the batch then runs as several launches over row ranges, one after the other.
+static int lstm_chunk_tiles(int tiles) {
+    if (cluster_split(tiles)) return tiles;
+    const int most = pnmn::cluster_max_tiles();
+    return most > 0 && most < tiles ? most : 0;
+}
+
 int64_t pnmn_lstm_seq_workspace_bytes(int B, int backward) {
     const int tiles = (B + LROWS - 1) / LROWS;
-    const int S = cluster_split(tiles);
-    if (S == 0) return 0;
-    return (int64_t)SYNC_BYTES + (backward ? (int64_t)tiles * 2 * S * LROWS * LH * sizeof(float) : 0);
+    const int ctiles = lstm_chunk_tiles(tiles);
+    if (ctiles == 0) return 0;
+    const int S = cluster_split(ctiles);
+    return (int64_t)SYNC_BYTES + (backward ? (int64_t)ctiles * 2 * S * LROWS * LH * sizeof(float) : 0);
+}
+
+int pnmn_cluster_reserve_cus(int cus) {
+    if (cus >= 0) pnmn::cluster_reserved_cus() = cus;
+    return pnmn::device_cus();
 }
 
 int pnmn_lstm_seq_fwd(const float* xp, const int64_t* tokens, int64_t token_stride, const float* w_hh, float* hs,
@@ -705,16 +720,27 @@ int pnmn_lstm_seq_fwd(const float* xp, const int64_t* tokens, int64_t token_stri
     if (hidden != LH) return PNMN_ESHAPE;
     const int tiles = (B + LROWS - 1) / LROWS;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int S = workspace ? cluster_split(tiles) : 0;
-    if (S) {
+    const int ctiles = workspace ? lstm_chunk_tiles(tiles) : 0;
+    if (ctiles) {
         int* sync = nullptr;
         hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
-        const dim3 grid(8 * S * ((tiles + 7) / 8));
-        auto kern = S == 8 ? (tokens ? lstm_seq_fwd_cluster_kernel<8, true> : lstm_seq_fwd_cluster_kernel<8, false>)
-                           : (tokens ? lstm_seq_fwd_cluster_kernel<4, true> : lstm_seq_fwd_cluster_kernel<4, false>);
-        hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, xp, tokens, tstride, w_hh, hs, cs, act, sync, B, T, tiles);
-        return (int)hipGetLastError();
+        for (int t0 = 0; t0 < tiles; t0 += ctiles) {
+            const int nt = tiles - t0 < ctiles ? tiles - t0 : ctiles;
+            const int S = cluster_split(nt);
+            if (!S) return PNMN_ESHAPE;
+            const size_t r0 = (size_t)t0 * LROWS;
+            const int rows = (int)((size_t)B - r0 < (size_t)nt * LROWS ? (size_t)B - r0 : (size_t)nt * LROWS);
+            const dim3 grid(8 * S * ((nt + 7) / 8));
+            auto kern = S == 8 ? (tokens ? lstm_seq_fwd_cluster_kernel<8, true> : lstm_seq_fwd_cluster_kernel<8, false>)
+                               : (tokens ? lstm_seq_fwd_cluster_kernel<4, true> : lstm_seq_fwd_cluster_kernel<4, false>);
+            // (with tokens, xp is the per-token table: only the token rows move with the range)
+            hipLaunchKernelGGL(kern, grid, dim3(512), 0, st, tokens ? xp : xp + r0 * T * (4 * LH),
+                               tokens ? tokens + r0 * tstride : nullptr, tstride, w_hh, hs + r0 * T * LH, cs + r0 * T * LH,
+                               act ? act + r0 * T * (4 * LH) : nullptr, sync, rows, T, nt);
+            if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        }
+        return 0;
     }
     hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(tiles), dim3(512), 0, st, xp, tokens, tstride, w_hh, hs, cs, act, B, T);
     return (int)hipGetLastError();
@@ -727,18 +753,30 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
     if (hidden != LH) return PNMN_ESHAPE;
     const int tiles = (B + LROWS - 1) / LROWS;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int S = workspace ? cluster_split(tiles) : 0;
-    if (S) {
+    const int ctiles = workspace ? lstm_chunk_tiles(tiles) : 0;
+    if (ctiles) {
         int* sync = nullptr;
         hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
         if (e != hipSuccess) return (int)e;
-        const dim3 grid(8 * S * ((tiles + 7) / 8));
         float* px = reinterpret_cast<float*>(static_cast<char*>(workspace) + SYNC_BYTES);
-        if (S == 8)
-            hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<8>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
-        else
-            hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<4>, grid, dim3(512), 0, st, dhs, act, cs, w_hh_t, dgates, px, sync, B, T, tiles);
-        return (int)hipGetLastError();
+        for (int t0 = 0; t0 < tiles; t0 += ctiles) {  // (row ranges, as in pnmn_lstm_seq_fwd; px is reused)
+            const int nt = tiles - t0 < ctiles ? tiles - t0 : ctiles;
+            const int S = cluster_split(nt);
+            if (!S) return PNMN_ESHAPE;
+            const size_t r0 = (size_t)t0 * LROWS;
+            const int rows = (int)((size_t)B - r0 < (size_t)nt * LROWS ? (size_t)B - r0 : (size_t)nt * LROWS);
+            const dim3 grid(8 * S * ((nt + 7) / 8));
+            const float* d = dhs + r0 * T * LH;
+            const float* a = act + r0 * T * (4 * LH);
+            const float* c = cs + r0 * T * LH;
+            float* dg = dgates + r0 * T * (4 * LH);
+            if (S == 8)
+                hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<8>, grid, dim3(512), 0, st, d, a, c, w_hh_t, dg, px, sync, rows, T, nt);
+            else
+                hipLaunchKernelGGL(lstm_seq_bwd_cluster_kernel<4>, grid, dim3(512), 0, st, d, a, c, w_hh_t, dg, px, sync, rows, T, nt);
+            if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        }
+        return 0;
     }
     constexpr size_t lds = (size_t)LROWS * (4 * LH + 4) * sizeof(float);
     static bool cfg = false;

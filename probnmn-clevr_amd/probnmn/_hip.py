@@ -73,6 +73,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_token_table_fwd": (_P, _P, ctypes.c_int64, _P, _I, _I, _I, _P, _P),
     "pnmn_token_table_bwd": (_P, _P, _P, ctypes.c_int64, _I, _I, _I, _I, _P, _P, _P, _P),
     "pnmn_lstm_seq_workspace_bytes": (_I, _I),
+    "pnmn_cluster_reserve_cus": (_I,),
     "pnmn_attn_lstm_fwd": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P),
     "pnmn_attn_lstm_bwd": (_P,) * 14 + (_I,) * 4 + (_P,),
     "pnmn_attn_lstm_multi_workspace_bytes": (_I, _I),
@@ -86,7 +87,7 @@ SIGNATURES: Dict[str, tuple] = {
 }
 
 
-ABI_VERSION = 3  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 4  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:

@@ -105,6 +105,9 @@ class NMNEngine:
         # being timed one by one (event_log) or spread over two streams (overlap_wgrad)
         self._list: Optional[_hip.LaunchList] = None
         self.launch_lists = os.environ.get("PNMN_LAUNCH_LISTS", "1") != "0"
+        # data parallel: called with k when every kernel that writes gradient piece k of the arena has been
+        # queued (see grad_pieces); a trainer points it at its EarlyReducer.piece_ready
+        self.on_grad_piece = None
 
     def _conv_bytes(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
         """Algorithmic HBM bytes of one grouped conv call (roofline accounting only): every map an item must
@@ -197,6 +200,17 @@ class NMNEngine:
             self._ws.clear()
             self._fixed_cache.clear()
         return self.arena
+
+    def grad_pieces(self):
+        """The trunk gradient arena as contiguous float ranges in the order backward completes them: piece 0 =
+        classifier conv + every module (final once the deferred module / projection weight gradients are queued:
+        ~48 of 52 MB), piece 1 = the stem (final with the last kernel of the trunk backward).  Parameters sit in
+        ``named_parameters`` order: stem.0, stem.2, classifier.0, then one child per program token."""
+        a = self.ensure_arena()
+        cut = a.offsets["classifier.0.weight"]
+        assert all(a.offsets[n] < cut for n in a.names if n.startswith("stem.")) and \
+            all(a.offsets[n] >= cut for n in a.names if not n.startswith("stem."))
+        return [(a, cut, a.total), (a, 0, cut)]
 
     def _build_tables(self) -> None:
         a = self.arena
@@ -462,8 +476,8 @@ class NMNEngine:
                 # with them, whereas in run_backward nothing runs on this stream until the list is complete
                 # (0.4 ms of host time per step on the critical path of a small batch)
                 self._begin_list()
-                cut, where = self._queue_backward(state, 0, st, live=False)
-                state.backward_rows = (np.array(self._list._rows, dtype=np.uint64), cut, where)
+                cuts, where = self._queue_backward(state, 0, st, live=False)
+                state.backward_rows = (np.array(self._list._rows, dtype=np.uint64), cuts, where)
                 self._list = None
         return pooled, state
 
@@ -503,7 +517,15 @@ class NMNEngine:
         plan, pack, B = state.plan, state.pack, state.B
         H, W, HW = self.H, self.W, self.HW
         ws = self._ws
-        cut = 0
+        cuts = []  # (rows queued before it, what the host does there): "feat" = the torch op, ("piece", k) = on_grad_piece(k)
+
+        def host_action(what):
+            if live:
+                self._flush_list(st, "trunk backward")  # (everything before it must be queued)
+                self._host_action(what, plan, ws, B, dev)
+            else:
+                cuts.append((len(self._list), what))
+
         self._op(_hip.OP_TRANSPOSE_WEIGHTS, "pnmn_transpose_weights", self._wt_count, self._wt_records.data_ptr(), st,
                  "transpose weights")
 
@@ -532,11 +554,7 @@ class NMNEngine:
                     "classifier wgrad")
         self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad", rec=state.fixed["cls_dgrad"])
         if plan.feat_result_examples.size:
-            if live:
-                self._flush_list(st, "classifier backward")  # (a torch op follows: everything before it must be queued)
-                self._feat_result_backward(plan, ws, B, dev)
-            else:
-                cut = len(self._list)
+            host_action("feat")
 
         # module programs, levels in reverse; each group of module-conv weight gradients is released
         # to the side stream as soon as the data-gradient chain has passed its lowest level
@@ -576,6 +594,8 @@ class NMNEngine:
         if nj:
             self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, side,
                         "projection wgrad")
+        if self.on_grad_piece is not None and side is main:
+            host_action(("piece", 0))  # classifier conv + all module gradients are final behind these launches
 
         # stem: gfeat is complete here
         nj = len(state.fixed["stem2_wg_jobs"])
@@ -589,7 +609,13 @@ class NMNEngine:
             ev = torch.cuda.Event()
             ev.record(side)
             main.wait_event(ev)
-        return cut, where
+        return cuts, where
+
+    def _host_action(self, what, plan, ws, B, dev) -> None:
+        if what == "feat":
+            self._feat_result_backward(plan, ws, B, dev)
+        elif self.on_grad_piece is not None:
+            self.on_grad_piece(what[1])
 
 
     def run_backward(self, state: _State, dpooled: torch.Tensor):
@@ -615,18 +641,22 @@ class NMNEngine:
         pre = state.backward_rows
         if pre is not None and self.event_log is None and not self.overlap_wgrad and self.launch_lists:
             # the launch list was put together behind the forward pass (run_forward): only d(pooled) is new
-            rows, cut, where = pre
+            rows, cuts, where = pre
             rows[where, 1] = dpooled.data_ptr()
             lib_run = _hip.lib().pnmn_run_launches
-            if cut:
-                chk(lib_run(rows.ctypes.data, cut, st), "classifier backward")
-                self._feat_result_backward(plan, ws, B, dev)
-            if rows.shape[0] > cut:
-                chk(lib_run(rows[cut:].ctypes.data, rows.shape[0] - cut, st), "trunk backward")
+            at = 0
+            for upto, what in cuts + [(rows.shape[0], None)]:
+                if upto > at:
+                    chk(lib_run(rows[at:upto].ctypes.data, upto - at, st), "trunk backward")
+                    at = upto
+                if what is not None:
+                    self._host_action(what, plan, ws, B, dev)
         else:
             self._begin_list()
-            cut, _ = self._queue_backward(state, dpooled.data_ptr(), st, live=True)
+            self._queue_backward(state, dpooled.data_ptr(), st, live=True)
             self._flush_list(st, "trunk backward", end=True)
+        if self.on_grad_piece is not None:
+            self.on_grad_piece(1)  # the stem's gradients: the last kernels of the trunk backward are queued
 
         if self.direct_grads:
             a.attach_grads()

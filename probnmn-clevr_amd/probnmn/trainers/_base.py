@@ -33,6 +33,8 @@ class StepBase:
         early = getattr(self, "_early", None)
         if early is not None:
             early.remove()
+            for e in getattr(early, "engines", ()):
+                e.on_grad_piece = None
             self._early = None
 
     # ---- checkpoint (reference layout) -----------------------------------------------------------

@@ -58,7 +58,7 @@ class _TrainerBase(StepBase):
         # (plain grouped launches), well before the multi-CU recurrent kernels of the seq2seq backward,
         # which want the whole chip to themselves
         big = [p for p in optimizer.loose if p.numel() >= (1 << 20)]
-        self._early = parallel.EarlyReducer(big) if big else None
+        self._early = parallel.early_reducer_for(big, [m.engine for m in models if hasattr(m, "engine")])
         return optimizer
 
     def _finish(self, loss: torch.Tensor) -> None:

@@ -22,7 +22,7 @@ class ModuleTrainingStep(StepBase):
         self.optimizer = ClampAdam(nmn.parameters(), arenas=[arena], lr=lr, weight_decay=weight_decay, clamp=5.0)
         # data parallel: the big loose FC gradient starts its all-reduce while the trunk is still in backward
         big = [p for p in self.optimizer.loose if p.numel() >= (1 << 20)]
-        self._early = parallel.EarlyReducer(big) if big else None
+        self._early = parallel.early_reducer_for(big, [nmn.engine])
         self.models = {"nmn": nmn}  # (the frozen program generator is not checkpointed by this phase)
         self._init_schedule(lr_gamma, lr_patience)
         self.iteration = 0

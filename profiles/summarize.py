@@ -4,8 +4,38 @@
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o NAME -- python bench.py ...
     python profiles/summarize.py gpurun_out/prof/NAME_results.db > profiles/rNN_kernel_stats.txt
 """
+import glob
+import hashlib
+import os
 import sqlite3
+import subprocess
 import sys
+
+
+def source_sha(root=None):
+    """16 hex digits over everything a kernel's HBM traffic depends on: csrc/*.hip, csrc/*.h, include/*.h and the
+    launch planner (probnmn/runtime/*.py).  bench.py quotes a PMC summary only when this matches its own."""
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "probnmn-clevr_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h"))
+                   + glob.glob(os.path.join(root, "include", "*.h")) + glob.glob(os.path.join(pkg, "probnmn", "runtime", "*.py")))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def provenance():
+    """Header lines tying a summary to the sources it was measured on (and to the commit, where git is at hand)."""
+    print("# source_sha: %s" % source_sha())
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10)
+        if head.returncode == 0:
+            print("# commit: %s" % head.stdout.strip())
+    except Exception:
+        pass
 
 
 def main(path):
@@ -20,6 +50,7 @@ def main(path):
     rows = list(cur.execute(q))
     total = sum(r[2] for r in rows)
     print("# kernel-trace summary of %s" % path)
+    provenance()
     print("# total kernel time %.3f ms over %d dispatches" % (total / 1e6, sum(r[1] for r in rows)))
     print("%-72s %8s %12s %11s %10s %10s %6s %5s %5s %5s %7s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct", "vgpr", "agpr", "sgpr", "lds"))
     for r in rows:
@@ -40,6 +71,7 @@ def pmc(path):
             join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
             join rocpd_info_pmc{suffix} i on i.id = e.pmc_id
             group by s.kernel_name, i.name order by 4 desc"""
+    provenance()
     print("# PMC summary of %s (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide" % path)
     print("# coalesced reads at half their bytes -- MI355X_MICROARCH.md, HBM section)")
     print("%-72s %-12s %8s %14s %12s" % ("kernel", "counter", "calls", "sum", "avg/launch"))
@@ -69,6 +101,7 @@ def mfma(path):
         a[ctr + "#"] = n / max(disp, 1)  # instances the counter is reported in per dispatch (XCDs / shader engines)
         a["calls"] = disp
     print("# MFMA utilisation of %s" % path)
+    provenance()
     print("# util = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip) / (GPU-active cycles x 1024 SIMDs); GRBM_GUI_ACTIVE")
     print("# is reported once per XCD, so active cycles = its sum / its instances per dispatch")
     print("%-88s %8s %16s %14s %8s" % ("kernel", "calls", "MFMA_BUSY_CYCLES", "active cycles", "util"))

@@ -49,13 +49,23 @@ def _worker(rank, world, port, out_path):
     parallel.broadcast_parameters([arena], [loose, scale, shift])
     w = arena.flat.view(3, 5).clone().requires_grad_(True)
     early = parallel.EarlyReducer([])          # no parameters registered: everything reduced at the end
-    early2 = parallel.EarlyReducer([loose])    # the loose parameter's all-reduce starts inside backward
+    # the loose parameter's all-reduce starts inside backward; the arena travels as two pieces (engine.grad_pieces:
+    # floats 5..15 are final first, 0..5 last) plus whatever no piece covers (nothing here)
+    early2 = parallel.EarlyReducer([loose], pieces=[(arena, 5, 15), (arena, 0, 5)])
     shard = slice(rank * 4, rank * 4 + 4)
     loss = (((X[shard] @ w.T + loose) * scale + shift - Y[shard]) ** 2).sum(1).mean()
     early2.arm()  # (what a trainer does right before its backward)
     loss.backward()
     arena.grad.copy_(w.grad.reshape(-1))
     assert id(loose) in early2._pending  # the hook fired during backward; taken by all_reduce_gradients below
+    if rank == 0:
+        # only THIS rank announces piece 0 during "backward" (the other's shard had no rows for it): rank 1 issues
+        # the same collective from all_reduce_gradients, in the same slot order
+        early2.piece_ready(0)
+        assert ("piece", 0) in early2._pending and ("piece", 1) not in early2._pending
+    else:
+        early2.piece_ready(1)  # out of order: held back until the slots before it have been started
+        assert ("piece", 1) not in early2._pending
     parallel.all_reduce_gradients([arena], [loose, scale, shift], early=early2)
     sums = parallel.all_reduce_scalars(torch.tensor([float(rank + 1), 4.0]))
     # loss terms are means over data-dependent subsets: shard sizes 3 and 5 here.  The trainers weight
