@@ -370,6 +370,7 @@ class NMNEngine:
         # probnmn.data.feature_store: the ingest kernel writes NHWC): used in place, no layout pass
         nhwc = (features.dtype == torch.float32 and not features.is_contiguous()
                 and features.is_contiguous(memory_format=torch.channels_last))
+        subset = rows is not None
         if nhwc and rows is not None:  # (a row subset of an NHWC batch: gather it, the layout pass is what reads through rows)
             features, rows = features[rows], None
             nhwc = (not features.is_contiguous()) and features.is_contiguous(memory_format=torch.channels_last)
@@ -406,14 +407,14 @@ class NMNEngine:
         self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2", rec=fixed["stem2"])
         self._flush_list(st, "stem", end=True)
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
-                "features": features, "pack": pack, "rows": rows}
+                "features": features, "pack": pack, "rows": rows, "subset": subset}
 
     def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
                     started=None):
         if started is None:
             started = self.begin_forward(features, need_backward)
         elif (started["generation"] != self.generation or started["need_backward"] != need_backward
-              or (started["rows"] is None and started["B"] != features.size(0))):
+              or (not started["subset"] and started["B"] != features.size(0))):
             raise ValueError("begin_forward token does not belong to this forward pass")
         a = self.ensure_arena()
         lib = _hip.lib()

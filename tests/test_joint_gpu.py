@@ -6,7 +6,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_joint_training_step_matches_oracle():
+@pytest.mark.parametrize("nhwc_images", [False, True])
+def test_joint_training_step_matches_oracle(nhwc_images):
+    """``nhwc_images``: the batch's features as the ingest kernel hands them over (a channels_last tensor, used in
+    place by the stem; the joint step then takes the unsupervised rows out of it)."""
     from oracle.train_oracle import OracleJointTrainer
     from probnmn.data.synthetic import synthetic_batch
     from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
@@ -29,6 +32,8 @@ def test_joint_training_step_matches_oracle():
     step = JointTrainingStep(pg, qr, prior, nmn, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=lr)
     dbatch = {k: v.to(dev) for k, v in batch.items()}
     dbatch["supervision"] = batch["supervision"]  # host copy: no sync for the split
+    if nhwc_images:
+        dbatch["image"] = dbatch["image"].contiguous(memory_format=torch.channels_last)
     out = step.step(dbatch)
     seen = {"z": out["programs"].detach().cpu()}  # the sampled programs the elbo saw
     torch.cuda.synchronize()
@@ -99,3 +104,70 @@ def test_question_coding_step_matches_oracle():
             got = p.grad.detach().cpu().clamp(-5, 5)
             scale = float(g_ref.abs().max()) + 1e-12
             assert float((got - g_ref).abs().max()) / scale < 5e-3, (key, name)
+
+
+def test_joint_training_step_at_config5_shapes_matches_oracle():
+    """BASELINE configs[4] as ONE composed iteration: 28x28 feature maps through the banded conv kernels, a generator
+    that decodes 40 steps (supervised programs of up to 40 tokens, synthetic deep shapes), reconstructor, prior,
+    REINFORCE-ELBO, clamp, Adam -- against OracleJointTrainer(pg_steps=40) replaying the device's samples.  (Reduced
+    classifier widths: the 200704 -> 1024 layer is covered at full size by tests/test_nmn_gpu.py.)"""
+    from oracle.train_oracle import OracleJointTrainer
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    size = (1024, 28, 28)
+    torch.manual_seed(5)
+    pg, qr = ProgramGenerator(vocab, max_decoding_steps=40), QuestionReconstructor(vocab)
+    prior = ProgramPrior(vocab, hidden_size=256)
+    nmn = NeuralModuleNetwork(vocab, image_feature_size=size, class_projection_channels=128, classifier_linear_size=64)
+    sds = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (pg, qr, prior, nmn)]
+    sds[2].pop("_output_layer.weight")
+    batch = synthetic_batch(vocab, 10, image_feature_size=size, seed=6, deep=True)
+    assert int((batch["program"] != 0).sum(1).max()) > 26  # longer than the 14x14 configurations' 26 steps
+    batch["supervision"] = torch.tensor([1, 0, 0, 1, 0, 1, 0, 0, 1, 0])
+    for m in (pg, qr, prior, nmn):
+        m.to(dev)
+    # teach the generator the deep programs for a few iterations so that its SAMPLES contain valid long programs
+    from probnmn.optim import ClampAdam
+
+    opt = ClampAdam(list(pg.parameters()), lr=2e-3, clamp=5.0)
+    q_dev, p_dev = batch["question"].to(dev), batch["program"].to(dev)
+    for _ in range(150):
+        opt.zero_grad()
+        pg(q_dev, p_dev, decoding_strategy="sampling")["loss"].mean().backward()
+        opt.step()
+    sds[0] = {k: v.detach().cpu().clone() for k, v in pg.state_dict().items()}
+    lr = 1e-4
+    hyper = dict(objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=lr)
+    step = JointTrainingStep(pg, qr, prior, nmn, **hyper)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    dbatch["supervision"] = batch["supervision"]
+    out = step.step(dbatch)
+    z = out["programs"].detach().cpu()
+    torch.cuda.synchronize()
+    assert z.shape[1] == 40
+    ref = OracleJointTrainer(*sds, vocab.get_index_to_token_vocabulary("programs"), pg_steps=40, **hyper)
+    ref_out = ref.step(batch, forced_programs=z)
+    assert torch.equal(ref_out["programs"], z)
+    valid = nmn.engine.compiler.compile_batch(z)
+    assert sum(1 for c in valid if c.valid) >= 3, "the fitted generator should sample valid deep programs"
+    assert float(out["loss"]["nmn"]) == pytest.approx(float(ref_out["nmn_loss"]), rel=1e-4, abs=1e-4)
+    for k in ("elbo", "kl_divergence", "reconstruction_likelihood", "reinforce_reward"):
+        assert float(out["elbo"][k]) == pytest.approx(float(ref_out["elbo"][k]), rel=1e-4, abs=1e-4), k
+    assert float(out["objective"]) == pytest.approx(float(ref_out["objective"]), rel=1e-4, abs=1e-3)
+    for key, model in (("pg", pg), ("qr", qr), ("nmn", nmn)):
+        for name, p in model.named_parameters():
+            g_ref = ref_out["grads"][key][name]
+            if g_ref is None or p.grad is None:
+                continue
+            got = p.grad.detach().cpu().clamp(-5, 5)
+            # flip-proof l2 bar for the trunk (a gate within round-off of zero reroutes one example's gradient:
+            # tests/test_nmn_per_module_gpu.py holds the tight per-kind bar), max-norm bar for the seq2seq models
+            if key == "nmn":
+                assert float((got - g_ref).norm()) <= 5e-2 * float(g_ref.norm()) + 1e-9, (key, name)
+            else:
+                assert float((got - g_ref).abs().max()) / (float(g_ref.abs().max()) + 1e-12) < 5e-3, (key, name)
