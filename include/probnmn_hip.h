@@ -193,6 +193,10 @@ typedef struct pnmn_axpy_item {
     int64_t      n;
 } pnmn_axpy_item;         /* 24 bytes */
 int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream);
+/* dst[0..n) = src[0..n), or zeros where src is NULL: the classifier-input rows of programs whose result is the stem's
+ * feature map itself (nmn.py:227-233: `output` stays feat_input) and of invalid programs (nmn.py:236-238:
+ * zeros_like(feat_input)) -- one launch instead of an index_fill_ and an index_copy_ between the grouped launches. */
+int pnmn_set_rows(const pnmn_axpy_item* items, int n_items, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout changes at the boundary: the reference hands NCHW features (datasets.py:137-142).
@@ -474,6 +478,9 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
 #define PNMN_OP_MAXPOOL_FWD       10
 #define PNMN_OP_MAXPOOL_BWD       11
 #define PNMN_OP_NCHW_TO_NHWC      12
+#define PNMN_OP_SET_ROWS          13   /* a items, n                                      (pnmn_set_rows) */
+#define PNMN_OP_ACCUMULATE        14   /* a items, n                                      (pnmn_accumulate) */
+#define PNMN_OP_ZERO              15   /* a device pointer, b = byte count (as a pointer-sized integer): hipMemsetAsync */
 typedef struct pnmn_launch {
     const void* a;
     const void* b;
@@ -483,6 +490,59 @@ typedef struct pnmn_launch {
     int32_t     p[8];
 } pnmn_launch;             /* 64 bytes */
 int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Trunk planner: sampled programs -> launched module programs in ONE call (host side; replaces the per-example
+ * interpreter loop nmn.py:191-241 together with the Python half of the scheduler that used to sit between the
+ * sampling decode and the first module launch of a joint-training step: joint_training_trainer.py:150-166).
+ *
+ *   create   per network: token kinds (program_compiler.classify_token), per-token weight offset tables (floats
+ *            into the parameter / gradient / transposed-weight arenas; -1 = none), map size.
+ *   plan_and_launch
+ *            programs (HOST int64 [n][length]) -> compiled (cache keyed by the token row) -> structure templates
+ *            (cache keyed by the call structure: primitives, dependency levels, arena offsets) -> pnmn_plan_batch
+ *            straight into page-locked staging -> one H2D copy into a device buffer the planner owns -> the forward
+ *            launch list (SET_ROWS for invalid / feature-result programs, the level-ordered grouped launches,
+ *            `fwd_tail`) issued on `stream`; the backward list (`bwd_head`, ZERO of the gradient arena block,
+ *            ACCUMULATE for feature-result programs, levels in reverse, deferred weight gradients, `bwd_tail`) is
+ *            written to `bwd` for pnmn_run_launches once d(pooled) exists.  `bwd_piece_cut` = number of leading
+ *            entries of `bwd` after which every module / classifier-conv gradient has been queued (data parallel:
+ *            that range of the gradient arena may start its all-reduce).
+ *            Returns PNMN_EAGAIN with `arena_floats` set when the activation arena is too small (nothing launched).
+ *   The records stay valid until the next call on the same planner (the backward of this step must be queued, on
+ *   the same stream, before that).
+ * ------------------------------------------------------------------------------------------- */
+#define PNMN_EAGAIN (-3)
+typedef struct pnmn_trunk_config {
+    const int32_t* kinds;      /* [n_kinds] */
+    const int64_t* w3;         /* [n_kinds][6] projection, conv1..conv5 weights */
+    const int64_t* b3;         /* [n_kinds][6] biases */
+    const int64_t* wt3;        /* [n_kinds][6] transposed copies */
+    const int64_t* dotw;       /* [n_kinds] one-channel head weight */
+    const int64_t* dotb;       /* [n_kinds] */
+    int32_t n_kinds, channels, H, W, wgrad_chunk, wgrad_groups, fuse_mask_bwd, sole_writer, sort_by_weight, reserved;
+} pnmn_trunk_config;       /* 88 bytes */
+typedef struct pnmn_trunk_io {
+    const int64_t*     programs;      /* in: host [n_programs][length] */
+    uint64_t           params, grads, wt, act, gact, feat, gfeat, final_, gfinal, ones;  /* in: device bases */
+    int64_t            act_capacity;  /* in: floats behind act (and gact) */
+    const pnmn_launch* fwd_tail;      /* in: host, appended to the forward list */
+    const pnmn_launch* bwd_head;      /* in: host, opens the backward list */
+    const pnmn_launch* bwd_tail;      /* in: host, closes it */
+    pnmn_launch*       bwd;           /* out: host [bwd_capacity] */
+    uint8_t*           valid;         /* out: host [n_programs] */
+    int64_t            arena_floats;  /* out */
+    int32_t            n_programs, length, n_fwd_tail, n_bwd_head, n_bwd_tail, bwd_capacity, need_backward, launch;
+    int32_t            n_bwd, bwd_piece_cut, n_prims, n_fwd, depth, n_invalid, n_feat_result, reserved;
+} pnmn_trunk_io;           /* 208 bytes */
+int pnmn_trunk_planner_create(const pnmn_trunk_config* config, void** planner);
+int pnmn_trunk_planner_destroy(void* planner);
+int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream);
+/* test hook: the forward list of the last call (launch == 0 leaves it un-issued); returns the entry count */
+int pnmn_trunk_last_forward(void* planner, pnmn_launch* out, int capacity);
+/* test hook: the record words of the last launch == 0 call (the list entries then point into a buffer that would start
+ * at device address 0x10000); returns their size in bytes */
+int64_t pnmn_trunk_last_records_bytes(void* planner, uint64_t* out, int64_t capacity_words);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side batch planner (no device work)                    replaces the per-example interpreter loop of
@@ -535,7 +595,7 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
-/* Library self-description (no GPU needed).  4 = round 3: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* Library self-description (no GPU needed).  5 = round 3: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

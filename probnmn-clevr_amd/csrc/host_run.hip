@@ -4,6 +4,7 @@
 // bound by exactly that host time.  The list is built by the scheduler (probnmn/runtime/engine.py) from the
 // same work-item records; each entry is one call of the entry point named by `op` with the arguments it
 // would have received -- nothing else changes.
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
@@ -61,6 +62,16 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
                                                   static_cast<const int64_t*>(l.c), l.n, p[0], p[1], stream)
                          : pnmn_nchw_to_nhwc(static_cast<const float*>(l.a), static_cast<float*>(const_cast<void*>(l.b)), l.n,
                                              p[0], p[1], stream);
+                break;
+            case PNMN_OP_SET_ROWS:
+                rc = pnmn_set_rows(static_cast<const pnmn_axpy_item*>(l.a), l.n, stream);
+                break;
+            case PNMN_OP_ACCUMULATE:
+                rc = pnmn_accumulate(static_cast<const pnmn_axpy_item*>(l.a), l.n, stream);
+                break;
+            case PNMN_OP_ZERO:
+                rc = (int)hipMemsetAsync(const_cast<void*>(l.a), 0, (size_t)reinterpret_cast<uintptr_t>(l.b),
+                                         static_cast<hipStream_t>(stream));
                 break;
             default:
                 return PNMN_EINVAL;

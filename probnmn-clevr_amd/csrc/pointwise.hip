@@ -352,6 +352,17 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const pnmn_axpy_item* _
     for (int64_t i = (n4 << 2) + threadIdx.x; i < it.n; i += blockDim.x) it.dst[i] += it.src[i];
 }
 
+// dst = src (or zeros): a few 100 KB rows per launch, eight workgroups per row
+__global__ __launch_bounds__(256) void set_rows_kernel(const pnmn_axpy_item* __restrict__ items) {
+    const pnmn_axpy_item it = items[blockIdx.x];
+    const int64_t n4 = it.n >> 2;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.y * blockDim.x)
+        reinterpret_cast<f32x4*>(it.dst)[i] = it.src ? reinterpret_cast<const f32x4*>(it.src)[i] : zero;
+    if (blockIdx.y == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < it.n; i += blockDim.x) it.dst[i] = it.src ? it.src[i] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight transposition for dgrad: [Cout][T][Cin] -> [Cin][T-1-t][Cout]
 // ------------------------------------------------------------------------------------------------
@@ -688,7 +699,7 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
 
 extern "C" {
 
-int pnmn_abi_version(void) { return 4; }
+int pnmn_abi_version(void) { return 5; }
 
 int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
     if (n_items <= 0) return 0;
@@ -743,6 +754,13 @@ int pnmn_accumulate(const pnmn_axpy_item* items, int n_items, void* stream) {
     if (n_items <= 0) return 0;
     if (!items) return PNMN_EINVAL;
     hipLaunchKernelGGL(accumulate_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items);
+    return last_error();
+}
+
+int pnmn_set_rows(const pnmn_axpy_item* items, int n_items, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items) return PNMN_EINVAL;
+    hipLaunchKernelGGL(set_rows_kernel, dim3(n_items, 8), dim3(256), 0, STREAM(stream), items);
     return last_error();
 }
 

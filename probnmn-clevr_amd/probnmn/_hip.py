@@ -81,13 +81,19 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_bwd_multi": (_P,) * 15 + (_I,) * 4 + (_P, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_run_launches": (_P, _I, _P),
+    "pnmn_set_rows": (_P, _I, _P),
+    "pnmn_trunk_planner_create": (_P, _P),
+    "pnmn_trunk_planner_destroy": (_P,),
+    "pnmn_trunk_plan_and_launch": (_P, _P, _P),
+    "pnmn_trunk_last_forward": (_P, _P, _I),
+    "pnmn_trunk_last_records_bytes": (_P, _P, ctypes.c_int64),
     "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
 
 
-ABI_VERSION = 4  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 5  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:
@@ -201,11 +207,23 @@ PLAN_IN = np.dtype([(n, _u64) for n in ("tables", "nprims", "tids", "examples", 
                                          "final_", "gfinal", "ones")]
                    + [(n, _i32) for n in ("n_templates", "pmax", "nv", "cmax", "hw", "channels", "wgrad_chunk",
                                           "wgrad_groups", "fuse_mask_bwd", "sole_writer", "sort_by_weight", "reserved")])
+TRUNK_CONFIG = np.dtype([(n, _u64) for n in ("kinds", "w3", "b3", "wt3", "dotw", "dotb")]
+                        + [(n, _i32) for n in ("n_kinds", "channels", "H", "W", "wgrad_chunk", "wgrad_groups", "fuse_mask_bwd",
+                                               "sole_writer", "sort_by_weight", "reserved")])
+TRUNK_IO = np.dtype([(n, _u64) for n in ("programs", "params", "grads", "wt", "act", "gact", "feat", "gfeat", "final_", "gfinal",
+                                          "ones")]
+                    + [("act_capacity", np.int64)]
+                    + [(n, _u64) for n in ("fwd_tail", "bwd_head", "bwd_tail", "bwd", "valid")]
+                    + [("arena_floats", np.int64)]
+                    + [(n, _i32) for n in ("n_programs", "length", "n_fwd_tail", "n_bwd_head", "n_bwd_tail", "bwd_capacity",
+                                           "need_backward", "launch", "n_bwd", "bwd_piece_cut", "n_prims", "n_fwd", "depth",
+                                           "n_invalid", "n_feat_result", "reserved")])
+EAGAIN = -3
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
 (OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
- OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC) = range(13)
+ OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO) = range(16)
 
 
 class LaunchList:
@@ -245,6 +263,8 @@ ITEM_SIZES = {
     "pnmn_adam_item": (ADAM_ITEM, 40),
     "pnmn_derive_job": (DERIVE_JOB, 40),
     "pnmn_plan_in": (PLAN_IN, 216),
+    "pnmn_trunk_config": (TRUNK_CONFIG, 88),
+    "pnmn_trunk_io": (TRUNK_IO, 208),
 }
 
 

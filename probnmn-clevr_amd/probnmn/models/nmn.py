@@ -30,13 +30,26 @@ from probnmn.running_metrics import Average, BooleanAccuracy
 INVALID_PROGRAM_LOSS = 3.33  # ~ ln(28), the reference's constant (nmn.py:260,269)
 
 
+class _Tokens:
+    """A batch of programs as the host token matrix, on its way through the library's trunk planner
+    (``NMNEngine.run_forward_tokens``); ``valid`` is filled in by the forward pass."""
+
+    __slots__ = ("tokens", "valid")
+
+    def __init__(self, tokens):
+        self.tokens, self.valid = tokens, None
+
+
 class _Trunk(torch.autograd.Function):
     """stem -> module programs -> classifier conv + max-pool, as one autograd node."""
 
     @staticmethod
     def forward(ctx, features, engine, compiled, started, *params):
         need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
-        pooled, state = engine.run_forward(features, compiled, need_backward, started)
+        if isinstance(compiled, _Tokens):  # the library compiles, plans and launches from the token matrix
+            pooled, state, compiled.valid = engine.run_forward_tokens(features, compiled.tokens, need_backward, started)
+        else:
+            pooled, state = engine.run_forward(features, compiled, need_backward, started)
         ctx.engine, ctx.state, ctx.n_params = engine, state, len(params)
         return pooled
 
@@ -178,7 +191,8 @@ class NeuralModuleNetwork(nn.Module):
         # the programs decide the launch schedule, so they are needed on the host (the reference
         # also reads them back, once per example: nmn.py:203)
         # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
-        compiled = engine.compiler.compile_batch(programs.detach().cpu().numpy())
+        tokens = programs.detach().cpu().numpy()
+        compiled = _Tokens(tokens) if engine.use_native() else engine.compiler.compile_batch(tokens)
 
         # the trunk's parameters as inputs of its autograd node -- all of them when autograd is to receive
         # their gradients; ONE anchor when a trainer reads the gradients straight from the arena
@@ -201,7 +215,11 @@ class NeuralModuleNetwork(nn.Module):
         pooled, compiled, trunk_stream = trunk
         # (staged here, not in forward_trunk: the host's time between the sampled programs' arrival and the trunk's
         # launch is on the critical path of a small-batch step)
-        valid = _hip.small_to_device([int(p.valid) for p in compiled], torch.int32, pooled.device)
+        if isinstance(compiled, _Tokens):
+            valid_host = compiled.valid.tolist()
+        else:
+            valid_host = [int(p.valid) for p in compiled]
+        valid = _hip.small_to_device(valid_host, torch.int32, pooled.device)
         if trunk_stream is not None:
             current = torch.cuda.current_stream(pooled.device)
             current.wait_stream(trunk_stream)
@@ -220,7 +238,7 @@ class NeuralModuleNetwork(nn.Module):
         loss, answer_predictions = _AnswerLoss.apply(answer_logits, answers, valid, self._unknown_answer)
         if answers is not None and (self.report_batch_metrics or not self.training):
             self._answer_accuracy(answer_predictions, answers)
-            self._average_invalid_programs(sum(1 for p in compiled if not p.valid))
+            self._average_invalid_programs(sum(1 for v in valid_host if not v))
 
         output_dict = {"predictions": answer_predictions, "loss": loss}
         if self.training and self.report_batch_metrics:

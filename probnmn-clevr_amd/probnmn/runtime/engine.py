@@ -63,6 +63,16 @@ class _Pack:
         return self.device_buf.data_ptr() + self._offsets[name] + index * self._itemsize[name]
 
 
+class _NativePlan:
+    """What callers read of a step planned by the library (bench.py, tests): counts only."""
+
+    __slots__ = ("n_prims", "arena_floats", "n_forward_launches", "n_backward_launches")
+
+    def __init__(self, n_prims, arena_floats, n_fwd, n_bwd):
+        self.n_prims, self.arena_floats = n_prims, arena_floats
+        self.n_forward_launches, self.n_backward_launches = n_fwd, n_bwd
+
+
 class _State:
     __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows")
 
@@ -108,6 +118,14 @@ class NMNEngine:
         # data parallel: called with k when every kernel that writes gradient piece k of the arena has been
         # queued (see grad_pieces); a trainer points it at its EarlyReducer.piece_ready
         self.on_grad_piece = None
+        # The trunk planner of the library (csrc/host_trunk.hip): programs -> compiled -> templates -> records ->
+        # upload -> launches in ONE call.  The Python planner below (BatchScheduler / _Pack / LaunchList) stays as the
+        # instrumented path: per-launch events for bench.py's roofline pass (event_log), weight gradients on a second
+        # stream (overlap_wgrad), PNMN_NATIVE_PLANNER=0 -- same kernels, same pnmn_plan_batch, same launch order
+        # (tests/test_trunk_planner.py compares the two lists entry for entry).
+        self.native = os.environ.get("PNMN_NATIVE_PLANNER", "1") != "0"
+        self._planner = None
+        self._native_fixed: Dict[tuple, dict] = {}
 
     def _conv_bytes(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
         """Algorithmic HBM bytes of one grouped conv call (roofline accounting only): every map an item must
@@ -499,6 +517,133 @@ class NMNEngine:
             else:
                 raise AssertionError(l.kind)
 
+
+    # ---- the library's trunk planner ------------------------------------------------------------------
+    def use_native(self) -> bool:
+        return self.native and self.event_log is None and not self.overlap_wgrad and self.launch_lists
+
+    def _native_planner(self) -> int:
+        if self._planner is None:
+            t = self.tables
+            kinds = np.ascontiguousarray(self.compiler.kinds, dtype=np.int32)
+            arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (t.w3, t.b3, t.wt3, t.dotw, t.dotb)]
+            cfg = np.zeros(1, _hip.TRUNK_CONFIG)
+            cfg[0] = (kinds.ctypes.data,) + tuple(a.ctypes.data for a in arrs) + (
+                kinds.size, C, self.H, self.W, self.scheduler.wgrad_chunk, self.scheduler.wgrad_groups,
+                int(self.scheduler.fuse_mask_bwd), int(self.scheduler.sole_writer_rmw),
+                int(not os.environ.get("PNMN_NO_WEIGHT_SORT")), 0)
+            out = np.zeros(1, np.uint64)
+            _hip.check(_hip.lib().pnmn_trunk_planner_create(cfg.ctypes.data, out.ctypes.data), "trunk_planner_create")
+            self._planner = int(out[0])
+            self._planner_io = np.zeros(1, _hip.TRUNK_IO)
+            self._planner_bwd = np.zeros((1024, 8), np.uint64)
+            self._planner_valid = np.zeros(4096, np.uint8)
+        return self._planner
+
+    def __del__(self):
+        try:
+            if getattr(self, "_planner", None):
+                _hip.lib().pnmn_trunk_planner_destroy(self._planner)
+        except Exception:
+            pass
+
+    def _native_fixed_rows(self, B: int, ws: Dict[str, torch.Tensor], fixed, dev) -> dict:
+        """What the planner's lists have around the module programs: depends only on B and the workspace addresses,
+        so the records are uploaded ONCE and the launch rows are kept (pooled / d(pooled) are patched in per step)."""
+        key = (B,) + tuple(ws[k].data_ptr() for k in sorted(ws))
+        hit = self._native_fixed.get(key)
+        if hit is not None:
+            return hit
+        if len(self._native_fixed) > 8:
+            self._native_fixed.clear()
+        a = self.arena
+        H, W, HW = self.H, self.W, self.HW
+        pack = _Pack()
+        for k in ("cls", "cls_dgrad", "stem2_dgrad", "cls_wg", "cls_wg_jobs", "stem2_wg", "stem2_wg_jobs", "stem1_wg", "stem1_wg_jobs"):
+            pack.add(k, fixed[k])
+        pack.upload(dev)
+
+        def rows(build):
+            lst = _hip.LaunchList()
+            build(lst)
+            return np.array(lst._rows, dtype=np.uint64).reshape(-1, 8)
+
+        def fwd_tail(l):
+            l.add(_hip.OP_CONV, B, pack.ptr("cls"), p=(H, W, 1, 1, C, self.cproj, self.cproj // C, 1))
+            l.add(_hip.OP_MAXPOOL_FWD, B, ws["cls"].data_ptr(), 0, 0, (H, W, self.cproj))  # b = pooled: per step
+
+        def bwd_head(l):
+            l.add(_hip.OP_ZERO, 0, a.grad.data_ptr(), a.total * 4)
+            l.add(_hip.OP_ZERO, 0, ws["gfeat"].data_ptr(), B * HW * C * 4)
+            l.add(_hip.OP_TRANSPOSE_WEIGHTS, self._wt_count, self._wt_records.data_ptr())
+            l.add(_hip.OP_MAXPOOL_BWD, B, ws["cls"].data_ptr(), 0, ws["gcls"].data_ptr(), (H, W, self.cproj))  # b = d(pooled)
+            l.add(_hip.OP_WGRAD, len(fixed["cls_wg_jobs"]), pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"),
+                  p=(H, W, 1, 1, self.cproj // C, C, self.cproj))
+            l.add(_hip.OP_CONV, B, pack.ptr("cls_dgrad"), p=(H, W, self.cproj // C, 1, self.cproj, C, 1, 0))
+
+        def bwd_tail(l):
+            l.add(_hip.OP_WGRAD, len(fixed["stem2_wg_jobs"]), pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), p=(H, W, 9, 1, 1, C, C))
+            l.add(_hip.OP_CONV, B, pack.ptr("stem2_dgrad"), p=(H, W, 1, 9, C, C, 1, 0))
+            l.add(_hip.OP_WGRAD, len(fixed["stem1_wg_jobs"]), pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"),
+                  p=(H, W, 9, self.cin // C, 1, self.cin, C))
+
+        hit = {"pack": pack, "fwd_tail": rows(fwd_tail), "bwd_head": rows(bwd_head), "bwd_tail": rows(bwd_tail), "dpooled_row": 3}
+        self._native_fixed[key] = hit
+        return hit
+
+    def run_forward_tokens(self, features: torch.Tensor, programs: np.ndarray, need_backward: bool, started=None):
+        """``run_forward`` from the token matrix (HOST int64 [B, T]) through the library's trunk planner: one call
+        compiles, plans, uploads and launches.  Returns (pooled, backward state, validity of every program)."""
+        if started is None:
+            started = self.begin_forward(features, need_backward)
+        elif (started["generation"] != self.generation or started["need_backward"] != need_backward
+              or (not started["subset"] and started["B"] != features.size(0))):
+            raise ValueError("begin_forward token does not belong to this forward pass")
+        a = self.ensure_arena()
+        dev = a.device
+        B, ws, fixed = started["B"], started["ws"], started["fixed"]
+        programs = np.ascontiguousarray(programs, dtype=np.int64)
+        if programs.ndim != 2 or programs.shape[0] != B:
+            raise ValueError("programs must be (%d, length), got shape %s" % (B, programs.shape))
+        st = _hip.stream_ptr(dev)
+        planner = self._native_planner()
+        rows = self._native_fixed_rows(B, ws, fixed, dev)
+        H, W, HW = self.H, self.W, self.HW
+        pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
+        rows["fwd_tail"][1, 1] = pooled.data_ptr()
+        if B > self._planner_valid.size:
+            self._planner_valid = np.zeros(2 * B, np.uint8)
+        act = self._ws.get("act")
+        if act is None:
+            act = self._buf("act", 1 << 20)
+        io = self._planner_io
+        while True:
+            gact = self._buf("gact", act.numel()) if need_backward else act
+            io[0] = (programs.ctypes.data, a.flat.data_ptr(), a.grad.data_ptr(), self.wt.data_ptr(), act.data_ptr(), gact.data_ptr(),
+                     ws["feat"].data_ptr(), ws["gfeat"].data_ptr(), ws["final"].data_ptr(), ws["gfinal"].data_ptr(),
+                     self.ones.data_ptr(), min(act.numel(), gact.numel()),
+                     rows["fwd_tail"].ctypes.data, rows["bwd_head"].ctypes.data, rows["bwd_tail"].ctypes.data,
+                     self._planner_bwd.ctypes.data, self._planner_valid.ctypes.data, 0,
+                     B, programs.shape[1], rows["fwd_tail"].shape[0], rows["bwd_head"].shape[0], rows["bwd_tail"].shape[0],
+                     self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, 0)
+            rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, st)
+            if rc != _hip.EAGAIN:
+                break
+            act = self._buf("act", int(io[0]["arena_floats"]))  # (grows by a quarter beyond what is asked for)
+        _hip.check(rc, "trunk plan_and_launch")
+        out = io[0]
+        valid = self._planner_valid[:B].copy()
+        self.last_plan = _NativePlan(int(out["n_prims"]), int(out["arena_floats"]), int(out["n_fwd"]), int(out["n_bwd"]))
+        state = None
+        if need_backward:
+            state = _State()
+            state.plan, state.pack, state.fixed, state.B = self.last_plan, rows["pack"], fixed, B
+            state.features = started["features"]  # (the stem's weight gradient reads the input again)
+            state.generation = self.generation
+            n = int(out["n_bwd"])
+            state.backward_rows = (self._planner_bwd[:n].copy(), int(out["bwd_piece_cut"]), rows["dpooled_row"])
+        return pooled, state, valid
+
     # ---- backward -------------------------------------------------------------------------------
     def _feat_result_backward(self, plan, ws, B, dev) -> None:
         """Programs whose result is the stem's feature map itself: d(final) goes straight to d(features)."""
@@ -633,6 +778,27 @@ class NMNEngine:
         ws = self._ws
         dpooled = dpooled.contiguous()
 
+        if isinstance(plan, _NativePlan):
+            # the whole list came out of the planner (zeroing of the gradient buffers included): d(pooled) is the only
+            # thing that was not known then
+            rows, piece_cut, where = state.backward_rows
+            rows[where, 1] = dpooled.data_ptr()
+            lib_run = _hip.lib().pnmn_run_launches
+            _hip.mark("trunk backward begins (dpooled ready)")
+            if self.on_grad_piece is not None and 0 < piece_cut < rows.shape[0]:
+                chk(lib_run(rows.ctypes.data, piece_cut, st), "trunk backward")
+                self.on_grad_piece(0)  # classifier conv + all module gradients are final behind these launches
+                chk(lib_run(rows[piece_cut:].ctypes.data, rows.shape[0] - piece_cut, st), "trunk backward (stem)")
+            else:
+                chk(lib_run(rows.ctypes.data, rows.shape[0], st), "trunk backward")
+            if self.on_grad_piece is not None:
+                if not 0 < piece_cut < rows.shape[0]:
+                    self.on_grad_piece(0)
+                self.on_grad_piece(1)
+            if self.direct_grads:
+                a.attach_grads()
+                return [None] * len(a.names)
+            return [a.grad_view(n) for n in a.names]
         _hip.mark("trunk backward begins (dpooled ready)")
         a.grad.zero_()
         if plan.arena_floats:
