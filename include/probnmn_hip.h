@@ -320,6 +320,23 @@ int pnmn_seq_nll_bwd(const float* logits, int64_t logits_bstride, const int64_t*
 int pnmn_elbo_rows(const float* pg_loss, const float* qr_loss, const float* prior_loss, const float* nmn_loss,
                    const float* baseline, float beta, float gamma, int n, float* sums, float* dpg, void* stream);
 
+/* The scalar end of a question-coding / joint-training iteration in ONE launch   question_coding_trainer.py:128-165,
+ * joint_training_trainer.py:150-191 (with elbo.py as above): the ELBO combination over the n sampled rows, the means
+ * of the m supervised rows' cross entropies, the objective
+ *     J = w_unsup (gamma mean(nmn) - mean(elbo)) + w_sup alpha (mean(pg_sup) + mean(qr[n..n+m)))
+ * and its per-row derivatives (the reference's chain of ~30 scalar torch ops and their autograd nodes).
+ *   qr       [n + m]: the reconstructor's per-row losses, sampled rows first, supervised rows behind them
+ *   w_*      device scalars (data parallel: n_local * world / n_global) or NULL = 1
+ *   baseline device scalar b; update_baseline != 0: b += decay * mean(c) after the rows have read it (a single
+ *            process; under data parallelism the caller all-reduces stats[5] = sum(c) and stats[9] = n first)
+ *   stats    [10] = mean(-qr), mean(kl), mean(elbo), mean(R), mean(nmn), sum(c), mean(pg_sup), mean(qr_sup), J, n
+ *   objective [1] = J again (its own tensor on the autograd side)
+ *   d_pg [n], d_qr [n + m], d_nmn [n] (NULL with nmn == NULL), d_pg_sup [m] = dJ / d(row loss) */
+int pnmn_joint_objective(const float* pg, const float* qr, const float* prior, const float* nmn, const float* pg_sup,
+                         float* baseline, const float* w_unsup, const float* w_sup, float alpha, float beta, float gamma,
+                         float decay, int update_baseline, int n, int m, float* stats, float* objective, float* d_pg,
+                         float* d_qr, float* d_nmn, float* d_pg_sup, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused gradient clamp + Adam (trainers: clamp_(-5,5) then optimizer.step()).
  * module_training_trainer.py:94-96, joint_training_trainer.py:182-188, _trainer.py:103-108,193

@@ -120,9 +120,85 @@ __global__ __launch_bounds__(256) void elbo_rows_kernel(const float* __restrict_
     if (threadIdx.x < 6) sums[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// The whole scalar end of a question-coding / joint-training iteration in one launch (one workgroup): the ELBO
+// combination above over the n sampled rows, the means of the m supervised rows' cross entropies, the objective
+//     J = w_u (gamma mean(nmn) - mean(elbo)) + w_s alpha (mean(pg_s) + mean(qr_s))
+// its per-row derivatives, and (single process) the moving-baseline update b += decay mean(c).  qr holds the n
+// sampled rows followed by the m supervised ones (the reconstructor ran once over both).
+//   stats[10] = mean rec, mean kl, mean elbo, mean R, mean nmn, sum c, mean pg_s, mean qr_s, J, n
+//   grads: d_pg[n] = -w_u (c - beta) / n ; d_qr[0..n) = w_u / n, d_qr[n..n+m) = w_s alpha / m ;
+//          d_nmn[n] = w_u gamma / n ; d_pgs[m] = w_s alpha / m
+__global__ __launch_bounds__(256) void joint_objective_kernel(
+    const float* __restrict__ pg, const float* __restrict__ qr, const float* __restrict__ pr, const float* __restrict__ nmn,
+    const float* __restrict__ pgs, float* baseline, const float* __restrict__ w_u_ptr, const float* __restrict__ w_s_ptr,
+    float alpha, float beta, float gamma, float decay, int update_baseline, int n, int m, float* __restrict__ stats,
+    float* __restrict__ objective, float* __restrict__ d_pg, float* __restrict__ d_qr, float* __restrict__ d_nmn, float* __restrict__ d_pgs) {
+    __shared__ float red[8][4];
+    const float b = baseline[0];
+    const float w_u = w_u_ptr ? w_u_ptr[0] : 1.f, w_s = w_s_ptr ? w_s_ptr[0] : 1.f;
+    const float inv_n = n > 0 ? 1.f / (float)n : 0.f, inv_m = m > 0 ? 1.f / (float)m : 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float logq = -pg[i], rec = -qr[i];
+        const float prior = pr ? -pr[i] : 0.f;
+        const float ans = nmn ? -nmn[i] : 0.f;
+        const float R = rec + beta * prior - beta * logq + gamma * ans;
+        const float c = R - b;
+        const float kl = logq * c - beta * logq;
+        acc[0] += rec;
+        acc[1] += kl;
+        acc[2] += rec - kl;
+        acc[3] += R;
+        acc[4] += nmn ? nmn[i] : 0.f;
+        acc[5] += c;
+        d_pg[i] = -w_u * (c - beta) * inv_n;
+        d_qr[i] = w_u * inv_n;
+        if (d_nmn) d_nmn[i] = w_u * gamma * inv_n;
+    }
+    for (int j = threadIdx.x; j < m; j += 256) {
+        acc[6] += pgs[j];
+        acc[7] += qr[n + j];
+        d_pgs[j] = w_s * alpha * inv_m;
+        d_qr[n + j] = w_s * alpha * inv_m;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[k][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+        stats[0] = t[0] * inv_n, stats[1] = t[1] * inv_n, stats[2] = t[2] * inv_n, stats[3] = t[3] * inv_n;
+        stats[4] = t[4] * inv_n, stats[5] = t[5];
+        stats[6] = t[6] * inv_m, stats[7] = t[7] * inv_m;
+        stats[8] = w_u * (gamma * t[4] * inv_n - t[2] * inv_n) + w_s * alpha * (t[6] * inv_m + t[7] * inv_m);
+        stats[9] = (float)n;
+        objective[0] = stats[8];
+        if (update_baseline && n > 0) baseline[0] = b + decay * t[5] * inv_n;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pnmn_joint_objective(const float* pg, const float* qr, const float* prior, const float* nmn, const float* pg_sup,
+                         float* baseline, const float* w_unsup, const float* w_sup, float alpha, float beta, float gamma,
+                         float decay, int update_baseline, int n, int m, float* stats, float* objective, float* d_pg,
+                         float* d_qr, float* d_nmn, float* d_pg_sup, void* stream) {
+    if (n < 0 || m < 0 || !baseline || !stats || !objective) return PNMN_EINVAL;
+    if (n > 0 && (!pg || !qr || !d_pg || !d_qr)) return PNMN_EINVAL;
+    if (m > 0 && (!pg_sup || !qr || !d_pg_sup || !d_qr)) return PNMN_EINVAL;
+    if ((nmn != nullptr) != (d_nmn != nullptr)) return PNMN_EINVAL;
+    hipLaunchKernelGGL(joint_objective_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), pg, qr, prior, nmn,
+                       pg_sup, baseline, w_unsup, w_sup, alpha, beta, gamma, decay, update_baseline, n, m, stats, objective, d_pg,
+                       d_qr, d_nmn, d_pg_sup);
+    return (int)hipGetLastError();
+}
 
 int pnmn_seq_nll_fwd(const float* logits, int64_t logits_bstride, const int64_t* tokens, int64_t tok_bstride,
                      const int64_t* mask_tokens, int64_t mask_bstride, int pad, float* loss, float* lse, int B, int T,

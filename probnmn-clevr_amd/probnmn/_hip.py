@@ -65,6 +65,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_embedding_grad_workspace_bytes": (_I, _I, _I),
     "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
+    "pnmn_joint_objective": (_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),

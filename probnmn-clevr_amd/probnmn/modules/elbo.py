@@ -81,6 +81,50 @@ class _FusedElbo(torch.autograd.Function):
         return d_pg, d_qr, None, d_nmn, None, None, None
 
 
+class _Objective(torch.autograd.Function):
+    """``pnmn_joint_objective``: the ELBO combination over the sampled rows, the supervised rows' mean cross entropies,
+    the objective J = w_u (gamma mean(nmn) - mean(elbo)) + w_s alpha (mean(pg_sup) + mean(qr_sup)) and every per-row
+    derivative in one launch; backward is ONE multiply of the stored derivatives by the incoming dJ.  Replaces the
+    ~30 scalar torch ops (and their autograd nodes) between the models' per-row losses and ``backward()`` of a
+    question-coding / joint-training iteration (reference question_coding_trainer.py:128-165,
+    joint_training_trainer.py:150-191) -- at 128 questions per GPU that chain alone was 0.5 ms of host time."""
+
+    @staticmethod
+    def forward(ctx, pg, qr, prior, nmn, pg_sup, baseline, w_u, w_s, alpha, beta, gamma, decay, update_baseline, n, m):
+        from probnmn import _hip
+
+        dev = baseline.device
+        keep = [None if t is None else t.detach().contiguous() for t in (pg, qr, prior, nmn, pg_sup, w_u, w_s)]
+        out = torch.zeros(11, dtype=torch.float32, device=dev)  # stats[10] + J
+        has_nmn = nmn is not None
+        sizes = (n, n + m, n if has_nmn else 0, m)
+        grads = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        ptrs, at = [], 0
+        for k in sizes:
+            ptrs.append(grads.data_ptr() + 4 * at if k else 0)
+            at += k
+        p = [0 if t is None else t.data_ptr() for t in keep]
+        _hip.check(_hip.lib().pnmn_joint_objective(
+            p[0], p[1], p[2], p[3], p[4], baseline.data_ptr(), p[5], p[6], float(alpha), float(beta), float(gamma),
+            float(decay), int(update_baseline), n, m, out.data_ptr(), out.data_ptr() + 40, ptrs[0], ptrs[1], ptrs[2],
+            ptrs[3], _hip.stream_ptr(dev)), "joint_objective")
+        ctx.save_for_backward(grads)
+        ctx.sizes = sizes
+        ctx.present = (pg is not None, qr is not None, has_nmn, pg_sup is not None)
+        stats, objective = out[:10], out[10]
+        ctx.mark_non_differentiable(stats)
+        return objective, stats
+
+    @staticmethod
+    def backward(ctx, d_objective, _):
+        (grads,) = ctx.saved_tensors
+        grads = grads * d_objective
+        d_pg, d_qr, d_nmn, d_pgs = grads.split(ctx.sizes)
+        has_pg, has_qr, has_nmn, has_pgs = ctx.present
+        return (d_pg if has_pg else None, d_qr if has_qr else None, None, d_nmn if has_nmn else None,
+                d_pgs if has_pgs else None, None, None, None, None, None, None, None, None, None, None)
+
+
 class _ElboWithReinforce(nn.Module):
     def __init__(self, beta: float = 0.1, baseline_decay: float = 0.99):
         super().__init__()
@@ -96,6 +140,30 @@ class _ElboWithReinforce(nn.Module):
             "elbo": fully_monte_carlo_elbo.mean(),
             "reinforce_reward": reinforce_reward.mean(),
         }
+
+    def objective(self, generation_loss, reconstruction_rows, prior_loss, nmn_loss, supervised_generation_loss,
+                  w_unsup, w_sup, alpha: float, gamma: float, n: int, m: int):
+        """The "ours" objective of an iteration from the models' per-row losses, on the device in one launch (see
+        ``_Objective``).  ``reconstruction_rows``: the n sampled rows' reconstruction losses followed by the m supervised
+        ones.  Returns (J, dict of the detached batch statistics the trainers report).  The REINFORCE baseline is
+        updated here (in the kernel in a single process; from the all-reduced sum under data parallelism)."""
+        r = self._reinforce
+        dev = reconstruction_rows.device
+        if r._baseline is None or r._baseline.device != dev:
+            value = 0.0 if r._baseline is None else float(r._baseline)
+            r._baseline = torch.full((), value, dtype=torch.float32, device=dev)
+        single = parallel.world() == 1
+        w_u = w_unsup if isinstance(w_unsup, torch.Tensor) else None
+        w_s = w_sup if isinstance(w_sup, torch.Tensor) else None
+        J, stats = _Objective.apply(generation_loss, reconstruction_rows, prior_loss, nmn_loss, supervised_generation_loss,
+                                    r._baseline, w_u, w_s, alpha, self._beta, gamma, r._baseline_decay, single, n, m)
+        if not single:
+            with torch.no_grad():
+                total = parallel.all_reduce_scalars(torch.stack((stats[5], stats[9])))
+                r._baseline = r._baseline + r._baseline_decay * total[0] / total[1].clamp(min=1.0)
+        out = {"reconstruction_likelihood": stats[0], "kl_divergence": stats[1], "elbo": stats[2], "reinforce_reward": stats[3],
+               "nmn_loss": stats[4], "program_generation_gt": stats[6], "question_reconstruction_gt": stats[7]}
+        return J, out
 
     def _fused(self, generation_loss, reconstruction_loss, prior_loss, nmn_loss, gamma: float) -> Dict[str, torch.Tensor]:
         """The "ours" objectives on the device in one launch (same arithmetic as ``combine`` -> ``_forward``

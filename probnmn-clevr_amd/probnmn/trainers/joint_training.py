@@ -112,6 +112,7 @@ class _TrainerBase(StepBase):
         out = {}
         n_sup, n_nosup = (sup_d.numel() if supervised else 0), (nosup_d.numel() if sampled else 0)
         if n_sup == 0 and n_nosup == 0:
+            out["n_nosup"], out["n_sup"] = 0, 0
             return out
         question = batch["question"]
         if n_sup:
@@ -133,21 +134,46 @@ class _TrainerBase(StepBase):
                 out["programs_host"] = self._host_copy(z)
             if after_sampling is not None:
                 out["after_sampling"] = after_sampling()
+        # per-row losses; "qr_rows" = the sampled rows' reconstruction losses followed by the supervised rows'
         if n_sup:
-            out["pg_sup"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"].mean()
+            out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
         if n_sup and n_nosup:
-            qr_loss = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
-            out["qr"], out["qr_sup"] = qr_loss[:n_nosup], qr_loss[n_nosup:].mean()
+            out["qr_rows"] = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
         elif n_sup:
-            out["qr_sup"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"].mean()
+            out["qr_rows"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"]
         elif reconstruct:
-            out["qr"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
+            out["qr_rows"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
+        out["n_nosup"], out["n_sup"] = n_nosup, n_sup
         if before_prior is not None and n_nosup:
             out["before_prior"] = before_prior(out["programs_host"])
         if n_nosup and prior:
             with torch.no_grad():  # frozen model whose output only enters the detached reward
                 out["prior"] = self.prior(z, need_predictions=False)["loss"]
         return out
+
+
+    @staticmethod
+    def _split_means(p) -> None:
+        """The reference's separate terms from the batched passes' rows (the unfused path: CPU tensors, the joint
+        "baseline" objective): p["qr"] = the sampled rows, p["pg_sup"] / p["qr_sup"] = the supervised rows' means."""
+        n, m = p.get("n_nosup", 0), p.get("n_sup", 0)
+        if "qr_rows" in p:
+            if n:
+                p["qr"] = p["qr_rows"][:n]
+            if m:
+                p["qr_sup"] = p["qr_rows"][n:].mean()
+        if "pg_sup_rows" in p:
+            p["pg_sup"] = p["pg_sup_rows"].mean()
+
+    def _fused_objective(self, p, nmn_rows, w_sup, w_nosup, alpha, gamma):
+        """(J, detached statistics) through ``pnmn_joint_objective`` -- one launch forward, one multiply backward."""
+        n, m = p["n_nosup"], p["n_sup"]
+        return self.elbo.objective(p["pg"]["loss"] if n else None, p["qr_rows"], p.get("prior"), nmn_rows,
+                                   p.get("pg_sup_rows"), w_nosup, w_sup, alpha, gamma, n, m)
+
+
+#: PNMN_FUSED_OBJECTIVE=0: the iteration's scalar end as the chain of torch ops it used to be (A/B aid)
+_FUSED_OBJECTIVE = os.environ.get("PNMN_FUSED_OBJECTIVE", "1") != "0"
 
 
 class QuestionCodingStep(_TrainerBase):
@@ -181,6 +207,17 @@ class QuestionCodingStep(_TrainerBase):
         # synchronised on EVERY rank, whatever this rank's shard holds -- a rank without supervised (or
         # without unsupervised) rows must issue the same sequence of collectives as the others.
         w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
+        if _FUSED_OBJECTIVE and ours and dev.type == "cuda" and "qr_rows" in p:
+            loss, stats = self._fused_objective(p, None, w_sup, w_nosup, self.alpha, 0.0)
+            if p["n_sup"]:
+                out["loss"] = {k: stats[k] for k in ("program_generation_gt", "question_reconstruction_gt")}
+            if p["n_nosup"]:
+                out["elbo"] = {k: stats[k] for k in ("reconstruction_likelihood", "kl_divergence", "elbo", "reinforce_reward")}
+                out["programs"] = p["programs"]
+            self._finish(loss)
+            out["objective"] = loss.detach()
+            return out
+        self._split_means(p)
         if "pg_sup" in p:
             loss = loss + w_sup * (self.alpha if ours else 1.0) * (p["pg_sup"] + p["qr_sup"])
             out["loss"] = {"program_generation_gt": p["pg_sup"].detach(), "question_reconstruction_gt": p["qr_sup"].detach()}
@@ -292,6 +329,19 @@ class JointTrainingStep(_TrainerBase):
                 copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
                 self.blocked_seconds += time.perf_counter() - t0
                 nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
+            if _FUSED_OBJECTIVE and ours and dev.type == "cuda":
+                loss, stats = self._fused_objective(p, nmn_out["loss"], w_sup, w_nosup, self.alpha, self.gamma)
+                _hip.mark("objective combined")
+                out["loss"]["nmn"] = stats["nmn_loss"]
+                out["elbo"] = {k: stats[k] for k in ("reconstruction_likelihood", "kl_divergence", "elbo", "reinforce_reward")}
+                out["programs"] = p["programs"]
+                if p["n_sup"]:
+                    out["loss"]["program_generation_gt"] = stats["program_generation_gt"]
+                    out["loss"]["question_reconstruction_gt"] = stats["question_reconstruction_gt"]
+                self._finish(loss)
+                out["objective"] = loss.detach()
+                return out
+            self._split_means(p)
             elbo_out = self.elbo.combine(p["pg"]["loss"], p.get("qr"), p.get("prior"), nmn_out)
             _hip.mark("elbo combined")
             nmn_loss = elbo_out.pop("nmn_loss")
@@ -301,6 +351,7 @@ class JointTrainingStep(_TrainerBase):
             out["programs"] = p["programs"]
         else:
             p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=False, prior=False)
+            self._split_means(p)
             self.elbo._reinforce.idle(dev)
             for a in self.optimizer.arenas:  # no NMN backward on this rank, which is what zeroes them
                 a.grad.zero_()

@@ -51,6 +51,11 @@ wrap(prior, "forward", "prior")
 wrap(nmn, "begin", "nmn.begin(stem)")
 wrap(nmn, "forward", "nmn.forward (plan + trunk + head)")
 wrap(nmn.engine, "run_forward", "trunk fwd")
+wrap(nmn.engine, "run_forward_tokens", "trunk fwd")
+wrap(nmn, "forward_trunk", "nmn.forward_trunk")
+wrap(nmn, "forward_head", "nmn.forward_head")
+wrap(step.elbo, "objective", "objective")
+wrap(step, "_finish", "_finish")
 wrap(nmn.engine, "run_backward", "trunk bwd")
 wrap(step.optimizer, "step", "optimizer")
 orig_backward = torch.Tensor.backward
