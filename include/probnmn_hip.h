@@ -71,6 +71,8 @@ typedef struct pnmn_conv_item {
 #define PNMN_CONV_ACCUMULATE 1
 #define PNMN_CONV_ATOMIC     2   /* with ACCUMULATE: add with fp32 atomics (concurrent writers) */
 #define PNMN_CONV_MASKBWD    4   /* fused mask backward epilogue (see the mb_* fields) */
+#define PNMN_CONV_DATTN     16   /* dx is STORED to `out` as usual and only mb_dattn[p] += sum_c dx[p][c] * mb_feats[p][c] is
+                                    fused (the d(feats) half of the mask backward is left to pnmn_feat_grad_gather) */
 #define PNMN_CONV_MB_SOLE     8   /* with MASKBWD: no other item of this launch adds into the same
                                      mb_dfeats map -> plain read-modify-write instead of atomics */
 
@@ -185,6 +187,13 @@ typedef struct pnmn_maskbwd_item {
     float*       dattn;
 } pnmn_maskbwd_item;      /* 40 bytes */
 int pnmn_mask_bwd(const pnmn_maskbwd_item* items, int n_items, int HW, void* stream);
+/* The d(feats) half of the backward of `feats * attn`, deferred to the end of the module programs' backward pass:
+ * for every example e of the batch, gfeat[e][p][c] += sum over the items i whose `dfeats` is gfeat[e] of
+ * items[i].dx[p][c] * items[i].attn[p] (attn == NULL: all ones).  `items` is sorted by `dfeats`; one workgroup per
+ * (example, pixel range) finds its items by bisection, reads every dx map once and writes its range of gfeat[e] once
+ * (no atomics, no read-modify-write per item: the fused epilogue this replaces re-read and re-wrote the 100 KB map
+ * of d(feats) once per masked convolution).  Only `dx`, `attn`, `dfeats` of the items are read. */
+int pnmn_feat_grad_gather(const pnmn_maskbwd_item* items, float* gfeat, int n_items, int n_examples, int HW, void* stream);
 
 /* dst[p][c] += src[p][c] for a list of [HW][128] maps (fan-in of value gradients). */
 typedef struct pnmn_axpy_item {
@@ -498,6 +507,7 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
 #define PNMN_OP_SET_ROWS          13   /* a items, n                                      (pnmn_set_rows) */
 #define PNMN_OP_ACCUMULATE        14   /* a items, n                                      (pnmn_accumulate) */
 #define PNMN_OP_ZERO              15   /* a device pointer, b = byte count (as a pointer-sized integer): hipMemsetAsync */
+#define PNMN_OP_FEAT_GATHER       16   /* a items, b gfeat, n = n_items, p = n_examples, HW   (pnmn_feat_grad_gather) */
 typedef struct pnmn_launch {
     const void* a;
     const void* b;

@@ -305,8 +305,11 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     // EG m-tiles at a time: all of them where the register budget allows (one workgroup per CU), four where
     // two workgroups share a CU (the other workgroup's MFMAs cover the extra round trips)
     constexpr int EG = (MT > 8) ? MT : 4;
-    if (mb == nullptr) {
+    if (mb == nullptr || (it.flags & PNMN_CONV_DATTN)) {
         const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
+        // PNMN_CONV_DATTN: besides the plain store of dx, d(attention)[p] += sum_c dx[p][c] * feats[p][c] (this wave's
+        // 16 channels: four lanes groups of four, then one atomic per pixel and wave)
+        const bool dattn = mb != nullptr && mb->attn != nullptr;
 #pragma unroll
         for (int m0 = 0; m0 < MT; m0 += EG) {
             f32x4 old[EG];
@@ -314,9 +317,13 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
             for (int j = 0; j < EG; ++j) {
                 const int mt = m0 + j;
                 const int p = (mbase + mt) * 16 + li;
+                // (an accumulating output and a d(attention) item never coincide: `old` carries the forward features
+                // for the latter)
                 old[j] = (mt < MT && accumulate && p < HW)
                              ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
+                             : (mt < MT && dattn && p < HW)
+                                   ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int j = 0; j < EG; ++j) {
@@ -336,9 +343,18 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
                         unsafeAtomicAdd(dstf + 1, v.y);
                         unsafeAtomicAdd(dstf + 2, v.z);
                         unsafeAtomicAdd(dstf + 3, v.w);
+                    } else if (dattn) {
+                        store4(as_global(dstf), v);
                     } else {
                         store4(as_global(dstf), v + old[j]);
                     }
+                }
+                if (dattn && mt < MT) {
+                    const f32x4 v = acc[mt < MT ? mt : 0];
+                    float part = (p < HW) ? v.x * old[j].x + v.y * old[j].y + v.z * old[j].z + v.w * old[j].w : 0.f;
+                    part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
+                    part += __shfl_xor(part, 32);
+                    if (p < HW && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
                 }
             }
         }

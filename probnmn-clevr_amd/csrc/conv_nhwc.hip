@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
     pnmn::conv_body<H, W, TH, KSPLIT, MSPLIT>(it, u % NB, sub % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
-                                              relu, lds, (it.flags & PNMN_CONV_MASKBWD) ? &mb : nullptr, sub / KSPLIT);
+                                              relu, lds, (it.flags & (PNMN_CONV_MASKBWD | PNMN_CONV_DATTN)) ? &mb : nullptr, sub / KSPLIT);
 }
 
 template <int H, int W, int TH, int KSPLIT, int MSPLIT = 1>

@@ -234,7 +234,16 @@ extern "C" int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int6
             f[0] = q.a_f, f[2] = mask_ptr, f[4] = P(w_off), f[5] = P(b_off), f[6] = q.o_f, f[7] = (uint64_t)dil;
             uint64_t* d = dg.add();
             d[0] = q.o_g, d[3] = q.o_f, d[4] = in->wt + (uint64_t)(wt_off * 4);
-            if (in->fuse_mask_bwd) {
+            if (in->fuse_mask_bwd == 2) {
+                // deferred d(feats): dx is stored to the conv's scratch map, only d(attention) stays in the epilogue;
+                // pnmn_feat_grad_gather sums the scratch maps per example at the end of the backward pass
+                d[6] = masked ? scratch : q.a_g;
+                const bool att = masked && mask_ptr != 0;
+                d[7] = (uint64_t)dil + (att ? (16ull << 32) : 0);
+                d[8] = att ? q.a_f : 0;
+                d[9] = att ? mask_ptr : 0;
+                d[11] = att ? q.b_g : 0;
+            } else if (in->fuse_mask_bwd) {
                 d[6] = masked ? 0 : q.a_g;
                 const bool sole = masked && in->sole_writer &&
                                   writers[(uint64_t)level * (1ull << 48) + (q.a_g >> 4)] == 1;
@@ -266,7 +275,19 @@ extern "C" int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int6
             const std::vector<int> didx = order_by(lv, in->sort_by_weight ? &dg : nullptr, 4);
             out.put(R_DGRAD, dg, &didx);
             out.cut(CUT_DGRAD, permuted(lv, didx));
-            if (!in->fuse_mask_bwd) {  // separate mask-backward records, in the forward order of the masked convs
+            if (in->fuse_mask_bwd == 2) {  // the gather's items: every masked conv, sorted by the d(feats) map it adds into
+                std::vector<std::pair<uint64_t, int>> order;
+                for (int i : idx)
+                    if (masked_v[i]) order.emplace_back(src[i]->a_g, i);
+                std::stable_sort(order.begin(), order.end(),
+                                 [](const std::pair<uint64_t, int>& x, const std::pair<uint64_t, int>& y) { return x.first < y.first; });
+                for (const auto& o : order) {
+                    const Prim& q = *src[o.second];
+                    uint64_t* m = mb.add();
+                    m[0] = scratch_v[o.second], m[1] = q.a_f, m[2] = q.b_f, m[3] = q.a_g, m[4] = 0;
+                }
+                out.put(R_MASKBWD, mb, nullptr);
+            } else if (!in->fuse_mask_bwd) {  // separate mask-backward records, in the forward order of the masked convs
                 std::vector<int64_t> mlv;
                 for (int i : idx) {
                     if (!masked_v[i]) continue;

@@ -479,7 +479,10 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
         in.params = io->params, in.grads = io->grads, in.wt = io->wt, in.act = io->act, in.gact = io->gact;
         in.feat = io->feat, in.gfeat = io->gfeat, in.final_ = io->final_, in.gfinal = io->gfinal, in.ones = io->ones;
         in.n_templates = (int)P.templates.size(), in.pmax = P.pmax, in.nv = nv, in.cmax = cmax, in.hw = HW, in.channels = C;
-        in.wgrad_chunk = P.wgrad_chunk, in.wgrad_groups = P.wgrad_groups, in.fuse_mask_bwd = P.fuse_mask_bwd;
+        // items per weight-gradient job: a job walks its items one after the other, so a small batch (few items per
+        // weight) is cut finer to put more workgroups on the chip -- 128 questions: 8 -> 3 items per job
+        in.wgrad_chunk = std::min<int>(P.wgrad_chunk, std::max<int>(2, (int)(n_total / 256)));
+        in.wgrad_groups = P.wgrad_groups, in.fuse_mask_bwd = P.fuse_mask_bwd;
         in.sole_writer = P.sole_writer, in.sort_by_weight = P.sort_by_weight;
         const int rc = pnmn_plan_batch(&in, words + row_words, (int64_t)plan_words, meta, P.cuts.data(), 4096);
         if (rc != 0) return rc;
@@ -554,6 +557,10 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
             for (const Cut& c : at[CUT_MASKBWD][lv])
                 bwd.push_back(make_launch(PNMN_OP_MASK_BWD, c.e - c.b, rec(R_MASKBWD, c.b), nullptr, nullptr, {HW}));
         }
+        // deferred d(feats) of the masked convs (fuse_mask_bwd == 2): one gather over all of them
+        if (P.fuse_mask_bwd == 2 && meta[3 + 3 * R_MASKBWD] > 0)
+            bwd.push_back(make_launch(PNMN_OP_FEAT_GATHER, (int)meta[3 + 3 * R_MASKBWD], rec(R_MASKBWD, 0),
+                                      reinterpret_cast<const void*>(io->gfeat), nullptr, {B, HW}));
         // every weight gradient of the module convs in ONE grouped launch: all (example, conv) pairs that share a
         // weight are contracted by the same workgroups
         if (n_jobs3)

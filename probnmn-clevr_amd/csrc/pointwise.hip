@@ -341,6 +341,53 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(const pnmn_maskbwd_item* 
     }
 }
 
+// deferred d(feats) of the masked convolutions: see pnmn_feat_grad_gather in the header
+__global__ __launch_bounds__(256) void feat_grad_gather_kernel(const pnmn_maskbwd_item* __restrict__ items, int n_items,
+                                                               float* __restrict__ gfeat, int HW) {
+    const int e = blockIdx.x;
+    float* target = gfeat + (size_t)e * HW * C;
+    // items are sorted by dfeats: [lo, hi) = those of this example
+    int lo = 0, hi = n_items;
+    {
+        int a = 0, b = n_items;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (items[mid].dfeats < target) a = mid + 1; else b = mid;
+        }
+        lo = a;
+        b = n_items;
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (items[mid].dfeats <= target) a = mid + 1; else b = mid;
+        }
+        hi = a;
+    }
+    if (lo == hi) return;
+    const int h = threadIdx.x & 31;    // four channels
+    const int row = threadIdx.x >> 5;  // 8 pixels per pass
+    const int p0 = blockIdx.y * (HW / gridDim.y), p1 = (blockIdx.y + 1 == gridDim.y) ? HW : p0 + HW / gridDim.y;
+    for (int p = p0 + row; p < p1; p += 8) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(target + (size_t)p * C + 4 * h);
+        int i = lo;
+        for (; i + 4 <= hi; i += 4) {  // four maps in flight
+            f32x4 dx[4];
+            float m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dx[k] = *reinterpret_cast<const f32x4*>(items[i + k].dx + (size_t)p * C + 4 * h);
+                m[k] = items[i + k].attn ? items[i + k].attn[p] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += dx[k] * m[k];
+        }
+        for (; i < hi; ++i) {
+            const f32x4 dx = *reinterpret_cast<const f32x4*>(items[i].dx + (size_t)p * C + 4 * h);
+            acc += dx * (items[i].attn ? items[i].attn[p] : 1.f);
+        }
+        *reinterpret_cast<f32x4*>(target + (size_t)p * C + 4 * h) = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void accumulate_kernel(const pnmn_axpy_item* __restrict__ items) {
     const pnmn_axpy_item it = items[blockIdx.x];
     const int64_t n4 = it.n >> 2;
@@ -747,6 +794,16 @@ int pnmn_mask_bwd(const pnmn_maskbwd_item* items, int n_items, int HW, void* str
     if (n_items <= 0) return 0;
     if (!items || HW <= 0) return PNMN_EINVAL;
     hipLaunchKernelGGL(mask_bwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW);
+    return last_error();
+}
+
+int pnmn_feat_grad_gather(const pnmn_maskbwd_item* items, float* gfeat, int n_items, int n_examples, int HW, void* stream) {
+    if (n_items <= 0 || n_examples <= 0) return 0;
+    if (!items || !gfeat || HW <= 0) return PNMN_EINVAL;
+    // enough workgroups to fill the chip at small batches: pixel ranges of >= 14 rows' worth
+    int parts = 1;
+    while (n_examples * parts < 512 && parts < 8 && HW / (parts * 2) >= 24) parts *= 2;
+    hipLaunchKernelGGL(feat_grad_gather_kernel, dim3(n_examples, parts), dim3(256), 0, STREAM(stream), items, n_items, gfeat, HW);
     return last_error();
 }
 

@@ -20,6 +20,7 @@ CHANNELS = 128
 CONV_ACCUMULATE = 1
 CONV_ATOMIC = 2
 CONV_MASKBWD = 4
+CONV_DATTN = 16
 
 
 class HipLibraryError(RuntimeError):
@@ -46,6 +47,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_minmax_fwd": (_P, _I, _I, _I, _P),
     "pnmn_minmax_bwd": (_P, _I, _I, _I, _P),
     "pnmn_mask_bwd": (_P, _I, _I, _P),
+    "pnmn_feat_grad_gather": (_P, _P, _I, _I, _I, _P),
     "pnmn_accumulate": (_P, _I, _P),
     "pnmn_nchw_to_nhwc": (_P, _P, _I, _I, _I, _P),
     "pnmn_nchw_to_nhwc_rows": (_P, _P, _P, _I, _I, _I, _P),
@@ -224,7 +226,7 @@ ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
 (OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
- OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO) = range(16)
+ OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO, OP_FEAT_GATHER) = range(17)
 
 
 class LaunchList:

@@ -142,7 +142,8 @@ class NMNEngine:
         maps += ((r["flags"] & _hip.CONV_ACCUMULATE) != 0) * cout_blocks
         mb = (r["flags"] & _hip.CONV_MASKBWD) != 0
         maps += mb * (1.0 + (r["mb_attn"] != 0))  # dFEAT read-modify-write (+ FEAT when an attention multiplies it)
-        extra = self.HW * 4.0 * ((r["mask"] != 0).sum() + 2 * (mb & (r["mb_attn"] != 0)).sum())
+        maps += ((r["flags"] & _hip.CONV_DATTN) != 0) * 1.0  # d(attention) only: FEAT is read, dx is the plain output
+        extra = self.HW * 4.0 * ((r["mask"] != 0).sum() + 2 * ((mb | ((r["flags"] & _hip.CONV_DATTN) != 0)) & (r["mb_attn"] != 0)).sum())
         return float(maps.sum()) * m + extra + np.unique(r["weight"]).size * wbytes
 
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what, rec=None):
@@ -732,6 +733,10 @@ class NMNEngine:
                 for _, jb, je in ready:
                     self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3,
                                 9, 1, 1, C, C, side, "module wgrad")
+        if self.scheduler.fuse_mask_bwd == 2 and len(plan.records["maskbwd"]):
+            # deferred d(feats) of the masked convs: one gather over all of them (pnmn_feat_grad_gather)
+            self._op(_hip.OP_FEAT_GATHER, "pnmn_feat_grad_gather", len(plan.records["maskbwd"]), pack.ptr("maskbwd"), st,
+                     "feat grad gather", b=ws["gfeat"].data_ptr(), p=(B, HW))
         fork()
         for _, jb, je in groups:
             self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3, 9, 1, 1,

@@ -226,7 +226,11 @@ class BatchScheduler:
         self.dt = record_dtypes
         self.wgrad_chunk = wgrad_chunk
         self.wgrad_groups = wgrad_groups
-        self.fuse_mask_bwd = True  # masked convs' data-gradients do the `feats * attn` backward in their epilogue
+        # backward of `feats * attn` in front of a masked conv: 2 = d(attention) in the data-gradient's epilogue, d(feats)
+        # deferred to ONE gather at the end of the backward pass (default); 1 = both fused into the epilogue (fp32
+        # atomics / read-modify-write of the 100 KB d(feats) map per masked conv: data gradients ran ~15 % behind
+        # the forward convs); 0 = a separate kernel per level
+        self.fuse_mask_bwd = int(os.environ.get("PNMN_MASK_BWD_MODE", "2"))
         self.sole_writer_rmw = os.environ.get("PNMN_MB_SOLE", "1") != "0"
         self._tables64 = tuple(np.ascontiguousarray(a, dtype=np.int64)
                                for a in (tables.w3, tables.b3, tables.wt3, tables.dotw, tables.dotb))
@@ -340,6 +344,7 @@ class BatchScheduler:
         rows = P[keep]  # [N, NCOLS]
         xi = np.broadcast_to(np.arange(nv)[:, None], keep.shape)[keep]  # index into the valid list
         N = rows.shape[0]
+        chunk = min(self.wgrad_chunk, max(2, N // 256))  # (items per weight-gradient job: finer for small batches)
         ex = E[xi]
         tok = tokens[xi, rows[:, C_CALL]]
         blockbase = base[xi]
@@ -395,7 +400,16 @@ class BatchScheduler:
             fw[:, 7] = dil[m]  # dilation in the low 32 bits, flags = 0
             dg = np.zeros((n, 12), u64)
             dg[:, 0], dg[:, 3], dg[:, 4] = o_g[m], o_f[m], buf.wt + wt_off * 4
-            if self.fuse_mask_bwd:
+            if self.fuse_mask_bwd == 2:
+                # deferred d(feats): dx goes to the conv's scratch map, d(attention) stays in the epilogue, and
+                # pnmn_feat_grad_gather sums the scratch maps per example at the end of the backward pass
+                att = masked & (mask_ptr != 0)
+                dg[:, 6] = np.where(masked, scratch, a_g[m])
+                dg[:, 7] = dil[m] + np.where(att, 16 << 32, 0)
+                dg[:, 8] = np.where(att, a_f[m], 0)
+                dg[:, 9] = np.where(att, mask_ptr, 0)
+                dg[:, 11] = np.where(att, b_g[m], 0)
+            elif self.fuse_mask_bwd:
                 # masked convs: the data-gradient kernel adds straight into dFEAT / d(attention)
                 dg[:, 6] = np.where(masked, 0, a_g[m])
                 # flags: fused mask backward; + "sole writer" when no other masked conv of the same level
@@ -418,6 +432,12 @@ class BatchScheduler:
             finish("dgrad", dg, lv, "conv", wcol=4)
             # mask backward for the masked convs (same level order as the dgrads)
             mm = masked[idx]
+            if mm.any() and self.fuse_mask_bwd == 2:  # the gather's items, sorted by the d(feats) map they add into
+                src = idx[mm]
+                src = src[np.argsort(a_g[m][src], kind="stable")]
+                mb = np.zeros((src.size, 5), u64)
+                mb[:, 0], mb[:, 1], mb[:, 2], mb[:, 3] = scratch[src], a_f[m][src], mask_ptr[src], a_g[m][src]
+                records["maskbwd"] = mb.view(self.dt["maskbwd"]).reshape(-1)
             if mm.any() and not self.fuse_mask_bwd:
                 src = idx[mm]
                 mb = np.zeros((src.size, 5), u64)
@@ -430,7 +450,7 @@ class BatchScheduler:
             depth3 = int(lv.max())
             grp = (depth3 - lv) * self.wgrad_groups // max(depth3, 1)  # 0 = deepest levels
             records["wg3"], jobs3, jgrp = self._wgrad_jobs(wg, grp * 4096 + wkey, buf.grads + w_off * 4,
-                                                           buf.grads + b_off * 4, group=grp)
+                                                           buf.grads + b_off * 4, group=grp, chunk=chunk)
             wgroups = []
             for gid, jb, je in _cut(jgrp):
                 wgroups.append((int(lv[grp == gid].min()), jb, je))
@@ -458,7 +478,7 @@ class BatchScheduler:
             finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + 1)), "conv", wcol=4)
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 1], wg[:, 3], wg[:, 4] = a_f[m], b_f[m], o_g[m], o_f[m]
-            records["wgp"], jobsp, _ = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4)
+            records["wgp"], jobsp, _ = self._wgrad_jobs(wg, t_, buf.grads + w_off * 4, buf.grads + b_off * 4, chunk=chunk)
         else:
             jobsp = empty_jobs["wgp"]
 
@@ -570,6 +590,8 @@ class BatchScheduler:
                 t = programs[e]._tokens
                 tokens[i, : t.size] = t
         n_total = int(nprims[tids].sum())
+        # (items per weight-gradient job: finer for small batches, as the library's trunk planner does)
+        chunk = min(self.wgrad_chunk, max(2, n_total // 256))
         words = np.empty(n_total * 48 + 64, np.uint64)  # (a projection: 12 + 24 + 6 + 3 words; a masked conv: 38)
         meta = np.zeros(40, np.int64)
         cuts = self.__dict__.get("_cuts")
@@ -579,7 +601,7 @@ class BatchScheduler:
         rec[0] = (tables.ctypes.data, nprims.ctypes.data, tids.ctypes.data, E.ctypes.data, base.ctypes.data,
                   tokens.ctypes.data) + self._tables64_ptrs + (
             buf.params, buf.grads, buf.wt, buf.act, buf.gact, buf.feat, buf.gfeat, buf.final, buf.gfinal, buf.ones,
-            tables.shape[0], tables.shape[1], nv, cmax, self.hw, self.channels, self.wgrad_chunk, self.wgrad_groups,
+            tables.shape[0], tables.shape[1], nv, cmax, self.hw, self.channels, chunk, self.wgrad_groups,
             int(self.fuse_mask_bwd), int(self.sole_writer_rmw),
             int(not os.environ.get("PNMN_NO_WEIGHT_SORT")), 0)  # (PNMN_NO_WEIGHT_SORT: a tuning hook)
         _hip.check(_hip.lib().pnmn_plan_batch(rec.ctypes.data, words.ctypes.data, words.size, meta.ctypes.data,
@@ -605,7 +627,7 @@ class BatchScheduler:
         fwd, bwd = self._order(launches, int(meta[1]))
         return StepPlan(records, fwd, bwd, jobs, arena, feat_result, int(meta[0]), wgroups)
 
-    def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray, group=None):
+    def _wgrad_jobs(self, items: np.ndarray, wkey: np.ndarray, dw: np.ndarray, db: np.ndarray, group=None, chunk=None):
         """Sort weight-gradient items by (group,) weight and cut each run into jobs of at most
         ``wgrad_chunk`` items (one workgroup column per job).  Returns (items, jobs, group id per job)."""
         idx = np.argsort(wkey, kind="stable")
@@ -618,9 +640,10 @@ class BatchScheduler:
         gstart = np.flatnonzero(newgrp)
         gid = np.cumsum(newgrp) - 1
         pos = np.arange(n) - gstart[gid]
-        jstart = np.flatnonzero(pos % self.wgrad_chunk == 0)
+        chunk = chunk or self.wgrad_chunk
+        jstart = np.flatnonzero(pos % chunk == 0)
         gend = np.concatenate((gstart[1:], [n]))
-        jend = np.minimum(jstart + self.wgrad_chunk, gend[gid[jstart]])
+        jend = np.minimum(jstart + chunk, gend[gid[jstart]])
         jobs = np.zeros((jstart.size, 3), np.uint64)
         jobs[:, 0], jobs[:, 1] = dw[jstart], db[jstart]
         jobs[:, 2] = jstart.astype(np.uint64) | (jend.astype(np.uint64) << np.uint64(32))

@@ -93,7 +93,7 @@ class _TrainerBase(StepBase):
 
     def _seq2seq_passes(self, batch, sup_d, nosup_d, supervised: bool, sampled: bool, prior: bool,
                         reconstruct: bool = True, host_programs: bool = False, after_sampling=None,
-                        before_prior=None):
+                        before_prior=None, after_encode=None):
         """All ProgramGenerator / QuestionReconstructor / ProgramPrior passes of one iteration, with the
         rows of the reference's separate calls batched into as few recurrent launches as the data
         dependencies allow (the persistent LSTM / decoder kernels are latency bound: a launch over
@@ -125,6 +125,8 @@ class _TrainerBase(StepBase):
             state_sup = self.pg.encode(ques_sup)
         else:
             state_nosup = self.pg.encode(question[nosup_d])
+        if after_encode is not None:
+            out["after_encode"] = after_encode()
         if n_nosup:
             ques_nosup = question[nosup_d]
             out["pg"] = self.pg.decode(state_nosup, None, "sampling")
@@ -253,6 +255,10 @@ class JointTrainingStep(_TrainerBase):
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
+        # the stem (side stream) is issued BEHIND the generator's encoder pass: the step's critical chain --
+        # encoder -> sampling decode -> programs to the host -- gets the host's first launches and finds the chip
+        # empty (a round of stem conv1 workgroups keeps the encoder's small kernels waiting ~0.3 ms otherwise)
+        self.stem_after_encode = os.environ.get("PNMN_STEM_AFTER_ENCODE", "1") != "0"
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
@@ -295,11 +301,18 @@ class JointTrainingStep(_TrainerBase):
                 # kernels that each wait for their own not-yet-resident workgroups can starve each other of
                 # CUs forever (that is what stalled the side-stream experiment of round 1).
                 side.wait_stream(main)  # the batch and the index tensors were produced on the main stream
-                with torch.cuda.stream(side):
-                    # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
-                    # layout kernel: no gathered copy)
-                    images = batch["image"]
-                    started = self.nmn.begin(images, rows=nosup_d)
+                images = batch["image"]
+                token = {}
+
+                def launch_stem():
+                    with torch.cuda.stream(side):
+                        # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
+                        # layout kernel: no gathered copy)
+                        token["started"] = self.nmn.begin(images, rows=nosup_d)
+
+                if not self.stem_after_encode:
+                    launch_stem()
+
                 def launch_trunk(programs_host):
                     # Between the reconstructor pass and the prior pass: by now the sampled programs are on the
                     # host, and the main stream has the reconstructor to work on while the host compiles and
@@ -309,11 +322,13 @@ class JointTrainingStep(_TrainerBase):
                     t0 = time.perf_counter()
                     copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
                     self.blocked_seconds += time.perf_counter() - t0
-                    return self.nmn.forward_trunk(images, host, started=started, trunk_stream=side, rows=nosup_d)
+                    return self.nmn.forward_trunk(images, host, started=token["started"], trunk_stream=side, rows=nosup_d)
 
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True,
-                                         before_prior=launch_trunk if self.trunk_before_prior else None)
+                                         before_prior=launch_trunk if self.trunk_before_prior else None,
+                                         after_encode=launch_stem if self.stem_after_encode else None)
+                started = token["started"]
             else:
                 images = batch["image"]
                 # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy

@@ -284,6 +284,55 @@ def test_conv_dgrad_fused_mask_backward(hip, sole, dilation):
     assert float(got[1].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n", [3, 37])
+def test_conv_dgrad_dattn_epilogue_and_deferred_feature_gradient(hip, n):
+    """The default backward of `feats * attn` in front of a masked conv: the data gradient stores dx to its own map and
+    fuses only d(attention) (PNMN_CONV_DATTN); pnmn_feat_grad_gather then adds, per example, every masked conv's
+    dx * attn into d(feats) in one pass.  Two masked convs share example 0's d(feats) map."""
+    g = gen(900 + n)
+    owner = [0, 0] + list(range(1, n - 1))  # conv i reads / adds into example owner[i]
+    n_ex = max(owner) + 1
+    feats = torch.relu(torch.randn(n_ex, C, H, W, generator=g)).requires_grad_(True)
+    attn = torch.sigmoid(torch.randn(n, 1, H, W, generator=g))
+    attn[2] = 1.0  # the all-ones attention `scene` produces (attn == NULL: no d(attention), plain dx)
+    attn.requires_grad_(True)
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    y = F.relu(F.conv2d(feats[owner] * attn, w, None, padding=1))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    wt = torch.empty(C, 9, C, device=dev())
+    t = np.zeros(1, hip.WTRANS_ITEM)
+    wd = wcl(w)
+    t[0]["src"], t[0]["dst"], t[0]["cout"], t[0]["cin"], t[0]["ntaps"] = ptr(wd), ptr(wt), C, C, 9
+    run(hip, "pnmn_transpose_weights", t)
+    dyd, yd, fd = nhwc(dy), nhwc(y.detach()), nhwc(feats.detach())
+    ad = attn.detach().reshape(n, HW).to(dev())
+    dx = torch.full((n, HW, C), float("nan"), device=dev())  # every element must be written
+    dat = torch.zeros(n, HW, device=dev())
+    prior = torch.randn(n_ex, HW, C, generator=g)  # d(feats) already holds other consumers' gradients
+    gfeat = prior.clone().to(dev())
+    recs = np.zeros(n, hip.CONV_ITEM)
+    gather = np.zeros(n, hip.MASKBWD_ITEM)
+    for i in range(n):
+        recs[i]["in"], recs[i]["gate"], recs[i]["weight"], recs[i]["out"] = ptr(dyd[i]), ptr(yd[i]), ptr(wt), ptr(dx[i])
+        recs[i]["dilation"] = 1
+        gather[i]["dx"], gather[i]["dfeats"] = ptr(dx[i]), ptr(gfeat[owner[i]])
+        if i != 2:
+            recs[i]["flags"] = hip.CONV_DATTN
+            recs[i]["mb_feats"], recs[i]["mb_attn"], recs[i]["mb_dattn"] = ptr(fd[owner[i]]), ptr(ad[i]), ptr(dat[i])
+            gather[i]["attn"] = ptr(ad[i])
+    run(hip, "pnmn_conv_nhwc", recs, H, W, 1, 9, C, C, 1, 0)
+    got = dat.cpu().reshape(n, 1, H, W)
+    keep = [i for i in range(n) if i != 2]
+    torch.testing.assert_close(got[keep], attn.grad[keep], rtol=RT, atol=20 * AT)
+    assert float(got[2].abs().max()) == 0.0 and not bool(torch.isnan(dx).any())
+    order = np.argsort(gather["dfeats"], kind="stable")
+    buf = hip.to_device(gather[order], dev())
+    hip.check(hip.lib().pnmn_feat_grad_gather(buf.data_ptr(), gfeat.data_ptr(), n, n_ex, HW, hip.stream_ptr(dev())), "gather")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(from_nhwc(gfeat, n_ex, C) - from_nhwc(prior.to(dev()), n_ex, C), feats.grad, rtol=RT, atol=2 * AT)
+
+
 def test_wgrad_1x1_two_sources_and_wide_output(hip):
     g = gen(31)
     n = 4

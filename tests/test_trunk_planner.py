@@ -124,6 +124,14 @@ def _compare(planner, comp, s, programs):
             _same_launch(bwd[i], op, l.end - l.begin, p)
             assert _records(words, bwd[i], rk).tobytes() == plan.records[rk][l.begin:l.end].tobytes(), (l.kind, l.level)
             i += 1
+    if s.fuse_mask_bwd == 2 and len(plan.records["maskbwd"]):  # deferred d(feats) of the masked convs: one gather
+        n_mb = len(plan.records["maskbwd"])
+        _same_launch(bwd[i], _hip.OP_FEAT_GATHER, n_mb, (len(compiled), HW))
+        assert int(bwd[i]["b"]) == BUF.gfeat
+        got = words[(int(bwd[i]["a"]) - FAKE_BASE) // 8:][: n_mb * 5].view(_hip.MASKBWD_ITEM)
+        assert got.tobytes() == plan.records["maskbwd"].tobytes()
+        assert np.all(np.diff(got["dfeats"].astype(np.int64)) >= 0)  # sorted by the map they add into
+        i += 1
     for key, ntaps, cin_blocks in (("wg3", 9, 1), ("wgp", 1, 2)):
         jobs = plan.wgrad_jobs[key]
         if len(jobs):
