@@ -637,7 +637,8 @@ def ingest_side(vocab, trainer, dev, rank, world, args, resident_ms):
             b["image_index"] = torch.randint(0, rows, (n,), generator=g)
             yield b
 
-    it = iter(PrefetchingLoader(batches(w + k + 1), store, dev))
+    method = os.environ.get("PNMN_INGEST", "dma")  # (A/B hook: "kernel" = the PCIe-reading gather kernel)
+    it = iter(PrefetchingLoader(batches(w + k + 1), store, dev, method=method))
     for _ in range(w):
         trainer.step(next(it))
     torch.cuda.synchronize()
@@ -661,9 +662,12 @@ def ingest_side(vocab, trainer, dev, rank, world, args, resident_ms):
             "value": round(n * world / (elapsed / k), 1), "unit": "questions/s", "ms_per_step": round(ms, 3),
             "steps": k, "warmup": w, "store_rows": rows, "pcie_GBs_per_gpu": round(feat_bytes / (ms * 1e-3) / 1e9, 2),
             "slowdown_vs_resident": round(ms / resident_ms, 4),
-            "workload": "the headline step with batch['image'] gathered every step from %d pinned fp32 rows (%.1f GB) by "
-                        "pnmn_gather_features on the loader's stream (PrefetchingLoader, one batch ahead); NHWC batch "
-                        "used in place by the stem" % (rows, rows * 1024 * 196 * 4 / 1e9)}
+            "method": method,
+            "workload": "the headline step with batch['image'] gathered every step from %d pinned fp32 rows (%.1f GB) on "
+                        "the loader's stream, one batch ahead (PrefetchingLoader): %s"
+                        % (rows, rows * 1024 * 196 * 4 / 1e9,
+                           "one copy-engine transfer per row into an NCHW batch (pnmn_copy_rows_h2d)" if method == "dma" else
+                           "pnmn_gather_features reads the rows over PCIe and writes the NHWC batch the stem uses in place")}
 
 
 def main():

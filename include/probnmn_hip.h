@@ -222,6 +222,12 @@ int pnmn_nhwc_to_nchw(const float* src, float* dst, int n, int C, int HW, void* 
  * device.  The kernel reads the selected rows over PCIe. */
 int pnmn_gather_features(const float* store, const int64_t* indices, float* dst, int n, int64_t n_store,
                          int C, int HW, void* stream);
+/* The same rows through the copy engines instead of a kernel: n hipMemcpyAsync of `row_bytes` each from the
+ * page-locked store into a contiguous (NCHW, as stored) device batch.  `indices` is a HOST array; an index outside
+ * [0, n_store) returns PNMN_EINVAL with the copies before it queued.  The stem's layout pass then reads the batch
+ * like any NCHW input (readers.py:63-108 + _trainer.py:272-287: lookup, cast, collate, .to(device)). */
+int pnmn_copy_rows_h2d(const void* store, const int64_t* indices, void* dst, int n, int64_t n_store,
+                       int64_t row_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * classifier.1-3: ReLU (already applied by the conv) + MaxPool2d(2,2) + Flatten   nmn.py:77-79
@@ -466,6 +472,13 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
                              const float* h0, const float* w_c_t, const float* w_hh_t,
                              float* dgates, float* dctx, float* dscore, float* weights, float* dh0,
                              int B, int T, int S, int hidden, void* workspace, void* stream);
+/* The encoder-output gradient from what pnmn_attn_lstm_bwd_multi emits, in one bandwidth-bound launch instead of two
+ * strided-batched library GEMMs of B tiny [S x T].[T x 256] products (allennlp SimpleSeq2Seq._prepare_attended_input /
+ * DotProductAttention under autograd; seq2seq_base.py:201):
+ *   denc[b][s][:] = sum_t weights[b][t][s] * dctx[b][t][:] + dscore[b][t][s] * h_{t-1}[b][:]   (h_{-1} = h0)
+ * hidden = 256, T <= 64. */
+int pnmn_attn_denc(const float* weights, const float* dscore, const float* dctx, const float* hs, const float* h0,
+                   float* denc, int B, int T, int S, int hidden, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One decoding step's token choice                                   seq2seq_base.py:203-220

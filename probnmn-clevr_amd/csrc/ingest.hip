@@ -11,48 +11,59 @@
 // prologue.  Bound by PCIe Gen5 x16 (63 GB/s spec): 0.8 MB per question -> ~78 k questions/s per GPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/probnmn_hip.h"
 
 namespace {
 
+// A FIXED, small number of workgroups walks the (example, 64-channel block, pixel range) work items: the kernel is
+// bound by PCIe, not by the chip -- a few hundred KB in flight saturate the link -- and it runs on the loader's
+// stream BESIDE a training step.  One workgroup per work item (round 2: 16 384 of them, 50 KB of LDS each) let the
+// dispatcher park two or three of these on every CU, where they wait out microsecond PCIe round trips while their
+// LDS keeps the step's convolution workgroups (98 KB) off the CU: the step ran 1.45x slower with its ingest beside
+// it.  With `gridDim.x` <= 64 resident workgroups and a 25 KB tile a convolution workgroup still fits next to one.
 __global__ __launch_bounds__(256) void gather_features_kernel(const float* __restrict__ store,
                                                               const int64_t* __restrict__ indices,
                                                               float* __restrict__ dst, int64_t n_store, int Cn,
-                                                              int HW, int PT) {
+                                                              int HW, int PT, int n, int parts) {
     extern __shared__ float tile[];  // [64][PT+1]
-    const int e = blockIdx.y;
-    const int c0 = blockIdx.x * 64;
-    const int p0 = blockIdx.z * PT;
-    const int np = (HW - p0) < PT ? (HW - p0) : PT;
-    const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
+    const int cblocks = (Cn + 63) / 64;
+    const int total_items = n * cblocks * parts;
     const int ld = PT + 1;
-    int64_t row = indices[e];
-    if (row < 0 || row >= n_store) row = 0;  // (validated on the host; never index outside the store)
-    const float* src = store + ((size_t)row * Cn + c0) * HW + p0;
-    // 8 loads in flight per thread: the PCIe round trip is microseconds
-    constexpr int NB = 8;
-    const int total = cw * np;
-    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
-        float v[NB];
+    constexpr int NB = 8;  // loads in flight per thread: the PCIe round trip is microseconds
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+        const int part = item % parts, cb = (item / parts) % cblocks, e = item / (parts * cblocks);
+        const int c0 = cb * 64;
+        const int p0 = part * PT;
+        const int np = (HW - p0) < PT ? (HW - p0) : PT;
+        const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
+        int64_t row = indices[e];
+        if (row < 0 || row >= n_store) row = 0;  // (validated on the host; never index outside the store)
+        const float* src = store + ((size_t)row * Cn + c0) * HW + p0;
+        const int total = cw * np;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
+            float v[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = i0 + k * 256;
-            const int c = i / np;
-            v[k] = i < total ? __builtin_nontemporal_load(src + (size_t)c * HW + (i - c * np)) : 0.f;
-        }
+            for (int k = 0; k < NB; ++k) {
+                const int i = i0 + k * 256;
+                const int c = i / np;
+                v[k] = i < total ? __builtin_nontemporal_load(src + (size_t)c * HW + (i - c * np)) : 0.f;
+            }
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = i0 + k * 256;
-            const int c = i / np;
-            if (i < total) tile[c * ld + (i - c * np)] = v[k];
+            for (int k = 0; k < NB; ++k) {
+                const int i = i0 + k * 256;
+                const int c = i / np;
+                if (i < total) tile[c * ld + (i - c * np)] = v[k];
+            }
         }
-    }
-    __syncthreads();
-    float* out = dst + ((size_t)e * HW + p0) * Cn + c0;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int p = i / cw, c = i - p * cw;
-        out[(size_t)p * Cn + c] = tile[c * ld + p];
+        __syncthreads();
+        float* out = dst + ((size_t)e * HW + p0) * Cn + c0;
+        for (int i = threadIdx.x; i < total; i += 256) {
+            const int p = i / cw, c = i - p * cw;
+            out[(size_t)p * Cn + c] = tile[c * ld + p];
+        }
+        __syncthreads();  // the tile is refilled by the next item
     }
 }
 
@@ -62,17 +73,38 @@ extern "C" int pnmn_gather_features(const float* store, const int64_t* indices, 
                                     int Cn, int HW, void* stream) {
     if (n <= 0) return 0;
     if (!store || !indices || !dst || Cn <= 0 || HW <= 0 || n_store <= 0) return PNMN_EINVAL;
-    int parts = 1;
-    while ((size_t)64 * ((HW + parts - 1) / parts + 1) * sizeof(float) > 112 * 1024) ++parts;
+    // pixel ranges of at most 98 pixels: a 25 KB tile (see the kernel's header)
+    const int parts = (HW + 97) / 98;
     const int PT = (HW + parts - 1) / parts;
     const size_t lds = (size_t)64 * (PT + 1) * sizeof(float);
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_features_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
-    hipLaunchKernelGGL(gather_features_kernel, dim3((Cn + 63) / 64, n, parts), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), store, indices, dst, n_store, Cn, HW, PT);
+    static const int max_wgs = [] {  // (tuning hook)
+        const char* e = getenv("PNMN_INGEST_WGS");
+        const int v = e ? atoi(e) : 64;
+        return v > 0 ? v : 64;
+    }();
+    const long items = (long)n * ((Cn + 63) / 64) * parts;
+    hipLaunchKernelGGL(gather_features_kernel, dim3((unsigned)(items < max_wgs ? items : max_wgs)), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), store, indices, dst, n_store, Cn, HW, PT, n, parts);
     return (int)hipGetLastError();
+}
+
+// The same ingest on the COPY ENGINES: one hipMemcpyAsync per selected row (0.8 MB, contiguous in the store) into a
+// plain NCHW batch, which the stem's layout pass reads like any other input.  No compute unit takes part: a kernel
+// that reads over PCIe keeps its loads outstanding for microseconds, and with enough of them in flight to fill the
+// link the step running beside it slowed down by 24-52 % whatever the grid size (r03h_ingest_step.txt); the DMA
+// engines move the same bytes without touching the CUs' memory pipelines.  `indices` is a HOST array.
+extern "C" int pnmn_copy_rows_h2d(const void* store, const int64_t* indices, void* dst, int n, int64_t n_store,
+                                  int64_t row_bytes, void* stream) {
+    if (n <= 0) return 0;
+    if (!store || !indices || !dst || n_store <= 0 || row_bytes <= 0) return PNMN_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        const int64_t row = indices[i];
+        if (row < 0 || row >= n_store) return PNMN_EINVAL;
+        const hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + (size_t)i * row_bytes,
+                                            static_cast<const char*>(store) + (size_t)row * row_bytes, (size_t)row_bytes,
+                                            hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
 }

@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_nchw_to_nhwc": (_P, _P, _I, _I, _I, _P),
     "pnmn_nchw_to_nhwc_rows": (_P, _P, _P, _I, _I, _I, _P),
     "pnmn_nhwc_to_nchw": (_P, _P, _I, _I, _I, _P),
+    "pnmn_copy_rows_h2d": (_P, _P, _P, _I, ctypes.c_int64, ctypes.c_int64, _P),
     "pnmn_gather_features": (_P, _P, _P, _I, ctypes.c_int64, _I, _I, _P),
     "pnmn_maxpool2_flatten_fwd": (_P, _P, _I, _I, _I, _I, _P),
     "pnmn_maxpool2_flatten_bwd": (_P, _P, _P, _I, _I, _I, _I, _P),
@@ -82,6 +83,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_multi_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P, _P),
     "pnmn_attn_lstm_bwd_multi": (_P,) * 15 + (_I,) * 4 + (_P, _P),
+    "pnmn_attn_denc": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_run_launches": (_P, _I, _P),
     "pnmn_set_rows": (_P, _I, _P),

@@ -65,6 +65,28 @@ class PinnedFeatureStore:
         return out
 
 
+    def copy_rows(self, indices: torch.Tensor, device: torch.device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Features of ``indices`` (HOST int64) as a contiguous (n, C, H, W) device tensor, moved by the copy engines
+        (``pnmn_copy_rows_h2d``: one asynchronous copy per row, queued by the library) on the current stream of
+        ``device`` -- no compute unit takes part, so a training step running beside it is not slowed down."""
+        if device.type != "cuda":
+            raise _hip.HipLibraryError("the feature store feeds a ROCm device, got %s" % device)
+        if indices.device.type != "cpu":
+            raise ValueError("copy_rows takes host indices (the copies are queued by the host)")
+        idx = np.ascontiguousarray(indices.to(torch.long).numpy())
+        n, (N, C, H, W) = int(idx.size), self.shape
+        if out is None:
+            out = torch.empty((n, C, H, W), dtype=torch.float32, device=device)
+        elif tuple(out.shape) != (n, C, H, W) or not out.is_contiguous():
+            raise ValueError("`out` must be a contiguous (n, C, H, W) tensor")
+        code = _hip.lib().pnmn_copy_rows_h2d(self.store.data_ptr(), idx.ctypes.data, out.data_ptr(), n, N, C * H * W * 4,
+                                             _hip.stream_ptr(device))
+        if code == -1:
+            raise IndexError("feature index out of range [0, %d)" % N)
+        _hip.check(code, "copy_rows_h2d")
+        return out
+
+
 class PrefetchingLoader:
     """Wraps an iterable of host-side batches ``{"image_index": LongTensor[B], ...other CPU tensors}`` and
     yields device batches with ``"image"`` filled from the store, one batch ahead: while the trainer works
@@ -73,7 +95,13 @@ class PrefetchingLoader:
     ``program`` stay on the host (they drive host-side scheduling)."""
 
     def __init__(self, batches: Iterable[Dict[str, torch.Tensor]], store: PinnedFeatureStore, device: torch.device,
-                 keep_on_host=("supervision",)):
+                 keep_on_host=("supervision",), method: str = "dma"):
+        """``method``: "dma" (default) moves the rows with the copy engines into a plain NCHW batch; "kernel" has the
+        GPU read them over PCIe and write NHWC (``PinnedFeatureStore.gather``) -- faster on an idle chip, but it
+        slows a step that runs beside it (bench.py: joint_training_ingest)."""
+        if method not in ("dma", "kernel"):
+            raise ValueError("method must be 'dma' or 'kernel'")
+        self.method = method
         self.batches, self.store, self.device = batches, store, device
         self.keep_on_host = set(keep_on_host)
         self.stream = torch.cuda.Stream(device=device)
@@ -85,12 +113,16 @@ class PrefetchingLoader:
         C, H, W = self.store.image_feature_size
         buf = self._buffers[slot]
         if buf is None or buf.size(0) < n:
-            buf = torch.empty((n, C, H, W), dtype=torch.float32, device=self.device, memory_format=torch.channels_last)
+            fmt = torch.channels_last if self.method == "kernel" else torch.contiguous_format
+            buf = torch.empty((n, C, H, W), dtype=torch.float32, device=self.device, memory_format=fmt)
             self._buffers[slot] = buf
         with torch.cuda.stream(self.stream):
             out = {k: (v if k in self.keep_on_host else v.to(self.device, non_blocking=True))
                    for k, v in host_batch.items() if k != "image_index"}
-            out["image"] = self.store.gather(idx, self.device, out=buf[:n])
+            if self.method == "kernel":
+                out["image"] = self.store.gather(idx, self.device, out=buf[:n])
+            else:
+                out["image"] = self.store.copy_rows(idx, self.device, out=buf[:n])
             ready = torch.cuda.Event()
             ready.record(self.stream)
         return out, ready

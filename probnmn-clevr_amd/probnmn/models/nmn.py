@@ -61,6 +61,42 @@ class _Trunk(torch.autograd.Function):
         return (None, None, None, None, *grads[: ctx.n_params])
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """``F.linear`` for the classifier's first fully connected layer (K = class_projection_channels * H * W / 4 = 50 176
+    inputs -> 1024 units; reference nmn.py:76-83) with the FORWARD product split along K: x [B, K] @ W^T [K, N] has only
+    B/32 x N/96 output tiles for the library GEMM (22 workgroups at 64 rows, 170 at 512) over a 50 176-long reduction;
+    sixteen K-slabs as ONE strided-batched GEMM (no copies: both operands are views) fill the chip and the partial
+    products add up after.  Measured (scripts/fc_gemm_probe.py): 179 -> 65 us at 64 rows, 579 -> 398 us at 512.
+    The two gradient products already have large outputs and stay plain GEMMs."""
+
+    SLABS = 16
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        B, K = x.shape
+        N, S = weight.size(0), _SplitKLinear.SLABS
+        xs = x.view(B, S, K // S).transpose(0, 1)             # [S, B, K/S]
+        ws = weight.view(N, S, K // S).permute(1, 2, 0)       # [S, K/S, N]
+        return torch.bmm(xs, ws).sum(0).add_(bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = dy.t() @ x if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def _first_fc(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    K = layer.in_features
+    if (x.is_cuda and x.dim() == 2 and x.is_contiguous() and layer.weight.is_contiguous() and layer.bias is not None
+            and K % _SplitKLinear.SLABS == 0 and K >= 8192):
+        return _SplitKLinear.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 class _AnswerLoss(torch.autograd.Function):
     """``pnmn_answer_loss``: log-softmax over the answers, arg-max prediction, cross entropy, the
     invalid-program overrides (prediction @@UNKNOWN@@, constant loss 3.33, no gradient) and d loss / d logits
@@ -224,7 +260,7 @@ class NeuralModuleNetwork(nn.Module):
             current = torch.cuda.current_stream(pooled.device)
             current.wait_stream(trunk_stream)
             pooled.record_stream(current)
-        hidden = F.relu(self.classifier[4](pooled))
+        hidden = F.relu(_first_fc(self.classifier[4], pooled))
         answer_logits = self.classifier[6](hidden)
         _hip.mark("classifier FC forward done")
         if answer_logits.requires_grad:

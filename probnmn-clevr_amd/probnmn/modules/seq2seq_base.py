@@ -543,7 +543,13 @@ class _AttnLSTMDecoder(torch.autograd.Function):
             # encoder-output gradient as two GEMMs per row over the T steps: enc_s enters step t through
             # the context (weight w_ts = masked, renormalised attention, written out by the kernel) and through the
             # score (gradient dscore_ts, times h_{t-1})
-            denc = torch.baddbmm(torch.bmm(weights.transpose(1, 2), dctx), dscore.transpose(1, 2), hprev)
+            if T <= 64:
+                denc = torch.empty_like(enc)
+                _hip.check(_hip.lib().pnmn_attn_denc(weights.data_ptr(), dscore.data_ptr(), dctx.data_ptr(), hs.data_ptr(),
+                                                     h0.data_ptr(), denc.data_ptr(), B, T, S, Hd, _hip.stream_ptr(dev)),
+                           "attn_denc")
+            else:
+                denc = torch.baddbmm(torch.bmm(weights.transpose(1, 2), dctx), dscore.transpose(1, 2), hprev)
         else:
             denc = torch.zeros_like(enc)
             _hip.check(_hip.lib().pnmn_attn_lstm_bwd(

@@ -57,7 +57,9 @@ def test_network_takes_the_gathered_batch_in_place():
         assert float((a - c).abs().max()) <= 2e-5 * float(c.abs().max()) + 1e-12, n  # (fp32 atomics order only)
 
 
-def test_prefetching_loader_yields_every_batch_with_its_features():
+@pytest.mark.parametrize("method", ["dma", "kernel"])
+def test_prefetching_loader_yields_every_batch_with_its_features(method):
+    """Both ingest paths: the copy engines into an NCHW batch (default) and the PCIe-reading gather kernel (NHWC)."""
     from probnmn.data.feature_store import PinnedFeatureStore, PrefetchingLoader
 
     rng = np.random.Generator(np.random.Philox(1))
@@ -69,10 +71,11 @@ def test_prefetching_loader_yields_every_batch_with_its_features():
         host_batches.append({"image_index": idx, "question": torch.full((idx.numel(), 4), k), "answer": idx % 28,
                              "supervision": (idx % 2)})
     seen = 0
-    for k, batch in enumerate(PrefetchingLoader(host_batches, store, DEV)):
+    for k, batch in enumerate(PrefetchingLoader(host_batches, store, DEV, method=method)):
         hb = host_batches[k]
         assert set(batch) == {"image", "question", "answer", "supervision"}
         assert batch["supervision"].device.type == "cpu" and batch["question"].is_cuda
+        assert batch["image"].is_contiguous() == (method == "dma")
         # consume on the compute stream (a kernel that reads the whole batch), then check
         total = batch["image"].double().sum()
         assert torch.equal(batch["image"].cpu(), torch.from_numpy(feats[hb["image_index"].numpy()]))
@@ -80,3 +83,13 @@ def test_prefetching_loader_yields_every_batch_with_its_features():
         assert torch.equal(batch["question"].cpu(), hb["question"])
         seen += 1
     assert seen == 5
+
+
+def test_copy_rows_rejects_an_index_outside_the_store():
+    from probnmn.data.feature_store import PinnedFeatureStore
+
+    store = PinnedFeatureStore(np.zeros((4, 8, 2, 2), np.float32))
+    with pytest.raises(IndexError):
+        store.copy_rows(torch.tensor([0, 4]), DEV)
+    got = store.copy_rows(torch.tensor([3, 0, 3]), DEV)
+    assert tuple(got.shape) == (3, 8, 2, 2) and got.is_contiguous()

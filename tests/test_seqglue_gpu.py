@@ -195,3 +195,20 @@ def test_token_table_matches_linear(V, K, N, sliced, pad):
     if pad is not None:
         want[pad] = 0.0
     torch.testing.assert_close(e2.grad, want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,S", [(5, 26, 46), (130, 46, 27), (3, 1, 1), (17, 64, 64)])
+def test_attn_denc_equals_the_two_batched_products(B, T, S):
+    """pnmn_attn_denc: denc = w^T dctx + dscore^T h_prev (h_prev = [h0, hs[:, :-1]]) against torch.baddbmm."""
+    from probnmn import _hip
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + T)
+    r = lambda *shape: torch.randn(*shape, generator=g).to(dev)  # noqa: E731
+    w, ds, dctx, hs, h0 = r(B, T, S).abs(), r(B, T, S), r(B, T, 256), r(B, T, 256), r(B, 256)
+    denc = torch.full((B, S, 256), float("nan"), device=dev)
+    _hip.check(_hip.lib().pnmn_attn_denc(w.data_ptr(), ds.data_ptr(), dctx.data_ptr(), hs.data_ptr(), h0.data_ptr(),
+                                         denc.data_ptr(), B, T, S, 256, _hip.stream_ptr(dev)), "attn_denc")
+    hprev = torch.cat((h0.unsqueeze(1), hs[:, :-1]), 1)
+    want = torch.baddbmm(torch.bmm(w.transpose(1, 2), dctx), ds.transpose(1, 2), hprev)
+    torch.testing.assert_close(denc, want, rtol=1e-4, atol=1e-4)
