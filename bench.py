@@ -697,6 +697,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--no-extras-but-ingest", action="store_true", help="of the side measurements only joint_training_ingest")
     ap.add_argument("--extras", action="store_true", help="N > 1: run the single-GPU side measurements too (default: N = 1 only)")
     args = ap.parse_args()
 
@@ -806,7 +807,7 @@ def main():
             hbm_kernels = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     extras = {}
-    want_extras = not args.no_extras and (world == 1 or args.extras)
+    want_extras = not args.no_extras and not args.no_extras_but_ingest and (world == 1 or args.extras)
 
     def side(name, metric, workload, n, make, k=10):
         try:

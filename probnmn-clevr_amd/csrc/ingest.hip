@@ -22,7 +22,12 @@ namespace {
 // stream BESIDE a training step.  One workgroup per work item (round 2: 16 384 of them, 50 KB of LDS each) let the
 // dispatcher park two or three of these on every CU, where they wait out microsecond PCIe round trips while their
 // LDS keeps the step's convolution workgroups (98 KB) off the CU: the step ran 1.45x slower with its ingest beside
-// it.  With `gridDim.x` <= 64 resident workgroups and a 25 KB tile a convolution workgroup still fits next to one.
+// it.  With `gridDim.x` <= 12 resident workgroups (16-byte loads, eight in flight per thread: 42.7 GB/s on an idle chip,
+// the most this kernel reaches with any grid) and a 26 KB tile a convolution workgroup still fits next to one.  Measured
+// beside the 1024-question step (round 3, gpurun_out r03k-r03n): 4 / 8 / 12 / 16 / 32 / 64 / 1024 workgroups -> 51.6 /
+// 40.8 / 39.5 / 39.8 / 44.7 / 49.3 / 52.8 ms per step against 32.4 ms with resident features -- below ~12 the link is
+// not filled (the ingest becomes the critical path), above it the step slows with the number of PCIe reads in flight
+// (they hold memory-system queue entries for microseconds each), and ~7 ms of the step's 32 stay unhidden at best.
 __global__ __launch_bounds__(256) void gather_features_kernel(const float* __restrict__ store,
                                                               const int64_t* __restrict__ indices,
                                                               float* __restrict__ dst, int64_t n_store, int Cn,
@@ -42,6 +47,31 @@ __global__ __launch_bounds__(256) void gather_features_kernel(const float* __res
         if (row < 0 || row >= n_store) row = 0;  // (validated on the host; never index outside the store)
         const float* src = store + ((size_t)row * Cn + c0) * HW + p0;
         const int total = cw * np;
+        if (((np | HW | p0) & 3) == 0) {
+            // 16-byte loads (every channel's pixel run starts 16-byte aligned): a quarter of the load instructions per
+            // byte -- the kernel shares its CUs' issue slots with the step it runs beside
+            const int nq = np >> 2, total4 = cw * nq;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            for (int i0 = threadIdx.x; i0 < total4; i0 += 256 * NB) {
+                f4 v[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int i = i0 + k * 256;
+                    const int c = i / nq;
+                    v[k] = i < total4 ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(src + (size_t)c * HW + 4 * (i - c * nq)))
+                                      : f4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int i = i0 + k * 256;
+                    const int c = i / nq;
+                    if (i < total4) {
+                        float* t = tile + c * ld + 4 * (i - c * nq);
+                        t[0] = v[k].x, t[1] = v[k].y, t[2] = v[k].z, t[3] = v[k].w;
+                    }
+                }
+            }
+        } else
         for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NB) {
             float v[NB];
 #pragma unroll
@@ -73,14 +103,14 @@ extern "C" int pnmn_gather_features(const float* store, const int64_t* indices, 
                                     int Cn, int HW, void* stream) {
     if (n <= 0) return 0;
     if (!store || !indices || !dst || Cn <= 0 || HW <= 0 || n_store <= 0) return PNMN_EINVAL;
-    // pixel ranges of at most 98 pixels: a 25 KB tile (see the kernel's header)
-    const int parts = (HW + 97) / 98;
-    const int PT = (HW + parts - 1) / parts;
+    // pixel ranges of 100 pixels (a multiple of four: 16-byte loads): a 26 KB tile (see the kernel's header)
+    const int PT = HW < 100 ? HW : 100;
+    const int parts = (HW + PT - 1) / PT;
     const size_t lds = (size_t)64 * (PT + 1) * sizeof(float);
     static const int max_wgs = [] {  // (tuning hook)
         const char* e = getenv("PNMN_INGEST_WGS");
-        const int v = e ? atoi(e) : 64;
-        return v > 0 ? v : 64;
+        const int v = e ? atoi(e) : 12;
+        return v > 0 ? v : 12;
     }();
     const long items = (long)n * ((Cn + 63) / 64) * parts;
     hipLaunchKernelGGL(gather_features_kernel, dim3((unsigned)(items < max_wgs ? items : max_wgs)), dim3(256), lds,
