@@ -637,7 +637,7 @@ def ingest_side(vocab, trainer, dev, rank, world, args, resident_ms):
             b["image_index"] = torch.randint(0, rows, (n,), generator=g)
             yield b
 
-    method = os.environ.get("PNMN_INGEST", "dma")  # (A/B hook: "kernel" = the PCIe-reading gather kernel)
+    method = os.environ.get("PNMN_INGEST", "kernel")  # (A/B hook: "dma" = one copy-engine transfer per row)
     it = iter(PrefetchingLoader(batches(w + k + 1), store, dev, method=method))
     for _ in range(w):
         trainer.step(next(it))
