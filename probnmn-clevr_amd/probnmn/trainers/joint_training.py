@@ -255,10 +255,11 @@ class JointTrainingStep(_TrainerBase):
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
-        # the stem (side stream) is issued BEHIND the generator's encoder pass: the step's critical chain --
-        # encoder -> sampling decode -> programs to the host -- gets the host's first launches and finds the chip
-        # empty (a round of stem conv1 workgroups keeps the encoder's small kernels waiting ~0.3 ms otherwise)
-        self.stem_after_encode = os.environ.get("PNMN_STEM_AFTER_ENCODE", "1") != "0"
+        # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
+        # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
+        # Measured at 128 questions (gpurun_out/r03f_ab.txt): 7.85-7.89 ms against 7.83-7.92 -- no difference, so the
+        # stem keeps going first (it then never waits for anything).
+        self.stem_after_encode = os.environ.get("PNMN_STEM_AFTER_ENCODE", "0") != "0"
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":

@@ -221,3 +221,36 @@ def test_row_subset_equals_the_gathered_batch(size):
     assert torch.equal(loss_a, loss_b) and torch.equal(pred_a, pred_b)
     for a, b in ((gs_a, gs_b), (gc_a, gc_b)):  # (weight gradients are summed with fp32 atomics: order varies run to run)
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+def test_mask_backward_modes_agree():
+    """The three ways the backward of `feats * attn` is scheduled (probnmn.runtime.schedule: 2 = d(attention) in the data
+    gradient's epilogue + ONE deferred gather of d(feats), the default; 1 = both fused into the epilogue; 0 = a separate
+    kernel per level) give the same gradients -- through the library's trunk planner AND through the Python planner."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    batch = synthetic_batch(vocab, 24, seed=21)
+    images, answers = batch["image"].to(dev), batch["answer"].to(dev)
+    results = {}
+    for mode in (2, 1, 0):
+        for native in (True, False):
+            torch.manual_seed(7)
+            net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
+            net.engine.ensure_arena()
+            net.engine.scheduler.fuse_mask_bwd = mode
+            net.engine.native = native
+            net.train()
+            out = net(images, batch["program"], answers)
+            out["loss"].mean().backward()
+            torch.cuda.synchronize()
+            results[(mode, native)] = (out["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    loss0, grads0 = results[(2, True)]
+    for key, (loss, grads) in results.items():
+        assert torch.equal(loss, loss0), key
+        for n, g in grads.items():
+            scale = float(grads0[n].abs().max()) + 1e-12
+            assert float((g - grads0[n]).abs().max()) <= 3e-5 * scale, (key, n)
