@@ -472,6 +472,32 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
                              const float* h0, const float* w_c_t, const float* w_hh_t,
                              float* dgates, float* dctx, float* dscore, float* weights, float* dh0,
                              int B, int T, int S, int hidden, void* workspace, void* stream);
+
+/* Two independent decoder passes side by side in ONE launch (a training iteration's teacher-forced decodes: the
+ * reconstructor over the questions and the generator over the supervised programs -- question_coding_trainer.py:128-160,
+ * joint_training_trainer.py:150-190 call them one after the other): these kernels are bound by their per-step hand-off
+ * latency, so two passes that fit the chip together take as long as the longer one instead of the sum.  A job = the
+ * arguments of pnmn_attn_lstm_fwd_multi / _bwd_multi.  Passes that do not fit one launch together run one after the
+ * other (identical results).  Workspace: pnmn_attn_lstm_pair_workspace_bytes(Ba, Bb, backward). */
+typedef struct pnmn_decoder_fwd_job {
+    const float *xe, *etable, *enc, *mask, *h0, *w_c, *w_hh, *w_p, *b_p;
+    float *hs, *cs, *act, *ctx, *probs;
+    int64_t* tokens;
+    const int64_t* in_tokens;
+    int64_t in_token_stride;
+    uint64_t seed, row_offset;
+    int32_t B, T, S, V, sample, pad_index, unk_index, start_index;
+} pnmn_decoder_fwd_job;    /* 184 bytes */
+typedef struct pnmn_decoder_bwd_job {
+    const float *dhs, *act, *cs, *hs, *probs, *enc, *mask, *h0, *w_c_t, *w_hh_t;
+    float *dgates, *dctx, *dscore, *weights, *dh0;
+    int32_t B, T, S, reserved;
+} pnmn_decoder_bwd_job;    /* 136 bytes */
+int64_t pnmn_attn_lstm_pair_workspace_bytes(int Ba, int Bb, int backward);
+int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* a, const pnmn_decoder_fwd_job* b, int hidden, void* workspace,
+                                  void* stream);
+int pnmn_attn_lstm_bwd_multi_pair(const pnmn_decoder_bwd_job* a, const pnmn_decoder_bwd_job* b, int hidden, void* workspace,
+                                  void* stream);
 /* The encoder-output gradient from what pnmn_attn_lstm_bwd_multi emits, in one bandwidth-bound launch instead of two
  * strided-batched library GEMMs of B tiny [S x T].[T x 256] products (allennlp SimpleSeq2Seq._prepare_attended_input /
  * DotProductAttention under autograd; seq2seq_base.py:201):

@@ -79,7 +79,7 @@ constexpr size_t FWD_FIXED_LDS = sizeof(float) * (4 * ROWS * GLD + RW * 4 * H + 
 // ALLPARTS: 16 KB more LDS behind `logl` (the launch adds them when S leaves room: S <= 59), so that the gates
 // phase can hold all four parts of its A operands at once.
 template <bool ALLPARTS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_multi_kernel(const MFwdArgs a) {
+__device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, const int tile, const int part) {
     extern __shared__ __attribute__((aligned(16))) char raw[];
     const int T = a.T, S = a.S;
     float* encl = reinterpret_cast<float*>(raw);                                       // [RW][S][H]
@@ -89,9 +89,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float (*cpart)[4][H] = reinterpret_cast<float (*)[4][H]>(tokl + ROWS);             // [RW][4][H]
     float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]  (+ 16 KB: ALLPARTS)
 
-    int tile, part;
-    pnmn::cluster_coords<MEMBERS>(tile, part);
-    if (tile >= a.tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
     pnmn::Cluster cl;
@@ -343,6 +340,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     cl.finish();
 }
 
+template <bool ALLPARTS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_multi_kernel(const MFwdArgs a) {
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile >= a.tiles) return;
+    attn_lstm_fwd_multi_body<ALLPARTS>(a, tile, part);
+}
+
+// TWO independent decoder passes in one launch (the reconstructor's teacher-forced decode and the generator's
+// supervised decode of a training iteration: different weights, step counts, source lengths): tiles [0, tiles0) run
+// pass a0, the tiles behind them pass a1.  These kernels are bound by their per-step hand-off latency, not by the
+// chip: at 128 questions per GPU a pass occupies 32-64 of the 256 CUs for 0.3-0.5 ms, and back to back the passes ADD
+// their step counts on the iteration's critical chain; side by side the launch takes as long as the longer one.
+// (Two launches on two streams would do the same but put two kernels that wait for their own workgroups on the chip
+// next to a third -- DESIGN 6; one grid is resident as a whole or not at all.)
+template <bool ALLPARTS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_pair_kernel(const MFwdArgs a0,
+                                                                                                           const MFwdArgs a1,
+                                                                                                           const int tiles0) {
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile < tiles0) {
+        if (tile >= a0.tiles) return;
+        attn_lstm_fwd_multi_body<ALLPARTS>(a0, tile, part);
+    } else {
+        tile -= tiles0;
+        if (tile >= a1.tiles) return;
+        attn_lstm_fwd_multi_body<ALLPARTS>(a1, tile, part);
+    }
+}
+
 struct MBwdArgs {
     const float* dhs;
     const float* act;
@@ -368,7 +396,7 @@ struct MBwdArgs {
 constexpr int DLD = 4 * UW + 4;
 constexpr size_t BWD_FIXED_LDS = sizeof(float) * (ROWS * DLD + 2 * RW * H + 2 * RW * MAXS + RW * 4 * H);
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_bwd_multi_kernel(const MBwdArgs a) {
+__device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, const int tile, const int part) {
     extern __shared__ __attribute__((aligned(16))) char raw[];
     const int T = a.T, S = a.S;
     float* encl = reinterpret_cast<float*>(raw);                                        // [RW][S][H]
@@ -378,9 +406,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float (*dwl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&dhl[RW][0]);                 // [RW][64] d weights -> d scores
     float (*dhpart)[4][H] = reinterpret_cast<float (*)[4][H]>(&dwl[2 * RW][0]);          // [RW][4][H]
 
-    int tile, part;
-    pnmn::cluster_coords<MEMBERS>(tile, part);
-    if (tile >= a.tiles) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
     pnmn::Cluster cl;
@@ -583,6 +608,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     cl.finish();
 }
 
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_bwd_multi_kernel(const MBwdArgs a) {
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile >= a.tiles) return;
+    attn_lstm_bwd_multi_body(a, tile, part);
+}
+
+// the backward passes of two decoders in one launch (see attn_lstm_fwd_pair_kernel)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_bwd_pair_kernel(const MBwdArgs a0,
+                                                                                                           const MBwdArgs a1,
+                                                                                                           const int tiles0) {
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile < tiles0) {
+        if (tile >= a0.tiles) return;
+        attn_lstm_bwd_multi_body(a0, tile, part);
+    } else {
+        tile -= tiles0;
+        if (tile >= a1.tiles) return;
+        attn_lstm_bwd_multi_body(a1, tile, part);
+    }
+}
+
 // rows one launch can take: all tiles x 8 members resident, one workgroup per CU
 int rows_per_launch() {
     const int cus = pnmn::device_cus();
@@ -689,6 +737,120 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+
+// ---- two passes side by side -----------------------------------------------------------------------------------
+static inline int padded_tiles(int B) { return 8 * ((((B + ROWS - 1) / ROWS) + 7) / 8); }  // (whole groups of 8 tiles)
+
+// both passes in one launch?  (their tile groups must be resident together)
+static bool pair_fits(int Ba, int Bb) {
+    const int chunk = rows_per_launch();
+    return chunk > 0 && Ba > 0 && Bb > 0 && (padded_tiles(Ba) + padded_tiles(Bb)) * ROWS <= chunk + 0 &&
+           (padded_tiles(Ba) + padded_tiles(Bb)) <= 128;
+}
+
+int64_t pnmn_attn_lstm_pair_workspace_bytes(int Ba, int Bb, int backward) {
+    if (!pair_fits(Ba, Bb)) {
+        const int64_t a = pnmn_attn_lstm_multi_workspace_bytes(Ba, backward), b = pnmn_attn_lstm_multi_workspace_bytes(Bb, backward);
+        return a > b ? a : b;
+    }
+    int64_t n = (int64_t)pnmn::CLUSTER_SYNC_BYTES;
+    if (backward) n += (int64_t)(padded_tiles(Ba) + padded_tiles(Bb)) * (2 * MEMBERS * 2 + 2) * ROWS * H * sizeof(float);
+    return n;
+}
+
+int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* ja, const pnmn_decoder_fwd_job* jb, int hidden, void* workspace,
+                                  void* stream) {
+    if (!ja || !jb || !workspace) return PNMN_EINVAL;
+    auto single = [&](const pnmn_decoder_fwd_job* j) {
+        return pnmn_attn_lstm_fwd_multi(j->xe, j->etable, j->enc, j->mask, j->h0, j->w_c, j->w_hh, j->w_p, j->b_p, j->hs, j->cs,
+                                        j->act, j->ctx, j->probs, j->tokens, j->B, j->T, j->S, j->V, hidden, j->sample, j->pad_index,
+                                        j->unk_index, j->start_index, j->seed, j->row_offset, j->in_tokens, j->in_token_stride,
+                                        workspace, stream);
+    };
+    if (!pair_fits(ja->B, jb->B) || ja->T <= 0 || jb->T <= 0) {  // (one after the other: same results)
+        const int rc = single(ja);
+        return rc != 0 ? rc : single(jb);
+    }
+    const pnmn_decoder_fwd_job* jobs[2] = {ja, jb};
+    for (const pnmn_decoder_fwd_job* j : jobs) {
+        if (!j->enc || !j->mask || !j->h0 || !j->w_c || !j->w_hh || !j->hs || !j->cs || !j->act || !j->ctx || !j->probs) return PNMN_EINVAL;
+        if (j->sample ? (!j->etable || !j->w_p || !j->b_p || !j->tokens) : (!j->xe && !(j->etable && j->in_tokens))) return PNMN_EINVAL;
+        if (hidden != H || j->S < 1 || j->S > MAXS || (j->sample && (j->V < 1 || j->V > MAXV))) return PNMN_ESHAPE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    constexpr size_t ALL_PARTS_LDS = sizeof(float) * 2 * 2 * ROWS * 64;
+    constexpr size_t LDS_LIMIT = 160 * 1024;
+    const int smax = ja->S > jb->S ? ja->S : jb->S;
+    const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + ALL_PARTS_LDS <= LDS_LIMIT;
+    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + (all_parts ? ALL_PARTS_LDS : 0);
+    static size_t allowed[2] = {0, 0};
+    if (lds > allowed[all_parts]) {
+        hipError_t e = all_parts ? allow_lds(attn_lstm_fwd_pair_kernel<true>, lds) : allow_lds(attn_lstm_fwd_pair_kernel<false>, lds);
+        if (e != hipSuccess) return (int)e;
+        allowed[all_parts] = lds;
+    }
+    int* sync = nullptr;
+    hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
+    if (e != hipSuccess) return (int)e;
+    const int tiles0 = padded_tiles(ja->B);
+    auto args = [&](const pnmn_decoder_fwd_job* j, int* sy) {
+        return MFwdArgs{j->xe, j->etable, j->enc, j->mask, j->h0, j->w_c, j->w_hh, j->w_p, j->b_p, j->hs, j->cs, j->act, j->ctx,
+                        j->probs, j->tokens, (!j->sample && !j->xe) ? j->in_tokens : nullptr, (long)j->in_token_stride, sy, j->B,
+                        j->T, j->S, j->V, (j->B + ROWS - 1) / ROWS, j->sample, j->pad_index, j->unk_index, j->start_index,
+                        j->seed, j->row_offset};
+    };
+    const MFwdArgs a0 = args(ja, sync), a1 = args(jb, sync + tiles0 * pnmn::CLUSTER_COUNTER_STRIDE);
+    const int groups = (tiles0 + padded_tiles(jb->B)) / 8;
+    hipLaunchKernelGGL(all_parts ? attn_lstm_fwd_pair_kernel<true> : attn_lstm_fwd_pair_kernel<false>, dim3(8 * MEMBERS * groups),
+                       dim3(512), lds, st, a0, a1, tiles0);
+    return (int)hipGetLastError();
+}
+
+int pnmn_attn_lstm_bwd_multi_pair(const pnmn_decoder_bwd_job* ja, const pnmn_decoder_bwd_job* jb, int hidden, void* workspace,
+                                  void* stream) {
+    if (!ja || !jb || !workspace) return PNMN_EINVAL;
+    auto single = [&](const pnmn_decoder_bwd_job* j) {
+        return pnmn_attn_lstm_bwd_multi(j->dhs, j->act, j->cs, j->hs, j->probs, j->enc, j->mask, j->h0, j->w_c_t, j->w_hh_t, j->dgates,
+                                        j->dctx, j->dscore, j->weights, j->dh0, j->B, j->T, j->S, hidden, workspace, stream);
+    };
+    if (!pair_fits(ja->B, jb->B) || ja->T <= 0 || jb->T <= 0) {
+        const int rc = single(ja);
+        return rc != 0 ? rc : single(jb);
+    }
+    const pnmn_decoder_bwd_job* jobs[2] = {ja, jb};
+    for (const pnmn_decoder_bwd_job* j : jobs) {
+        if (!j->dhs || !j->act || !j->cs || !j->hs || !j->probs || !j->enc || !j->mask || !j->h0 || !j->w_c_t || !j->w_hh_t ||
+            !j->dgates || !j->dctx || !j->dscore || !j->weights || !j->dh0)
+            return PNMN_EINVAL;
+        if (hidden != H || j->S < 1 || j->S > MAXS) return PNMN_ESHAPE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int smax = ja->S > jb->S ? ja->S : jb->S;
+    const size_t lds = BWD_FIXED_LDS + sizeof(float) * RW * smax * H;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        hipError_t e = allow_lds(attn_lstm_bwd_pair_kernel, lds);
+        if (e != hipSuccess) return (int)e;
+        allowed = lds;
+    }
+    int* sync = nullptr;
+    hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
+    if (e != hipSuccess) return (int)e;
+    const int tiles0 = padded_tiles(ja->B), total = tiles0 + padded_tiles(jb->B);
+    char* ws = static_cast<char*>(workspace);
+    float* x1 = reinterpret_cast<float*>(ws + pnmn::CLUSTER_SYNC_BYTES);
+    float* x2 = x1 + (size_t)total * 2 * MEMBERS * 2 * ROWS * H;
+    auto args = [&](const pnmn_decoder_bwd_job* j, int first_tile) {
+        return MBwdArgs{j->dhs, j->act, j->cs, j->hs, j->probs, j->enc, j->mask, j->h0, j->w_c_t, j->w_hh_t, j->dgates, j->dctx,
+                        j->dscore, j->weights, j->dh0, x1 + (size_t)first_tile * 2 * MEMBERS * 2 * ROWS * H,
+                        x2 + (size_t)first_tile * 2 * ROWS * H, sync + first_tile * pnmn::CLUSTER_COUNTER_STRIDE, j->B, j->T, j->S,
+                        (j->B + ROWS - 1) / ROWS};
+    };
+    const MBwdArgs a0 = args(ja, 0), a1 = args(jb, tiles0);
+    hipLaunchKernelGGL(attn_lstm_bwd_pair_kernel, dim3(8 * MEMBERS * (total / 8)), dim3(512), lds, st, a0, a1, tiles0);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -83,6 +83,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_multi_workspace_bytes": (_I, _I),
     "pnmn_attn_lstm_fwd_multi": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P, _P),
     "pnmn_attn_lstm_bwd_multi": (_P,) * 15 + (_I,) * 4 + (_P, _P),
+    "pnmn_attn_lstm_pair_workspace_bytes": (_I, _I, _I),
+    "pnmn_attn_lstm_fwd_multi_pair": (_P, _P, _I, _P, _P),
+    "pnmn_attn_lstm_bwd_multi_pair": (_P, _P, _I, _P, _P),
     "pnmn_attn_denc": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_run_launches": (_P, _I, _P),
@@ -223,6 +226,13 @@ TRUNK_IO = np.dtype([(n, _u64) for n in ("programs", "params", "grads", "wt", "a
                     + [(n, _i32) for n in ("n_programs", "length", "n_fwd_tail", "n_bwd_head", "n_bwd_tail", "bwd_capacity",
                                            "need_backward", "launch", "n_bwd", "bwd_piece_cut", "n_prims", "n_fwd", "depth",
                                            "n_invalid", "n_feat_result", "reserved")])
+DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "h0", "w_c", "w_hh", "w_p", "b_p", "hs", "cs", "act",
+                                                  "ctx", "probs", "tokens", "in_tokens")]
+                           + [("in_token_stride", np.int64), ("seed", _u64), ("row_offset", _u64)]
+                           + [(n, _i32) for n in ("B", "T", "S", "V", "sample", "pad_index", "unk_index", "start_index")])
+DECODER_BWD_JOB = np.dtype([(n, _u64) for n in ("dhs", "act", "cs", "hs", "probs", "enc", "mask", "h0", "w_c_t", "w_hh_t", "dgates",
+                                                  "dctx", "dscore", "weights", "dh0")]
+                           + [(n, _i32) for n in ("B", "T", "S", "reserved")])
 EAGAIN = -3
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
@@ -268,6 +278,8 @@ ITEM_SIZES = {
     "pnmn_adam_item": (ADAM_ITEM, 40),
     "pnmn_derive_job": (DERIVE_JOB, 40),
     "pnmn_plan_in": (PLAN_IN, 216),
+    "pnmn_decoder_fwd_job": (DECODER_FWD_JOB, 184),
+    "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
     "pnmn_trunk_io": (TRUNK_IO, 208),
 }

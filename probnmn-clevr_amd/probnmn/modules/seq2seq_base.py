@@ -573,6 +573,103 @@ class _AttnLSTMDecoder(torch.autograd.Function):
         return (dxe, detable, denc, None, dh0, dw_c, dw_hh) + (None,) * 11
 
 
+class _AttnLSTMDecoderPair(torch.autograd.Function):
+    """TWO teacher-forced decoder passes of different models in one launch each way (``pnmn_attn_lstm_fwd_multi_pair`` /
+    ``_bwd_multi_pair``): the passes are independent, and the persistent decoder kernels are bound by their per-step
+    hand-off latency -- side by side they take as long as the longer one.  Per side: etable [V,4H] (per-token input
+    projections, ``_TokenTable``), enc [B,S,H], mask [B,S], h0 [B,H], W_c, W_hh; ``meta`` carries what is not a tensor
+    input (step inputs ``in_tokens`` [B,T], fragment packs).  Same arithmetic as two ``_AttnLSTMDecoder`` calls (the
+    library runs the passes one after the other when they do not fit the chip together)."""
+
+    @staticmethod
+    def forward(ctx, etable_a, enc_a, mask_a, h0_a, w_c_a, w_hh_a, etable_b, enc_b, mask_b, h0_b, w_c_b, w_hh_b, meta):
+        dev = enc_a.device
+        sides, jobs = [], np.zeros(2, _hip.DECODER_FWD_JOB)
+        for k, (etable, enc, mask, h0, w_c, w_hh, m) in enumerate(((etable_a, enc_a, mask_a, h0_a, w_c_a, w_hh_a, meta[0]),
+                                                                  (etable_b, enc_b, mask_b, h0_b, w_c_b, w_hh_b, meta[1]))):
+            etable, enc, mask, h0 = etable.contiguous(), enc.contiguous(), mask.contiguous(), h0.contiguous()
+            w_c, w_hh = w_c.detach(), w_hh.detach()
+            packs = m["packs"] if m["packs"] is not None else (pack_fragments(w_c), pack_fragments(w_hh), None, None)
+            in_tokens, T = m["in_tokens"], m["T"]
+            if in_tokens.dtype != torch.long or in_tokens.stride(1) != 1:
+                in_tokens = in_tokens.long().contiguous()
+            B, S, Hd = enc.shape
+            f = dict(dtype=torch.float32, device=dev)
+            hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
+            act, probs = torch.empty(B, T, 4 * Hd, **f), torch.empty(B, T, S, **f)
+            j = jobs[k]
+            j["etable"], j["enc"], j["mask"], j["h0"] = etable.data_ptr(), enc.data_ptr(), mask.data_ptr(), h0.data_ptr()
+            j["w_c"], j["w_hh"] = packs[0].data_ptr(), packs[1].data_ptr()
+            j["hs"], j["cs"], j["act"], j["ctx"], j["probs"] = hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(), probs.data_ptr()
+            j["in_tokens"], j["in_token_stride"] = in_tokens.data_ptr(), in_tokens.stride(0)
+            j["B"], j["T"], j["S"], j["start_index"] = B, T, S, m["start"]
+            sides.append(dict(hs=hs, cs=cs, act=act, cx=cx, probs=probs, enc=enc, mask=mask, h0=h0, w_c=w_c, w_hh=w_hh,
+                              in_tokens=in_tokens, vocab=etable.size(0), packs_t=(packs[2], packs[3]) if packs[2] is not None else None,
+                              keep=(etable, packs)))
+        Ba, Bb = sides[0]["hs"].size(0), sides[1]["hs"].size(0)
+        ws = torch.empty(int(_hip.lib().pnmn_attn_lstm_pair_workspace_bytes(Ba, Bb, 0)), dtype=torch.uint8, device=dev)
+        _hip.check(_hip.lib().pnmn_attn_lstm_fwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, sides[0]["hs"].size(2),
+                                                            ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_fwd_multi_pair")
+        saved = []
+        for sd in sides:
+            saved += [sd["hs"], sd["cs"], sd["act"], sd["cx"], sd["probs"], sd["enc"], sd["mask"], sd["h0"], sd["w_c"], sd["w_hh"],
+                      sd["in_tokens"]]
+        ctx.save_for_backward(*saved)
+        ctx.side_meta = [(sd["vocab"], sd["packs_t"]) for sd in sides]
+        return sides[0]["hs"], sides[1]["hs"]
+
+    @staticmethod
+    def backward(ctx, dhs_a, dhs_b):
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        jobs = np.zeros(2, _hip.DECODER_BWD_JOB)
+        sides = []
+        for k, dhs in enumerate((dhs_a, dhs_b)):
+            hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, in_tokens = saved[11 * k: 11 * k + 11]
+            vocab, packs_t = ctx.side_meta[k]
+            B, T, Hd = hs.shape
+            S = enc.size(1)
+            dhs_c = torch.zeros_like(hs) if dhs is None else dhs.contiguous()
+            w_c_t, w_hh_t = packs_t if packs_t is not None else (pack_fragments(w_c.t()), pack_fragments(w_hh.t()))
+            dgates, dh0 = torch.empty_like(act), torch.empty_like(h0)
+            dctx, dscore, weights = torch.empty_like(hs), torch.empty_like(probs), torch.empty_like(probs)
+            j = jobs[k]
+            for name, t in (("dhs", dhs_c), ("act", act), ("cs", cs), ("hs", hs), ("probs", probs), ("enc", enc), ("mask", mask),
+                            ("h0", h0), ("w_c_t", w_c_t), ("w_hh_t", w_hh_t), ("dgates", dgates), ("dctx", dctx),
+                            ("dscore", dscore), ("weights", weights), ("dh0", dh0)):
+                j[name] = t.data_ptr()
+            j["B"], j["T"], j["S"] = B, T, S
+            sides.append(dict(hs=hs, cx=cx, enc=enc, h0=h0, in_tokens=in_tokens, vocab=vocab, dgates=dgates, dh0=dh0, dctx=dctx,
+                              dscore=dscore, weights=weights, keep=(dhs_c, w_c_t, w_hh_t), B=B, T=T, S=S, Hd=Hd))
+        ws = torch.empty(int(_hip.lib().pnmn_attn_lstm_pair_workspace_bytes(sides[0]["B"], sides[1]["B"], 1)), dtype=torch.uint8, device=dev)
+        _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, sides[0]["Hd"], ws.data_ptr(),
+                                                            _hip.stream_ptr(dev)), "attn_lstm_bwd_multi_pair")
+        grads = []
+        for k, sd in enumerate(sides):
+            B, T, S, Hd = sd["B"], sd["T"], sd["S"], sd["Hd"]
+            need = ctx.needs_input_grad[6 * k: 6 * k + 6]
+            denc = None
+            if need[1]:
+                if T <= 64:
+                    denc = torch.empty_like(sd["enc"])
+                    _hip.check(_hip.lib().pnmn_attn_denc(sd["weights"].data_ptr(), sd["dscore"].data_ptr(), sd["dctx"].data_ptr(),
+                                                         sd["hs"].data_ptr(), sd["h0"].data_ptr(), denc.data_ptr(), B, T, S, Hd,
+                                                         _hip.stream_ptr(dev)), "attn_denc")
+                else:
+                    hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
+                    denc = torch.baddbmm(torch.bmm(sd["weights"].transpose(1, 2), sd["dctx"]), sd["dscore"].transpose(1, 2), hprev)
+            flat = sd["dgates"].reshape(B * T, 4 * Hd)
+            dw_c = wgrad_gemm(flat, sd["cx"].reshape(B * T, Hd)) if need[4] else None
+            dw_hh = None
+            if need[5]:
+                hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
+                dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
+            detable = _table_grad(sd["dgates"], sd["in_tokens"], sd["vocab"]) if need[0] else None
+            grads += [detable, denc, None, sd["dh0"], dw_c, dw_hh]
+        return (*grads, None)
+
+
+
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
                   pad: int, unk: int, start: int):
     """One decoding step's token choice on the device; returns (tokens int64 [B], logprob [B] no grad)."""
@@ -926,6 +1023,38 @@ class Seq2SeqBase(nn.Module):
                 self._bleu(predictions, tgt)  # (reference :260: against the targets WITH their @start@, as allennlp)
         return output_dict
 
+    # ---- two teacher-forced decodes of a training iteration side by side -------------------------------------------
+    def decode_prepare(self, state: Dict[str, torch.Tensor], target_tokens: torch.LongTensor):
+        """First half of a teacher-forced training ``decode`` whose persistent-kernel launch is to be shared with another
+        model's (``decode_pair``): everything up to the launch.  ``None`` when this pass cannot take part (shapes outside
+        the fused kernels, evaluation: metrics want the predictions)."""
+        enc, h, fmask = state["enc"], state["h"], state["fmask"]
+        w_p = self._output_projection_layer.weight
+        Hd = h.size(1)
+        if not (self.training and torch.is_grad_enabled() and enc.is_cuda and Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128):
+            return None
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        tgt = _TokenPrep.run(target_tokens, pad, bos, eos, drop_first=False, want_mask=False)[0]
+        steps = tgt.size(1) - 1
+        w_ih = self._decoder_cell.weight_ih
+        w_c, w_e = _SplitColumns.apply(w_ih, Hd) if w_ih.requires_grad else (w_ih[:, :Hd], w_ih[:, Hd:])
+        derived = self._derived()
+        if derived is None:
+            return None
+        bias = _Alias.apply(self._decoder_cell.bias_ih, self._decoder_cell.bias_hh, derived["d.b"])
+        emb = self._target_embedder
+        etable = _TokenTable.apply(emb.weight, w_e, bias, emb.padding_idx)
+        return {"model": self, "tgt": tgt, "steps": steps, "etable": etable, "enc": enc, "fmask": fmask, "h": h, "w_c": w_c,
+                "w_hh": self._decoder_cell.weight_hh,
+                "meta": {"packs": (derived["d.c"], derived["d.hh"], derived["d.cT"], derived["d.hhT"]),
+                         "in_tokens": tgt[:, :steps], "T": steps, "start": bos}}
+
+    def decode_finish(self, prep, hs: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Second half: the output projection over all steps and the per-row cross entropy (reference :235-254)."""
+        logits_all = self._output_projection_layer(hs)
+        tgt = prep["tgt"]
+        return {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], self._pad_index, 1e-13)}
+
     def _decode_stepwise(self, enc, fmask, h, c, tgt, steps, greedy, seed):
         """Step-by-step decoding for shapes the persistent kernel is not built for (hidden != 256,
         more than 64 source positions or 128 target tokens): a GEMM per step + the cell kernel."""
@@ -992,3 +1121,12 @@ class Seq2SeqBase(nn.Module):
             "sequence_accuracy": self._sequence_accuracy.get_metric(reset=reset),
             "word_error_rate": 1 - self._unigram_recall.get_metric(reset=reset),
         }
+
+
+def decode_pair(prep_a, prep_b):
+    """The launches of two prepared teacher-forced decodes (``Seq2SeqBase.decode_prepare``) as one, then each model's
+    second half.  Returns the two output dicts ({"loss": per-row cross entropy})."""
+    hs_a, hs_b = _AttnLSTMDecoderPair.apply(prep_a["etable"], prep_a["enc"], prep_a["fmask"], prep_a["h"], prep_a["w_c"], prep_a["w_hh"],
+                                            prep_b["etable"], prep_b["enc"], prep_b["fmask"], prep_b["h"], prep_b["w_c"], prep_b["w_hh"],
+                                            (prep_a["meta"], prep_b["meta"]))
+    return prep_a["model"].decode_finish(prep_a, hs_a), prep_b["model"].decode_finish(prep_b, hs_b)

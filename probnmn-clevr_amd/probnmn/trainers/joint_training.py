@@ -137,11 +137,27 @@ class _TrainerBase(StepBase):
             if after_sampling is not None:
                 out["after_sampling"] = after_sampling()
         # per-row losses; "qr_rows" = the sampled rows' reconstruction losses followed by the supervised rows'
-        if n_sup:
-            out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
         if n_sup and n_nosup:
-            out["qr_rows"] = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
+            qr_src, qr_tgt = _cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0)
+            prep_pg = self.pg.decode_prepare(state_sup, prog_sup) if (_PAIR_DECODERS and dev.type == "cuda") else None
+            if prep_pg is not None:
+                # the generator's supervised decode and the reconstructor's decode are independent teacher-forced passes of
+                # latency-bound kernels: one launch each way for both (Seq2SeqBase.decode_prepare / decode_pair)
+                from probnmn.modules.seq2seq_base import decode_pair
+
+                qr_state = self.qr.encode(qr_src)
+                prep_qr = self.qr.decode_prepare(qr_state, qr_tgt)
+                if prep_qr is not None:
+                    o_pg, o_qr = decode_pair(prep_pg, prep_qr)
+                    out["pg_sup_rows"], out["qr_rows"] = o_pg["loss"], o_qr["loss"]
+                else:
+                    out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
+                    out["qr_rows"] = self.qr.decode(qr_state, qr_tgt, "sampling", False)["loss"]
+            else:
+                out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
+                out["qr_rows"] = self.qr(qr_src, qr_tgt, "sampling", False)["loss"]
         elif n_sup:
+            out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
             out["qr_rows"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"]
         elif reconstruct:
             out["qr_rows"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
@@ -173,6 +189,9 @@ class _TrainerBase(StepBase):
         return self.elbo.objective(p["pg"]["loss"] if n else None, p["qr_rows"], p.get("prior"), nmn_rows,
                                    p.get("pg_sup_rows"), w_nosup, w_sup, alpha, gamma, n, m)
 
+
+#: PNMN_PAIR_DECODERS=0: the two teacher-forced decodes of an iteration as two launches each way (A/B aid)
+_PAIR_DECODERS = os.environ.get("PNMN_PAIR_DECODERS", "1") != "0"
 
 #: PNMN_FUSED_OBJECTIVE=0: the iteration's scalar end as the chain of torch ops it used to be (A/B aid)
 _FUSED_OBJECTIVE = os.environ.get("PNMN_FUSED_OBJECTIVE", "1") != "0"

@@ -543,3 +543,50 @@ def test_program_prior_sample_and_training_step():
         want_g = ref_sd[name].grad
         assert float((p.grad.cpu() - want_g).abs().max()) / (float(want_g.abs().max()) + 1e-12) < 2e-3, name
     assert step.after_validation(1.0 / 3.0) == 1e-2 and set(step.state_dict()) == {"program_prior", "optimizer", "scheduler", "iteration"}
+
+
+@pytest.mark.parametrize("rows_a,rows_b", [(40, 70), (16, 16), (300, 300)])
+def test_paired_teacher_forced_decodes_equal_two_single_ones(rows_a, rows_b):
+    """Seq2SeqBase.decode_prepare / decode_pair: the generator's and the reconstructor's teacher-forced decodes in one
+    launch each way (attn_lstm_fwd_pair_kernel / bwd) against the same two passes launched one after the other -- same
+    kernels' bodies, same operand order: losses and every gradient bit for bit.  (300 + 300 rows do not fit one launch
+    together: the library then runs them back to back.)"""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator, QuestionReconstructor
+    from probnmn.modules.seq2seq_base import decode_pair
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(3)
+    pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
+    ba = synthetic_batch(vocab, rows_a, seed=31, with_image=False)
+    bb = synthetic_batch(vocab, rows_b, seed=32, with_image=False)
+    qa, pa = ba["question"].to(dev), ba["program"].to(dev)
+    qb, pb = bb["question"].to(dev), bb["program"].to(dev)
+    wa, wb = torch.rand(rows_a, device=dev), torch.rand(rows_b, device=dev)  # row weights: every row's gradient matters
+
+    def run(paired):
+        for m in (pg, qr):
+            m.train()
+            m.zero_grad(set_to_none=True)
+        sa, sb = pg.encode(qa), qr.encode(pb)
+        if paired:
+            prep_a, prep_b = pg.decode_prepare(sa, pa), qr.decode_prepare(sb, qb)
+            assert prep_a is not None and prep_b is not None
+            oa, ob = decode_pair(prep_a, prep_b)
+        else:
+            oa = pg.decode(sa, pa, "sampling", need_predictions=False)
+            ob = qr.decode(sb, qb, "sampling", need_predictions=False)
+        ((oa["loss"] * wa).sum() + (ob["loss"] * wb).sum()).backward()
+        torch.cuda.synchronize()
+        grads = {("pg", n): p.grad.clone() for n, p in pg.named_parameters()}
+        grads.update({("qr", n): p.grad.clone() for n, p in qr.named_parameters()})
+        return oa["loss"].detach().clone(), ob["loss"].detach().clone(), grads
+
+    la0, lb0, g0 = run(False)
+    la1, lb1, g1 = run(True)
+    assert torch.equal(la0, la1) and torch.equal(lb0, lb1)
+    for k in g0:
+        # (split-K weight-gradient GEMMs and atomics-free kernels: same order in both runs)
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-6, atol=1e-7, msg=lambda m, k=k: "%s: %s" % (k, m))
