@@ -21,6 +21,7 @@ performs no host synchronisation.
 import os
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F
