@@ -89,12 +89,15 @@ int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_c
 
 // Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
 // that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
-// work).  So the units are cut in two: as many as fill whole rounds go out with the split `s_main`,
-// the remainder follows in a second launch with a larger split `s_tail`, whose single round is
-// s_tail / s_main times shorter.  Relative costs only: one tap of one 128-channel chunk = 1 unit,
-// staging a chunk ~ 0.5 unit, a second launch ~ 0.3 unit.
+// work).  So the units are cut into up to THREE launches of non-decreasing split: as many as fill whole rounds
+// go out with the first split, the remainder follows with larger splits -- whose rounds are s times shorter --
+// again in whole rounds first (667 module-conv items: 512 at split 1, 128 at split 2 -- exactly one round of half
+// the work -- and 27 at split 8, instead of 512 + 155 at split 4 = three quarter rounds: round 3, -5 % on such a
+// launch).  Relative costs only: one tap of one 128-channel chunk = 1 unit, staging a chunk ~ 0.5 unit, every
+// further launch ~ 0.3 unit.
 struct LaunchPlan {
-    int s_main, n_main, s_tail;
+    int n_seg;
+    int split[3], count[3];
 };
 
 inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps) {
@@ -103,30 +106,46 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
         const char* e = getenv("PNMN_CONV_STAGE_COST");
         return e ? atof(e) : 0.5;
     }();
+    static const int max_seg = [] {  // (A/B hook: 2 = the round-2 planner)
+        const char* e = getenv("PNMN_CONV_MAX_LAUNCHES");
+        const int v = e ? atoi(e) : 3;
+        return v >= 1 && v <= 3 ? v : 3;
+    }();
     const double overhead = stage_cost * cin_chunks + 0.25;
     // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
     auto round_cost = [&](int s) { return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead; };
     static const int s_max = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
-    LaunchPlan best{1, 0, 1};
+    LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
-    for (int s = 1; s <= s_max; s *= 2) {
+    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s + 255) / 256; };
+    auto full_of = [&](long n, int s) {  // items that fill whole rounds at split s
         const long per_item = (long)cout_blocks * s;
-        const long full_rounds = (long)n_items * per_item / 256;
-        long n_main = full_rounds * 256 / per_item;
-        if (n_main > n_items) n_main = n_items;
-        const long n_tail = n_items - n_main;
-        const double t_main = (double)full_rounds * round_cost(s);
-        if (n_tail == 0) {
-            if (t_main < best_t * 0.97) best_t = t_main, best = LaunchPlan{s, n_items, s};
-            continue;
+        const long m = ((long)n * per_item / 256) * 256 / per_item;
+        return m > n ? n : m;
+    };
+    auto consider = [&](const LaunchPlan& p, double t) {
+        if (t < best_t * 0.97) {  // prefer fewer launches / smaller splits unless the gain is real
+            best_t = t;
+            best = p;
         }
-        for (int st = s; st <= s_max; st *= 2) {
-            const long tail_rounds = (n_tail * cout_blocks * st + 255) / 256;
-            const double t = t_main + (double)tail_rounds * round_cost(st) + (n_main > 0 ? 0.3 : 0.0);
-            if (t < best_t * 0.97) {  // prefer the smaller splits unless the gain is real
-                best_t = t;
-                best = LaunchPlan{s, (int)n_main, st};
-            }
+    };
+    for (int s0 = 1; s0 <= s_max; s0 *= 2) {
+        // one launch
+        consider(LaunchPlan{1, {s0, 0, 0}, {n_items, 0, 0}}, (double)rounds_of(n_items, s0) * round_cost(s0));
+        if (max_seg < 2) continue;
+        const long m0 = full_of(n_items, s0);
+        if (m0 <= 0 || m0 >= n_items) continue;
+        const double t0 = (double)rounds_of(m0, s0) * round_cost(s0);
+        const long r0 = n_items - m0;
+        for (int s1 = s0; s1 <= s_max; s1 *= 2) {
+            consider(LaunchPlan{2, {s0, s1, 0}, {(int)m0, (int)r0, 0}}, t0 + (double)rounds_of(r0, s1) * round_cost(s1) + 0.3);
+            if (max_seg < 3 || s1 == s0) continue;
+            const long m1 = full_of(r0, s1);
+            if (m1 <= 0 || m1 >= r0) continue;
+            const double t1 = t0 + (double)rounds_of(m1, s1) * round_cost(s1) + 0.3;
+            const long r1 = r0 - m1;
+            for (int s2 = s1 * 2; s2 <= s_max; s2 *= 2)
+                consider(LaunchPlan{3, {s0, s1, s2}, {(int)m0, (int)m1, (int)r1}}, t1 + (double)rounds_of(r1, s2) * round_cost(s2) + 0.3);
         }
     }
     return best;
@@ -159,14 +178,14 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
                 int out_stride, int cout_blocks, int relu, hipStream_t stream) {
     const int n_units = n_items * (H / TH);
     const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps);
-    if (lp.n_main > 0) {
-        const int rc = launch_conv_split<H, W, TH>(lp.s_main, items, 0, lp.n_main, cin_chunks, ntaps, in_stride,
+    int at = 0;
+    for (int k = 0; k < lp.n_seg; ++k) {
+        if (lp.count[k] <= 0) continue;
+        const int rc = launch_conv_split<H, W, TH>(lp.split[k], items, at, lp.count[k], cin_chunks, ntaps, in_stride,
                                                    out_stride, cout_blocks, relu, stream);
         if (rc != 0) return rc;
+        at += lp.count[k];
     }
-    if (lp.n_main < n_units)
-        return launch_conv_split<H, W, TH>(lp.s_tail, items, lp.n_main, n_units - lp.n_main, cin_chunks, ntaps,
-                                           in_stride, out_stride, cout_blocks, relu, stream);
     return 0;
 }
 
@@ -179,7 +198,9 @@ extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks
     const int nb = bands_of(H, W);
     if (n_items <= 0 || nb == 0) return 0;
     const LaunchPlan lp = plan_launch(n_items * nb, cout_blocks, cin_chunks, ntaps);
-    return (lp.n_main > 0 ? 1 : 0) + (lp.n_main < n_items * nb ? 1 : 0);
+    int n = 0;
+    for (int k = 0; k < lp.n_seg; ++k) n += lp.count[k] > 0 ? 1 : 0;
+    return n;
 }
 
 extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W,
