@@ -5,6 +5,7 @@ TAG=${1:-r03a}
 python -c "import torch" >/dev/null 2>&1
 timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log
 tail -4 gpurun_out/${TAG}_pytest.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1; tail -2 gpurun_out/${TAG}_smoke.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -2 gpurun_out/${TAG}_bench.err; cut -c1-200 gpurun_out/${TAG}_bench.json
 bash scripts/profile_round.sh $TAG
