@@ -575,12 +575,13 @@ class _AttnLSTMDecoder(torch.autograd.Function):
 
 
 class _AttnLSTMDecoderPair(torch.autograd.Function):
-    """TWO teacher-forced decoder passes of different models in one launch each way (``pnmn_attn_lstm_fwd_multi_pair`` /
-    ``_bwd_multi_pair``): the passes are independent, and the persistent decoder kernels are bound by their per-step
-    hand-off latency -- side by side they take as long as the longer one.  Per side: etable [V,4H] (per-token input
-    projections, ``_TokenTable``), enc [B,S,H], mask [B,S], h0 [B,H], W_c, W_hh; ``meta`` carries what is not a tensor
-    input (step inputs ``in_tokens`` [B,T], fragment packs).  Same arithmetic as two ``_AttnLSTMDecoder`` calls (the
-    library runs the passes one after the other when they do not fit the chip together)."""
+    """TWO independent decoder passes in one launch each way (``pnmn_attn_lstm_fwd_multi_pair`` / ``_bwd_multi_pair``):
+    the persistent decoder kernels are bound by their per-step hand-off latency, so side by side they take as long as
+    the longer pass.  Either side may be teacher forced (mode 0: step inputs ``in_tokens`` [B,T] index the per-token
+    table) or free running (mode 1 sampling / 2 greedy: the kernel picks each step's token; ``etable`` then is the
+    projected embedding table).  Per side the tensor inputs are etable [V,4H], enc [B,S,H], mask [B,S], h0 [B,H], W_c,
+    W_hh; ``meta`` carries the rest.  Same arithmetic as two ``_AttnLSTMDecoder`` calls (bit for bit: the kernels'
+    bodies are shared; the library runs the passes one after the other when they do not fit the chip together)."""
 
     @staticmethod
     def forward(ctx, etable_a, enc_a, mask_a, h0_a, w_c_a, w_hh_a, etable_b, enc_b, mask_b, h0_b, w_c_b, w_hh_b, meta):
@@ -591,9 +592,7 @@ class _AttnLSTMDecoderPair(torch.autograd.Function):
             etable, enc, mask, h0 = etable.contiguous(), enc.contiguous(), mask.contiguous(), h0.contiguous()
             w_c, w_hh = w_c.detach(), w_hh.detach()
             packs = m["packs"] if m["packs"] is not None else (pack_fragments(w_c), pack_fragments(w_hh), None, None)
-            in_tokens, T = m["in_tokens"], m["T"]
-            if in_tokens.dtype != torch.long or in_tokens.stride(1) != 1:
-                in_tokens = in_tokens.long().contiguous()
+            mode, T = m["mode"], m["T"]
             B, S, Hd = enc.shape
             f = dict(dtype=torch.float32, device=dev)
             hs, cs, cx = torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f), torch.empty(B, T, Hd, **f)
@@ -602,32 +601,49 @@ class _AttnLSTMDecoderPair(torch.autograd.Function):
             j["etable"], j["enc"], j["mask"], j["h0"] = etable.data_ptr(), enc.data_ptr(), mask.data_ptr(), h0.data_ptr()
             j["w_c"], j["w_hh"] = packs[0].data_ptr(), packs[1].data_ptr()
             j["hs"], j["cs"], j["act"], j["ctx"], j["probs"] = hs.data_ptr(), cs.data_ptr(), act.data_ptr(), cx.data_ptr(), probs.data_ptr()
-            j["in_tokens"], j["in_token_stride"] = in_tokens.data_ptr(), in_tokens.stride(0)
             j["B"], j["T"], j["S"], j["start_index"] = B, T, S, m["start"]
+            in_tokens = tokens = None
+            keep = [etable, packs]
+            if mode == 0:
+                in_tokens = m["in_tokens"]
+                if in_tokens.dtype != torch.long or in_tokens.stride(1) != 1:
+                    in_tokens = in_tokens.long().contiguous()
+                j["in_tokens"], j["in_token_stride"] = in_tokens.data_ptr(), in_tokens.stride(0)
+            else:
+                w_p, b_p = m["w_p"].detach().contiguous(), m["b_p"].detach().contiguous()
+                tokens = torch.empty(B, T, dtype=torch.long, device=dev)
+                j["w_p"], j["b_p"], j["tokens"], j["V"], j["sample"] = w_p.data_ptr(), b_p.data_ptr(), tokens.data_ptr(), w_p.size(0), mode
+                j["pad_index"], j["unk_index"], j["seed"], j["row_offset"] = m["pad"], m["unk"], m["seed"], m["row_offset"]
+                keep += [w_p, b_p]
             sides.append(dict(hs=hs, cs=cs, act=act, cx=cx, probs=probs, enc=enc, mask=mask, h0=h0, w_c=w_c, w_hh=w_hh,
-                              in_tokens=in_tokens, vocab=etable.size(0), packs_t=(packs[2], packs[3]) if packs[2] is not None else None,
-                              keep=(etable, packs)))
+                              in_tokens=in_tokens, tokens=tokens, vocab=etable.size(0), mode=mode, start=m["start"],
+                              packs_t=(packs[2], packs[3]) if packs[2] is not None else None, keep=keep))
         Ba, Bb = sides[0]["hs"].size(0), sides[1]["hs"].size(0)
         ws = torch.empty(int(_hip.lib().pnmn_attn_lstm_pair_workspace_bytes(Ba, Bb, 0)), dtype=torch.uint8, device=dev)
         _hip.check(_hip.lib().pnmn_attn_lstm_fwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, sides[0]["hs"].size(2),
                                                             ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_fwd_multi_pair")
-        saved = []
+        saved, outs = [], []
+        empty = torch.empty(0, dtype=torch.long, device=dev)
         for sd in sides:
+            step_tokens = sd["in_tokens"] if sd["mode"] == 0 else sd["tokens"]
             saved += [sd["hs"], sd["cs"], sd["act"], sd["cx"], sd["probs"], sd["enc"], sd["mask"], sd["h0"], sd["w_c"], sd["w_hh"],
-                      sd["in_tokens"]]
+                      step_tokens]
+            toks = sd["tokens"] if sd["tokens"] is not None else empty
+            outs += [sd["hs"], toks]
         ctx.save_for_backward(*saved)
-        ctx.side_meta = [(sd["vocab"], sd["packs_t"]) for sd in sides]
-        return sides[0]["hs"], sides[1]["hs"]
+        ctx.side_meta = [(sd["vocab"], sd["packs_t"], sd["mode"], sd["start"]) for sd in sides]
+        ctx.mark_non_differentiable(outs[1], outs[3])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dhs_a, dhs_b):
+    def backward(ctx, dhs_a, _ta, dhs_b, _tb):
         saved = ctx.saved_tensors
         dev = saved[0].device
         jobs = np.zeros(2, _hip.DECODER_BWD_JOB)
         sides = []
         for k, dhs in enumerate((dhs_a, dhs_b)):
-            hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, in_tokens = saved[11 * k: 11 * k + 11]
-            vocab, packs_t = ctx.side_meta[k]
+            hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, step_tokens = saved[11 * k: 11 * k + 11]
+            vocab, packs_t, mode, start = ctx.side_meta[k]
             B, T, Hd = hs.shape
             S = enc.size(1)
             dhs_c = torch.zeros_like(hs) if dhs is None else dhs.contiguous()
@@ -640,8 +656,9 @@ class _AttnLSTMDecoderPair(torch.autograd.Function):
                             ("dscore", dscore), ("weights", weights), ("dh0", dh0)):
                 j[name] = t.data_ptr()
             j["B"], j["T"], j["S"] = B, T, S
-            sides.append(dict(hs=hs, cx=cx, enc=enc, h0=h0, in_tokens=in_tokens, vocab=vocab, dgates=dgates, dh0=dh0, dctx=dctx,
-                              dscore=dscore, weights=weights, keep=(dhs_c, w_c_t, w_hh_t), B=B, T=T, S=S, Hd=Hd))
+            sides.append(dict(hs=hs, cx=cx, enc=enc, h0=h0, step_tokens=step_tokens, vocab=vocab, mode=mode, start=start,
+                              dgates=dgates, dh0=dh0, dctx=dctx, dscore=dscore, weights=weights, keep=(dhs_c, w_c_t, w_hh_t),
+                              B=B, T=T, S=S, Hd=Hd))
         ws = torch.empty(int(_hip.lib().pnmn_attn_lstm_pair_workspace_bytes(sides[0]["B"], sides[1]["B"], 1)), dtype=torch.uint8, device=dev)
         _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, sides[0]["Hd"], ws.data_ptr(),
                                                             _hip.stream_ptr(dev)), "attn_lstm_bwd_multi_pair")
@@ -665,10 +682,17 @@ class _AttnLSTMDecoderPair(torch.autograd.Function):
             if need[5]:
                 hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
                 dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
-            detable = _table_grad(sd["dgates"], sd["in_tokens"], sd["vocab"]) if need[0] else None
+            detable = None
+            if need[0]:
+                if sd["mode"] == 0:
+                    detable = _table_grad(sd["dgates"], sd["step_tokens"], sd["vocab"])
+                elif sd["vocab"] <= 128:  # step t's input is the token chosen at step t - 1 (@start@ first)
+                    detable = embedding_grad(sd["dgates"], sd["step_tokens"], sd["vocab"], shift=True, start=sd["start"])
+                else:
+                    tok_in = torch.cat((sd["step_tokens"].new_full((B, 1), sd["start"]), sd["step_tokens"][:, :-1]), 1).reshape(-1)
+                    detable = torch.zeros(sd["vocab"], 4 * Hd, dtype=flat.dtype, device=dev).index_add_(0, tok_in, flat)
             grads += [detable, denc, None, sd["dh0"], dw_c, dw_hh]
         return (*grads, None)
-
 
 
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
@@ -1025,36 +1049,51 @@ class Seq2SeqBase(nn.Module):
         return output_dict
 
     # ---- two teacher-forced decodes of a training iteration side by side -------------------------------------------
-    def decode_prepare(self, state: Dict[str, torch.Tensor], target_tokens: torch.LongTensor):
-        """First half of a teacher-forced training ``decode`` whose persistent-kernel launch is to be shared with another
-        model's (``decode_pair``): everything up to the launch.  ``None`` when this pass cannot take part (shapes outside
-        the fused kernels, evaluation: metrics want the predictions)."""
+    def decode_prepare(self, state: Dict[str, torch.Tensor], target_tokens: Optional[torch.LongTensor] = None,
+                       decoding_strategy: str = "sampling"):
+        """First half of a training ``decode`` whose persistent-kernel launch is to be shared with another pass
+        (``decode_pair``): everything up to the launch.  ``target_tokens`` given: teacher forced; ``None``: free running
+        (the kernel samples / arg-maxes each step's token).  Returns ``None`` when this pass cannot take part (shapes
+        outside the fused kernels, evaluation: metrics want predictions from the teacher-forced distributions)."""
         enc, h, fmask = state["enc"], state["h"], state["fmask"]
-        w_p = self._output_projection_layer.weight
+        w_p, b_p = self._output_projection_layer.weight, self._output_projection_layer.bias
         Hd = h.size(1)
         if not (self.training and torch.is_grad_enabled() and enc.is_cuda and Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128):
             return None
-        pad, bos, eos = self._pad_index, self._start_index, self._end_index
-        tgt = _TokenPrep.run(target_tokens, pad, bos, eos, drop_first=False, want_mask=False)[0]
-        steps = tgt.size(1) - 1
-        w_ih = self._decoder_cell.weight_ih
-        w_c, w_e = _SplitColumns.apply(w_ih, Hd) if w_ih.requires_grad else (w_ih[:, :Hd], w_ih[:, Hd:])
         derived = self._derived()
         if derived is None:
             return None
+        pad, bos, eos = self._pad_index, self._start_index, self._end_index
+        w_ih = self._decoder_cell.weight_ih
+        w_c, w_e = _SplitColumns.apply(w_ih, Hd) if w_ih.requires_grad else (w_ih[:, :Hd], w_ih[:, Hd:])
         bias = _Alias.apply(self._decoder_cell.bias_ih, self._decoder_cell.bias_hh, derived["d.b"])
         emb = self._target_embedder
-        etable = _TokenTable.apply(emb.weight, w_e, bias, emb.padding_idx)
+        meta = {"packs": (derived["d.c"], derived["d.hh"], derived["d.cT"], derived["d.hhT"]), "start": bos}
+        tgt = None
+        if target_tokens is not None:
+            tgt = _TokenPrep.run(target_tokens, pad, bos, eos, drop_first=False, want_mask=False)[0]
+            steps = tgt.size(1) - 1
+            etable = _TokenTable.apply(emb.weight, w_e, bias, emb.padding_idx)
+            meta.update(mode=0, in_tokens=tgt[:, :steps], T=steps)
+        else:
+            steps = self._max_decoding_steps
+            etable = F.linear(emb.weight, w_e, bias)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+            meta.update(mode=2 if decoding_strategy == "greedy" else 1, T=steps, pad=pad, unk=self._unk_index, seed=seed,
+                        row_offset=self.sample_row_offset, w_p=w_p, b_p=b_p)
         return {"model": self, "tgt": tgt, "steps": steps, "etable": etable, "enc": enc, "fmask": fmask, "h": h, "w_c": w_c,
-                "w_hh": self._decoder_cell.weight_hh,
-                "meta": {"packs": (derived["d.c"], derived["d.hh"], derived["d.cT"], derived["d.hhT"]),
-                         "in_tokens": tgt[:, :steps], "T": steps, "start": bos}}
+                "w_hh": self._decoder_cell.weight_hh, "meta": meta}
 
-    def decode_finish(self, prep, hs: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Second half: the output projection over all steps and the per-row cross entropy (reference :235-254)."""
+    def decode_finish(self, prep, hs: torch.Tensor, raw: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Second half: the output projection over all steps and the per-row loss -- the cross entropy of the targets
+        (reference :235-254) or, free running, the length-normalised negative log-probability of the trimmed samples
+        (reference :222-233)."""
         logits_all = self._output_projection_layer(hs)
         tgt = prep["tgt"]
-        return {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], self._pad_index, 1e-13)}
+        if tgt is not None:
+            return {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], self._pad_index, 1e-13)}
+        predictions = self._trim_predictions(raw)
+        return {"predictions": predictions, "loss": sequence_nll(logits_all, raw, predictions, self._pad_index, 1e-12)}
 
     def _decode_stepwise(self, enc, fmask, h, c, tgt, steps, greedy, seed):
         """Step-by-step decoding for shapes the persistent kernel is not built for (hidden != 256,
@@ -1125,9 +1164,10 @@ class Seq2SeqBase(nn.Module):
 
 
 def decode_pair(prep_a, prep_b):
-    """The launches of two prepared teacher-forced decodes (``Seq2SeqBase.decode_prepare``) as one, then each model's
-    second half.  Returns the two output dicts ({"loss": per-row cross entropy})."""
-    hs_a, hs_b = _AttnLSTMDecoderPair.apply(prep_a["etable"], prep_a["enc"], prep_a["fmask"], prep_a["h"], prep_a["w_c"], prep_a["w_hh"],
-                                            prep_b["etable"], prep_b["enc"], prep_b["fmask"], prep_b["h"], prep_b["w_c"], prep_b["w_hh"],
-                                            (prep_a["meta"], prep_b["meta"]))
-    return prep_a["model"].decode_finish(prep_a, hs_a), prep_b["model"].decode_finish(prep_b, hs_b)
+    """The launches of two prepared decodes (``Seq2SeqBase.decode_prepare``) as one, then each model's second half.
+    Returns the two output dicts ({"loss": per-row loss[, "predictions"]})."""
+    hs_a, tok_a, hs_b, tok_b = _AttnLSTMDecoderPair.apply(
+        prep_a["etable"], prep_a["enc"], prep_a["fmask"], prep_a["h"], prep_a["w_c"], prep_a["w_hh"],
+        prep_b["etable"], prep_b["enc"], prep_b["fmask"], prep_b["h"], prep_b["w_c"], prep_b["w_hh"],
+        (prep_a["meta"], prep_b["meta"]))
+    return prep_a["model"].decode_finish(prep_a, hs_a, tok_a), prep_b["model"].decode_finish(prep_b, hs_b, tok_b)

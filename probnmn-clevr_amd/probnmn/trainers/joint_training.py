@@ -127,9 +127,24 @@ class _TrainerBase(StepBase):
             state_nosup = self.pg.encode(question[nosup_d])
         if after_encode is not None:
             out["after_encode"] = after_encode()
+        paired = False
         if n_nosup:
             ques_nosup = question[nosup_d]
-            out["pg"] = self.pg.decode(state_nosup, None, "sampling")
+            if n_sup and _PAIR_DECODERS and dev.type == "cuda":
+                # the generator's sampling decode and its supervised (teacher-forced) decode start from the same encoder
+                # pass and are independent: one launch each way for both -- the persistent decoder kernels are latency
+                # bound, so the supervised pass rides along for free while the sampling pass, which the step's critical
+                # chain waits for, takes as long as it did alone (Seq2SeqBase.decode_prepare / decode_pair)
+                from probnmn.modules.seq2seq_base import decode_pair
+
+                prep_s = self.pg.decode_prepare(state_nosup, None, "sampling")
+                prep_t = self.pg.decode_prepare(state_sup, prog_sup) if prep_s is not None else None
+                if prep_t is not None:
+                    out["pg"], o_sup = decode_pair(prep_s, prep_t)
+                    out["pg_sup_rows"] = o_sup["loss"]
+                    paired = True
+            if not paired:
+                out["pg"] = self.pg.decode(state_nosup, None, "sampling")
             z = out["pg"]["predictions"]
             out["programs"] = z
             if host_programs:
@@ -137,27 +152,11 @@ class _TrainerBase(StepBase):
             if after_sampling is not None:
                 out["after_sampling"] = after_sampling()
         # per-row losses; "qr_rows" = the sampled rows' reconstruction losses followed by the supervised rows'
-        if n_sup and n_nosup:
-            qr_src, qr_tgt = _cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0)
-            prep_pg = self.pg.decode_prepare(state_sup, prog_sup) if (_PAIR_DECODERS and dev.type == "cuda") else None
-            if prep_pg is not None:
-                # the generator's supervised decode and the reconstructor's decode are independent teacher-forced passes of
-                # latency-bound kernels: one launch each way for both (Seq2SeqBase.decode_prepare / decode_pair)
-                from probnmn.modules.seq2seq_base import decode_pair
-
-                qr_state = self.qr.encode(qr_src)
-                prep_qr = self.qr.decode_prepare(qr_state, qr_tgt)
-                if prep_qr is not None:
-                    o_pg, o_qr = decode_pair(prep_pg, prep_qr)
-                    out["pg_sup_rows"], out["qr_rows"] = o_pg["loss"], o_qr["loss"]
-                else:
-                    out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
-                    out["qr_rows"] = self.qr.decode(qr_state, qr_tgt, "sampling", False)["loss"]
-            else:
-                out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
-                out["qr_rows"] = self.qr(qr_src, qr_tgt, "sampling", False)["loss"]
-        elif n_sup:
+        if n_sup and not paired:
             out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
+        if n_sup and n_nosup:
+            out["qr_rows"] = self.qr(_cat_padded(z, prog_sup), torch.cat((ques_nosup, ques_sup), 0), "sampling", False)["loss"]
+        elif n_sup:
             out["qr_rows"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"]
         elif reconstruct:
             out["qr_rows"] = self.qr(z, ques_nosup, "sampling", False)["loss"]
@@ -190,7 +189,7 @@ class _TrainerBase(StepBase):
                                    p.get("pg_sup_rows"), w_nosup, w_sup, alpha, gamma, n, m)
 
 
-#: PNMN_PAIR_DECODERS=0: the two teacher-forced decodes of an iteration as two launches each way (A/B aid)
+#: PNMN_PAIR_DECODERS=0: the generator's sampling and supervised decodes as two launches each way (A/B aid)
 _PAIR_DECODERS = os.environ.get("PNMN_PAIR_DECODERS", "1") != "0"
 
 #: PNMN_FUSED_OBJECTIVE=0: the iteration's scalar end as the chain of torch ops it used to be (A/B aid)

@@ -590,3 +590,49 @@ def test_paired_teacher_forced_decodes_equal_two_single_ones(rows_a, rows_b):
     for k in g0:
         # (split-K weight-gradient GEMMs and atomics-free kernels: same order in both runs)
         torch.testing.assert_close(g1[k], g0[k], rtol=1e-6, atol=1e-7, msg=lambda m, k=k: "%s: %s" % (k, m))
+
+
+@pytest.mark.parametrize("rows_s,rows_t", [(48, 80), (256, 256), (400, 300)])
+def test_paired_sampling_and_teacher_forced_decodes_equal_two_single_ones(rows_s, rows_t):
+    """What the training iterations launch: the generator's SAMPLING decode of the unsupervised rows and its
+    teacher-forced decode of the supervised rows as one launch each way, against the two passes one after the other
+    (same seed): sampled programs, both losses and every gradient identical."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator
+    from probnmn.modules.seq2seq_base import decode_pair
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(5)
+    pg = ProgramGenerator(vocab).to(dev)
+    pg.sample_row_offset = 1000
+    b = synthetic_batch(vocab, rows_s + rows_t, seed=41, with_image=False)
+    q, p = b["question"].to(dev), b["program"].to(dev)
+    idx_s, idx_t = torch.arange(rows_s, device=dev), torch.arange(rows_s, rows_s + rows_t, device=dev)
+    ws, wt = torch.rand(rows_s, device=dev), torch.rand(rows_t, device=dev)
+
+    def run(paired):
+        pg.train()
+        pg.zero_grad(set_to_none=True)
+        torch.manual_seed(77)  # the sampling seed comes from the CPU generator
+        state = pg.encode(q)
+        st_s, st_t = pg.select_rows(state, idx_s), pg.select_rows(state, idx_t)
+        if paired:
+            prep_s, prep_t = pg.decode_prepare(st_s, None, "sampling"), pg.decode_prepare(st_t, p[idx_t])
+            assert prep_s is not None and prep_t is not None
+            o_s, o_t = decode_pair(prep_s, prep_t)
+        else:
+            o_s = pg.decode(st_s, None, "sampling")
+            o_t = pg.decode(st_t, p[idx_t], "sampling", need_predictions=False)
+        ((o_s["loss"] * ws).sum() + (o_t["loss"] * wt).sum()).backward()
+        torch.cuda.synchronize()
+        return (o_s["predictions"].clone(), o_s["loss"].detach().clone(), o_t["loss"].detach().clone(),
+                {n: t.grad.clone() for n, t in pg.named_parameters()})
+
+    z0, ls0, lt0, g0 = run(False)
+    z1, ls1, lt1, g1 = run(True)
+    assert torch.equal(z0, z1) and torch.equal(ls0, ls1) and torch.equal(lt0, lt1)
+    assert int((z0 != 0).sum()) > rows_s  # real programs were sampled
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-6, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
