@@ -151,11 +151,6 @@ class _TrainerBase(StepBase):
                 out["programs_host"] = self._host_copy(z)
             if after_sampling is not None:
                 out["after_sampling"] = after_sampling()
-            if before_prior is not None and self.__dict__.get("trunk_first"):
-                # (PNMN_TRUNK_FIRST=1: plan and launch the trunk BEFORE the reconstructor pass is issued -- the main stream
-                # idles while the host waits for the programs and plans, the trunk gets the chip to itself for that long)
-                out["before_prior"] = before_prior(out["programs_host"])
-                before_prior = None
         # per-row losses; "qr_rows" = the sampled rows' reconstruction losses followed by the supervised rows'
         if n_sup and not paired:
             out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
@@ -278,7 +273,6 @@ class JointTrainingStep(_TrainerBase):
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
-        self.trunk_first = os.environ.get("PNMN_TRUNK_FIRST", "0") == "1"
         # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
         # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
         # Measured at 128 questions (gpurun_out/r03f_ab.txt): 7.85-7.89 ms against 7.83-7.92 -- no difference, so the
