@@ -79,6 +79,11 @@ typedef struct pnmn_conv_item {
 int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks,
                    int ntaps /* 9 or 1 */, int in_stride, int out_stride,
                    int cout_blocks /* cout_total / 128 */, int relu, void* stream);
+/* The same with the number of CUs the launch may count on (0 = all of them): the launch planner cuts the items into
+ * rounds of that many workgroups.  For launches that share the chip with other streams' kernels (the joint step's trunk
+ * beside the seq2seq passes).  In a pnmn_launch entry the `c` field of a CONV carries it. */
+int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks, int ntaps, int in_stride,
+                       int out_stride, int cout_blocks, int relu, int cus, void* stream);
 /* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 or 2: whole rounds of 256
  * workgroups with one K-split, the remainder with a larger one) -- for per-launch accounting. */
 int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks);
@@ -524,7 +529,7 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
  * point named by `op` with (a, b, c, n, p[...]) in that entry point's argument order (pointers first, then
  * the item count, then the integer arguments), all on `stream`; stops at the first non-zero return code.
  * Replaces ~160 one-by-one calls per step of the per-example interpreter loop (nmn.py:197-238) with two.
- *   CONV  a items, n, p = H, W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu
+ *   CONV  a items, n, p = H, W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu; c = CU budget (0 = all)
  *   WGRAD a items, b jobs, n = n_jobs, p = H, W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride
  *   TRANSPOSE_WEIGHTS a items, n      DOT_* / SAME_* / MASK_BWD a items, n, p = HW      MINMAX_* p = HW, C
  *   MAXPOOL_FWD a in, b out, n, p = H, W, C       MAXPOOL_BWD a in, b dout, c din, n, p = H, W, C
@@ -599,7 +604,8 @@ typedef struct pnmn_trunk_io {
     uint8_t*           valid;         /* out: host [n_programs] */
     int64_t            arena_floats;  /* out */
     int32_t            n_programs, length, n_fwd_tail, n_bwd_head, n_bwd_tail, bwd_capacity, need_backward, launch;
-    int32_t            n_bwd, bwd_piece_cut, n_prims, n_fwd, depth, n_invalid, n_feat_result, reserved;
+    int32_t            n_bwd, bwd_piece_cut, n_prims, n_fwd, depth, n_invalid, n_feat_result;
+    int32_t            conv_cus;      /* in: CU budget of the module programs' conv launches (0 = all CUs) */
 } pnmn_trunk_io;           /* 208 bytes */
 int pnmn_trunk_planner_create(const pnmn_trunk_config* config, void** planner);
 int pnmn_trunk_planner_destroy(void* planner);
@@ -661,7 +667,7 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
-/* Library self-description (no GPU needed).  5 = round 3: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* Library self-description (no GPU needed).  6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

@@ -100,7 +100,7 @@ struct LaunchPlan {
     int split[3], count[3];
 };
 
-inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps) {
+inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0) {
     const double work = (double)ntaps * cin_chunks;
     static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
         const char* e = getenv("PNMN_CONV_STAGE_COST");
@@ -117,10 +117,21 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     static const int s_max = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
-    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s + 255) / 256; };
+    // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
+    // joint step's trunk runs on its own stream beside the seq2seq passes, whose multi-CU kernels hold 64-96 CUs for
+    // hundreds of microseconds -- a launch cut for 256 workgroups then takes two rounds where one cut for the free
+    // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, gpurun_out/r03w_ab.txt).  PNMN_CONV_CUS overrides the
+    // default of launches that do not say (tuning hook).
+    static const long default_cus = [] {
+        const char* e = getenv("PNMN_CONV_CUS");
+        const long v = e ? atol(e) : 256;
+        return v >= 8 && v <= 256 ? v : 256;
+    }();
+    const long cus = (cu_budget >= 8 && cu_budget <= 256) ? cu_budget : default_cus;
+    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s + cus - 1) / cus; };
     auto full_of = [&](long n, int s) {  // items that fill whole rounds at split s
         const long per_item = (long)cout_blocks * s;
-        const long m = ((long)n * per_item / 256) * 256 / per_item;
+        const long m = ((long)n * per_item / cus) * cus / per_item;
         return m > n ? n : m;
     };
     auto consider = [&](const LaunchPlan& p, double t) {
@@ -175,9 +186,9 @@ int launch_conv_split(int split, const pnmn_conv_item* items, int unit0, int n_u
 
 template <int H, int W, int TH>
 int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
-                int out_stride, int cout_blocks, int relu, hipStream_t stream) {
+                int out_stride, int cout_blocks, int relu, int cus, hipStream_t stream) {
     const int n_units = n_items * (H / TH);
-    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps);
+    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus);
     int at = 0;
     for (int k = 0; k < lp.n_seg; ++k) {
         if (lp.count[k] <= 0) continue;
@@ -206,6 +217,12 @@ extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks
 extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W,
                               int cin_chunks, int ntaps, int in_stride, int out_stride,
                               int cout_blocks, int relu, void* stream) {
+    return pnmn_conv_nhwc_cus(items, n_items, H, W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, 0, stream);
+}
+
+extern "C" int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int H, int W,
+                                  int cin_chunks, int ntaps, int in_stride, int out_stride,
+                                  int cout_blocks, int relu, int cus, void* stream) {
     if (n_items <= 0) return 0;
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
@@ -219,10 +236,10 @@ extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, i
             return launch_conv_split<14, 14, 14>(atoi(force), items, 0, n_items, cin_chunks, ntaps, in_stride, out_stride,
                                                  cout_blocks, relu, s);
         return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                       cout_blocks, relu, s);
+                                       cout_blocks, relu, cus, s);
     }
     if (H == 28 && W == 28)
         return launch_conv<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                      cout_blocks, relu, s);
+                                      cout_blocks, relu, cus, s);
     return PNMN_ESHAPE;
 }

@@ -18,8 +18,8 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
         int rc;
         switch (l.op) {
             case PNMN_OP_CONV:
-                rc = pnmn_conv_nhwc(static_cast<const pnmn_conv_item*>(l.a), l.n, p[0], p[1], p[2], p[3], p[4], p[5], p[6],
-                                    p[7], stream);
+                rc = pnmn_conv_nhwc_cus(static_cast<const pnmn_conv_item*>(l.a), l.n, p[0], p[1], p[2], p[3], p[4], p[5], p[6],
+                                        p[7], (int)reinterpret_cast<uintptr_t>(l.c), stream);
                 break;
             case PNMN_OP_WGRAD:
                 rc = pnmn_conv_wgrad(static_cast<const pnmn_wgrad_item*>(l.a), static_cast<const pnmn_wgrad_job*>(l.b), l.n,

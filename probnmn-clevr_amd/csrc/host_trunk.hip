@@ -518,6 +518,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
         if (c[0] < 0 || c[0] >= CUT_KINDS || lv < 0 || lv > depth) return PNMN_EINVAL;
         at[c[0]][lv].push_back(Cut{c[2], c[3]});
     }
+    const void* conv_cus = reinterpret_cast<const void*>((uintptr_t)(io->conv_cus > 0 ? io->conv_cus : 0));
     P.fwd.clear();
     const size_t n_zero = (size_t)io->n_invalid, n_copy = (size_t)io->n_feat_result;
     if (n_zero + n_copy) P.fwd.push_back(make_launch(PNMN_OP_SET_ROWS, (int)(n_zero + n_copy), rows_at(0), nullptr, nullptr, {}));
@@ -529,9 +530,9 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
         for (const Cut& c : at[CUT_DOT][lv])
             P.fwd.push_back(make_launch(PNMN_OP_DOT_FWD, c.e - c.b, rec(R_DOT, c.b), nullptr, nullptr, {HW}));
         for (const Cut& c : at[CUT_PROJ][lv])
-            P.fwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_PROJ, c.b), nullptr, nullptr, {H, W, 2, 1, C, C, 1, 1}));
+            P.fwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_PROJ, c.b), nullptr, conv_cus, {H, W, 2, 1, C, C, 1, 1}));
         for (const Cut& c : at[CUT_CONV][lv])
-            P.fwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_CONV, c.b), nullptr, nullptr, {H, W, 1, 9, C, C, 1, 1}));
+            P.fwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_CONV, c.b), nullptr, conv_cus, {H, W, 1, 9, C, C, 1, 1}));
     }
     for (int i = 0; i < io->n_fwd_tail; ++i) P.fwd.push_back(io->fwd_tail[i]);
     io->n_fwd = (int)P.fwd.size();
@@ -551,9 +552,9 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
             for (const Cut& c : at[CUT_DOT][lv])
                 bwd.push_back(make_launch(PNMN_OP_DOT_BWD, c.e - c.b, rec(R_DOT, c.b), nullptr, nullptr, {HW}));
             for (const Cut& c : at[CUT_PDGRAD][lv])
-                bwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_PDGRAD, c.b), nullptr, nullptr, {H, W, 1, 1, C, C, 1, 0}));
+                bwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_PDGRAD, c.b), nullptr, conv_cus, {H, W, 1, 1, C, C, 1, 0}));
             for (const Cut& c : at[CUT_DGRAD][lv])
-                bwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_DGRAD, c.b), nullptr, nullptr, {H, W, 1, 9, C, C, 1, 0}));
+                bwd.push_back(make_launch(PNMN_OP_CONV, c.e - c.b, rec(R_DGRAD, c.b), nullptr, conv_cus, {H, W, 1, 9, C, C, 1, 0}));
             for (const Cut& c : at[CUT_MASKBWD][lv])
                 bwd.push_back(make_launch(PNMN_OP_MASK_BWD, c.e - c.b, rec(R_MASKBWD, c.b), nullptr, nullptr, {HW}));
         }

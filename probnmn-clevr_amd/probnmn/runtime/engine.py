@@ -123,6 +123,10 @@ class NMNEngine:
         # instrumented path: per-launch events for bench.py's roofline pass (event_log), weight gradients on a second
         # stream (overlap_wgrad), PNMN_NATIVE_PLANNER=0 -- same kernels, same pnmn_plan_batch, same launch order
         # (tests/test_trunk_planner.py compares the two lists entry for entry).
+        # CUs the trunk's conv launches are planned for: 0 = all of them; a trainer that runs the trunk on its own stream
+        # beside other work sets the number it may count on (JointTrainingStep: 192 -- the seq2seq passes' multi-CU
+        # kernels hold 64-96 CUs, and a launch cut for 256 workgroups then takes two rounds)
+        self.conv_cus = 0
         self.native = os.environ.get("PNMN_NATIVE_PLANNER", "1") != "0"
         self._planner = None
         self._native_fixed: Dict[tuple, dict] = {}
@@ -149,13 +153,14 @@ class NMNEngine:
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what, rec=None):
         log = self.event_log
         if self._list is not None:  # (collected into one pnmn_run_launches call)
-            self._list.add(_hip.OP_CONV, n, ptr, p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
+            self._list.add(_hip.OP_CONV, n, ptr, c=self.conv_cus,
+                           p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
             return
         if log is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        _hip.check(_hip.lib().pnmn_conv_nhwc(ptr, n, self.H, self.W, cin_chunks, ntaps, in_stride, out_stride,
-                                             cout_blocks, relu, st), what)
+        _hip.check(_hip.lib().pnmn_conv_nhwc_cus(ptr, n, self.H, self.W, cin_chunks, ntaps, in_stride, out_stride,
+                                                 cout_blocks, relu, self.conv_cus, st), what)
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -551,7 +556,7 @@ class NMNEngine:
     def _native_fixed_rows(self, B: int, ws: Dict[str, torch.Tensor], fixed, dev) -> dict:
         """What the planner's lists have around the module programs: depends only on B and the workspace addresses,
         so the records are uploaded ONCE and the launch rows are kept (pooled / d(pooled) are patched in per step)."""
-        key = (B,) + tuple(ws[k].data_ptr() for k in sorted(ws))
+        key = (B, self.conv_cus) + tuple(ws[k].data_ptr() for k in sorted(ws))
         hit = self._native_fixed.get(key)
         if hit is not None:
             return hit
@@ -570,7 +575,7 @@ class NMNEngine:
             return np.array(lst._rows, dtype=np.uint64).reshape(-1, 8)
 
         def fwd_tail(l):
-            l.add(_hip.OP_CONV, B, pack.ptr("cls"), p=(H, W, 1, 1, C, self.cproj, self.cproj // C, 1))
+            l.add(_hip.OP_CONV, B, pack.ptr("cls"), c=self.conv_cus, p=(H, W, 1, 1, C, self.cproj, self.cproj // C, 1))
             l.add(_hip.OP_MAXPOOL_FWD, B, ws["cls"].data_ptr(), 0, 0, (H, W, self.cproj))  # b = pooled: per step
 
         def bwd_head(l):
@@ -580,11 +585,11 @@ class NMNEngine:
             l.add(_hip.OP_MAXPOOL_BWD, B, ws["cls"].data_ptr(), 0, ws["gcls"].data_ptr(), (H, W, self.cproj))  # b = d(pooled)
             l.add(_hip.OP_WGRAD, len(fixed["cls_wg_jobs"]), pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"),
                   p=(H, W, 1, 1, self.cproj // C, C, self.cproj))
-            l.add(_hip.OP_CONV, B, pack.ptr("cls_dgrad"), p=(H, W, self.cproj // C, 1, self.cproj, C, 1, 0))
+            l.add(_hip.OP_CONV, B, pack.ptr("cls_dgrad"), c=self.conv_cus, p=(H, W, self.cproj // C, 1, self.cproj, C, 1, 0))
 
         def bwd_tail(l):
             l.add(_hip.OP_WGRAD, len(fixed["stem2_wg_jobs"]), pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), p=(H, W, 9, 1, 1, C, C))
-            l.add(_hip.OP_CONV, B, pack.ptr("stem2_dgrad"), p=(H, W, 1, 9, C, C, 1, 0))
+            l.add(_hip.OP_CONV, B, pack.ptr("stem2_dgrad"), c=self.conv_cus, p=(H, W, 1, 9, C, C, 1, 0))
             l.add(_hip.OP_WGRAD, len(fixed["stem1_wg_jobs"]), pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"),
                   p=(H, W, 9, self.cin // C, 1, self.cin, C))
 
@@ -626,7 +631,7 @@ class NMNEngine:
                      rows["fwd_tail"].ctypes.data, rows["bwd_head"].ctypes.data, rows["bwd_tail"].ctypes.data,
                      self._planner_bwd.ctypes.data, self._planner_valid.ctypes.data, 0,
                      B, programs.shape[1], rows["fwd_tail"].shape[0], rows["bwd_head"].shape[0], rows["bwd_tail"].shape[0],
-                     self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, 0)
+                     self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, self.conv_cus)
             rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, st)
             if rc != _hip.EAGAIN:
                 break
