@@ -300,7 +300,7 @@ class NMNEngine:
 
     def _fixed_records(self, B: int, ws: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
         """Work lists of the stem and classifier convs: depend only on B and buffer addresses."""
-        key = (B,) + tuple(ws[k].data_ptr() for k in sorted(ws))
+        key = (B, self.conv_cus) + tuple(ws[k].data_ptr() for k in sorted(ws))
         hit = self._fixed_cache.get(key)
         if hit is not None:
             return hit
@@ -343,7 +343,8 @@ class NMNEngine:
                 sizes = range(1, 9)
             else:
                 sizes = range(4, 33)
-            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // 256)) * (c + 0.5))
+            cus = self.conv_cus or 256  # (a trunk that shares the chip: rounds of the CUs it can count on)
+            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // cus)) * (c + 0.5))
             starts = np.arange(0, B, chunk)
             j = np.zeros(starts.size, _hip.WGRAD_JOB)
             j["dw"], j["dbias"] = dw, db
