@@ -273,7 +273,10 @@ class JointTrainingStep(_TrainerBase):
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
-        self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "192"))
+        # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream): what
+        # their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 192 at 128 questions (measured
+        # best of 160-256: 7.06-7.14 ms against 7.37-7.42 at 256, gpurun_out/r03x_ab.txt).  PNMN_SHARED_CONV_CUS fixes it.
+        self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
         # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
         # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
         # Measured at 128 questions (gpurun_out/r03f_ab.txt): 7.85-7.89 ms against 7.83-7.92 -- no difference, so the
@@ -313,7 +316,9 @@ class JointTrainingStep(_TrainerBase):
             # conv launches of a trunk that shares the chip are cut for the CUs it can count on (engine.conv_cus)
             engine = getattr(self.nmn, "engine", None)
             if engine is not None:
-                engine.conv_cus = self.shared_conv_cus if side is not None else 0
+                rows = int(batch["question"].size(0))
+                free = self.shared_conv_cus or max(64, 256 - 8 * (-(-rows // 16)))
+                engine.conv_cus = free if side is not None else 0
             if side is not None:
                 # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
                 # starts at once (next to the generator's encoder and sampling decode); its module programs
