@@ -274,8 +274,10 @@ class JointTrainingStep(_TrainerBase):
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
         # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream): what
-        # their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 192 at 128 questions (measured
-        # best of 160-256: 7.06-7.14 ms against 7.37-7.42 at 256, gpurun_out/r03x_ab.txt).  PNMN_SHARED_CONV_CUS fixes it.
+        # their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU -- but never fewer than 192:
+        # 224 at 64 questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of
+        # 160-256), 192 at 256 (10.31-10.45 = the same as 256; 128: 11.2-11.3) -- gpurun_out/r03x_ab.txt, r03z_ab.txt.
+        # PNMN_SHARED_CONV_CUS fixes it.
         self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
         # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
         # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
@@ -317,7 +319,7 @@ class JointTrainingStep(_TrainerBase):
             engine = getattr(self.nmn, "engine", None)
             if engine is not None:
                 rows = int(batch["question"].size(0))
-                free = self.shared_conv_cus or max(64, 256 - 8 * (-(-rows // 16)))
+                free = self.shared_conv_cus or max(192, 256 - 8 * (-(-rows // 16)))
                 engine.conv_cus = free if side is not None else 0
             if side is not None:
                 # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
