@@ -114,6 +114,10 @@ typedef struct pnmn_wgrad_job {
 int pnmn_conv_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int H,
                     int W, int ntaps, int cin_blocks, int cout_blocks, int x_stride,
                     int dy_stride, void* stream);
+/* The same with a CU budget (0 = none; 14x14 maps): at most `cus` workgroups, each walking several (job, slab) units --
+ * for launches that share the chip with other streams' kernels.  In a pnmn_launch entry p[7] of a WGRAD carries it. */
+int pnmn_conv_wgrad_cus(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int H, int W, int ntaps,
+                        int cin_blocks, int cout_blocks, int x_stride, int dy_stride, int cus, void* stream);
 
 /* [Cout][taps][Cin] -> [Cin][taps reversed][Cout] for a list of weights (dgrad operand). */
 typedef struct pnmn_wtrans_item {
@@ -530,7 +534,7 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
  * the item count, then the integer arguments), all on `stream`; stops at the first non-zero return code.
  * Replaces ~160 one-by-one calls per step of the per-example interpreter loop (nmn.py:197-238) with two.
  *   CONV  a items, n, p = H, W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu; c = CU budget (0 = all)
- *   WGRAD a items, b jobs, n = n_jobs, p = H, W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride
+ *   WGRAD a items, b jobs, n = n_jobs, p = H, W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, CU budget (0 = none)
  *   TRANSPOSE_WEIGHTS a items, n      DOT_* / SAME_* / MASK_BWD a items, n, p = HW      MINMAX_* p = HW, C
  *   MAXPOOL_FWD a in, b out, n, p = H, W, C       MAXPOOL_BWD a in, b dout, c din, n, p = H, W, C
  *   NCHW_TO_NHWC a src, b dst, n, p = C, HW
@@ -606,7 +610,9 @@ typedef struct pnmn_trunk_io {
     int32_t            n_programs, length, n_fwd_tail, n_bwd_head, n_bwd_tail, bwd_capacity, need_backward, launch;
     int32_t            n_bwd, bwd_piece_cut, n_prims, n_fwd, depth, n_invalid, n_feat_result;
     int32_t            conv_cus;      /* in: CU budget of the module programs' conv launches (0 = all CUs) */
-} pnmn_trunk_io;           /* 208 bytes */
+    int32_t            wgrad_cus;     /* in: CU budget of their weight-gradient launches (0 = none) */
+    int32_t            reserved;
+} pnmn_trunk_io;           /* 216 bytes */
 int pnmn_trunk_planner_create(const pnmn_trunk_config* config, void** planner);
 int pnmn_trunk_planner_destroy(void* planner);
 int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream);

@@ -40,7 +40,7 @@ constexpr int CH = 64;  // output channels per workgroup
 template <int H, int W, int TAPS>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     const pnmn_wgrad_item* __restrict__ items, const pnmn_wgrad_job* __restrict__ jobs, int cin_blocks,
-    int x_stride, int dy_stride) {
+    int x_stride, int dy_stride, int n_jobs, int ny) {
     constexpr int HW = H * W;
     static_assert(HW % 4 == 0, "pixel count must be a multiple of the MFMA k (4)");
 
@@ -65,12 +65,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     const int li = lane & 15;
     const int g = lane >> 4;
 
-    // blockIdx.y enumerates (64-channel output half-block, cin block)
-    const int cib = blockIdx.y % cin_blocks;
-    const int coh = blockIdx.y / cin_blocks;  // output channels [64*coh, 64*coh + 64)
     const int cin_total = cin_blocks * CB;
+    // Units = (job, slab) pairs, job fastest.  The grid normally holds one workgroup per unit; a launch that shares
+    // the chip with other streams' kernels (pnmn_conv_wgrad_cus) holds only as many workgroups as it may count on CUs,
+    // and each walks its units -- these workgroups own a CU (150 KB of LDS) for hundreds of microseconds, and one per
+    // CU across the whole chip keeps the multi-CU recurrent kernels of the other stream waiting for that long.
+    for (int unit = blockIdx.x; unit < n_jobs * ny; unit += gridDim.x) {
+    const int slab = unit / n_jobs;
+    // `slab` enumerates (64-channel output half-block, cin block)
+    const int cib = slab % cin_blocks;
+    const int coh = slab / cin_blocks;  // output channels [64*coh, 64*coh + 64)
 
-    const pnmn_wgrad_job job = jobs[blockIdx.x];
+    const pnmn_wgrad_job job = jobs[unit % n_jobs];
 
     f32x4 acc[TAPS][4];
 #pragma unroll
@@ -186,6 +192,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     }
     if (job.dbias != nullptr && cib == 0) {
         unsafeAtomicAdd(job.dbias + coh * CH + (tid & 63), bias_acc);
+    }
+    __syncthreads();  // (the next unit rebuilds the tiles)
     }
 }
 
@@ -416,7 +424,7 @@ int launch_wgrad_band(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, 
 
 template <int H, int W, int TAPS>
 int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int cin_blocks,
-                 int cout_blocks, int x_stride, int dy_stride, hipStream_t stream) {
+                 int cout_blocks, int x_stride, int dy_stride, int cus, hipStream_t stream) {
     constexpr int HW = H * W;
     constexpr size_t lds_bytes = ((size_t)(HW + 2) * CB + (size_t)HW * CH + (size_t)TAPS * HW) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "tiles must fit the CU's LDS");
@@ -428,9 +436,11 @@ int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(n_jobs, cout_blocks * 2 * cin_blocks);
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, jobs, cin_blocks, x_stride,
-                       dy_stride);
+    const int ny = cout_blocks * 2 * cin_blocks;
+    const long units = (long)n_jobs * ny;
+    const long wgs = (cus >= 8 && cus < units) ? cus : units;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), lds_bytes, stream, items, jobs, cin_blocks, x_stride,
+                       dy_stride, n_jobs, ny);
     return (int)hipGetLastError();
 }
 
@@ -439,6 +449,12 @@ int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n
 extern "C" int pnmn_conv_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs,
                                int H, int W, int ntaps, int cin_blocks, int cout_blocks,
                                int x_stride, int dy_stride, void* stream) {
+    return pnmn_conv_wgrad_cus(items, jobs, n_jobs, H, W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, 0, stream);
+}
+
+extern "C" int pnmn_conv_wgrad_cus(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs,
+                                   int H, int W, int ntaps, int cin_blocks, int cout_blocks,
+                                   int x_stride, int dy_stride, int cus, void* stream) {
     if (n_jobs <= 0) return 0;
     if (!items || !jobs || cin_blocks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1))
         return PNMN_EINVAL;
@@ -447,9 +463,9 @@ extern "C" int pnmn_conv_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_jo
     if (H == 14 && W == 14) {
         if (ntaps == 9)
             return launch_wgrad<14, 14, 9>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride,
-                                           dy_stride, s);
+                                           dy_stride, cus, s);
         return launch_wgrad<14, 14, 1>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride,
-                                       dy_stride, s);
+                                       dy_stride, cus, s);
     }
     if (H == 28 && W == 28) {
         if (ntaps == 9)

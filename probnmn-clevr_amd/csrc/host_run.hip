@@ -22,8 +22,8 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
                                         p[7], (int)reinterpret_cast<uintptr_t>(l.c), stream);
                 break;
             case PNMN_OP_WGRAD:
-                rc = pnmn_conv_wgrad(static_cast<const pnmn_wgrad_item*>(l.a), static_cast<const pnmn_wgrad_job*>(l.b), l.n,
-                                     p[0], p[1], p[2], p[3], p[4], p[5], p[6], stream);
+                rc = pnmn_conv_wgrad_cus(static_cast<const pnmn_wgrad_item*>(l.a), static_cast<const pnmn_wgrad_job*>(l.b), l.n,
+                                         p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], stream);
                 break;
             case PNMN_OP_TRANSPOSE_WEIGHTS:
                 rc = pnmn_transpose_weights(static_cast<const pnmn_wtrans_item*>(l.a), l.n, stream);

@@ -565,9 +565,9 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
         // every weight gradient of the module convs in ONE grouped launch: all (example, conv) pairs that share a
         // weight are contracted by the same workgroups
         if (n_jobs3)
-            bwd.push_back(make_launch(PNMN_OP_WGRAD, n_jobs3, rec(R_WG3, 0), rec(R_JOBS3, 0), nullptr, {H, W, 9, 1, 1, C, C}));
+            bwd.push_back(make_launch(PNMN_OP_WGRAD, n_jobs3, rec(R_WG3, 0), rec(R_JOBS3, 0), nullptr, {H, W, 9, 1, 1, C, C, io->wgrad_cus}));
         if (n_jobsp)
-            bwd.push_back(make_launch(PNMN_OP_WGRAD, n_jobsp, rec(R_WGP, 0), rec(R_JOBSP, 0), nullptr, {H, W, 1, 2, 1, C, C}));
+            bwd.push_back(make_launch(PNMN_OP_WGRAD, n_jobsp, rec(R_WGP, 0), rec(R_JOBSP, 0), nullptr, {H, W, 1, 2, 1, C, C, io->wgrad_cus}));
         io->bwd_piece_cut = (int)bwd.size();
         for (int i = 0; i < io->n_bwd_tail; ++i) bwd.push_back(io->bwd_tail[i]);
         io->n_bwd = (int)bwd.size();

@@ -39,6 +39,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_abi_version": (),
     "pnmn_conv_nhwc": (_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P),
     "pnmn_conv_nhwc_cus": (_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P),
+    "pnmn_conv_wgrad_cus": (_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P),
     "pnmn_conv_wgrad": (_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P),
     "pnmn_transpose_weights": (_P, _I, _P),
     "pnmn_dot1_sigmoid_fwd": (_P, _I, _I, _P),
@@ -226,7 +227,7 @@ TRUNK_IO = np.dtype([(n, _u64) for n in ("programs", "params", "grads", "wt", "a
                     + [("arena_floats", np.int64)]
                     + [(n, _i32) for n in ("n_programs", "length", "n_fwd_tail", "n_bwd_head", "n_bwd_tail", "bwd_capacity",
                                            "need_backward", "launch", "n_bwd", "bwd_piece_cut", "n_prims", "n_fwd", "depth",
-                                           "n_invalid", "n_feat_result", "conv_cus")])
+                                           "n_invalid", "n_feat_result", "conv_cus", "wgrad_cus", "reserved")])
 DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "h0", "w_c", "w_hh", "w_p", "b_p", "hs", "cs", "act",
                                                   "ctx", "probs", "tokens", "in_tokens")]
                            + [("in_token_stride", np.int64), ("seed", _u64), ("row_offset", _u64)]
@@ -282,7 +283,7 @@ ITEM_SIZES = {
     "pnmn_decoder_fwd_job": (DECODER_FWD_JOB, 184),
     "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
-    "pnmn_trunk_io": (TRUNK_IO, 208),
+    "pnmn_trunk_io": (TRUNK_IO, 216),
 }
 
 

@@ -127,6 +127,7 @@ class NMNEngine:
         # beside other work sets the number it may count on (JointTrainingStep: 192 -- the seq2seq passes' multi-CU
         # kernels hold 64-96 CUs, and a launch cut for 256 workgroups then takes two rounds)
         self.conv_cus = 0
+        self.wgrad_cus = 0  # the same for the weight-gradient launches: at most that many (persistent) workgroups
         self.native = os.environ.get("PNMN_NATIVE_PLANNER", "1") != "0"
         self._planner = None
         self._native_fixed: Dict[tuple, dict] = {}
@@ -174,13 +175,14 @@ class NMNEngine:
         log = self.event_log
         st = stream.cuda_stream
         if self._list is not None:
-            self._list.add(_hip.OP_WGRAD, n_jobs, items, jobs, p=(self.H, self.W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride))
+            self._list.add(_hip.OP_WGRAD, n_jobs, items, jobs,
+                           p=(self.H, self.W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, self.wgrad_cus))
             return
         if log is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        _hip.check(_hip.lib().pnmn_conv_wgrad(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
-                                              x_stride, dy_stride, st), what)
+        _hip.check(_hip.lib().pnmn_conv_wgrad_cus(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
+                                                  x_stride, dy_stride, self.wgrad_cus, st), what)
         if log is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(stream)
@@ -557,7 +559,7 @@ class NMNEngine:
     def _native_fixed_rows(self, B: int, ws: Dict[str, torch.Tensor], fixed, dev) -> dict:
         """What the planner's lists have around the module programs: depends only on B and the workspace addresses,
         so the records are uploaded ONCE and the launch rows are kept (pooled / d(pooled) are patched in per step)."""
-        key = (B, self.conv_cus) + tuple(ws[k].data_ptr() for k in sorted(ws))
+        key = (B, self.conv_cus, self.wgrad_cus) + tuple(ws[k].data_ptr() for k in sorted(ws))
         hit = self._native_fixed.get(key)
         if hit is not None:
             return hit
@@ -585,14 +587,14 @@ class NMNEngine:
             l.add(_hip.OP_TRANSPOSE_WEIGHTS, self._wt_count, self._wt_records.data_ptr())
             l.add(_hip.OP_MAXPOOL_BWD, B, ws["cls"].data_ptr(), 0, ws["gcls"].data_ptr(), (H, W, self.cproj))  # b = d(pooled)
             l.add(_hip.OP_WGRAD, len(fixed["cls_wg_jobs"]), pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"),
-                  p=(H, W, 1, 1, self.cproj // C, C, self.cproj))
+                  p=(H, W, 1, 1, self.cproj // C, C, self.cproj, self.wgrad_cus))
             l.add(_hip.OP_CONV, B, pack.ptr("cls_dgrad"), c=self.conv_cus, p=(H, W, self.cproj // C, 1, self.cproj, C, 1, 0))
 
         def bwd_tail(l):
-            l.add(_hip.OP_WGRAD, len(fixed["stem2_wg_jobs"]), pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), p=(H, W, 9, 1, 1, C, C))
+            l.add(_hip.OP_WGRAD, len(fixed["stem2_wg_jobs"]), pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), p=(H, W, 9, 1, 1, C, C, self.wgrad_cus))
             l.add(_hip.OP_CONV, B, pack.ptr("stem2_dgrad"), c=self.conv_cus, p=(H, W, 1, 9, C, C, 1, 0))
             l.add(_hip.OP_WGRAD, len(fixed["stem1_wg_jobs"]), pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"),
-                  p=(H, W, 9, self.cin // C, 1, self.cin, C))
+                  p=(H, W, 9, self.cin // C, 1, self.cin, C, self.wgrad_cus))
 
         hit = {"pack": pack, "fwd_tail": rows(fwd_tail), "bwd_head": rows(bwd_head), "bwd_tail": rows(bwd_tail), "dpooled_row": 3}
         self._native_fixed[key] = hit
@@ -632,7 +634,7 @@ class NMNEngine:
                      rows["fwd_tail"].ctypes.data, rows["bwd_head"].ctypes.data, rows["bwd_tail"].ctypes.data,
                      self._planner_bwd.ctypes.data, self._planner_valid.ctypes.data, 0,
                      B, programs.shape[1], rows["fwd_tail"].shape[0], rows["bwd_head"].shape[0], rows["bwd_tail"].shape[0],
-                     self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, self.conv_cus)
+                     self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, self.conv_cus, self.wgrad_cus, 0)
             rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, st)
             if rc != _hip.EAGAIN:
                 break

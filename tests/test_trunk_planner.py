@@ -44,7 +44,7 @@ def _run(planner, programs, capacity=1 << 40):
     io = np.zeros(1, _hip.TRUNK_IO)
     io[0] = (programs.ctypes.data, BUF.params, BUF.grads, BUF.wt, BUF.act, BUF.gact, BUF.feat, BUF.gfeat, BUF.final, BUF.gfinal,
              BUF.ones, capacity, fwd_tail.ctypes.data, bwd_head.ctypes.data, bwd_tail.ctypes.data, bwd.ctypes.data,
-             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, None)
     out = io[0]
     if rc != 0:
@@ -135,7 +135,7 @@ def _compare(planner, comp, s, programs):
     for key, ntaps, cin_blocks in (("wg3", 9, 1), ("wgp", 1, 2)):
         jobs = plan.wgrad_jobs[key]
         if len(jobs):
-            _same_launch(bwd[i], _hip.OP_WGRAD, len(jobs), (14, 14, ntaps, cin_blocks, 1, C, C))
+            _same_launch(bwd[i], _hip.OP_WGRAD, len(jobs), (14, 14, ntaps, cin_blocks, 1, C, C, 0))
             items = words[(int(bwd[i]["a"]) - FAKE_BASE) // 8:][: len(plan.records[key]) * 6].view(_hip.WGRAD_ITEM)
             assert items.tobytes() == plan.records[key].tobytes()
             got_jobs = words[(int(bwd[i]["b"]) - FAKE_BASE) // 8:][: len(jobs) * 3].view(_hip.WGRAD_JOB)
