@@ -438,7 +438,7 @@ int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n
     }
     const int ny = cout_blocks * 2 * cin_blocks;
     const long units = (long)n_jobs * ny;
-    const long wgs = (cus >= 8 && cus < units) ? cus : units;
+    const long wgs = (cus >= 1 && cus < units) ? cus : units;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), lds_bytes, stream, items, jobs, cin_blocks, x_stride,
                        dy_stride, n_jobs, ny);
     return (int)hipGetLastError();

@@ -279,6 +279,8 @@ class JointTrainingStep(_TrainerBase):
         # 160-256), 192 at 256 (10.31-10.45 = the same as 256; 128: 11.2-11.3) -- gpurun_out/r03x_ab.txt, r03z_ab.txt.
         # PNMN_SHARED_CONV_CUS fixes it.
         self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
+        # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
+        # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, gpurun_out/r04a_ab.txt)
         self.shared_wgrad_cus = int(os.environ.get("PNMN_SHARED_WGRAD_CUS", "0"))
         # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
         # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
@@ -322,7 +324,7 @@ class JointTrainingStep(_TrainerBase):
                 rows = int(batch["question"].size(0))
                 free = self.shared_conv_cus or max(192, 256 - 8 * (-(-rows // 16)))
                 engine.conv_cus = free if side is not None else 0
-                engine.wgrad_cus = (self.shared_wgrad_cus or free) if side is not None else 0
+                engine.wgrad_cus = self.shared_wgrad_cus if side is not None else 0
             if side is not None:
                 # The NMN runs on its own stream, beside the seq2seq passes: its stem needs no programs and
                 # starts at once (next to the generator's encoder and sampling decode); its module programs

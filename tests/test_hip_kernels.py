@@ -240,6 +240,16 @@ def test_conv_dgrad_and_wgrad_match_autograd(hip, dilation):
     ref_dw = w.grad.permute(0, 2, 3, 1).reshape(C, 9, C)
     torch.testing.assert_close(dw.cpu(), ref_dw, rtol=RT, atol=5 * AT)
     torch.testing.assert_close(db.cpu(), b.grad, rtol=RT, atol=5 * AT)
+    # the same launch with a CU budget (pnmn_conv_wgrad_cus: 3 workgroups walk the 2 jobs x 2 slabs; the banded 28x28
+    # kernel ignores the budget): same sums
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    jobs["dw"], jobs["dbias"] = ptr(dw2), ptr(db2)
+    jbuf2 = hip.to_device(jobs, dev())
+    hip.check(hip.lib().pnmn_conv_wgrad_cus(ibuf.data_ptr(), jbuf2.data_ptr(), 2, H, W, 9, 1, 1, C, C, 3 if H == 14 else 0,
+                                            hip.stream_ptr(dev())), "wgrad (budget)")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dw2, dw, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db2, db, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("sole", [0, 1])
