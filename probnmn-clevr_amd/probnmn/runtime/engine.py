@@ -790,6 +790,11 @@ class NMNEngine:
         H, W, HW = self.H, self.W, self.HW
         ws = self._ws
         dpooled = dpooled.contiguous()
+        # d(pooled) was produced (and is owned) by the stream of the fully connected layers; when the trunk runs on its own
+        # stream the launches below read it there AFTER this function has returned and autograd has dropped the tensor --
+        # without this the allocator may hand its memory to the next main-stream allocation while the max-pool backward
+        # has not run yet (seen as NMN gradients off by ~1e-3 in one run in four of the 1024-row side-stream test)
+        dpooled.record_stream(torch.cuda.current_stream(dev))
 
         if isinstance(plan, _NativePlan):
             # the whole list came out of the planner (zeroing of the gradient buffers included): d(pooled) is the only
