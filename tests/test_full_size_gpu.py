@@ -143,10 +143,11 @@ def test_joint_step_1024_rows_with_the_nmn_on_its_own_stream():
         # move a weight by lr whatever the size of its gradient, a rounding-level difference can flip a sampled token)
         step.shared_conv_cus = 256
         torch.manual_seed(1)
+        grads = []
         for _ in range(3):
             out = step.step(batch)
-        torch.cuda.synchronize()
-        grads = {n: p.grad.detach().clone() for m in (pg, qr, nmn) for n, p in m.named_parameters() if p.grad is not None}
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.detach().clone() for m in (pg, qr, nmn) for n, p in m.named_parameters() if p.grad is not None})
         results.append((out, grads))
         step.close()
         del step, nmn, pg, qr, prior
@@ -155,7 +156,20 @@ def test_joint_step_1024_rows_with_the_nmn_on_its_own_stream():
     for k in a["elbo"]:
         torch.testing.assert_close(a["elbo"][k], b["elbo"][k], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a["objective"], b["objective"], rtol=1e-5, atol=1e-5)
-    assert len(ga) > 200
-    for n in ga:
-        ok, err = _close(ga[n], gb[n], typical=1e-4, worst=5e-2)  # (atomics order; lr 1e-6 keeps the weights equal)
+    assert len(ga[0]) > 200
+    # First step: the same weights in both schedules, so the gradients differ by the order of the atomic adds alone.
+    for n in ga[0]:
+        ok, err = _close(ga[0][n], gb[0][n], typical=1e-4, worst=5e-2)
         assert ok, (n, err)
+    # Later steps: Adam has moved every weight by ~lr whatever the size of its gradient, so the weights of the two
+    # schedules differ by ~1e-9 and one hidden unit of one example can sit on the other side of the classifier's ReLU
+    # (scripts/diag_side_stream.py found exactly that in 1 run of ~8: row 297, unit 72, pre-activation +1.3e-8 / -7.9e-9
+    # at the third step; every other pre-activation within 6e-8).  With few valid sampled programs carrying the NMN's
+    # gradient, that one example moves the trunk's gradients by ~1e-3 of their largest entry.  The bar for these steps
+    # is therefore on the whole tensor (l2), wide enough for one such flip and far below what a missed dependency
+    # between the streams produces (stale or half-written activations: errors of order one).
+    for step_grads_a, step_grads_b in zip(ga[1:], gb[1:]):
+        for n in step_grads_a:
+            x, y = step_grads_a[n].double(), step_grads_b[n].double()
+            rel = float((x - y).norm() / y.norm().clamp_min(1e-30))
+            assert rel < 5e-2, (n, rel)
