@@ -35,66 +35,77 @@ namespace {
 
 using pnmn::CB;
 
-// A unit = one band of one item (14x14: unit = item, or one of two 7-row half maps; 28x28: four units per
-// item).  WPS = minimum waves per SIMD the register allocation must leave room for: 2 = one workgroup per
-// CU (the 98 KiB tile allows no more), 4 = two (half-map tiles of 68 KiB: one workgroup stages or stores
-// while the other one's MFMAs run).
-template <int H, int W, int TH, int KSPLIT, int WPS, int MSPLIT = 1>
-__global__ __launch_bounds__(512, WPS) void conv_nhwc_kernel(
-    const pnmn_conv_item* __restrict__ items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
-    int out_stride, int relu, int per_xcd) {
+// A unit = one band of one item (14x14: unit = item; 28x28: four units per item).
+//
+// One launch holds up to three SEGMENTS of units, each with its own split (plan_launch below): workgroups are
+// dispatched in the order of their ids, so the short workgroups of the larger splits fill the chip behind the last
+// whole round of the first split without the drain + launch gap a kernel boundary costs (round 3: the segments used to
+// be separate launches).  A segment's workgroup count is a multiple of 8, so (blockIdx.x & 7) -- the XCD -- means the
+// same inside every segment.
+struct Segments {
+    int n;
+    int wg_begin[3];  // first blockIdx.x of the segment
+    int split[3];     // 1, 2, 4, 8 (K-split) or 16 (K-split 8 x two m-halves)
+    int unit0[3], n_units[3], per_xcd[3];
+};
+
+template <int H, int W, int TH>
+__global__ __launch_bounds__(512, 2) void conv_nhwc_kernel(
+    const pnmn_conv_item* __restrict__ items, const Segments sg, int cin_chunks, int ntaps, int in_stride,
+    int out_stride, int relu) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);  // [lds_rows][128], the last rows are zero
     constexpr int NB = H / TH;
+    int wg_begin = sg.wg_begin[0], split = sg.split[0], unit0 = sg.unit0[0], n_units = sg.n_units[0], per_xcd = sg.per_xcd[0];
+    if (sg.n > 1 && (int)blockIdx.x >= sg.wg_begin[1])
+        wg_begin = sg.wg_begin[1], split = sg.split[1], unit0 = sg.unit0[1], n_units = sg.n_units[1], per_xcd = sg.per_xcd[1];
+    if (sg.n > 2 && (int)blockIdx.x >= sg.wg_begin[2])
+        wg_begin = sg.wg_begin[2], split = sg.split[2], unit0 = sg.unit0[2], n_units = sg.n_units[2], per_xcd = sg.per_xcd[2];
     // XCD-aware mapping: the hardware deals workgroups round-robin over the 8 XCDs (XCD = linear id % 8), each
-    // with its own L2.  XCD x takes the CONTIGUOUS range [x per_xcd, (x+1) per_xcd) of the launch's units: the
+    // with its own L2.  XCD x takes the CONTIGUOUS range [x per_xcd, (x+1) per_xcd) of the segment's units: the
     // host sorts a launch's items by weight, so an XCD streams one or two 590 KB weights through its 4 MB L2
     // instead of all ~15 of the level (dealing units round-robin fetched 380-700 KB per item, ranges 130-160;
-    // scripts/pmc_conv.sh).  The KSPLIT workgroups of a unit all stage the same input region and get ids that
-    // are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 KSPLIT-1 times.
-    const int slot = blockIdx.x >> 3;
-    const int j = slot / (KSPLIT * MSPLIT);
-    const int sub = slot % (KSPLIT * MSPLIT);
-    const int unit = per_xcd ? (blockIdx.x & 7) * per_xcd + j : j * 8 + (blockIdx.x & 7);
+    // scripts/pmc_conv.sh).  The `split` workgroups of a unit all stage the same input region and get ids that
+    // are congruent mod 8: the region is fetched from HBM once and hit in that XCD's L2 split-1 times.
+    const int local = (int)blockIdx.x - wg_begin;
+    const int slot = local >> 3;
+    const int j = slot / split;
+    const int sub = slot % split;
+    const int unit = per_xcd ? (local & 7) * per_xcd + j : j * 8 + (local & 7);
     if (unit >= n_units || (per_xcd && j >= per_xcd)) return;
     const int u = unit0 + unit;
     const pnmn_conv_item it = items[u / NB];
     const pnmn::MaskBwd mb{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
-    pnmn::conv_body<H, W, TH, KSPLIT, MSPLIT>(it, u % NB, sub % KSPLIT, blockIdx.y, cin_chunks, ntaps, in_stride, out_stride,
-                                              relu, lds, (it.flags & (PNMN_CONV_MASKBWD | PNMN_CONV_DATTN)) ? &mb : nullptr, sub / KSPLIT);
-}
-
-template <int H, int W, int TH, int KSPLIT, int MSPLIT = 1>
-int launch_conv_k(const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps, int in_stride,
-                  int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows<H, W, TH>() * CB * sizeof(float);
-    constexpr int WPS = (2 * lds_bytes <= 160 * 1024) ? 4 : 2;
-    static_assert(lds_bytes <= 160 * 1024, "the staged region must fit the CU's LDS");
-    static_assert((size_t)(KSPLIT - 1) * (8 / KSPLIT) * ((TH * W + 15) / 16) * 64 * 16 <= lds_bytes,
-                  "reduction scratch must fit in the input image");
-    static bool configured = false;
-    auto kern = conv_nhwc_kernel<H, W, TH, KSPLIT, WPS, MSPLIT>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
+    const pnmn::MaskBwd* mbp = (it.flags & (PNMN_CONV_MASKBWD | PNMN_CONV_DATTN)) ? &mb : nullptr;
+    const int band = u % NB, cb = blockIdx.y;
+    switch (split) {  // (uniform over the workgroup)
+        case 1:
+            pnmn::conv_body<H, W, TH, 1>(it, band, 0, cb, cin_chunks, ntaps, in_stride, out_stride, relu, lds, mbp);
+            break;
+        case 2:
+            pnmn::conv_body<H, W, TH, 2>(it, band, sub, cb, cin_chunks, ntaps, in_stride, out_stride, relu, lds, mbp);
+            break;
+        case 4:
+            pnmn::conv_body<H, W, TH, 4>(it, band, sub, cb, cin_chunks, ntaps, in_stride, out_stride, relu, lds, mbp);
+            break;
+        case 8:
+            pnmn::conv_body<H, W, TH, 8>(it, band, sub, cb, cin_chunks, ntaps, in_stride, out_stride, relu, lds, mbp);
+            break;
+        default:  // 16
+            pnmn::conv_body<H, W, TH, 8, 2>(it, band, sub % 8, cb, cin_chunks, ntaps, in_stride, out_stride, relu, lds, mbp,
+                                            sub / 8);
+            break;
     }
-    dim3 grid(((n_units + 7) / 8) * 8 * KSPLIT * MSPLIT, cout_blocks);
-    static const bool round_robin = getenv("PNMN_CONV_XCD_ROUNDROBIN") != nullptr;  // (tuning hook: the former mapping)
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, unit0, n_units, cin_chunks, ntaps, in_stride,
-                       out_stride, relu, round_robin ? 0 : (n_units + 7) / 8);
-    return (int)hipGetLastError();
 }
 
 // Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
 // that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
-// work).  So the units are cut into up to THREE launches of non-decreasing split: as many as fill whole rounds
+// work).  So the units are cut into up to THREE segments of one launch (conv_nhwc_kernel), of non-decreasing split: as many as fill whole rounds
 // go out with the first split, the remainder follows with larger splits -- whose rounds are s times shorter --
 // again in whole rounds first (667 module-conv items: 512 at split 1, 128 at split 2 -- exactly one round of half
 // the work -- and 27 at split 8, instead of 512 + 155 at split 4 = three quarter rounds: round 3, -5 % on such a
 // launch).  Relative costs only: one tap of one 128-channel chunk = 1 unit, staging a chunk ~ 0.5 unit, every
-// further launch ~ 0.3 unit.
+// further segment ~ 0.3 unit.
 struct LaunchPlan {
     int n_seg;
     int split[3], count[3];
@@ -110,6 +121,10 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
         const char* e = getenv("PNMN_CONV_MAX_LAUNCHES");
         const int v = e ? atoi(e) : 3;
         return v >= 1 && v <= 3 ? v : 3;
+    }();
+    static const double seg_cost = [] {  // a further segment: its workgroups start behind a partly drained round
+        const char* e = getenv("PNMN_CONV_SEG_COST");
+        return e ? atof(e) : 0.3;
     }();
     const double overhead = stage_cost * cin_chunks + 0.25;
     // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
@@ -149,53 +164,77 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
         const double t0 = (double)rounds_of(m0, s0) * round_cost(s0);
         const long r0 = n_items - m0;
         for (int s1 = s0; s1 <= s_max; s1 *= 2) {
-            consider(LaunchPlan{2, {s0, s1, 0}, {(int)m0, (int)r0, 0}}, t0 + (double)rounds_of(r0, s1) * round_cost(s1) + 0.3);
+            consider(LaunchPlan{2, {s0, s1, 0}, {(int)m0, (int)r0, 0}}, t0 + (double)rounds_of(r0, s1) * round_cost(s1) + seg_cost);
             if (max_seg < 3 || s1 == s0) continue;
             const long m1 = full_of(r0, s1);
             if (m1 <= 0 || m1 >= r0) continue;
-            const double t1 = t0 + (double)rounds_of(m1, s1) * round_cost(s1) + 0.3;
+            const double t1 = t0 + (double)rounds_of(m1, s1) * round_cost(s1) + seg_cost;
             const long r1 = r0 - m1;
             for (int s2 = s1 * 2; s2 <= s_max; s2 *= 2)
-                consider(LaunchPlan{3, {s0, s1, s2}, {(int)m0, (int)m1, (int)r1}}, t1 + (double)rounds_of(r1, s2) * round_cost(s2) + 0.3);
+                consider(LaunchPlan{3, {s0, s1, s2}, {(int)m0, (int)m1, (int)r1}}, t1 + (double)rounds_of(r1, s2) * round_cost(s2) + seg_cost);
         }
     }
     return best;
 }
 
 template <int H, int W, int TH>
-int launch_conv_split(int split, const pnmn_conv_item* items, int unit0, int n_units, int cin_chunks, int ntaps,
-                      int in_stride, int out_stride, int cout_blocks, int relu, hipStream_t stream) {
-    switch (split) {
-        case 16:
-            return launch_conv_k<H, W, TH, 8, 2>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
-                                                 cout_blocks, relu, stream);
-        case 8:
-            return launch_conv_k<H, W, TH, 8>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
-                                              cout_blocks, relu, stream);
-        case 4:
-            return launch_conv_k<H, W, TH, 4>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
-                                              cout_blocks, relu, stream);
-        case 2:
-            return launch_conv_k<H, W, TH, 2>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
-                                              cout_blocks, relu, stream);
-        default:
-            return launch_conv_k<H, W, TH, 1>(items, unit0, n_units, cin_chunks, ntaps, in_stride, out_stride,
-                                              cout_blocks, relu, stream);
+int launch_segments(const pnmn_conv_item* items, const LaunchPlan& lp, int first, int last, int unit_at, int cin_chunks,
+                    int ntaps, int in_stride, int out_stride, int cout_blocks, int relu, hipStream_t stream) {
+    constexpr size_t lds_bytes = (size_t)pnmn::lds_rows<H, W, TH>() * CB * sizeof(float);
+    static_assert(lds_bytes <= 160 * 1024, "the staged region must fit the CU's LDS");
+    static_assert((size_t)7 * ((TH * W + 15) / 16) * 64 * 16 <= lds_bytes, "reduction scratch must fit in the input image");
+    static bool configured = false;
+    auto kern = conv_nhwc_kernel<H, W, TH>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
     }
+    static const bool round_robin = getenv("PNMN_CONV_XCD_ROUNDROBIN") != nullptr;  // (tuning hook: the former mapping)
+    Segments sg{};
+    int wgs = 0;
+    for (int k = first; k < last; ++k) {
+        if (lp.count[k] <= 0) continue;
+        const int i = sg.n++;
+        sg.wg_begin[i] = wgs;
+        sg.split[i] = lp.split[k];
+        sg.unit0[i] = unit_at;
+        sg.n_units[i] = lp.count[k];
+        sg.per_xcd[i] = round_robin ? 0 : (lp.count[k] + 7) / 8;
+        wgs += ((lp.count[k] + 7) / 8) * 8 * lp.split[k];
+        unit_at += lp.count[k];
+    }
+    if (sg.n == 0) return 0;
+    hipLaunchKernelGGL(kern, dim3(wgs, cout_blocks), dim3(512), lds_bytes, stream, items, sg, cin_chunks, ntaps, in_stride,
+                       out_stride, relu);
+    return (int)hipGetLastError();
+}
+
+// (A/B hook: PNMN_CONV_MERGED=0 issues the segments as separate launches, as rounds 1-2 did)
+inline bool merged_launches() {
+    static const bool merged = [] {
+        const char* e = getenv("PNMN_CONV_MERGED");
+        return !e || atoi(e) != 0;
+    }();
+    return merged;
 }
 
 template <int H, int W, int TH>
 int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
-                int out_stride, int cout_blocks, int relu, int cus, hipStream_t stream) {
+                int out_stride, int cout_blocks, int relu, int cus, int force_split, hipStream_t stream) {
     const int n_units = n_items * (H / TH);
-    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus);
+    const LaunchPlan lp = force_split ? LaunchPlan{1, {force_split, 0, 0}, {n_units, 0, 0}}
+                                      : plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus);
+    if (merged_launches())
+        return launch_segments<H, W, TH>(items, lp, 0, lp.n_seg, 0, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu,
+                                         stream);
     int at = 0;
     for (int k = 0; k < lp.n_seg; ++k) {
-        if (lp.count[k] <= 0) continue;
-        const int rc = launch_conv_split<H, W, TH>(lp.split[k], items, at, lp.count[k], cin_chunks, ntaps, in_stride,
-                                                   out_stride, cout_blocks, relu, stream);
+        const int rc = launch_segments<H, W, TH>(items, lp, k, k + 1, at, cin_chunks, ntaps, in_stride, out_stride, cout_blocks,
+                                                 relu, stream);
         if (rc != 0) return rc;
-        at += lp.count[k];
+        at += lp.count[k] > 0 ? lp.count[k] : 0;
     }
     return 0;
 }
@@ -208,6 +247,7 @@ inline int bands_of(int H, int W) { return (H == 14 && W == 14) ? 1 : (H == 28 &
 extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks) {
     const int nb = bands_of(H, W);
     if (n_items <= 0 || nb == 0) return 0;
+    if (merged_launches()) return 1;
     const LaunchPlan lp = plan_launch(n_items * nb, cout_blocks, cin_chunks, ntaps);
     int n = 0;
     for (int k = 0; k < lp.n_seg; ++k) n += lp.count[k] > 0 ? 1 : 0;
@@ -227,19 +267,17 @@ extern "C" int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int 
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (H == 14 && W == 14) {
-        // tuning hook: PNMN_CONV_KSPLIT=<1|2|4|8> forces one launch with that K-split (scripts/conv_modes.py).
-        // (Measured and rejected: two 7-row half maps per item with two workgroups per CU -- the M-split
-        // counterpart of K-split 2 -- is within 3 % of it at every launch size.)
-        static const char* force = getenv("PNMN_CONV_KSPLIT");
-        if (force)
-            return launch_conv_split<14, 14, 14>(atoi(force), items, 0, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                                 cout_blocks, relu, s);
-        return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                       cout_blocks, relu, cus, s);
-    }
+    // tuning hook: PNMN_CONV_KSPLIT=<1|2|4|8|16> forces one segment with that split (scripts/conv_modes.py).
+    // (Measured and rejected: two 7-row half maps per item with two workgroups per CU -- the M-split
+    // counterpart of K-split 2 -- is within 3 % of it at every launch size.)
+    static const int force = [] {
+        const char* e = getenv("PNMN_CONV_KSPLIT");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+    }();
+    if (H == 14 && W == 14)
+        return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, force, s);
     if (H == 28 && W == 28)
-        return launch_conv<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride,
-                                      cout_blocks, relu, cus, s);
+        return launch_conv<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, 0, s);
     return PNMN_ESHAPE;
 }
