@@ -1,0 +1,100 @@
+// Launch planner of the grouped convolution (host side): how a call's units are cut into segments of different splits.
+// Shared by conv_nhwc.hip (one launch per call) and host_trunk.hip (the units of the trunk executor).
+#pragma once
+#include <stdlib.h>
+
+namespace pnmn {
+
+// Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
+// that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
+// work).  So the units are cut into up to THREE segments of one launch (conv_nhwc_kernel), of non-decreasing split: as many as fill whole rounds
+// go out with the first split, the remainder follows with larger splits -- whose rounds are s times shorter --
+// again in whole rounds first (667 module-conv items: 512 at split 1, 128 at split 2 -- exactly one round of half
+// the work -- and 27 at split 8, instead of 512 + 155 at split 4 = three quarter rounds: round 3, -5 % on such a
+// launch).  Relative costs only: one tap of one 128-channel chunk = 1 unit, staging a chunk ~ 0.5 unit, every
+// further segment ~ 0.3 unit.
+struct LaunchPlan {
+    int n_seg;
+    int split[3], count[3];
+};
+
+// One split for every launch (0 = the planner decides): PNMN_CONV_KSPLIT=<1|2|4|8|16> or pnmn_conv_force_split() --
+// scripts/conv_modes.py measures the splits with it, and tests that compare two schedules of the same convolutions pin
+// it so that both sum in the same order.  One instance per library (inline, C++17).
+inline int& forced_split() {
+    static int forced = [] {
+        const char* e = getenv("PNMN_CONV_KSPLIT");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+    }();
+    return forced;
+}
+
+inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0) {
+    if (forced_split()) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
+    const double work = (double)ntaps * cin_chunks;
+    static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
+        const char* e = getenv("PNMN_CONV_STAGE_COST");
+        return e ? atof(e) : 0.5;
+    }();
+    static const int max_seg = [] {  // (A/B hook: 2 = the round-2 planner)
+        const char* e = getenv("PNMN_CONV_MAX_LAUNCHES");
+        const int v = e ? atoi(e) : 3;
+        return v >= 1 && v <= 3 ? v : 3;
+    }();
+    static const double seg_cost = [] {  // a further segment: its workgroups start behind a partly drained round
+        const char* e = getenv("PNMN_CONV_SEG_COST");
+        return e ? atof(e) : 0.3;
+    }();
+    const double overhead = stage_cost * cin_chunks + 0.25;
+    // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
+    auto round_cost = [&](int s) { return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead; };
+    static const int s_max = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
+    LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
+    double best_t = 1e30;
+    // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
+    // joint step's trunk runs on its own stream beside the seq2seq passes, whose multi-CU kernels hold 64-96 CUs for
+    // hundreds of microseconds -- a launch cut for 256 workgroups then takes two rounds where one cut for the free
+    // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, gpurun_out/r03w_ab.txt).  PNMN_CONV_CUS overrides the
+    // default of launches that do not say (tuning hook).
+    static const long default_cus = [] {
+        const char* e = getenv("PNMN_CONV_CUS");
+        const long v = e ? atol(e) : 256;
+        return v >= 8 && v <= 256 ? v : 256;
+    }();
+    const long cus = (cu_budget >= 8 && cu_budget <= 256) ? cu_budget : default_cus;
+    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s + cus - 1) / cus; };
+    auto full_of = [&](long n, int s) {  // items that fill whole rounds at split s
+        const long per_item = (long)cout_blocks * s;
+        const long m = ((long)n * per_item / cus) * cus / per_item;
+        return m > n ? n : m;
+    };
+    auto consider = [&](const LaunchPlan& p, double t) {
+        if (t < best_t * 0.97) {  // prefer fewer launches / smaller splits unless the gain is real
+            best_t = t;
+            best = p;
+        }
+    };
+    for (int s0 = 1; s0 <= s_max; s0 *= 2) {
+        // one launch
+        consider(LaunchPlan{1, {s0, 0, 0}, {n_items, 0, 0}}, (double)rounds_of(n_items, s0) * round_cost(s0));
+        if (max_seg < 2) continue;
+        const long m0 = full_of(n_items, s0);
+        if (m0 <= 0 || m0 >= n_items) continue;
+        const double t0 = (double)rounds_of(m0, s0) * round_cost(s0);
+        const long r0 = n_items - m0;
+        for (int s1 = s0; s1 <= s_max; s1 *= 2) {
+            consider(LaunchPlan{2, {s0, s1, 0}, {(int)m0, (int)r0, 0}}, t0 + (double)rounds_of(r0, s1) * round_cost(s1) + seg_cost);
+            if (max_seg < 3 || s1 == s0) continue;
+            const long m1 = full_of(r0, s1);
+            if (m1 <= 0 || m1 >= r0) continue;
+            const double t1 = t0 + (double)rounds_of(m1, s1) * round_cost(s1) + seg_cost;
+            const long r1 = r0 - m1;
+            for (int s2 = s1 * 2; s2 <= s_max; s2 *= 2)
+                consider(LaunchPlan{3, {s0, s1, s2}, {(int)m0, (int)m1, (int)r1}}, t1 + (double)rounds_of(r1, s2) * round_cost(s2) + seg_cost);
+        }
+    }
+    return best;
+}
+
+}  // namespace pnmn

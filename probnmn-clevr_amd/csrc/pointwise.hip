@@ -746,7 +746,7 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
 
 extern "C" {
 
-int pnmn_abi_version(void) { return 6; }
+int pnmn_abi_version(void) { return 7; }
 
 int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
     if (n_items <= 0) return 0;

@@ -254,3 +254,66 @@ def test_mask_backward_modes_agree():
         for n, g in grads.items():
             scale = float(grads0[n].abs().max()) + 1e-12
             assert float((g - grads0[n]).abs().max()) <= 3e-5 * scale, (key, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n, deep, cus, split", [(24, False, 0, 4), (200, False, 0, 2), (96, True, 192, 2), (700, False, 0, 1),
+                                                 (64, False, 192, 8)])
+def test_trunk_executor_equals_the_grouped_launches(n, deep, cus, split):
+    """The module programs as ONE launch each way (csrc/trunk_exec.hip: persistent workgroups, examples pinned to XCDs,
+    per-example progress counters) give the losses and gradients of the level-ordered grouped launches.  With the
+    convolutions' split pinned (pnmn_conv_force_split: both schedules then sum every convolution in the same order) the
+    forward pass is bit-equal and the gradients differ by the order of the fp32 atomic adds alone; with the planner free
+    (split 0: the executor cuts a launch per XCD, the grouped path per chip) activations differ in the last bit and, rarely,
+    one lands on the other side of a ReLU -- that case only gets the whole-tensor bar.  Three steps on the same network:
+    the first call with a longer list may reserve room and still run the grouped launches."""
+    from probnmn import _hip
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    batch = synthetic_batch(vocab, n, seed=31 + n, deep=deep)
+    images, answers = batch["image"].to(dev), batch["answer"].to(dev)
+    results = {}
+    _hip.check(_hip.lib().pnmn_conv_force_split(split), "force split")
+    try:
+        for executor in (0, 1):
+            torch.manual_seed(7)
+            net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
+            net.engine.ensure_arena()
+            net.engine.exec_trunk = executor
+            net.engine.conv_cus = cus
+            net.train()
+            used = []
+            for _ in range(3):
+                net.zero_grad(set_to_none=True)
+                out = net(images, batch["program"], answers)
+                out["loss"].mean().backward()
+                torch.cuda.synchronize()
+                used.append(net.engine.last_exec[:2])
+            assert net.engine.use_native()
+            if executor:
+                assert used[-1][0] > 0 and used[-1][1] > 0, used
+            else:
+                assert used[-1][:2] == (0, 0)
+            results[executor] = (out["loss"].detach().clone(), out["predictions"].clone(),
+                                 {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        _hip.lib().pnmn_conv_force_split(0)
+    (loss0, pred0, grads0), (loss1, pred1, grads1) = results[0], results[1]
+    assert torch.equal(pred0, pred1)
+    if split:
+        assert torch.equal(loss0, loss1)
+    else:
+        assert float((loss0 - loss1).abs().max()) <= 2e-6
+    assert grads0.keys() == grads1.keys() and len(grads0) > 20
+    for k, g in grads1.items():
+        scale = float(grads0[k].abs().max()) + 1e-12
+        err = (g - grads0[k]).abs().reshape(-1) / scale
+        rel = float((g - grads0[k]).double().norm() / grads0[k].double().norm().clamp_min(1e-30))
+        if split:
+            assert float(err.max()) <= 3e-5, (k, float(err.max()))
+        else:
+            assert rel <= 2e-2 and float(err.max()) <= 5e-2, (k, rel, float(err.max()))
