@@ -354,6 +354,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void trunk_exec_kernel(const pnmn_exec
     };
     trace(5, (int)xcc), trace(7, n_units), trace(0, 1);
     int units_run = 0;
+    // (debugging only: where this workgroup's time goes, in units of 1024 cycles of the 100 MHz constant clock)
+    long long t_begin = dbg ? (long long)__builtin_amdgcn_s_memrealtime() : 0, t_wait = 0, t_work = 0, t0 = t_begin;
 
     for (;;) {
         if (tid == 0) taken = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -377,6 +379,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void trunk_exec_kernel(const pnmn_exec
         }
         __syncthreads();  // (also: everyone has read `taken`)
         trace(0, 4);
+        if (dbg) {
+            const long long t = (long long)__builtin_amdgcn_s_memrealtime();
+            t_wait += t - t0, t0 = t;
+        }
 
         if (u.kind <= PNMN_EXEC_PDGRAD) {
             conv_unit<H, W, TH>(static_cast<const pnmn_conv_item*>(prog->records[u.kind]) + u.record,
@@ -411,6 +417,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void trunk_exec_kernel(const pnmn_exec
         __syncthreads();  // (also: nobody reads LDS or `taken` any more)
         if (tid == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         trace(6, ++units_run), trace(0, 6);
+        if (dbg) {
+            const long long t = (long long)__builtin_amdgcn_s_memrealtime();
+            t_work += t - t0, t0 = t;
+            trace(10, (int)t_wait), trace(11, (int)t_work), trace(12, (int)(t - t_begin));
+        }
     }
     trace(0, 7);
 }
