@@ -12,3 +12,5 @@ bash scripts/profile_round.sh $TAG
 bash scripts/steady_profile.sh ${TAG}_b128 --batch 128 --steps 40 --warmup 5
 timeout 300 python scripts/step_timeline.py 128 40 --free > gpurun_out/${TAG}_b128_step_timeline_free.txt 2>&1
 timeout 300 python scripts/recurrent_rate.py > gpurun_out/${TAG}_recurrent_rate.txt 2>&1
+# the trunk executor (opt-in): dispatches per iteration and step time of the 128-question step with it
+PNMN_TRUNK_EXEC=1 bash scripts/steady_profile.sh ${TAG}_b128_exec --batch 128 --steps 40 --warmup 5
