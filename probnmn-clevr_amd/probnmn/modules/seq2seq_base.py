@@ -797,6 +797,20 @@ def lstm_derived_params(lstm: nn.LSTM):
             for n in ("weight_hh", "bias_ih", "bias_hh")]
 
 
+_SLOW_PATHS_NOTED = set()
+
+
+def _note_slow_path(what: str, why: str) -> None:
+    """The step-by-step paths (a GEMM and a cell kernel per time step) serve shapes no reference config has; they are
+    correct and ~10x slower than the persistent kernels, so they say so once instead of engaging silently."""
+    if what not in _SLOW_PATHS_NOTED:
+        _SLOW_PATHS_NOTED.add(what)
+        import warnings
+
+        warnings.warn("probnmn seq2seq %s runs step by step (one GEMM + one cell launch per time step): %s" % (what, why),
+                      RuntimeWarning, stacklevel=3)
+
+
 def lstm_bias(lstm: nn.LSTM, layer: int, derived: Optional[Dict[str, torch.Tensor]], prefix: str = "l") -> torch.Tensor:
     b_ih, b_hh = getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)
     if derived is None:
@@ -837,6 +851,7 @@ def masked_lstm(lstm: nn.LSTM, x: torch.Tensor, mask: torch.Tensor, first_projec
             else:
                 inp = _LSTMLayerSeq.apply(xp, w_hh, None, None, tokens)
         else:  # other widths: step by step (GEMM per step + the cell kernel)
+            _note_slow_path("LSTM layer", "hidden size %d (the persistent layer kernel is built for 256)" % lstm.hidden_size)
             h = xp.new_zeros(B, lstm.hidden_size)
             c = xp.new_zeros(B, lstm.hidden_size)
             w_hh_t = w_hh.t()
@@ -1033,6 +1048,8 @@ class Seq2SeqBase(nn.Module):
             ce = output_dict["loss"]
             predictions = output_dict.get("predictions")
         else:
+            _note_slow_path("decoder", "hidden size %d, %d source positions, %d target tokens (the persistent decoder kernel is "
+                            "built for 256 / <= 64 / <= 128)" % (Hd, enc.size(1), w_p.size(0)))
             raw, logits_all, logprobs = self._decode_stepwise(enc, fmask, h, torch.zeros_like(h), tgt, steps, greedy, seed)
             predictions = self._trim_predictions(raw)
             pmask = (predictions != pad).float()

@@ -30,6 +30,10 @@ class StepBase:
     def close(self) -> None:
         """Detach this trainer's gradient hooks from the models (another trainer may hook the same
         parameters afterwards -- the reference's phase pipeline reuses the NMN across trainers)."""
+        for m in getattr(self, "models", {}).values():
+            engine = getattr(m, "engine", None)
+            if engine is not None:  # (a joint step's CU budgets must not outlive it: the next trainer may have the chip alone)
+                engine.conv_cus = engine.wgrad_cus = 0
         early = getattr(self, "_early", None)
         if early is not None:
             early.remove()

@@ -75,6 +75,11 @@ class _TrainerBase(StepBase):
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
         self.optimizer.step()
         self.iteration += 1
+        engine = getattr(getattr(self, "nmn", None), "engine", None)
+        if engine is not None:
+            # the step's CU budgets end with it (everything is queued): a validation pass or another trainer that runs
+            # this network next has the chip to itself
+            engine.conv_cus = engine.wgrad_cus = 0
 
     def _host_copy(self, tokens: torch.Tensor):
         """Start the device -> host copy of the sampled programs into a (cached) pinned buffer and

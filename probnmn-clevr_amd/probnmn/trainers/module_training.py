@@ -19,6 +19,9 @@ class ModuleTrainingStep(StepBase):
         self.report_metrics = report_metrics
         arena = nmn.engine.ensure_arena()
         nmn.engine.direct_grads = True  # gradients stay in the arena; the optimizer reads them there
+        # this iteration has the chip to itself: no CU budget left over from a joint step that ran the same network's
+        # trunk beside its seq2seq passes (bench.py's r03c record: 12.7 -> 14.1 ms with a stale budget of 192)
+        nmn.engine.conv_cus = nmn.engine.wgrad_cus = 0
         self.optimizer = ClampAdam(nmn.parameters(), arenas=[arena], lr=lr, weight_decay=weight_decay, clamp=5.0)
         # data parallel: the big loose FC gradient starts its all-reduce while the trunk is still in backward
         big = [p for p in self.optimizer.loose if p.numel() >= (1 << 20)]

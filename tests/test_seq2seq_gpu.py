@@ -636,3 +636,37 @@ def test_paired_sampling_and_teacher_forced_decodes_equal_two_single_ones(rows_s
     assert int((z0 != 0).sum()) > rows_s  # real programs were sampled
     for n in g0:
         torch.testing.assert_close(g1[n], g0[n], rtol=1e-6, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
+
+
+def test_other_widths_run_step_by_step_and_say_so():
+    """Shapes the persistent kernels are not built for (here hidden size 128; no reference config has one) take the
+    step-by-step paths -- a GEMM and a cell launch per time step: same results as the oracle, and a RuntimeWarning the
+    first time instead of a silent 10x slowdown."""
+    import warnings
+
+    from oracle import seq2seq_oracle as so
+    from probnmn.models import ProgramGenerator
+    from probnmn.modules import seq2seq_base
+    from probnmn.vocabulary import Vocabulary
+
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(3)
+    model = ProgramGenerator(vocab, input_size=64, hidden_size=128, num_layers=2)
+    vq, vp = vocab.get_vocab_size("questions"), vocab.get_vocab_size("programs")
+    src, tgt = _tokens(6, 14, vq, 5), _tokens(6, 9, vp, 6)
+    cpu_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in cpu_sd.items()}
+    ref = so.seq2seq_forward(ref_sd, src, tgt, "greedy")
+    ref["loss"].mean().backward()
+    seq2seq_base._SLOW_PATHS_NOTED.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = model(src.to(DEV), tgt.to(DEV), decoding_strategy="greedy")
+        out["loss"].mean().backward()
+        model(src.to(DEV), tgt.to(DEV), decoding_strategy="greedy")  # (said once per path, not once per call)
+    said = [str(w.message) for w in caught if issubclass(w.category, RuntimeWarning) and "step by step" in str(w.message)]
+    assert len(said) == 2 and any("LSTM layer" in m for m in said) and any("decoder" in m for m in said), said
+    torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(out["predictions"].cpu(), ref["predictions"])
+    _cmp_grads(model, ref_sd, "hidden128/tf")
