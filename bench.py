@@ -281,6 +281,10 @@ def roofline_object(agg, kernel=None):
         "passes": agg["_passes"],
         "tflops_per_pass": a["tflops_per_pass"],
         "single_stream_step_ms": round(agg["_step_ms"], 3),
+        # the timed steps run the NMN trunk on its own stream beside the seq2seq passes; a kernel's duration is its own
+        # only when nothing shares the chip with it, so the instrumented passes (and profiles/*_kernel_stats.txt, taken
+        # with PNMN_NMN_STREAM=0) use the single-stream schedule of the same launches
+        "schedule": "instrumented passes: one stream (PNMN_NMN_STREAM=0); timed steps: trunk on its own stream",
         "kernels": {
             k: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(v["ms"], 3),
                 "by_call_site": {w: {"tflops": round(b[0] / (b[1] * 1e-3) / 1e12, 2), "ms_per_step": round(b[1], 3)}

@@ -276,12 +276,18 @@ class JointTrainingStep(_TrainerBase):
         self.blocked_seconds = 0.0  # host time spent waiting for the sampled programs (diagnostic, bench.py)
         # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
-        self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", "320"))
+        # (round 2 kept batches beyond 320 sampled rows on one stream: "either side fills the chip on its own".  Measured
+        # again in round 3, gpurun_out/r04i_ab.txt / r04j_ab.txt, one box each: 512 questions 19.37 -> 17.8-18.9 ms,
+        # 768: 25.55 -> 23.8, 1024: 32.3-32.4 -> 30.9-31.1 -- the deep program levels' launches of a few dozen items no
+        # longer have the chip to themselves.  The switch stays for A/B.)
+        self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", str(1 << 30)))
         self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
-        # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream): what
-        # their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU -- but never fewer than 192:
-        # 224 at 64 questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of
-        # 160-256), 192 at 256 (10.31-10.45 = the same as 256; 128: 11.2-11.3) -- gpurun_out/r03x_ab.txt, r03z_ab.txt.
+        # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream).  Up to
+        # 128 questions: what their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 224 at 64
+        # questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of 160-256;
+        # gpurun_out/r03x_ab.txt, r03z_ab.txt).  Beyond: the whole chip -- the multi-CU kernels then take (nearly) all of
+        # it whenever they run, and the convs run between them: 256 questions 10.28-10.38 ms at 256 against 10.53-10.56 at
+        # 192, 512: 17.8-18.9 / 18.5, 1024: 31.0-31.1 against 31.4-31.5 at 224 and 31.8 at 208 (gpurun_out/r04j_ab.txt).
         # PNMN_SHARED_CONV_CUS fixes it.
         self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
         # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
@@ -319,15 +325,13 @@ class JointTrainingStep(_TrainerBase):
         if nosup.numel():
             answers = batch["answer"][nosup_d]
             main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-            # (beyond ~320 sampled rows either side fills the chip on its own: sharing it gains < 1 % and
-            # only blurs per-kernel timings, so larger batches stay on one stream)
             side = self._nmn_stream(dev) if (self.nmn_stream and main is not None
                                              and nosup.numel() <= self.nmn_stream_max_rows) else None
             # conv launches of a trunk that shares the chip are cut for the CUs it can count on (engine.conv_cus)
             engine = getattr(self.nmn, "engine", None)
             if engine is not None:
                 rows = int(batch["question"].size(0))
-                free = self.shared_conv_cus or max(192, 256 - 8 * (-(-rows // 16)))
+                free = self.shared_conv_cus or (256 - 8 * (-(-rows // 16)) if rows <= 128 else 0)
                 engine.conv_cus = free if side is not None else 0
                 engine.wgrad_cus = self.shared_wgrad_cus if side is not None else 0
             if side is not None:

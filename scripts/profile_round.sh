@@ -6,16 +6,20 @@ R=$GRAFT_REPO_ROOT
 python -c "import torch" >/dev/null 2>&1
 cd $R
 TAG=${1:-r01d}
-# 1) headline workload only (the bench line's roofline must agree with this table)
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/${TAG}_prof_bench.log 2>&1
+# 1) headline workload only, single-stream schedule: the bench line's roofline (instrumented passes on one stream) must agree
+#    with this table.  The default schedule (trunk on its own stream: kernels of the two streams share the chip, so a
+#    kernel's duration is no longer its own) goes into ${TAG}_kernel_stats_two_streams.txt.
+PNMN_NMN_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/${TAG}_prof_bench.log 2>&1
 python profiles/summarize.py $(find /tmp/prof_$TAG -name '*_results.db' | head -1) > gpurun_out/${TAG}_kernel_stats.txt 2>&1
 grep '^{' gpurun_out/${TAG}_prof_bench.log > gpurun_out/${TAG}_prof_bench.json
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof2_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_prof2_bench.log 2>&1
+python profiles/summarize.py $(find /tmp/prof2_$TAG -name '*_results.db' | head -1) > gpurun_out/${TAG}_kernel_stats_two_streams.txt 2>&1
 # 2) HBM traffic counters, one counter per pass (MI355X_MICROARCH.md: no mixing with other trace domains)
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_$C.log 2>&1
+  PNMN_NMN_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_$C.log 2>&1
   python profiles/summarize.py --pmc $(find /tmp/pmc_$C -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_$C.txt 2>&1
 done
 # 3) MFMA utilisation (SQ + GRBM counters share a pass)
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_MFMA.log 2>&1
+PNMN_NMN_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_MFMA.log 2>&1
 python profiles/summarize.py --mfma $(find /tmp/pmc_mfma -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_MFMA.txt 2>&1
 cut -c1-400 gpurun_out/${TAG}_prof_bench.json
