@@ -281,7 +281,13 @@ class JointTrainingStep(_TrainerBase):
         # 768: 25.55 -> 23.8, 1024: 32.3-32.4 -> 30.9-31.1 -- the deep program levels' launches of a few dozen items no
         # longer have the chip to themselves.  The switch stays for A/B.)
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", str(1 << 30)))
-        self.trunk_before_prior = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR", "1") != "0"
+        # the module programs are scheduled and launched between the reconstructor and the prior pass (the prior then runs
+        # beside them) -- up to 511 questions; from 512 on after ALL seq2seq passes are issued: 128 questions 7.20-7.27 ms
+        # against 7.28-7.42, 256: equal, 512: 17.92 against 17.80, 1024: 30.96 against 30.48-30.55 (the host's planning
+        # of ~500 programs would otherwise hold the prior pass back; gpurun_out/r04k_ab.txt, r04l_ab.txt).
+        # PNMN_TRUNK_BEFORE_PRIOR=0 / 1 fixes it.
+        env = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR")
+        self.trunk_before_prior = None if env is None else env != "0"
         # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream).  Up to
         # 128 questions: what their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 224 at 64
         # questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of 160-256;
@@ -368,9 +374,11 @@ class JointTrainingStep(_TrainerBase):
                     self.blocked_seconds += time.perf_counter() - t0
                     return self.nmn.forward_trunk(images, host, started=token["started"], trunk_stream=side, rows=nosup_d)
 
+                before_prior = (self.trunk_before_prior if self.trunk_before_prior is not None
+                                else int(batch["question"].size(0)) < 512)
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True,
-                                         before_prior=launch_trunk if self.trunk_before_prior else None,
+                                         before_prior=launch_trunk if before_prior else None,
                                          after_encode=launch_stem if self.stem_after_encode else None)
                 started = token["started"]
             else:
