@@ -308,7 +308,8 @@ class JointTrainingStep(_TrainerBase):
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
         if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
+            # (PNMN_NMN_STREAM_PRIORITY: -1 = high; A/B hook)
+            self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PNMN_NMN_STREAM_PRIORITY", "0")))
         return self._side
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
