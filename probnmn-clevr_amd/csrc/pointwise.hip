@@ -11,6 +11,7 @@
 
 #include "../../include/probnmn_hip.h"
 #include "global_ptr.h"
+#include "pointwise_body.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -18,303 +19,46 @@ namespace {
 
 constexpr int C = PNMN_CHANNELS;  // 128
 
-__device__ __forceinline__ float half_wave_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
-    return v;
-}
+using pnmn::pointwise::dot4;
+using pnmn::pointwise::half_wave_sum;
 
-__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) {
-    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-}
+// One workgroup of 256 threads per item; the bodies are shared with the trunk executor (pointwise_body.h).
+constexpr int NT = 256;
 
-__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
-
-// ------------------------------------------------------------------------------------------------
 // conv1x1 (128 -> 1) + sigmoid
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dot1_sigmoid_fwd_kernel(const pnmn_dot1_item* __restrict__ items,
-                                                               int HW) {
-    // Each half-wave walks every eighth pixel; the pixel rows of a batch are all requested before the
-    // first reduction (one memory round trip per batch of 13 pixels instead of one per pixel -- the
-    // rolled loop made this kernel take 14 us however few items it had).
-    constexpr int NB = 13;
+__global__ __launch_bounds__(NT) void dot1_sigmoid_fwd_kernel(const pnmn_dot1_item* __restrict__ items, int HW) {
     const pnmn_dot1_item it = items[blockIdx.x];
-    const int h = threadIdx.x & 31;
-    const int hw = threadIdx.x >> 5;  // half-wave id 0..7
-    const pnmn::gfloat* in = pnmn::as_global(it.in);
-    pnmn::gfloat* out = pnmn::as_global(it.out);
-    const f32x4 w = pnmn::load4(pnmn::as_global(it.w) + 4 * h);
-    const float b = pnmn::as_global(it.b)[0];
-    for (int p0 = hw; p0 < HW; p0 += 8 * NB) {
-        f32x4 x[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int p = p0 + 8 * k;
-            x[k] = p < HW ? pnmn::load4(in + (size_t)p * C + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int p = p0 + 8 * k;
-            const float s = half_wave_sum(dot4(x[k], w));
-            if (h == 0 && p < HW) out[p] = sigmoidf(s + b);
-        }
-    }
+    pnmn::pointwise::dot1_fwd<NT>(it, HW);
 }
 
-__global__ __launch_bounds__(256) void dot1_sigmoid_bwd_kernel(const pnmn_dot1_item* __restrict__ items,
-                                                               int HW) {
-    constexpr int NB = 7;
-    __shared__ float red[8][C + 1];
+__global__ __launch_bounds__(NT) void dot1_sigmoid_bwd_kernel(const pnmn_dot1_item* __restrict__ items, int HW) {
+    __shared__ float scratch[pnmn::pointwise::scratch_floats<NT>()];
     const pnmn_dot1_item it = items[blockIdx.x];
-    const int h = threadIdx.x & 31;
-    const int hw = threadIdx.x >> 5;
-    const pnmn::gfloat* in = pnmn::as_global(it.in);
-    const pnmn::gfloat* outv = pnmn::as_global(it.out);
-    const pnmn::gfloat* dout = pnmn::as_global(it.dout);
-    pnmn::gfloat* din = pnmn::as_global(it.din);
-    const f32x4 w = pnmn::load4(pnmn::as_global(it.w) + 4 * h);
-    f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f};
-    float db = 0.f;
-    for (int p0 = hw; p0 < HW; p0 += 8 * NB) {
-        f32x4 x[NB];
-        float o[NB], g[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int p = p0 + 8 * k;
-            const bool in_range = p < HW;
-            x[k] = in_range ? pnmn::load4(in + (size_t)p * C + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
-            o[k] = in_range ? outv[p] : 0.f;
-            g[k] = in_range ? dout[p] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int p = p0 + 8 * k;
-            const float dz = g[k] * o[k] * (1.f - o[k]);
-            dw += x[k] * dz;
-            db += dz;
-            if (p < HW) pnmn::store4(din + (size_t)p * C + 4 * h, w * dz);
-        }
-    }
-    red[hw][4 * h + 0] = dw.x;
-    red[hw][4 * h + 1] = dw.y;
-    red[hw][4 * h + 2] = dw.z;
-    red[hw][4 * h + 3] = dw.w;
-    if (h == 0) red[hw][C] = db;
-    __syncthreads();
-    if (threadIdx.x <= C) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-        if (threadIdx.x < C)
-            unsafeAtomicAdd(it.dw + threadIdx.x, s);
-        else
-            unsafeAtomicAdd(it.db, s);
-    }
+    pnmn::pointwise::dot1_bwd<NT>(it, HW, scratch);
 }
 
-// ------------------------------------------------------------------------------------------------
 // SameModule
-// ------------------------------------------------------------------------------------------------
-__device__ int block_first_argmax(const float* __restrict__ attn, int HW, float* sval, int* sidx) {
-    // first maximum in scan order (what max_pool2d(return_indices=True) reports)
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        const float v = attn[p];
-        if (v > best || (v != v && best == best)) {
-            best = v;
-            bi = p;
-        }
-    }
-    sval[threadIdx.x] = best;
-    sidx[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            const float ov = sval[threadIdx.x + s];
-            const int oi = sidx[threadIdx.x + s];
-            const float mv = sval[threadIdx.x];
-            const int mi = sidx[threadIdx.x];
-            if (ov > mv || (ov == mv && oi < mi)) {
-                sval[threadIdx.x] = ov;
-                sidx[threadIdx.x] = oi;
-            }
-        }
-        __syncthreads();
-    }
-    const int r = sidx[0];
-    __syncthreads();
-    return r == 0x7fffffff ? 0 : r;
-}
-
-__global__ __launch_bounds__(256) void same_fwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
-    __shared__ float sval[256];
-    __shared__ int sidx[256];
+__global__ __launch_bounds__(NT) void same_fwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
+    __shared__ float scratch[pnmn::pointwise::scratch_floats<NT>()];
     const pnmn_same_item it = items[blockIdx.x];
-    const int j = block_first_argmax(it.attn, HW, sval, sidx);
-    const int h = threadIdx.x & 31;
-    const int hw = threadIdx.x >> 5;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(it.feats + (size_t)j * C + 4 * h);
-    const f32x4 wv = *reinterpret_cast<const f32x4*>(it.w + 4 * h) * v;
-    const float wa = it.w[C];
-    const float b = it.b[0];
-    for (int p = hw; p < HW; p += 8) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(it.feats + (size_t)p * C + 4 * h);
-        const float s = half_wave_sum(dot4(x, wv));
-        if (h == 0) it.out[p] = sigmoidf(s + wa * it.attn[p] + b);
-    }
+    pnmn::pointwise::same_fwd<NT>(it, HW, scratch);
 }
 
-__global__ __launch_bounds__(256) void same_bwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
-    __shared__ float sval[256];
-    __shared__ int sidx[256];
-    __shared__ float red[8][2 * C + 2];
+__global__ __launch_bounds__(NT) void same_bwd_kernel(const pnmn_same_item* __restrict__ items, int HW) {
+    __shared__ float scratch[pnmn::pointwise::scratch_floats<NT>()];
     const pnmn_same_item it = items[blockIdx.x];
-    const int j = block_first_argmax(it.attn, HW, sval, sidx);
-    const int h = threadIdx.x & 31;
-    const int hw = threadIdx.x >> 5;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(it.feats + (size_t)j * C + 4 * h);
-    const f32x4 w = *reinterpret_cast<const f32x4*>(it.w + 4 * h);
-    const f32x4 wv = w * v;
-    const float wa = it.w[C];
-    f32x4 sfx = f32x4{0.f, 0.f, 0.f, 0.f};  // sum_p dz[p] * feats[p][c]
-    float dwa = 0.f, db = 0.f;
-    for (int p = hw; p < HW; p += 8) {
-        const float o = it.out[p];
-        const float dz = it.dout[p] * o * (1.f - o);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(it.feats + (size_t)p * C + 4 * h);
-        sfx += x * dz;
-        if (h == 0) {
-            dwa += dz * it.attn[p];
-            db += dz;
-            if (it.dattn) unsafeAtomicAdd(it.dattn + p, dz * wa);
-        }
-        const f32x4 df = wv * dz;  // through x = feats * v, wrt feats[p]
-        float* d = it.dfeats + (size_t)p * C + 4 * h;
-        unsafeAtomicAdd(d + 0, df.x);
-        unsafeAtomicAdd(d + 1, df.y);
-        unsafeAtomicAdd(d + 2, df.z);
-        unsafeAtomicAdd(d + 3, df.w);
-    }
-    red[hw][4 * h + 0] = sfx.x;
-    red[hw][4 * h + 1] = sfx.y;
-    red[hw][4 * h + 2] = sfx.z;
-    red[hw][4 * h + 3] = sfx.w;
-    if (h == 0) {
-        red[hw][2 * C] = dwa;
-        red[hw][2 * C + 1] = db;
-    }
-    __syncthreads();
-    if (threadIdx.x < C) {
-        const int c = threadIdx.x;
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][c];
-        const float vc = it.feats[(size_t)j * C + c];
-        const float wc = it.w[c];
-        unsafeAtomicAdd(it.dw + c, s * vc);                       // d/dw[c]
-        unsafeAtomicAdd(it.dfeats + (size_t)j * C + c, s * wc);   // through v = feats[j]
-    } else if (threadIdx.x == C || threadIdx.x == C + 1) {
-        const int k2 = 2 * C + (threadIdx.x - C);
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][k2];
-        unsafeAtomicAdd(threadIdx.x == C ? it.dw + C : it.db, s);
-    }
+    pnmn::pointwise::same_bwd<NT>(it, HW, scratch);
 }
 
-// ------------------------------------------------------------------------------------------------
 // And / Or
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void minmax_fwd_kernel(const pnmn_minmax_item* __restrict__ items,
-                                                         int HW, int Cn) {
+__global__ __launch_bounds__(NT) void minmax_fwd_kernel(const pnmn_minmax_item* __restrict__ items, int HW, int Cn) {
     const pnmn_minmax_item it = items[blockIdx.x];
-    const int oc = it.a_channels > it.b_channels ? it.a_channels : it.b_channels;
-    const int n = HW * oc;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int p = i / oc;
-        const int c = i - p * oc;
-        const float a = it.a[it.a_channels == 1 ? p : p * Cn + c];
-        const float b = it.b[it.b_channels == 1 ? p : p * Cn + c];
-        // torch.min/max propagate NaN; fminf/fmaxf would not
-        float r;
-        if (a != a || b != b)
-            r = NAN;
-        else
-            r = it.is_max ? (a > b ? a : b) : (a < b ? a : b);
-        it.out[i] = r;
-    }
+    pnmn::pointwise::minmax_fwd<NT>(it, HW);
 }
 
-__global__ __launch_bounds__(256) void minmax_bwd_kernel(const pnmn_minmax_item* __restrict__ items,
-                                                         int HW, int Cn) {
+__global__ __launch_bounds__(NT) void minmax_bwd_kernel(const pnmn_minmax_item* __restrict__ items, int HW, int Cn) {
     const pnmn_minmax_item it = items[blockIdx.x];
-    const int oc = it.a_channels > it.b_channels ? it.a_channels : it.b_channels;
-    const int h = threadIdx.x & 31;
-    const int hw = threadIdx.x >> 5;
-    if (oc == 1) {
-        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-            const float a = it.a[p], b = it.b[p], g = it.dout[p];
-            const bool a_wins = it.is_max ? (a > b) : (a < b);
-            const float ga = (a == b) ? 0.5f * g : (a_wins ? g : 0.f);
-            const float gb = (a == b) ? 0.5f * g : (a_wins ? 0.f : g);
-            if (it.da) unsafeAtomicAdd(it.da + p, ga);
-            if (it.db) unsafeAtomicAdd(it.db + p, gb);
-        }
-        return;
-    }
-    // oc == Cn == 128: half-wave per pixel, 4 channels per lane
-    for (int p = hw; p < HW; p += 8) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(it.dout + (size_t)p * Cn + 4 * h);
-        f32x4 a, b;
-        if (it.a_channels == 1) {
-            const float s = it.a[p];
-            a = f32x4{s, s, s, s};
-        } else {
-            a = *reinterpret_cast<const f32x4*>(it.a + (size_t)p * Cn + 4 * h);
-        }
-        if (it.b_channels == 1) {
-            const float s = it.b[p];
-            b = f32x4{s, s, s, s};
-        } else {
-            b = *reinterpret_cast<const f32x4*>(it.b + (size_t)p * Cn + 4 * h);
-        }
-        f32x4 ga, gb;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool a_wins = it.is_max ? (a[k] > b[k]) : (a[k] < b[k]);
-            ga[k] = (a[k] == b[k]) ? 0.5f * g[k] : (a_wins ? g[k] : 0.f);
-            gb[k] = (a[k] == b[k]) ? 0.5f * g[k] : (a_wins ? 0.f : g[k]);
-        }
-        if (it.da) {
-            if (it.a_channels == 1) {
-                const float s = half_wave_sum(ga.x + ga.y + ga.z + ga.w);
-                if (h == 0) unsafeAtomicAdd(it.da + p, s);
-            } else {
-                float* d = it.da + (size_t)p * Cn + 4 * h;
-                unsafeAtomicAdd(d + 0, ga.x);
-                unsafeAtomicAdd(d + 1, ga.y);
-                unsafeAtomicAdd(d + 2, ga.z);
-                unsafeAtomicAdd(d + 3, ga.w);
-            }
-        }
-        if (it.db) {
-            if (it.b_channels == 1) {
-                const float s = half_wave_sum(gb.x + gb.y + gb.z + gb.w);
-                if (h == 0) unsafeAtomicAdd(it.db + p, s);
-            } else {
-                float* d = it.db + (size_t)p * Cn + 4 * h;
-                unsafeAtomicAdd(d + 0, gb.x);
-                unsafeAtomicAdd(d + 1, gb.y);
-                unsafeAtomicAdd(d + 2, gb.z);
-                unsafeAtomicAdd(d + 3, gb.w);
-            }
-        }
-    }
+    pnmn::pointwise::minmax_bwd<NT>(it, HW);
 }
 
 // ------------------------------------------------------------------------------------------------
