@@ -338,7 +338,10 @@ class JointTrainingStep(_TrainerBase):
             engine = getattr(self.nmn, "engine", None)
             if engine is not None:
                 rows = int(batch["question"].size(0))
-                free = self.shared_conv_cus or (256 - 8 * (-(-rows // 16)) if rows <= 128 else 0)
+                # (28x28 maps: four band units per item, launches four times as large -- the whole chip, as for the large
+                # batches: 35.6-36.1 ms at 256 against 36.2-38.0 at 192, gpurun_out/r04r_c5.txt)
+                small = rows <= 128 and not getattr(engine, "banded", False)
+                free = self.shared_conv_cus or (256 - 8 * (-(-rows // 16)) if small else 0)
                 engine.conv_cus = free if side is not None else 0
                 engine.wgrad_cus = self.shared_wgrad_cus if side is not None else 0
             if side is not None:
