@@ -299,11 +299,15 @@ class JointTrainingStep(_TrainerBase):
         # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
         # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, gpurun_out/r04a_ab.txt)
         self.shared_wgrad_cus = int(os.environ.get("PNMN_SHARED_WGRAD_CUS", "0"))
-        # PNMN_STEM_AFTER_ENCODE=1: issue the stem (side stream) BEHIND the generator's encoder pass, so that the step's
-        # critical chain -- encoder -> sampling decode -> programs to the host -- gets the host's first launches.
-        # Measured at 128 questions (gpurun_out/r03f_ab.txt): 7.85-7.89 ms against 7.83-7.92 -- no difference, so the
-        # stem keeps going first (it then never waits for anything).
-        self.stem_after_encode = os.environ.get("PNMN_STEM_AFTER_ENCODE", "0") != "0"
+        # When the stem (side stream) goes out.  0: first thing in the step (it then never waits for anything) -- below 256
+        # questions.  2: issued behind the generator's encoder pass AND made to wait for it on the GPU -- from 256 questions
+        # on: the encoder's multi-CU kernels otherwise become resident one workgroup at a time behind the stem's 1 ms conv
+        # workgroups (encoder 0.9 -> 3.2 ms beside the stem at 1024 questions), and the sampled programs the module
+        # programs wait for arrive that much later: 30.77-30.82 -> 30.43-30.49 ms, 512 questions 17.66 -> 17.31, 256: 10.30 -> 10.07
+        # (gpurun_out/r04t_ab.txt, r04u_ab.txt; 128 questions: no difference).  1: issued behind the encoder pass without the wait (measured at 128 questions, r03f_ab.txt:
+        # 7.85-7.89 against 7.83-7.92 ms, and at 1024: 30.78-30.96 -- no difference).  PNMN_STEM_AFTER_ENCODE fixes it.
+        env = os.environ.get("PNMN_STEM_AFTER_ENCODE")
+        self.stem_after_encode = None if env is None else int(env)
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
@@ -358,13 +362,18 @@ class JointTrainingStep(_TrainerBase):
                 images = batch["image"]
                 token = {}
 
+                stem_mode = (self.stem_after_encode if self.stem_after_encode is not None
+                             else (2 if int(batch["question"].size(0)) >= 256 else 0))
+
                 def launch_stem():
+                    if stem_mode == 2:  # (the stem also WAITS for the encoder pass on the GPU)
+                        side.wait_stream(main)
                     with torch.cuda.stream(side):
                         # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
                         # layout kernel: no gathered copy)
                         token["started"] = self.nmn.begin(images, rows=nosup_d)
 
-                if not self.stem_after_encode:
+                if not stem_mode:
                     launch_stem()
 
                 def launch_trunk(programs_host):
@@ -383,7 +392,7 @@ class JointTrainingStep(_TrainerBase):
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True,
                                          before_prior=launch_trunk if before_prior else None,
-                                         after_encode=launch_stem if self.stem_after_encode else None)
+                                         after_encode=launch_stem if stem_mode else None)
                 started = token["started"]
             else:
                 images = batch["image"]
