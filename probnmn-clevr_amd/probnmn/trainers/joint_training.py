@@ -43,6 +43,26 @@ def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
     return torch.cat((a, b), 0)
 
 
+def shared_conv_cus(questions: int, banded: bool) -> int:
+    """CUs the trunk's conv launches are cut for while it runs beside the seq2seq passes (0 = all of them).  Up to 128
+    questions of 14x14 maps: what the passes' multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU
+    (224 at 64 questions, 192 at 128).  Beyond, and for 28x28 maps (four band units per item): the whole chip.  Measured:
+    JointTrainingStep.__init__ / DESIGN 5-6."""
+    return 256 - 8 * (-(-questions // 16)) if (questions <= 128 and not banded) else 0
+
+
+def stem_waits_for_encoder(questions: int) -> int:
+    """PNMN_STEM_AFTER_ENCODE mode of a step of that many questions: 2 (issued behind the generator's encoder pass and
+    waiting for it on the GPU) from 256 questions on, 0 (first thing in the step) below."""
+    return 2 if questions >= 256 else 0
+
+
+def trunk_before_prior(questions: int) -> bool:
+    """Module programs launched between the reconstructor and the prior pass (below 512 questions) or after all seq2seq
+    passes are issued (from 512 on)."""
+    return questions < 512
+
+
 class _TrainerBase(StepBase):
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
@@ -344,8 +364,7 @@ class JointTrainingStep(_TrainerBase):
                 rows = int(batch["question"].size(0))
                 # (28x28 maps: four band units per item, launches four times as large -- the whole chip, as for the large
                 # batches: 35.6-36.1 ms at 256 against 36.2-38.0 at 192, gpurun_out/r04r_c5.txt)
-                small = rows <= 128 and not getattr(engine, "banded", False)
-                free = self.shared_conv_cus or (256 - 8 * (-(-rows // 16)) if small else 0)
+                free = self.shared_conv_cus or shared_conv_cus(rows, getattr(engine, "banded", False))
                 engine.conv_cus = free if side is not None else 0
                 engine.wgrad_cus = self.shared_wgrad_cus if side is not None else 0
             if side is not None:
@@ -363,7 +382,7 @@ class JointTrainingStep(_TrainerBase):
                 token = {}
 
                 stem_mode = (self.stem_after_encode if self.stem_after_encode is not None
-                             else (2 if int(batch["question"].size(0)) >= 256 else 0))
+                             else stem_waits_for_encoder(int(batch["question"].size(0))))
 
                 def launch_stem():
                     if stem_mode == 2:  # (the stem also WAITS for the encoder pass on the GPU)
@@ -388,7 +407,7 @@ class JointTrainingStep(_TrainerBase):
                     return self.nmn.forward_trunk(images, host, started=token["started"], trunk_stream=side, rows=nosup_d)
 
                 before_prior = (self.trunk_before_prior if self.trunk_before_prior is not None
-                                else int(batch["question"].size(0)) < 512)
+                                else trunk_before_prior(int(batch["question"].size(0))))
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
                                          reconstruct=ours, host_programs=True,
                                          before_prior=launch_trunk if before_prior else None,

@@ -182,3 +182,13 @@ def test_unarmed_reducer_starts_no_collective(monkeypatch):
     assert len(calls) == 1 and id(p) in new._pending  # started from the hook
     parallel.all_reduce_gradients([], [p], early=new, average=False)
     assert len(calls) == 1 and not new._pending and not new.armed
+
+
+def test_joint_step_schedule_rules_follow_the_batch():
+    """The three batch-dependent rules of the joint step's two-stream schedule (measured thresholds)."""
+    from probnmn.trainers import joint_training as jt
+
+    assert [jt.shared_conv_cus(n, False) for n in (16, 64, 128, 129, 256, 1024)] == [248, 224, 192, 0, 0, 0]
+    assert jt.shared_conv_cus(128, True) == 0  # 28x28 maps: four band units per item
+    assert [jt.stem_waits_for_encoder(n) for n in (128, 255, 256, 1024)] == [0, 0, 2, 2]
+    assert [jt.trunk_before_prior(n) for n in (128, 511, 512, 1024)] == [True, True, False, False]
