@@ -297,34 +297,34 @@ class JointTrainingStep(_TrainerBase):
         # the NMN on its own stream beside the seq2seq passes (PNMN_NMN_STREAM=0: everything on one stream)
         self.nmn_stream = os.environ.get("PNMN_NMN_STREAM", "1") != "0"
         # (round 2 kept batches beyond 320 sampled rows on one stream: "either side fills the chip on its own".  Measured
-        # again in round 3, gpurun_out/r04i_ab.txt / r04j_ab.txt, one box each: 512 questions 19.37 -> 17.8-18.9 ms,
+        # again in round 3, profiles/ab/r04i_ab.txt / r04j_ab.txt, one box each: 512 questions 19.37 -> 17.8-18.9 ms,
         # 768: 25.55 -> 23.8, 1024: 32.3-32.4 -> 30.9-31.1 -- the deep program levels' launches of a few dozen items no
         # longer have the chip to themselves.  The switch stays for A/B.)
         self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", str(1 << 30)))
         # the module programs are scheduled and launched between the reconstructor and the prior pass (the prior then runs
         # beside them) -- up to 511 questions; from 512 on after ALL seq2seq passes are issued: 128 questions 7.20-7.27 ms
         # against 7.28-7.42, 256: equal, 512: 17.92 against 17.80, 1024: 30.96 against 30.48-30.55 (the host's planning
-        # of ~500 programs would otherwise hold the prior pass back; gpurun_out/r04k_ab.txt, r04l_ab.txt).
+        # of ~500 programs would otherwise hold the prior pass back; profiles/ab/r04k_ab.txt, r04l_ab.txt).
         # PNMN_TRUNK_BEFORE_PRIOR=0 / 1 fixes it.
         env = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR")
         self.trunk_before_prior = None if env is None else env != "0"
         # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream).  Up to
         # 128 questions: what their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 224 at 64
         # questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of 160-256;
-        # gpurun_out/r03x_ab.txt, r03z_ab.txt).  Beyond: the whole chip -- the multi-CU kernels then take (nearly) all of
+        # profiles/ab/r03x_ab.txt, r03z_ab.txt).  Beyond: the whole chip -- the multi-CU kernels then take (nearly) all of
         # it whenever they run, and the convs run between them: 256 questions 10.28-10.38 ms at 256 against 10.53-10.56 at
-        # 192, 512: 17.8-18.9 / 18.5, 1024: 31.0-31.1 against 31.4-31.5 at 224 and 31.8 at 208 (gpurun_out/r04j_ab.txt).
+        # 192, 512: 17.8-18.9 / 18.5, 1024: 31.0-31.1 against 31.4-31.5 at 224 and 31.8 at 208 (profiles/ab/r04j_ab.txt).
         # PNMN_SHARED_CONV_CUS fixes it.
         self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
         # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
-        # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, gpurun_out/r04a_ab.txt)
+        # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, profiles/ab/r04a_ab.txt)
         self.shared_wgrad_cus = int(os.environ.get("PNMN_SHARED_WGRAD_CUS", "0"))
         # When the stem (side stream) goes out.  0: first thing in the step (it then never waits for anything) -- below 256
         # questions.  2: issued behind the generator's encoder pass AND made to wait for it on the GPU -- from 256 questions
         # on: the encoder's multi-CU kernels otherwise become resident one workgroup at a time behind the stem's 1 ms conv
         # workgroups (encoder 0.9 -> 3.2 ms beside the stem at 1024 questions), and the sampled programs the module
         # programs wait for arrive that much later: 30.77-30.82 -> 30.43-30.49 ms, 512 questions 17.66 -> 17.31, 256: 10.30 -> 10.07
-        # (gpurun_out/r04t_ab.txt, r04u_ab.txt; 128 questions: no difference).  1: issued behind the encoder pass without the wait (measured at 128 questions, r03f_ab.txt:
+        # (profiles/ab/r04t_ab.txt, r04u_ab.txt; 128 questions: no difference).  1: issued behind the encoder pass without the wait (measured at 128 questions, r03f_ab.txt:
         # 7.85-7.89 against 7.83-7.92 ms, and at 1024: 30.78-30.96 -- no difference).  PNMN_STEM_AFTER_ENCODE fixes it.
         env = os.environ.get("PNMN_STEM_AFTER_ENCODE")
         self.stem_after_encode = None if env is None else int(env)
@@ -363,7 +363,7 @@ class JointTrainingStep(_TrainerBase):
             if engine is not None:
                 rows = int(batch["question"].size(0))
                 # (28x28 maps: four band units per item, launches four times as large -- the whole chip, as for the large
-                # batches: 35.6-36.1 ms at 256 against 36.2-38.0 at 192, gpurun_out/r04r_c5.txt)
+                # batches: 35.6-36.1 ms at 256 against 36.2-38.0 at 192, profiles/ab/r04r_c5.txt)
                 free = self.shared_conv_cus or shared_conv_cus(rows, getattr(engine, "banded", False))
                 engine.conv_cus = free if side is not None else 0
                 engine.wgrad_cus = self.shared_wgrad_cus if side is not None else 0
