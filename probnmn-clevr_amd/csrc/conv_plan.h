@@ -55,7 +55,7 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
     // joint step's trunk runs on its own stream beside the seq2seq passes, whose multi-CU kernels hold 64-96 CUs for
     // hundreds of microseconds -- a launch cut for 256 workgroups then takes two rounds where one cut for the free
-    // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, profiles/ab/r03w_ab.txt).  PNMN_CONV_CUS overrides the
+    // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, gpurun_out/r03w_ab.txt).  PNMN_CONV_CUS overrides the
     // default of launches that do not say (tuning hook).
     static const long default_cus = [] {
         const char* e = getenv("PNMN_CONV_CUS");
