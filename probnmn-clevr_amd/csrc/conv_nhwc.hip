@@ -31,6 +31,7 @@
 
 #include "conv_body.h"
 #include "conv_plan.h"
+#include "conv_stream.h"
 
 namespace {
 
@@ -163,6 +164,59 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
     return 0;
 }
 
+// ---- streamed kernel (conv_stream.h): persistent workgroups of 8 contraction waves + 1 loader wave ----
+template <int H, int W, int TH>
+__global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_stream_kernel(const pnmn_conv_item* __restrict__ items,
+                                                                                  const pnmn::stream::Launch L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    pnmn::stream::conv_stream<H, W, TH>(L, items, smem_raw);
+}
+
+inline bool streamed() {
+    static const bool on = [] {
+        const char* e = getenv("PNMN_CONV_STREAM");
+        return e && atoi(e) != 0;  // (off until it beats the one-workgroup-per-unit kernel in the step)
+    }();
+    return on;
+}
+
+template <int H, int W, int TH>
+int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride, int out_stride,
+                  int cout_blocks, int relu, int cus, hipStream_t stream) {
+    using G = pnmn::stream::Geom<H, W, TH>;
+    static bool configured = false;
+    auto kern = conv_stream_kernel<H, W, TH>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)G::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int n_units = n_items * (H / TH);
+    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus, /*streamed=*/true);
+    pnmn::stream::Launch L{};
+    int wgs = 0, unit_at = 0;
+    for (int k = 0; k < lp.n_seg; ++k) {
+        if (lp.count[k] <= 0) continue;
+        const int i = L.n_seg++;
+        L.wg_begin[i] = wgs;
+        L.split[i] = 2 * lp.split[k];  // workgroups per 128-channel block: a workgroup computes 64 / split channels
+        L.unit0[i] = unit_at;
+        L.n_units[i] = lp.count[k];
+        L.per_xcd[i] = (lp.count[k] + 7) / 8;
+        wgs += L.per_xcd[i] * 8 * L.split[i];
+        unit_at += lp.count[k];
+    }
+    if (L.n_seg == 0) return 0;
+    L.wgs_x = wgs;
+    L.total = wgs * cout_blocks;
+    L.cin_chunks = cin_chunks, L.ntaps = ntaps, L.in_stride = in_stride, L.out_stride = out_stride, L.relu = relu;
+    int grid = (cus >= 8 && cus <= 256) ? (cus & ~7) : pnmn::default_conv_cus();
+    if (grid > L.total) grid = L.total;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pnmn::stream::NTHREADS), G::LDS_BYTES, stream, items, L);
+    return (int)hipGetLastError();
+}
+
 // bands per item of the shapes the kernels are built for (0: unsupported)
 inline int bands_of(int H, int W) { return (H == 14 && W == 14) ? 1 : (H == 28 && W == 28) ? 4 : 0; }
 
@@ -177,7 +231,7 @@ extern "C" int pnmn_conv_force_split(int split) {
 extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks) {
     const int nb = bands_of(H, W);
     if (n_items <= 0 || nb == 0) return 0;
-    if (merged_launches()) return 1;
+    if (merged_launches() || streamed()) return 1;
     const LaunchPlan lp = plan_launch(n_items * nb, cout_blocks, cin_chunks, ntaps);
     int n = 0;
     for (int k = 0; k < lp.n_seg; ++k) n += lp.count[k] > 0 ? 1 : 0;
@@ -197,6 +251,13 @@ extern "C" int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int 
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (streamed()) {
+        if (H == 14 && W == 14)
+            return launch_stream<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+        if (H == 28 && W == 28)
+            return launch_stream<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+        return PNMN_ESHAPE;
+    }
     if (H == 14 && W == 14)
         return launch_conv<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
     if (H == 28 && W == 28)

@@ -1,0 +1,684 @@
+// Streamed grouped NHWC convolution for gfx950 (see conv_nhwc.hip for the launch side).
+//
+// A workgroup is PERSISTENT and WAVE-SPECIALISED: 4 contraction waves (one per SIMD) + 1 loader wave (320 threads, one
+// workgroup per CU).  It walks its share of the launch's units -- unit = (item, band of 196 output pixels, block of 128 / split
+// output channels) -- and sees the input of every unit as a sequence of STAGES of 32 input channels:
+//
+//     14x14 maps, 28x28 with dilation 1 / 1x1:  stage = one quarter of a 128-channel chunk, all taps
+//     28x28 maps with dilation 2 / 4 / 8:        stage = (tap row ky, quarter): the 7 image rows that tap row reads
+//
+// The loader wave moves stages from global memory straight into a RING of LDS slots with 16-byte direct-to-LDS loads
+// (global_load_lds_dwordx4: no registers, no ds_write pass), several stages ahead of the contraction waves and ACROSS
+// unit boundaries, applies the fused prologue in place in LDS (attention-mask multiply; ReLU-backward gate, whose map
+// travels through the ring slot behind its stage) and announces a stage with one s_barrier.  The contraction waves
+// therefore never wait for memory: the next unit's first stage is resident when the previous unit's epilogue ends, and a
+// stage hand-over is one barrier.  The loader has its own vmcnt queue, so the long-latency tile loads never stand in
+// front of the contraction waves' weight stream (loads complete in order per wave).
+//
+// Inside a workgroup the waves split OUTPUT work only.  A workgroup computes 64 / 32 / 16 output channels of a unit
+// (WSPLIT 2 / 4 / 8 workgroups per 128-channel block; the launch planner's split 1 / 2 / 4) and a wave one 16-channel
+// tile x 13 / 7 / 4 m-tiles.  Every wave contracts ALL
+// input channels of its outputs, so there is no partial-sum exchange and the summation order of an output does not depend
+// on the split (all splits are bit-identical).  One wave per SIMD: the MFMA stream of a wave is long runs over 14-26
+// independent accumulators with ~0.3 other instructions per MFMA, which a single wave issues without gaps; two waves
+// per SIMD (rounds 1-3) ran the pair at 78 % of the pipe and left the early finisher waiting at every barrier.
+//
+// Taps that fall outside the image contribute nothing: the loader publishes, per tap, which m-tiles have at least one
+// pixel whose tap lands inside the staged rows; the contraction waves skip the others (dilation 8 on a 14x14 map: 42 of
+// 117 (tap, m-tile) pairs; dilation 4: 21; the reference op is nn.Conv2d(..., dilation=d, padding=d),
+// /root/reference/probnmn/modules/nmn_modules.py:146-160).
+//
+// LDS image of a slot: two SUB-SLOTS, one per 16-channel block kb of the stage, so that the two steps of a tap read at
+// one register address + an immediate offset.  In a sub-slot pixel row r = 4 pieces of 16 bytes; piece g -- channels
+// [4 g, +4) of the block -- sits at piece position
+//     (g & 1) << 1  |  (((r >> 2) & 1) ^ (g >> 1))
+// ds_read_b128 is served in groups of 16 lanes (conv_body.h of rounds 1-3 measured the grouping): eight lanes of lane
+// group g (pixels li in {0-3, 12-15}) and eight of g ^ 1 (li in {4-11}), sixteen different pixel rows.  Rows of equal
+// r & 3 share banks: of each lane group two lanes fall into one such class, their rows 4 or 12 apart, so (r >> 2) & 1
+// separates them and bit 1 separates g from g ^ 1: no bank conflicts for any tap or dilation.  A direct-to-LDS load
+// writes lane-linear (base + 16 lane), so the permutation is applied to the SOURCE address: lane l of piece i fetches
+// the channels that belong at position l & 3 of row 16 i + (l >> 2).  Rows a tap reads outside the staged region are
+// the sub-slot's own eight zero rows (same r & 7, so the bank argument holds).
+// The row a lane reads for (tap, output pixel) comes from a per-unit-geometry table [tap][208] of 16-bit row offsets the
+// loader computes once (dilation / band changes between units are rare: a launch's items are sorted by weight), so a
+// tap costs the contraction waves one ds_read_u16 and one v_xad per m-tile instead of ~10 VALU of border arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "../../include/probnmn_hip.h"
+#include "global_ptr.h"
+
+namespace pnmn {
+namespace stream {
+
+constexpr int CB = 128;          // channels of a chunk / of an output block
+constexpr int QC = 32;           // channels of a stage
+constexpr int NTHREADS = 320;    // 4 contraction waves + the loader wave
+constexpr int LOADER_WAVE = 4;
+constexpr int MTILES = 13;       // 196 output pixels = 12.25 tiles of 16
+constexpr int TAB_ROWS = 208;    // table entries per tap (13 tiles x 16 pixels)
+
+using lchar = __attribute__((address_space(3))) char;
+
+template <int H, int W, int TH>
+struct Geom {
+    static constexpr bool WHOLE = (TH == H);
+    static constexpr int NB = H / TH;                                  // bands per item
+    static constexpr int RP = (WHOLE ? H : TH + 2) * W;                // pixel rows of the largest staged region
+    static constexpr int Z0 = (RP + 7) & ~7;                           // first zero row of a sub-slot
+    static constexpr int SUB_PIECES = (Z0 + 15) / 16;                  // 1 KiB wave-loads per sub-slot (16 rows each)
+    static constexpr int PIECES = 2 * SUB_PIECES;                      // ... per slot
+    static constexpr int SUB_BYTES = (Z0 + 8) * 64;                    // 13 312 (14x14) / 16 896 (28x28)
+    static constexpr int SLOT_BYTES = 2 * SUB_BYTES;
+    static constexpr int RING = WHOLE ? 6 : 4;
+    static constexpr int TAB_OFF = RING * SLOT_BYTES;                  // uint16 [9][208]
+    static constexpr int LIVE_OFF = TAB_OFF + 9 * TAB_ROWS * 2;        // uint32 [9] (+ padding to 16 entries)
+    static constexpr int LDS_BYTES = LIVE_OFF + 16 * 4 + 128;          // (+ the table rows of the m-tiles past the 13th)
+    static_assert(LDS_BYTES <= 160 * 1024, "ring + table must fit the CU's LDS");
+    static_assert((Z0 + 7) * 64 + 16 < 65536 && SUB_BYTES < 65536, "table entries and the kb offset are 16 bits");
+};
+
+// kernel argument: the launch's segments (conv_plan.h) and the convolution's uniform shape
+struct Launch {
+    int n_seg;
+    int wg_begin[3], split[3], unit0[3], n_units[3], per_xcd[3];
+    int wgs_x;       // virtual workgroups per output-channel block (sum over the segments, a multiple of 8)
+    int total;       // wgs_x * cout_blocks
+    int cin_chunks, ntaps, in_stride, out_stride, relu;
+};
+
+__device__ __forceinline__ void lds_barrier() {
+    // every LDS access of this wave has completed; no wait on the vector-memory counter (the contraction waves keep
+    // their weight prefetch in flight across the hand-over, the loader its tile loads)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// image rows [rs, re) a stage of (band, dilation, pass) holds and the taps [t0, t1) that read them; false: the tap
+// row lies wholly outside the image
+template <int H, int W, int TH>
+__device__ __forceinline__ bool pass_rows(int band, int dil, int npass, int pass, int ntaps, int& rs, int& re, int& t0, int& t1) {
+    if (Geom<H, W, TH>::WHOLE) {
+        rs = 0, re = H, t0 = 0, t1 = ntaps;
+        return true;
+    }
+    const int y0 = band * TH;
+    if (npass == 1) {
+        const int halo = (ntaps == 1) ? 0 : 1;
+        rs = y0 - halo < 0 ? 0 : y0 - halo;
+        re = y0 + TH + halo > H ? H : y0 + TH + halo;
+        t0 = 0, t1 = ntaps;
+        return true;
+    }
+    const int a = y0 + (pass - 1) * dil;
+    rs = a < 0 ? 0 : (a > H ? H : a);
+    re = a + TH < 0 ? 0 : (a + TH > H ? H : a + TH);
+    t0 = 3 * pass, t1 = t0 + 3;
+    return re > rs;
+}
+
+// The (unit, stage) sequence of this workgroup.  Every wave -- and both cursors of the loader -- walks it with the same
+// arithmetic, so all agree on the order without exchanging anything.  All members are wave-uniform.
+template <int H, int W, int TH>
+struct Walker {
+    using G = Geom<H, W, TH>;
+    const pnmn_conv_item* items;
+    int vid, total;          // virtual workgroup id of the current unit (>= total: done)
+    int item, band, sub, split, cb;
+    int dil, npass, slots;   // of the unit's item; slots per stage: 1, or 2 with a gate map
+    int chunk, pass, kq;     // stage cursor
+    int rs, re, t0, t1;      // rows / taps of the current stage
+
+    __device__ __forceinline__ bool valid() const { return vid < total; }
+
+    __device__ __forceinline__ bool decode(const Launch& L) {
+        const int cbi = vid / L.wgs_x;
+        const int x = vid - cbi * L.wgs_x;
+        int wb = L.wg_begin[0], sp = L.split[0], u0 = L.unit0[0], nu = L.n_units[0], per = L.per_xcd[0];
+        if (L.n_seg > 1 && x >= L.wg_begin[1]) wb = L.wg_begin[1], sp = L.split[1], u0 = L.unit0[1], nu = L.n_units[1], per = L.per_xcd[1];
+        if (L.n_seg > 2 && x >= L.wg_begin[2]) wb = L.wg_begin[2], sp = L.split[2], u0 = L.unit0[2], nu = L.n_units[2], per = L.per_xcd[2];
+        const int local = x - wb;
+        const int slot = local >> 3;
+        const int j = slot / sp;
+        const int unit = (local & 7) * per + j;   // XCD (vid & 7) takes a contiguous range of the segment's units
+        if (unit >= nu || j >= per) return false;
+        const int u = u0 + unit;
+        item = u / G::NB, band = u % G::NB, sub = slot - j * sp, split = sp, cb = cbi;
+        return true;
+    }
+    __device__ __forceinline__ void open_unit(const Launch& L) {
+        while (vid < total && !decode(L)) vid += (int)gridDim.x;
+        if (vid >= total) return;
+        const pnmn_conv_item* it = items + item;
+        dil = it->dilation;
+        slots = it->gate ? 2 : 1;
+        npass = (G::WHOLE || L.ntaps == 1 || dil == 1) ? 1 : 3;
+        chunk = 0, pass = 0, kq = 0;
+        while (!pass_rows<H, W, TH>(band, dil, npass, pass, L.ntaps, rs, re, t0, t1)) ++pass;  // (the centre row always exists)
+    }
+    __device__ __forceinline__ void start(const Launch& L, const pnmn_conv_item* its) {
+        items = its, vid = (int)blockIdx.x, total = L.total;
+        open_unit(L);
+    }
+    // next stage of the same unit; false: the unit is finished (the cursor is then undefined until next_unit())
+    __device__ __forceinline__ bool next_stage(const Launch& L) {
+        if (++kq < 4) return true;
+        kq = 0;
+        while (++pass < npass)
+            if (pass_rows<H, W, TH>(band, dil, npass, pass, L.ntaps, rs, re, t0, t1)) return true;
+        if (++chunk >= L.cin_chunks) return false;
+        pass = 0;
+        while (!pass_rows<H, W, TH>(band, dil, npass, pass, L.ntaps, rs, re, t0, t1)) ++pass;
+        return true;
+    }
+    __device__ __forceinline__ void next_unit(const Launch& L) {
+        vid += (int)gridDim.x;
+        open_unit(L);
+    }
+    __device__ __forceinline__ int cbase() const { return chunk * CB + kq * QC; }  // first input channel of the stage
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// loader wave
+// ------------------------------------------------------------------------------------------------------------------
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one stage (32 channels of the rows [rs, re) of one source map) into the slot at LDS byte address `slot`
+template <int H, int W, int TH>
+__device__ __forceinline__ void issue_rows(const float* src, int in_stride, int rs, int re, lchar* slot, int lane) {
+    using G = Geom<H, W, TH>;
+    const int nr = (re - rs) * W;
+    const gfloat* base = as_global(src) + (size_t)rs * W * in_stride;
+    const int s = lane & 3;
+#pragma unroll 2
+    for (int i = 0; i < G::SUB_PIECES; ++i) {
+        // Every lane of a direct-to-LDS load writes its 16 bytes, whatever EXEC says (measured: a last piece issued
+        // under a partial mask overwrote the zero rows behind it with stale data).  So every piece is 16 full rows,
+        // and the last one starts early enough to end in front of the zero rows, overlapping its predecessor.
+        const int r0 = i * 16 < G::Z0 - 16 ? i * 16 : G::Z0 - 16;
+        const int row = r0 + (lane >> 2);
+        const int g = (((s & 1) ^ ((row >> 2) & 1)) << 1) | (s >> 1);
+        const int rr = row < nr ? row : nr - 1;  // rows past the region re-read its last row (never addressed)
+        const gfloat* gp = base + (size_t)rr * in_stride + g * 4;
+        __builtin_amdgcn_global_load_lds(gp, slot + r0 * 64, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gp + 16, slot + G::SUB_BYTES + r0 * 64, 16, 0, 0);
+    }
+}
+
+// prologue in place: x *= mask[pixel], x = gate > 0 ? x : 0
+template <int H, int W, int TH>
+__device__ __forceinline__ void fixup(char* lds, int slot_x, int slot_g, const float* mask, int rs, int re, bool gated, int lane) {
+    using G = Geom<H, W, TH>;
+    const int nr = (re - rs) * W;
+    const gfloat* msrc = mask ? as_global(mask) + rs * W : nullptr;
+#pragma unroll 1
+    for (int i = 0; i < G::SUB_PIECES; ++i) {
+        const int row = i * 16 + (lane >> 2);
+        if (row >= G::Z0) break;
+        const float mk = msrc ? msrc[row < nr ? row : nr - 1] : 1.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int off = kb * G::SUB_BYTES + i * 1024 + lane * 16;
+            f32x4* px = reinterpret_cast<f32x4*>(lds + slot_x + off);
+            f32x4 v = *px;
+            v *= mk;
+            if (gated) {
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(lds + slot_g + off);
+                v.x = gt.x > 0.f ? v.x : 0.f;
+                v.y = gt.y > 0.f ? v.y : 0.f;
+                v.z = gt.z > 0.f ? v.z : 0.f;
+                v.w = gt.w > 0.f ? v.w : 0.f;
+            }
+            *px = v;
+        }
+    }
+}
+
+// row table + live m-tiles of a unit geometry (band, dilation)
+template <int H, int W, int TH>
+__device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npass, int ntaps, int lane) {
+    using G = Geom<H, W, TH>;
+    constexpr int HW = TH * W;
+    uint16_t* tab = reinterpret_cast<uint16_t*>(lds + G::TAB_OFF);
+    uint32_t* live = reinterpret_cast<uint32_t*>(lds + G::LIVE_OFF);
+    if (lane < 16) live[lane] = 0;
+    const int y0 = G::WHOLE ? 0 : band * TH;
+    const int ntile = ntaps * MTILES;
+    for (int t4 = 0; t4 < ntile; t4 += 4) {  // four m-tiles per pass of the wave
+        const int tile = t4 + (lane >> 4);
+        const int tap = tile / MTILES;
+        const int m = tile - tap * MTILES;
+        const int p = m * 16 + (lane & 15);
+        int rs, re, t0, t1;
+        const int pass = npass == 1 ? 0 : tap / 3;
+        const bool rows_ok = tile < ntile && pass_rows<H, W, TH>(band, dil, npass, pass, ntaps, rs, re, t0, t1);
+        int dy = 0, dx = 0;
+        if (ntaps == 9) dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
+        const int yy = y0 + p / W + dy, xx = p % W + dx;
+        const bool ok = rows_ok && p < HW && yy >= rs && yy < re && (unsigned)xx < (unsigned)W;
+        const int qv = rows_ok ? (yy - rs) * W + xx : p;
+        const int row = ok ? qv : G::Z0 + (qv & 7);
+        if (tile < ntile) tab[tap * TAB_ROWS + p] = (uint16_t)(row * 64 + ((row >> 2) & 1) * 16);
+        const unsigned long long b = __ballot(ok);
+        if ((lane & 15) == 0 && tile < ntile && ((b >> (lane & 48)) & 0xffffull)) atomicOr(&live[tap], 1u << m);
+    }
+    // the contraction's compile-time tile ranges (run_unit, split 1): first half / second half of the m-tiles only
+    if (lane < ntaps) {
+        const uint32_t lv = live[lane];
+        uint32_t variant = 0;
+        if (lv != 0u && (lv >> 7) == 0u) variant = 1;          // tiles [0, 7)
+        else if (lv != 0u && (lv & 0x7fu) == 0u) variant = 2;  // tiles [7, 13)
+        live[lane] = lv | (variant << 16);
+    }
+}
+
+template <int H, int W, int TH>
+__device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane) {
+    using G = Geom<H, W, TH>;
+    lchar* ring = (lchar*)lds;
+    Walker<H, W, TH> P, C;   // producer (issue) and consumer (hand-over) cursors
+    P.start(L, items);
+    C = P;
+    int issued = 0, freed = 0, cstart = 0;  // in slots, cumulative
+    const pnmn_conv_item* pit = P.valid() ? items + P.item : nullptr;
+    auto top_up = [&] {
+        while (P.valid() && issued - freed + P.slots <= G::RING) {
+            const float* src = (pit->in2 != nullptr && P.chunk > 0) ? pit->in2 + P.kq * QC : pit->in + P.cbase();
+            // The vector-memory counter holds 63.  With more loads than that in flight (the first top-up used to
+            // issue six slots = 156 back to back) the zero rows of the ring came out dirty on the box; a slot is
+            // therefore issued only once all but the last 63 - PIECES loads have landed.
+            wait_vm<63 - G::PIECES>();
+            issue_rows<H, W, TH>(src, L.in_stride, P.rs, P.re, ring + (issued % G::RING) * G::SLOT_BYTES, lane);
+            if (P.slots == 2) {
+                wait_vm<63 - G::PIECES>();
+                issue_rows<H, W, TH>(pit->gate + P.cbase(), L.in_stride, P.rs, P.re,
+                                     ring + ((issued + 1) % G::RING) * G::SLOT_BYTES, lane);
+            }
+            issued += P.slots;
+            if (!P.next_stage(L)) {
+                P.next_unit(L);
+                pit = P.valid() ? items + P.item : nullptr;
+            }
+        }
+    };
+    int tab_band = -1, tab_dil = -1;
+    bool unit_end = false;   // the contraction waves stand (or will stand) at the end-of-unit barrier
+    top_up();
+    while (C.valid()) {
+        const pnmn_conv_item* cit = items + C.item;
+        // the stage's loads (and the gate map's) have landed: everything issued up to the end of this stage
+        const int younger = issued - (cstart + C.slots);
+        // (the counter holds 63: at most two younger slots are told apart at 14x14, one at 28x28)
+        constexpr int TWO = 2 * G::PIECES <= 63 ? 2 * G::PIECES : G::PIECES;
+        if (younger == 0) wait_vm<0>();
+        else if (younger == 1) wait_vm<G::PIECES>();
+        else wait_vm<TWO>();
+        if (cit->mask != nullptr || C.slots == 2)
+            fixup<H, W, TH>(lds, (cstart % G::RING) * G::SLOT_BYTES, ((cstart + 1) % G::RING) * G::SLOT_BYTES, cit->mask, C.rs,
+                            C.re, C.slots == 2, lane);
+        if (unit_end) {  // the previous unit's contraction is over: its table may go
+            lds_barrier();
+            unit_end = false;
+        }
+        if (C.band != tab_band || C.dil != tab_dil) {
+            fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane);
+            tab_band = C.band, tab_dil = C.dil;
+        }
+        lds_barrier();        // hand-over: the stage is the contraction waves'; every stage before it is finished
+        freed = cstart;
+        cstart += C.slots;
+        if (!C.next_stage(L)) {
+            C.next_unit(L);
+            unit_end = true;
+        }
+        top_up();
+    }
+    if (unit_end) lds_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// contraction waves
+// ------------------------------------------------------------------------------------------------------------------
+
+// acc += a (x) b, IN PLACE.  The builtin leaves vDst free to differ from SrcC, and under this kernel's pinned order the
+// register allocator then rotates the 13 accumulators through spare registers and spills them (measured: 25 scratch
+// accesses per tap at a 256-register budget for ~160 live values).  The tied operand takes that freedom away.  No MFMA
+// result is ever an A / B operand, dependent MFMAs are >= 2 issue slots apart (40 cycles dependent latency, 32 issue),
+// and the compiler still sees the register dependencies on the loaded fragments (it inserts the s_waitcnt).
+__device__ __forceinline__ void mfma(f32x4& acc, float a, float b) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+struct MaskBwd {
+    const float* feats;  // [HW][128] forward features (stem output)
+    const float* attn;   // [HW] or nullptr for the all-ones attention
+    float* dfeats;       // [HW][128], +=
+    float* dattn;        // [HW], += (ignored when attn == nullptr)
+};
+
+template <int H, int W, int TH, int MTW>
+__device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* acc, int mbase, int n0, int band, int out_stride,
+                                         int relu, int lane) {
+    constexpr int HW = TH * W;
+    const int li = lane & 15, g = lane >> 4;
+    const int p_img = Geom<H, W, TH>::WHOLE ? 0 : band * TH * W;
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
+    const MaskBwd mbv{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
+    const MaskBwd* mb = (it.flags & (PNMN_CONV_MASKBWD | PNMN_CONV_DATTN)) ? &mbv : nullptr;
+    // Every load of the epilogue (previous contents for accumulation, forward features, attention) is requested for
+    // all m-tiles before the first use.
+    if (mb == nullptr || (it.flags & PNMN_CONV_DATTN)) {
+        const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
+        // PNMN_CONV_DATTN: besides the plain store of dx, d(attention)[p] += sum_c dx[p][c] * feats[p][c] (this wave's
+        // 16 channels: four lane groups of four, then one atomic per pixel and wave)
+        const bool dattn = mb != nullptr && mb->attn != nullptr;
+        f32x4 old[MTW];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            old[j] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
+                     : (dattn && p < HW)    ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            if (p < HW) {
+                f32x4 v = acc[j] + bias4;
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                float* dstf = it.out + (size_t)(p_img + p) * out_stride + n0 + 4 * g;
+                if (it.flags & PNMN_CONV_ATOMIC) {
+                    unsafeAtomicAdd(dstf + 0, v.x);
+                    unsafeAtomicAdd(dstf + 1, v.y);
+                    unsafeAtomicAdd(dstf + 2, v.z);
+                    unsafeAtomicAdd(dstf + 3, v.w);
+                } else if (dattn) {
+                    store4(as_global(dstf), v);
+                } else {
+                    store4(as_global(dstf), v + old[j]);
+                }
+            }
+            if (dattn) {
+                const f32x4 v = acc[j];
+                float part = (p < HW) ? v.x * old[j].x + v.y * old[j].y + v.z * old[j].z + v.w * old[j].w : 0.f;
+                part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
+                part += __shfl_xor(part, 32);
+                if (p < HW && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+            }
+        }
+    } else {
+        // fused backward of (feats * attn): this wave owns channels n0..n0+15 of its pixels
+        const bool sole = it.flags & PNMN_CONV_MB_SOLE;
+        const gfloat* attn = as_global(mb->attn);
+        float am[MTW];
+        f32x4 fv[MTW], dold[MTW];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            const bool ok = p < HW;
+            am[j] = (ok && attn) ? attn[p_img + p] : 1.f;
+            fv[j] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dold[j] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            const bool ok = p < HW;
+            const f32x4 v = acc[j];
+            float part = v.x * fv[j].x + v.y * fv[j].y + v.z * fv[j].z + v.w * fv[j].w;
+            if (ok) {
+                float* d = mb->dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
+                if (sole) {  // only this wave touches these 4 channels of pixel p
+                    store4(as_global(d), dold[j] + v * am[j]);
+                } else {
+                    unsafeAtomicAdd(d + 0, v.x * am[j]);
+                    unsafeAtomicAdd(d + 1, v.y * am[j]);
+                    unsafeAtomicAdd(d + 2, v.z * am[j]);
+                    unsafeAtomicAdd(d + 3, v.w * am[j]);
+                }
+            }
+            if (attn) {
+                part += __shfl_xor(part, 16);
+                part += __shfl_xor(part, 32);
+                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+            }
+        }
+    }
+}
+
+// One unit at WSPLIT workgroups per 128-channel block: all its stages, then the epilogue.  Leaves the walker at the
+// next unit.  `cstart`: cumulative ring slots consumed by this workgroup so far (the same count the loader keeps).
+// KIND (chosen per UNIT, so that no two bodies meet inside the stage loop -- merging them there made the register
+// allocator shuffle and spill accumulators):
+//   0  3x3, every tap contracts all of the wave's m-tiles
+//   1  3x3 with dilation 8 on a 14x14 map: the taps of row -8 see only the m-tiles [7, 13), those of row +8 only [0, 6)
+//      -- 39 of 117 (tap, m-tile) pairs are skipped (the zero rows would contribute exact zeros)
+//   2  1x1 (one tap per stage)
+template <int H, int W, int TH, int SPLIT, int KIND>
+__device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, char* lds, int& cstart, int wave, int lane) {
+    using G = Geom<H, W, TH>;
+    using std::integral_constant;
+    static_assert(SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
+    constexpr int MW = SPLIT / 2;                                 // waves that share a channel tile's m-tiles
+    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 7 / 4
+    constexpr int MH = (MTW + 1) / 2;
+    constexpr int NT = KIND == 2 ? 1 : 9;
+    constexpr uint32_t FULL = (1u << MTW) - 1u;
+    const int li = lane & 15, g = lane >> 4;
+    const int nt = wave % (4 / MW);                               // which of the workgroup's 16-channel tiles
+    const int mbase = (wave / (4 / MW)) * MTW;                    // first m-tile of this wave
+    const pnmn_conv_item it = Wk.items[Wk.item];
+    const int n0 = Wk.cb * CB + Wk.sub * (CB / SPLIT) + nt * 16;  // this wave's first output channel
+    const int band = Wk.band;
+    const int cin_total = L.cin_chunks * CB;
+    const int slots = Wk.slots;
+
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight row of this lane: output channel n0 + li, channels 4g.. of each 16-block
+    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * NT * cin_total + 4 * g;
+    const uint32_t gconst = (uint32_t)((g >> 1) * 16 | (g & 1) * 32);
+    uint32_t tab_lane = (uint32_t)(G::TAB_OFF + (mbase * 16 + li) * 2);
+    asm volatile("" : "+v"(tab_lane));  // (keep the table base in a register: the per-tile offsets are immediates)
+    // tiles of this wave that exist at all (the 14th..16th lie outside the band)
+    const uint32_t exist = (mbase >= MTILES) ? 0u : (MTILES - mbase >= MTW ? FULL : ((1u << (MTILES - mbase)) - 1u));
+
+    // Weights: two 16-byte pieces per lane and tap (the two 16-channel blocks of the stage), requested TWO TAPS ahead
+    // into a ring of three sets (a lone wave per SIMD has only its own MFMAs to hide an L2 / MALL round trip behind:
+    // one step is 1 664 cycles).  Set = tap % 3; a 3x3 stage holds 9 or 3 taps and starts at tap 0 / 3 / 6, so the
+    // indices are compile-time.  1x1 convolutions (one tap per stage) alternate two sets, one stage ahead.
+    f32x4 wq[3][2];
+    auto wload = [&](f32x4 (&dst)[2], const gfloat* p) {
+        dst[0] = load4(p);
+        dst[1] = load4(p + 16);
+    };
+    {
+        const gfloat* w0 = wrow + (size_t)Wk.t0 * cin_total + Wk.cbase();
+        wload(wq[0], w0);
+        if (KIND != 2) wload(wq[1], w0 + cin_total);
+    }
+
+    uint32_t rb[MTW];
+    uint32_t rt[MTW];
+    f32x4 afrag[MTW];
+    uint32_t slot_base = 0;
+    auto row_fetch = [&](int j, const char* tp) { rt[j] = *reinterpret_cast<const uint16_t*>(tp + j * 32); };
+    auto row_apply = [&](int j) { rb[j] = (rt[j] ^ gconst) + slot_base; };
+    auto frag_load = [&](int j, int kb) { afrag[j] = *reinterpret_cast<const f32x4*>(lds + rb[j] + kb * G::SUB_BYTES); };
+
+    // One half (tiles [lo, hi)) of a step, hand-ordered for a lone wave: the k-slices 0..2 of all its tiles with one
+    // FILLER instruction behind each MFMA (the pipe is busy 32 cycles per MFMA, the wave issues the filler in its
+    // shadow), then k-slice 3, where every tile's fragment register is re-loaded for the NEXT step right behind its
+    // last reader.  k-slices outermost: consecutive MFMAs never share an accumulator (40 cycles dependent).
+    // DO = false: the half's tiles see nothing of this tap (zero rows): fillers and reloads only.
+    auto half = [&](auto DO, auto LO, auto HI, const f32x4 bw, auto NFILL, auto&& fill, auto&& reload) {
+        constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value, nfill = decltype(NFILL)::value;
+        constexpr int slots3 = 3 * (hi - lo);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = lo; j < hi; ++j) {
+                if (decltype(DO)::value) mfma(acc[j], bw[c], afrag[j][c]);
+                if (c * (hi - lo) + (j - lo) < nfill) fill(c * (hi - lo) + (j - lo));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int j = lo; j < hi; ++j) {
+            if (decltype(DO)::value) mfma(acc[j], bw[3], afrag[j][3]);
+            reload(j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = slots3; k < nfill; ++k) fill(k);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // One tap = two steps (kb = 0, 1).  HALVES: 0 both halves' MFMAs, 1 the first half's only, 2 the second's only.
+    // SET / FAR: the weight sets of this tap and of the request it issues (`wfar`).  The fragments of the NEXT tap
+    // are requested through its table row `tp` (after a stage's last tap they are discarded: the next stage's slot
+    // may not be read before its barrier).
+    auto tap_body = [&](auto HALVES, auto SET, auto FAR, const char* tp, const gfloat* wfar) {
+        constexpr int hv = decltype(HALVES)::value;
+        constexpr int set = decltype(SET)::value, far = decltype(FAR)::value;
+        using D0 = integral_constant<bool, hv == 0 || hv == 1>;
+        using D1 = integral_constant<bool, hv == 0 || hv == 2>;
+        using LO0 = integral_constant<int, 0>;
+        using MID = integral_constant<int, MH>;
+        using END = integral_constant<int, MTW>;
+        // step kb = 0; fillers: the far weights' two loads, then the next tap's table rows
+        constexpr int nf0 = 2 + MTW, cap0 = 3 * MH;
+        auto fill0 = [&](int i) {
+            if (i == 0) wq[far][0] = load4(wfar);
+            else if (i == 1) wq[far][1] = load4(wfar + 16);
+            else row_fetch(i - 2, tp);
+        };
+        auto fill0b = [&](int i) { fill0(i + cap0); };
+        auto nofill = [&](int) {};
+        auto reload1 = [&](int j) { frag_load(j, 1); };
+        half(D0{}, LO0{}, MID{}, wq[set][0], integral_constant<int, (nf0 < cap0 ? nf0 : cap0)>{}, fill0, reload1);
+        half(D1{}, MID{}, END{}, wq[set][0], integral_constant<int, (nf0 > cap0 ? nf0 - cap0 : 0)>{}, fill0b, reload1);
+        // step kb = 1; fillers: the next tap's rows applied (every load through the old rows has been issued)
+        auto fill1 = [&](int i) { row_apply(i); };
+        auto reload0 = [&](int j) { frag_load(j, 0); };
+        half(D0{}, LO0{}, MID{}, wq[set][1], integral_constant<int, MTW>{}, fill1, reload0);
+        half(D1{}, MID{}, END{}, wq[set][1], integral_constant<int, 0>{}, nofill, reload0);
+    };
+    using I0 = integral_constant<int, 0>;
+    using I1 = integral_constant<int, 1>;
+    using I2 = integral_constant<int, 2>;
+
+    bool more = true;
+    while (more) {
+        const int t0 = Wk.t0, t1 = Wk.t1, cb0 = Wk.cbase();
+        slot_base = (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
+        cstart += slots;
+        more = Wk.next_stage(L);  // (the cursor now names the NEXT stage: its first weights are requested below)
+        // first tap of the next stage (the unit's last stage re-requests its own: never used)
+        const gfloat* wnext_stage = more ? wrow + (size_t)Wk.t0 * cin_total + Wk.cbase() : wrow + (size_t)t0 * cin_total + cb0;
+        // weights of the tap two behind `tap` in the unit's order (the unit's last two taps re-request their own)
+        auto far_ptr = [&](int tap) -> const gfloat* {
+            if (tap + 2 < t1) return wrow + (size_t)(tap + 2) * cin_total + cb0;
+            return more ? wnext_stage + (size_t)(tap + 2 - t1) * cin_total : wrow + (size_t)tap * cin_total + cb0;
+        };
+        // table row of the tap behind `tap` (clamped: the fragments requested behind a stage's last tap are discarded)
+        auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < NT ? tap + 1 : NT - 1) * (TAB_ROWS * 2); };
+
+        lds_barrier();  // the stage is resident (and the table, on a unit's first stage)
+
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) row_fetch(j, lds + tab_lane + t0 * (TAB_ROWS * 2));
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) row_apply(j);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) frag_load(j, 0);
+        if (KIND == 2) {
+            // two stages per trip (a unit has 4 cin_chunks of them), so that the weight sets alternate at compile time
+            tap_body(I0{}, I0{}, I1{}, next_row(0), wnext_stage);
+            const int cb1 = Wk.cbase();
+            slot_base = (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
+            cstart += slots;
+            more = Wk.next_stage(L);
+            const gfloat* wnext2 = more ? wrow + Wk.cbase() : wrow + cb1;
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) row_apply(j);   // (the same table row; the next slot)
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) frag_load(j, 0);
+            tap_body(I0{}, I1{}, I0{}, next_row(0), wnext2);
+        } else if (KIND == 1) {
+            tap_body(I2{}, I0{}, I2{}, next_row(0), far_ptr(0));
+            tap_body(I2{}, I1{}, I0{}, next_row(1), far_ptr(1));
+            tap_body(I2{}, I2{}, I1{}, next_row(2), far_ptr(2));
+            tap_body(I0{}, I0{}, I2{}, next_row(3), far_ptr(3));
+            tap_body(I0{}, I1{}, I0{}, next_row(4), far_ptr(4));
+            tap_body(I0{}, I2{}, I1{}, next_row(5), far_ptr(5));
+            tap_body(I1{}, I0{}, I2{}, next_row(6), far_ptr(6));
+            tap_body(I1{}, I1{}, I0{}, next_row(7), far_ptr(7));
+            tap_body(I1{}, I2{}, I1{}, next_row(8), far_ptr(8));
+        } else {
+            for (int ta = t0; ta < t1; ta += 3) {  // the three taps of a tap row
+                tap_body(I0{}, I0{}, I2{}, next_row(ta), far_ptr(ta));
+                tap_body(I0{}, I1{}, I0{}, next_row(ta + 1), far_ptr(ta + 1));
+                tap_body(I0{}, I2{}, I1{}, next_row(ta + 2), far_ptr(ta + 2));
+            }
+        }
+    }
+    lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
+    if (exist != 0u) epilogue<H, W, TH, MTW>(it, acc, mbase, n0, band, L.out_stride, L.relu, lane);
+    Wk.next_unit(L);
+}
+
+template <int H, int W, int TH>
+__device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_item* items, char* lds) {
+    using G = Geom<H, W, TH>;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    // the zero rows of every slot (no load ever writes them)
+    for (int t = tid; t < G::RING * 64; t += NTHREADS) {  // (8 rows x 64 bytes per sub-slot: 32 lanes each)
+        const int sl = t >> 6, kb = (t >> 5) & 1;
+        *reinterpret_cast<f32x4*>(lds + sl * G::SLOT_BYTES + kb * G::SUB_BYTES + G::Z0 * 64 + (t & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (wave == LOADER_WAVE) {
+        loader<H, W, TH>(L, items, lds, lane);
+        return;
+    }
+    Walker<H, W, TH> Wk;
+    Wk.start(L, items);
+    int cstart = 0;
+    while (Wk.valid()) {
+        // (all uniform over the workgroup)
+        if (L.ntaps == 1) {
+            switch (Wk.split) {
+                case 2: run_unit<H, W, TH, 2, 2>(Wk, L, lds, cstart, wave, lane); break;
+                case 4: run_unit<H, W, TH, 4, 2>(Wk, L, lds, cstart, wave, lane); break;
+                default: run_unit<H, W, TH, 8, 2>(Wk, L, lds, cstart, wave, lane); break;
+            }
+        } else if (G::WHOLE && Wk.dil == 8 && Wk.split == 2) {
+            run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane);
+        } else {
+            switch (Wk.split) {
+                case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane); break;
+                case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane); break;
+                default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane); break;
+            }
+        }
+    }
+}
+
+}  // namespace stream
+}  // namespace pnmn
