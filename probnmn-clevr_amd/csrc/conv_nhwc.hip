@@ -211,6 +211,10 @@ int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int 
     L.wgs_x = wgs;
     L.total = wgs * cout_blocks;
     L.cin_chunks = cin_chunks, L.ntaps = ntaps, L.in_stride = in_stride, L.out_stride = out_stride, L.relu = relu;
+    {
+        const char* e = getenv("PNMN_CONV_DBGPTR");
+        L.dbg = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
+    }
     int grid = (cus >= 8 && cus <= 256) ? (cus & ~7) : pnmn::default_conv_cus();
     if (grid > L.total) grid = L.total;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pnmn::stream::NTHREADS), G::LDS_BYTES, stream, items, L);

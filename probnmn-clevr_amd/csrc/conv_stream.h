@@ -88,6 +88,7 @@ struct Launch {
     int wgs_x;       // virtual workgroups per output-channel block (sum over the segments, a multiple of 8)
     int total;       // wgs_x * cout_blocks
     int cin_chunks, ntaps, in_stride, out_stride, relu;
+    unsigned long long* dbg;  // (PNMN_CONV_DBGPTR: cycle counters per contraction wave, scripts/r04_cycles.py)
 };
 
 __device__ __forceinline__ void lds_barrier() {
@@ -217,25 +218,36 @@ __device__ __forceinline__ void fixup(char* lds, int slot_x, int slot_g, const f
     using G = Geom<H, W, TH>;
     const int nr = (re - rs) * W;
     const gfloat* msrc = mask ? as_global(mask) + rs * W : nullptr;
-#pragma unroll 1
+    // the mask values of all pieces are requested before the first is used (one round trip, not SUB_PIECES of them:
+    // the first version kept the contraction waves waiting 18 % of their time at the hand-over)
+    float mk[G::SUB_PIECES];
+#pragma unroll
     for (int i = 0; i < G::SUB_PIECES; ++i) {
         const int row = i * 16 + (lane >> 2);
-        if (row >= G::Z0) break;
-        const float mk = msrc ? msrc[row < nr ? row : nr - 1] : 1.f;
+        mk[i] = msrc ? msrc[row < nr ? row : nr - 1] : 1.f;
+    }
+    // one sub-slot at a time, all of its pieces read before the first is written back (13-16 LDS round trips in
+    // flight instead of one after the other; the loader has the registers)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x4 v[G::SUB_PIECES], gt[G::SUB_PIECES];
+#pragma unroll
+        for (int i = 0; i < G::SUB_PIECES; ++i) {
             const int off = kb * G::SUB_BYTES + i * 1024 + lane * 16;
-            f32x4* px = reinterpret_cast<f32x4*>(lds + slot_x + off);
-            f32x4 v = *px;
-            v *= mk;
+            v[i] = *reinterpret_cast<const f32x4*>(lds + slot_x + off);
+            if (gated) gt[i] = *reinterpret_cast<const f32x4*>(lds + slot_g + off);
+        }
+#pragma unroll
+        for (int i = 0; i < G::SUB_PIECES; ++i) {
+            const int off = kb * G::SUB_BYTES + i * 1024 + lane * 16;
+            f32x4 x = v[i] * mk[i];
             if (gated) {
-                const f32x4 gt = *reinterpret_cast<const f32x4*>(lds + slot_g + off);
-                v.x = gt.x > 0.f ? v.x : 0.f;
-                v.y = gt.y > 0.f ? v.y : 0.f;
-                v.z = gt.z > 0.f ? v.z : 0.f;
-                v.w = gt.w > 0.f ? v.w : 0.f;
+                x.x = gt[i].x > 0.f ? x.x : 0.f;
+                x.y = gt[i].y > 0.f ? x.y : 0.f;
+                x.z = gt[i].z > 0.f ? x.z : 0.f;
+                x.w = gt[i].w > 0.f ? x.w : 0.f;
             }
-            *px = v;
+            if (i * 16 + (lane >> 2) < G::Z0) *reinterpret_cast<f32x4*>(lds + slot_x + off) = x;
         }
     }
 }
@@ -282,6 +294,9 @@ template <int H, int W, int TH>
 __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane) {
     using G = Geom<H, W, TH>;
     lchar* ring = (lchar*)lds;
+    // The loader shares its SIMD with a contraction wave whose MFMA stream would otherwise win nearly every issue
+    // slot: at the default priority issuing one stage (26 loads and their addresses) took as long as contracting it.
+    __builtin_amdgcn_s_setprio(3);
     Walker<H, W, TH> P, C;   // producer (issue) and consumer (hand-over) cursors
     P.start(L, items);
     C = P;
@@ -309,7 +324,15 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
     };
     int tab_band = -1, tab_dil = -1;
     bool unit_end = false;   // the contraction waves stand (or will stand) at the end-of-unit barrier
+    unsigned long long lc[4] = {0, 0, 0, 0};  // cycles: issuing, waiting for loads, prologue in place, at barriers
+    unsigned long long lt = __builtin_readcyclecounter();
+    auto lap = [&](int k) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        lc[k] += now - lt;
+        lt = now;
+    };
     top_up();
+    lap(0);
     while (C.valid()) {
         const pnmn_conv_item* cit = items + C.item;
         // the stage's loads (and the gate map's) have landed: everything issued up to the end of this stage
@@ -319,18 +342,23 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
         if (younger == 0) wait_vm<0>();
         else if (younger == 1) wait_vm<G::PIECES>();
         else wait_vm<TWO>();
+        lap(1);
         if (cit->mask != nullptr || C.slots == 2)
             fixup<H, W, TH>(lds, (cstart % G::RING) * G::SLOT_BYTES, ((cstart + 1) % G::RING) * G::SLOT_BYTES, cit->mask, C.rs,
                             C.re, C.slots == 2, lane);
+        lap(2);
         if (unit_end) {  // the previous unit's contraction is over: its table may go
             lds_barrier();
             unit_end = false;
+            lap(3);
         }
         if (C.band != tab_band || C.dil != tab_dil) {
             fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane);
             tab_band = C.band, tab_dil = C.dil;
         }
+        lap(2);
         lds_barrier();        // hand-over: the stage is the contraction waves'; every stage before it is finished
+        lap(3);
         freed = cstart;
         cstart += C.slots;
         if (!C.next_stage(L)) {
@@ -338,8 +366,13 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
             unit_end = true;
         }
         top_up();
+        lap(0);
     }
     if (unit_end) lds_barrier();
+    if (L.dbg && lane == 0) {
+        unsigned long long* d = L.dbg + ((size_t)gridDim.x * 4 + blockIdx.x) * 8;
+        d[0] = lc[0], d[1] = lc[1], d[2] = lc[2], d[3] = lc[3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -355,73 +388,69 @@ __device__ __forceinline__ void mfma(f32x4& acc, float a, float b) {
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-struct MaskBwd {
-    const float* feats;  // [HW][128] forward features (stem output)
-    const float* attn;   // [HW] or nullptr for the all-ones attention
-    float* dfeats;       // [HW][128], +=
-    float* dattn;        // [HW], += (ignored when attn == nullptr)
-};
 
+// Epilogue of one wave: lane holds output channels n0 + 4g .. +3 of pixel (mbase + j) * 16 + li of its m-tiles.
+// One straight-line variant per kind of item, chosen ONCE (uniform): on gfx9 stores count on vmcnt like loads, so a
+// shared body -- "add the previous contents, which may or may not have been loaded" -- made every tile's store wait for
+// the store of the tile before it: 13 write round trips in a row, 7 % of a unit.
 template <int H, int W, int TH, int MTW>
 __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* acc, int mbase, int n0, int band, int out_stride,
-                                         int relu, int lane) {
+                                         int relu, int lane, const f32x4 bias4) {
     constexpr int HW = TH * W;
     const int li = lane & 15, g = lane >> 4;
     const int p_img = Geom<H, W, TH>::WHOLE ? 0 : band * TH * W;
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
-    const MaskBwd mbv{it.mb_feats, it.mb_attn, it.mb_dfeats, it.mb_dattn};
-    const MaskBwd* mb = (it.flags & (PNMN_CONV_MASKBWD | PNMN_CONV_DATTN)) ? &mbv : nullptr;
-    // Every load of the epilogue (previous contents for accumulation, forward features, attention) is requested for
-    // all m-tiles before the first use.
-    if (mb == nullptr || (it.flags & PNMN_CONV_DATTN)) {
-        const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
-        // PNMN_CONV_DATTN: besides the plain store of dx, d(attention)[p] += sum_c dx[p][c] * feats[p][c] (this wave's
-        // 16 channels: four lane groups of four, then one atomic per pixel and wave)
-        const bool dattn = mb != nullptr && mb->attn != nullptr;
-        f32x4 old[MTW];
+    auto act = [&](f32x4 v) {
+        v += bias4;
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        return v;
+    };
+    float* const out0 = it.out + (size_t)p_img * out_stride + n0 + 4 * g;
+    if (!(it.flags & (PNMN_CONV_ACCUMULATE | PNMN_CONV_MASKBWD | PNMN_CONV_DATTN))) {
+        // plain store
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
             const int p = (mbase + j) * 16 + li;
-            old[j] = (accumulate && p < HW) ? load4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g)
-                     : (dattn && p < HW)    ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < HW) store4(as_global(out0 + (size_t)p * out_stride), act(acc[j]));
+        }
+        return;
+    }
+    if (it.flags & PNMN_CONV_DATTN) {
+        // dx is stored; d(attention)[p] += sum_c dx[p][c] * feats[p][c] (this wave's 16 channels: four lane groups of
+        // four channels, then one atomic per pixel and wave).  mb_attn == nullptr: the all-ones attention, no gradient.
+        const bool dattn = it.mb_attn != nullptr;
+        f32x4 fv[MTW];
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            fv[j] = (dattn && p < HW) ? load4(as_global(it.mb_feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
             const int p = (mbase + j) * 16 + li;
-            if (p < HW) {
-                f32x4 v = acc[j] + bias4;
-                if (relu) {
-                    v.x = fmaxf(v.x, 0.f);
-                    v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f);
-                    v.w = fmaxf(v.w, 0.f);
-                }
-                float* dstf = it.out + (size_t)(p_img + p) * out_stride + n0 + 4 * g;
-                if (it.flags & PNMN_CONV_ATOMIC) {
-                    unsafeAtomicAdd(dstf + 0, v.x);
-                    unsafeAtomicAdd(dstf + 1, v.y);
-                    unsafeAtomicAdd(dstf + 2, v.z);
-                    unsafeAtomicAdd(dstf + 3, v.w);
-                } else if (dattn) {
-                    store4(as_global(dstf), v);
-                } else {
-                    store4(as_global(dstf), v + old[j]);
-                }
-            }
-            if (dattn) {
+            if (p < HW) store4(as_global(out0 + (size_t)p * out_stride), act(acc[j]));
+        }
+        if (dattn) {
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) {
+                const int p = (mbase + j) * 16 + li;
                 const f32x4 v = acc[j];
-                float part = (p < HW) ? v.x * old[j].x + v.y * old[j].y + v.z * old[j].z + v.w * old[j].w : 0.f;
-                part += __shfl_xor(part, 16);  // sum the four channel groups g = 0..3 of this pixel
+                float part = (p < HW) ? v.x * fv[j].x + v.y * fv[j].y + v.z * fv[j].z + v.w * fv[j].w : 0.f;
+                part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
-                if (p < HW && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+                if (p < HW && g == 0) unsafeAtomicAdd(it.mb_dattn + p_img + p, part);
             }
         }
-    } else {
-        // fused backward of (feats * attn): this wave owns channels n0..n0+15 of its pixels
+        return;
+    }
+    if (it.flags & PNMN_CONV_MASKBWD) {
+        // fused backward of (feats * attn): dfeats += dx * attn, dattn += sum_c dx * feats
         const bool sole = it.flags & PNMN_CONV_MB_SOLE;
-        const gfloat* attn = as_global(mb->attn);
+        const gfloat* attn = as_global(it.mb_attn);
         float am[MTW];
         f32x4 fv[MTW], dold[MTW];
 #pragma unroll
@@ -429,8 +458,8 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
             const int p = (mbase + j) * 16 + li;
             const bool ok = p < HW;
             am[j] = (ok && attn) ? attn[p_img + p] : 1.f;
-            fv[j] = (ok && attn) ? load4(as_global(mb->feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-            dold[j] = (ok && sole) ? load4(as_global(mb->dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            fv[j] = (ok && attn) ? load4(as_global(it.mb_feats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            dold[j] = (ok && sole) ? load4(as_global(it.mb_dfeats) + (size_t)(p_img + p) * CB + n0 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
@@ -439,7 +468,7 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
             const f32x4 v = acc[j];
             float part = v.x * fv[j].x + v.y * fv[j].y + v.z * fv[j].z + v.w * fv[j].w;
             if (ok) {
-                float* d = mb->dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
+                float* d = it.mb_dfeats + (size_t)(p_img + p) * CB + n0 + 4 * g;
                 if (sole) {  // only this wave touches these 4 channels of pixel p
                     store4(as_global(d), dold[j] + v * am[j]);
                 } else {
@@ -452,9 +481,37 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
             if (attn) {
                 part += __shfl_xor(part, 16);
                 part += __shfl_xor(part, 32);
-                if (ok && g == 0) unsafeAtomicAdd(mb->dattn + p_img + p, part);
+                if (ok && g == 0) unsafeAtomicAdd(it.mb_dattn + p_img + p, part);
             }
         }
+        return;
+    }
+    if (it.flags & PNMN_CONV_ATOMIC) {
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            const int p = (mbase + j) * 16 + li;
+            if (p < HW) {
+                const f32x4 v = act(acc[j]);
+                float* d = out0 + (size_t)p * out_stride;
+                unsafeAtomicAdd(d + 0, v.x);
+                unsafeAtomicAdd(d + 1, v.y);
+                unsafeAtomicAdd(d + 2, v.z);
+                unsafeAtomicAdd(d + 3, v.w);
+            }
+        }
+        return;
+    }
+    // out += result: every previous value requested before the first store
+    f32x4 old[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int p = (mbase + j) * 16 + li;
+        old[j] = p < HW ? load4(as_global(out0 + (size_t)p * out_stride)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int p = (mbase + j) * 16 + li;
+        if (p < HW) store4(as_global(out0 + (size_t)p * out_stride), act(acc[j]) + old[j]);
     }
 }
 
@@ -467,9 +524,11 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
 //      -- 39 of 117 (tap, m-tile) pairs are skipped (the zero rows would contribute exact zeros)
 //   2  1x1 (one tap per stage)
 template <int H, int W, int TH, int SPLIT, int KIND>
-__device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, char* lds, int& cstart, int wave, int lane) {
+__device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, char* lds, int& cstart, int wave, int lane,
+                                         unsigned long long (&cyc)[4]) {
     using G = Geom<H, W, TH>;
     using std::integral_constant;
+    const unsigned long long c_unit = __builtin_readcyclecounter();
     static_assert(SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
     constexpr int MW = SPLIT / 2;                                 // waves that share a channel tile's m-tiles
     constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 7 / 4
@@ -501,6 +560,8 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     // into a ring of three sets (a lone wave per SIMD has only its own MFMAs to hide an L2 / MALL round trip behind:
     // one step is 1 664 cycles).  Set = tap % 3; a 3x3 stage holds 9 or 3 taps and starts at tap 0 / 3 / 6, so the
     // indices are compile-time.  1x1 convolutions (one tap per stage) alternate two sets, one stage ahead.
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};  // (requested now: the epilogue is one memory round trip shorter)
+    if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
     f32x4 wq[3][2];
     auto wload = [&](f32x4 (&dst)[2], const gfloat* p) {
         dst[0] = load4(p);
@@ -517,8 +578,12 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     f32x4 afrag[MTW];
     uint32_t slot_base = 0;
     auto row_fetch = [&](int j, const char* tp) { rt[j] = *reinterpret_cast<const uint16_t*>(tp + j * 32); };
+    // (rb holds ABSOLUTE LDS byte addresses -- the ring's base folded into slot_base -- so that a fragment read is one
+    // ds_read_b128 with an immediate offset, without a per-read add of the workgroup's LDS base)
+    using lf32x4 = __attribute__((address_space(3))) f32x4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lchar*)lds;
     auto row_apply = [&](int j) { rb[j] = (rt[j] ^ gconst) + slot_base; };
-    auto frag_load = [&](int j, int kb) { afrag[j] = *reinterpret_cast<const f32x4*>(lds + rb[j] + kb * G::SUB_BYTES); };
+    auto frag_load = [&](int j, int kb) { afrag[j] = *reinterpret_cast<const lf32x4*>((uintptr_t)(rb[j] + kb * G::SUB_BYTES)); };
 
     // One half (tiles [lo, hi)) of a step, hand-ordered for a lone wave: the k-slices 0..2 of all its tiles with one
     // FILLER instruction behind each MFMA (the pipe is busy 32 cycles per MFMA, the wave issues the filler in its
@@ -533,17 +598,23 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
 #pragma unroll
             for (int j = lo; j < hi; ++j) {
                 if (decltype(DO)::value) mfma(acc[j], bw[c], afrag[j][c]);
+#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 2
                 if (c * (hi - lo) + (j - lo) < nfill) fill(c * (hi - lo) + (j - lo));
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
         for (int j = lo; j < hi; ++j) {
             if (decltype(DO)::value) mfma(acc[j], bw[3], afrag[j][3]);
+#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 3
             reload(j);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 2
 #pragma unroll
         for (int k = slots3; k < nfill; ++k) fill(k);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     // One tap = two steps (kb = 0, 1).  HALVES: 0 both halves' MFMAs, 1 the first half's only, 2 the second's only.
@@ -583,7 +654,7 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     bool more = true;
     while (more) {
         const int t0 = Wk.t0, t1 = Wk.t1, cb0 = Wk.cbase();
-        slot_base = (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
+        slot_base = lds0 + (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
         cstart += slots;
         more = Wk.next_stage(L);  // (the cursor now names the NEXT stage: its first weights are requested below)
         // first tap of the next stage (the unit's last stage re-requests its own: never used)
@@ -596,7 +667,11 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         // table row of the tap behind `tap` (clamped: the fragments requested behind a stage's last tap are discarded)
         auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < NT ? tap + 1 : NT - 1) * (TAB_ROWS * 2); };
 
-        lds_barrier();  // the stage is resident (and the table, on a unit's first stage)
+        {
+            const unsigned long long c0 = __builtin_readcyclecounter();
+            lds_barrier();  // the stage is resident (and the table, on a unit's first stage)
+            cyc[0] += __builtin_readcyclecounter() - c0;
+        }
 
 #pragma unroll
         for (int j = 0; j < MTW; ++j) row_fetch(j, lds + tab_lane + t0 * (TAB_ROWS * 2));
@@ -608,7 +683,7 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
             // two stages per trip (a unit has 4 cin_chunks of them), so that the weight sets alternate at compile time
             tap_body(I0{}, I0{}, I1{}, next_row(0), wnext_stage);
             const int cb1 = Wk.cbase();
-            slot_base = (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
+            slot_base = lds0 + (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
             cstart += slots;
             more = Wk.next_stage(L);
             const gfloat* wnext2 = more ? wrow + Wk.cbase() : wrow + cb1;
@@ -636,9 +711,16 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
             }
         }
     }
+    const unsigned long long c_u = __builtin_readcyclecounter();
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
-    if (exist != 0u) epilogue<H, W, TH, MTW>(it, acc, mbase, n0, band, L.out_stride, L.relu, lane);
+    const unsigned long long c_e = __builtin_readcyclecounter();
+    if (exist != 0u) epilogue<H, W, TH, MTW>(it, acc, mbase, n0, band, L.out_stride, L.relu, lane, bias4);
     Wk.next_unit(L);
+    const unsigned long long c_x = __builtin_readcyclecounter();
+    cyc[0] += c_e - c_u;
+    cyc[1] += c_x - c_e;
+    cyc[2] += c_x - c_unit;
+    cyc[3] += 1;
 }
 
 template <int H, int W, int TH>
@@ -660,23 +742,29 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     Walker<H, W, TH> Wk;
     Wk.start(L, items);
     int cstart = 0;
+    unsigned long long cyc[4] = {0, 0, 0, 0};  // barrier waits, epilogues, units, unit count
+    const unsigned long long c_begin = __builtin_readcyclecounter();
     while (Wk.valid()) {
         // (all uniform over the workgroup)
         if (L.ntaps == 1) {
             switch (Wk.split) {
-                case 2: run_unit<H, W, TH, 2, 2>(Wk, L, lds, cstart, wave, lane); break;
-                case 4: run_unit<H, W, TH, 4, 2>(Wk, L, lds, cstart, wave, lane); break;
-                default: run_unit<H, W, TH, 8, 2>(Wk, L, lds, cstart, wave, lane); break;
+                case 2: run_unit<H, W, TH, 2, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 4: run_unit<H, W, TH, 4, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                default: run_unit<H, W, TH, 8, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
             }
         } else if (G::WHOLE && Wk.dil == 8 && Wk.split == 2) {
-            run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane);
+            run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane, cyc);
         } else {
             switch (Wk.split) {
-                case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane); break;
-                case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane); break;
-                default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane); break;
+                case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
             }
         }
+    }
+    if (L.dbg && lane == 0) {
+        unsigned long long* d = L.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        d[0] = cyc[0], d[1] = cyc[1], d[2] = cyc[2], d[3] = cyc[3], d[4] = __builtin_readcyclecounter() - c_begin;
     }
 }
 
