@@ -200,7 +200,7 @@ int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int 
         if (lp.count[k] <= 0) continue;
         const int i = L.n_seg++;
         L.wg_begin[i] = wgs;
-        L.split[i] = 2 * lp.split[k];  // workgroups per 128-channel block: a workgroup computes 64 / split channels
+        L.split[i] = lp.split[k];
         L.unit0[i] = unit_at;
         L.n_units[i] = lp.count[k];
         L.per_xcd[i] = (lp.count[k] + 7) / 8;
@@ -255,7 +255,7 @@ extern "C" int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int 
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (streamed()) {
+    if (streamed() && ntaps == 9) {  // (1x1 convolutions -- two steps per 32-channel stage -- stay on the kernel below)
         if (H == 14 && W == 14)
             return launch_stream<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
         if (H == 28 && W == 28)

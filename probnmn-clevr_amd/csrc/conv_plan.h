@@ -41,10 +41,10 @@ inline int default_conv_cus() {
 }
 
 // streamed: the persistent kernel of conv_stream.h -- staging is hidden behind the contraction (no per-chunk cost); a
-// workgroup computes 64 / split output channels, so a "round" is 128 units at split 1; split 2 / 4 share an item's 13
-// m-tiles among 2 / 4 waves per channel tile (7 / 4 tiles on the longest wave); there is no split 8 / 16.
+// workgroup computes 128 / split output channels; split 2 halves a wave's channels, split 4 / 8 also share an item's 13
+// m-tiles among 2 / 4 waves per channel tile (7 / 4 tiles on the longest wave); there is no split 16.
 inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0, bool streamed = false) {
-    if (forced_split()) return LaunchPlan{1, {streamed && forced_split() > 4 ? 4 : forced_split(), 0, 0}, {n_items, 0, 0}};
+    if (forced_split()) return LaunchPlan{1, {streamed && forced_split() > 8 ? 8 : forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
     static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
         const char* e = getenv("PNMN_CONV_STAGE_COST");
@@ -62,11 +62,11 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     const double overhead = streamed ? 0.25 : stage_cost * cin_chunks + 0.25;
     // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
     auto round_cost = [&](int s) {
-        if (streamed) return work * (s == 1 ? 1.0 : s == 2 ? 7.0 / 13.0 : 4.0 / 13.0) + overhead;
+        if (streamed) return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : 2.0 / 13.0) + overhead;
         return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead;
     };
     static const int s_max_old = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
-    const int s_max = streamed ? 4 : s_max_old;
+    const int s_max = streamed ? 8 : s_max_old;
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
@@ -75,7 +75,7 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, gpurun_out/r03w_ab.txt).  PNMN_CONV_CUS overrides the
     // default of launches that do not say (tuning hook).
     const long cus = (cu_budget >= 8 && cu_budget <= 256) ? cu_budget : default_conv_cus();
-    const int wg_per = streamed ? 2 : 1;  // workgroups of a unit at split 1
+    const int wg_per = 1;
     auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s * wg_per + cus - 1) / cus; };
     auto full_of = [&](long n, int s) {  // items that fill whole rounds at split s
         const long per_item = (long)cout_blocks * s * wg_per;

@@ -15,9 +15,9 @@
 // stage hand-over is one barrier.  The loader has its own vmcnt queue, so the long-latency tile loads never stand in
 // front of the contraction waves' weight stream (loads complete in order per wave).
 //
-// Inside a workgroup the waves split OUTPUT work only.  A workgroup computes 64 / 32 / 16 output channels of a unit
-// (WSPLIT 2 / 4 / 8 workgroups per 128-channel block; the launch planner's split 1 / 2 / 4) and a wave one 16-channel
-// tile x 13 / 7 / 4 m-tiles.  Every wave contracts ALL
+// Inside a workgroup the waves split OUTPUT work only.  Split 1: a workgroup computes the unit's 128 output channels,
+// a wave 32 of them (two 16-channel tiles sharing every A fragment) x all 13 m-tiles; split 2 / 4 / 8 (launches that do
+// not fill the chip): 64 / 32 / 16 channels per workgroup and one channel tile x 13 / 7 / 4 m-tiles per wave.  Every wave contracts ALL
 // input channels of its outputs, so there is no partial-sum exchange and the summation order of an output does not depend
 // on the split (all splits are bit-identical).  One wave per SIMD: the MFMA stream of a wave is long runs over 14-26
 // independent accumulators with ~0.3 other instructions per MFMA, which a single wave issues without gaps; two waves
@@ -397,6 +397,10 @@ template <int H, int W, int TH, int MTW>
 __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* acc, int mbase, int n0, int band, int out_stride,
                                          int relu, int lane, const f32x4 bias4) {
     constexpr int HW = TH * W;
+    // (the pixel offsets below depend on nothing the contraction computes: left visible, the compiler forms all of them
+    // BEFORE the stage loop, spills them across it and reloads them one scratch round trip at a time -- 27 000 cycles
+    // per unit with two channel tiles.  An opaque lane id keeps them here.)
+    asm volatile("" : "+v"(lane));
     const int li = lane & 15, g = lane >> 4;
     const int p_img = Geom<H, W, TH>::WHOLE ? 0 : band * TH * W;
     auto act = [&](f32x4 v) {
@@ -515,106 +519,117 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
     }
 }
 
-// One unit at WSPLIT workgroups per 128-channel block: all its stages, then the epilogue.  Leaves the walker at the
-// next unit.  `cstart`: cumulative ring slots consumed by this workgroup so far (the same count the loader keeps).
+// One unit at SPLIT workgroups per 128-channel block: all its stages, then the epilogue.  Leaves the walker at the next
+// unit.  `cstart`: cumulative ring slots consumed by this workgroup so far (the same count the loader keeps).
+//   SPLIT 1: a wave owns 32 output channels (two 16-channel tiles that share every A fragment and table row) x 13 m-tiles
+//   SPLIT 2 / 4 / 8: one channel tile x 13 / 7 / 4 m-tiles
 // KIND (chosen per UNIT, so that no two bodies meet inside the stage loop -- merging them there made the register
 // allocator shuffle and spill accumulators):
-//   0  3x3, every tap contracts all of the wave's m-tiles
-//   1  3x3 with dilation 8 on a 14x14 map: the taps of row -8 see only the m-tiles [7, 13), those of row +8 only [0, 6)
+//   0  every tap contracts all of the wave's m-tiles
+//   1  dilation 8 on a 14x14 map: the taps of row -8 see only the m-tiles [7, 13), those of row +8 only [0, 6)
 //      -- 39 of 117 (tap, m-tile) pairs are skipped (the zero rows would contribute exact zeros)
-//   2  1x1 (one tap per stage)
 template <int H, int W, int TH, int SPLIT, int KIND>
 __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, char* lds, int& cstart, int wave, int lane,
                                          unsigned long long (&cyc)[4]) {
     using G = Geom<H, W, TH>;
     using std::integral_constant;
     const unsigned long long c_unit = __builtin_readcyclecounter();
-    static_assert(SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
-    constexpr int MW = SPLIT / 2;                                 // waves that share a channel tile's m-tiles
-    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 7 / 4
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
+    constexpr int NW = SPLIT == 1 ? 2 : 1;                        // 16-channel output tiles of a wave
+    constexpr int MW = SPLIT <= 2 ? 1 : SPLIT / 2;                // waves that share a channel tile's m-tiles
+    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 13 / 7 / 4
     constexpr int MH = (MTW + 1) / 2;
-    constexpr int NT = KIND == 2 ? 1 : 9;
+    constexpr int WSETS = NW == 2 ? 2 : 3;                        // weight sets in flight (taps ahead + 1)
     constexpr uint32_t FULL = (1u << MTW) - 1u;
     const int li = lane & 15, g = lane >> 4;
-    const int nt = wave % (4 / MW);                               // which of the workgroup's 16-channel tiles
+    const int nt = wave % (4 / MW);                               // which of the workgroup's wave-sized channel groups
     const int mbase = (wave / (4 / MW)) * MTW;                    // first m-tile of this wave
     const pnmn_conv_item it = Wk.items[Wk.item];
-    const int n0 = Wk.cb * CB + Wk.sub * (CB / SPLIT) + nt * 16;  // this wave's first output channel
+    const int n0 = Wk.cb * CB + Wk.sub * (CB / SPLIT) + nt * 16 * NW;  // this wave's first output channel
     const int band = Wk.band;
     const int cin_total = L.cin_chunks * CB;
     const int slots = Wk.slots;
 
-    f32x4 acc[MTW];
+    f32x4 acc[NW][MTW];
 #pragma unroll
-    for (int j = 0; j < MTW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NW; ++n)
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) acc[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weight row of this lane: output channel n0 + li, channels 4g.. of each 16-block
-    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * NT * cin_total + 4 * g;
+    // weight row of this lane: output channel n0 + li (+ 16 for the second tile), channels 4g.. of each 16-block
+    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * 9 * cin_total + 4 * g;
+    const size_t wtile = (size_t)16 * 9 * cin_total;
     const uint32_t gconst = (uint32_t)((g >> 1) * 16 | (g & 1) * 32);
     uint32_t tab_lane = (uint32_t)(G::TAB_OFF + (mbase * 16 + li) * 2);
     asm volatile("" : "+v"(tab_lane));  // (keep the table base in a register: the per-tile offsets are immediates)
     // tiles of this wave that exist at all (the 14th..16th lie outside the band)
     const uint32_t exist = (mbase >= MTILES) ? 0u : (MTILES - mbase >= MTW ? FULL : ((1u << (MTILES - mbase)) - 1u));
 
-    // Weights: two 16-byte pieces per lane and tap (the two 16-channel blocks of the stage), requested TWO TAPS ahead
-    // into a ring of three sets (a lone wave per SIMD has only its own MFMAs to hide an L2 / MALL round trip behind:
-    // one step is 1 664 cycles).  Set = tap % 3; a 3x3 stage holds 9 or 3 taps and starts at tap 0 / 3 / 6, so the
-    // indices are compile-time.  1x1 convolutions (one tap per stage) alternate two sets, one stage ahead.
-    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};  // (requested now: the epilogue is one memory round trip shorter)
-    if (it.bias) bias4 = load4(as_global(it.bias) + n0 + 4 * g);
-    f32x4 wq[3][2];
-    auto wload = [&](f32x4 (&dst)[2], const gfloat* p) {
-        dst[0] = load4(p);
-        dst[1] = load4(p + 16);
+    // Weights: per channel tile two 16-byte pieces per lane and tap (the two 16-channel blocks of the stage), requested
+    // WSETS - 1 taps ahead into a ring of sets (a lone wave per SIMD has only its own MFMAs to hide an L2 / MALL round
+    // trip behind: a tap is 3 300 cycles with one channel tile, 6 700 with two).  A stage holds 9 or 3 taps and starts
+    // at tap 0 / 3 / 6; with three sets, set = tap % 3; with two, the taps of a unit alternate (an odd stage flips the
+    // parity, so the stage loop is unrolled by two).
+    f32x4 bias4[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        bias4[n] = f32x4{0.f, 0.f, 0.f, 0.f};  // (requested now: the epilogue is one memory round trip shorter)
+        if (it.bias) bias4[n] = load4(as_global(it.bias) + n0 + 16 * n + 4 * g);
+    }
+    f32x4 wq[WSETS][NW][2];
+    auto wload = [&](f32x4 (&dst)[NW][2], const gfloat* p) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            dst[n][0] = load4(p + n * wtile);
+            dst[n][1] = load4(p + n * wtile + 16);
+        }
     };
     {
         const gfloat* w0 = wrow + (size_t)Wk.t0 * cin_total + Wk.cbase();
         wload(wq[0], w0);
-        if (KIND != 2) wload(wq[1], w0 + cin_total);
+        if constexpr (WSETS == 3) wload(wq[1], w0 + cin_total);
     }
 
     uint32_t rb[MTW];
-    uint32_t rt[MTW];
     f32x4 afrag[MTW];
     uint32_t slot_base = 0;
-    auto row_fetch = [&](int j, const char* tp) { rt[j] = *reinterpret_cast<const uint16_t*>(tp + j * 32); };
     // (rb holds ABSOLUTE LDS byte addresses -- the ring's base folded into slot_base -- so that a fragment read is one
     // ds_read_b128 with an immediate offset, without a per-read add of the workgroup's LDS base)
     using lf32x4 = __attribute__((address_space(3))) f32x4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lchar*)lds;
-    auto row_apply = [&](int j) { rb[j] = (rt[j] ^ gconst) + slot_base; };
+    auto row_fetch = [&](int j, const char* tp) { rb[j] = *reinterpret_cast<const uint16_t*>(tp + j * 32); };
+    auto row_apply = [&](int j) { rb[j] = (rb[j] ^ gconst) + slot_base; };
     auto frag_load = [&](int j, int kb) { afrag[j] = *reinterpret_cast<const lf32x4*>((uintptr_t)(rb[j] + kb * G::SUB_BYTES)); };
 
     // One half (tiles [lo, hi)) of a step, hand-ordered for a lone wave: the k-slices 0..2 of all its tiles with one
-    // FILLER instruction behind each MFMA (the pipe is busy 32 cycles per MFMA, the wave issues the filler in its
-    // shadow), then k-slice 3, where every tile's fragment register is re-loaded for the NEXT step right behind its
-    // last reader.  k-slices outermost: consecutive MFMAs never share an accumulator (40 cycles dependent).
-    // DO = false: the half's tiles see nothing of this tap (zero rows): fillers and reloads only.
-    auto half = [&](auto DO, auto LO, auto HI, const f32x4 bw, auto NFILL, auto&& fill, auto&& reload) {
-        constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value, nfill = decltype(NFILL)::value;
-        constexpr int slots3 = 3 * (hi - lo);
+    // FILLER instruction behind each MFMA, then k-slice 3, where every tile's fragment register is re-loaded for the
+    // NEXT step right behind its last reader.  k-slices outermost: consecutive MFMAs never share an accumulator (40
+    // cycles dependent, 32 issue).  DO = false: the half's tiles see nothing of this tap (zero rows): fillers and
+    // reloads only.  (Fillers are not free for a lone wave -- ~5 cycles each, measured -- which is what the second
+    // channel tile per wave buys back: the same fragments and rows feed twice the MFMAs.)
+    auto half = [&](auto DO, auto LO, auto HI, const f32x4 (&bw)[NW][2], auto KB, auto NFILL, auto&& fill, auto&& reload) {
+        constexpr int lo = decltype(LO)::value, hi = decltype(HI)::value, nfill = decltype(NFILL)::value, kb = decltype(KB)::value;
+        constexpr int per = (hi - lo) * NW;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = lo; j < hi; ++j) {
-                if (decltype(DO)::value) mfma(acc[j], bw[c], afrag[j][c]);
-#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 2
-                if (c * (hi - lo) + (j - lo) < nfill) fill(c * (hi - lo) + (j - lo));
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int j = lo; j < hi; ++j)
+#pragma unroll
+                for (int n = 0; n < NW; ++n) {
+                    if (decltype(DO)::value) mfma(acc[n][j], bw[n][kb][c], afrag[j][c]);
+                    if (c * per + (j - lo) * NW + n < nfill) fill(c * per + (j - lo) * NW + n);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
         for (int j = lo; j < hi; ++j) {
-            if (decltype(DO)::value) mfma(acc[j], bw[3], afrag[j][3]);
-#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 3
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+                if (decltype(DO)::value) mfma(acc[n][j], bw[n][kb][3], afrag[j][3]);
             reload(j);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
-#if !defined(PNMN_STREAM_EXP) || PNMN_STREAM_EXP == 2
 #pragma unroll
-        for (int k = slots3; k < nfill; ++k) fill(k);
-#endif
+        for (int k = 3 * per; k < nfill; ++k) fill(k);
         __builtin_amdgcn_sched_barrier(0);
     };
     // One tap = two steps (kb = 0, 1).  HALVES: 0 both halves' MFMAs, 1 the first half's only, 2 the second's only.
@@ -629,92 +644,115 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         using LO0 = integral_constant<int, 0>;
         using MID = integral_constant<int, MH>;
         using END = integral_constant<int, MTW>;
-        // step kb = 0; fillers: the far weights' two loads, then the next tap's table rows
-        constexpr int nf0 = 2 + MTW, cap0 = 3 * MH;
-        auto fill0 = [&](int i) {
-            if (i == 0) wq[far][0] = load4(wfar);
-            else if (i == 1) wq[far][1] = load4(wfar + 16);
-            else row_fetch(i - 2, tp);
-        };
-        auto fill0b = [&](int i) { fill0(i + cap0); };
+        using K0 = integral_constant<int, 0>;
+        using K1 = integral_constant<int, 1>;
+        // step kb = 0; fillers: the far weights' loads
+        auto fill0 = [&](int i) { wq[far][i >> 1][i & 1] = load4(wfar + (i >> 1) * wtile + (i & 1) * 16); };
         auto nofill = [&](int) {};
         auto reload1 = [&](int j) { frag_load(j, 1); };
-        half(D0{}, LO0{}, MID{}, wq[set][0], integral_constant<int, (nf0 < cap0 ? nf0 : cap0)>{}, fill0, reload1);
-        half(D1{}, MID{}, END{}, wq[set][0], integral_constant<int, (nf0 > cap0 ? nf0 - cap0 : 0)>{}, fill0b, reload1);
-        // step kb = 1; fillers: the next tap's rows applied (every load through the old rows has been issued)
-        auto fill1 = [&](int i) { row_apply(i); };
+        half(D0{}, LO0{}, MID{}, wq[set], K0{}, integral_constant<int, 2 * NW>{}, fill0, reload1);
+        half(D1{}, MID{}, END{}, wq[set], K0{}, integral_constant<int, 0>{}, nofill, reload1);
+        // step kb = 1; fillers: the next tap's table rows fetched, then applied (every load through the old rows has
+        // been issued; a fetched row has a k-slice of MFMAs to arrive before it is applied)
+        auto fill1 = [&](int i) {
+            if (i < MTW) row_fetch(i, tp);
+            else row_apply(i - MTW);
+        };
         auto reload0 = [&](int j) { frag_load(j, 0); };
-        half(D0{}, LO0{}, MID{}, wq[set][1], integral_constant<int, MTW>{}, fill1, reload0);
-        half(D1{}, MID{}, END{}, wq[set][1], integral_constant<int, 0>{}, nofill, reload0);
+        constexpr int cap1 = 3 * MH * NW;  // filler places of the first half
+        static_assert(2 * MTW <= cap1 || NW == 1, "the first half must hold the row fillers");
+        half(D0{}, LO0{}, MID{}, wq[set], K1{}, integral_constant<int, (2 * MTW < cap1 ? 2 * MTW : cap1)>{}, fill1, reload0);
+        half(D1{}, MID{}, END{}, wq[set], K1{}, integral_constant<int, (2 * MTW > cap1 ? 2 * MTW - cap1 : 0)>{},
+             [&](int i) { fill1(i + cap1); }, reload0);
     };
     using I0 = integral_constant<int, 0>;
     using I1 = integral_constant<int, 1>;
     using I2 = integral_constant<int, 2>;
 
     bool more = true;
-    while (more) {
+    // one stage: PAR (two weight sets only) = parity of the stage's first tap in the unit's tap order
+    auto stage = [&](auto PAR) {
+        constexpr int par = decltype(PAR)::value;
         const int t0 = Wk.t0, t1 = Wk.t1, cb0 = Wk.cbase();
         slot_base = lds0 + (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
         cstart += slots;
         more = Wk.next_stage(L);  // (the cursor now names the NEXT stage: its first weights are requested below)
         // first tap of the next stage (the unit's last stage re-requests its own: never used)
         const gfloat* wnext_stage = more ? wrow + (size_t)Wk.t0 * cin_total + Wk.cbase() : wrow + (size_t)t0 * cin_total + cb0;
-        // weights of the tap two behind `tap` in the unit's order (the unit's last two taps re-request their own)
-        auto far_ptr = [&](int tap) -> const gfloat* {
-            if (tap + 2 < t1) return wrow + (size_t)(tap + 2) * cin_total + cb0;
-            return more ? wnext_stage + (size_t)(tap + 2 - t1) * cin_total : wrow + (size_t)tap * cin_total + cb0;
+        // weights of the tap `d` behind `tap` in the unit's order (the unit's last taps re-request their own)
+        auto far_ptr = [&](int tap, int d) -> const gfloat* {
+            if (tap + d < t1) return wrow + (size_t)(tap + d) * cin_total + cb0;
+            return more ? wnext_stage + (size_t)(tap + d - t1) * cin_total : wrow + (size_t)tap * cin_total + cb0;
         };
         // table row of the tap behind `tap` (clamped: the fragments requested behind a stage's last tap are discarded)
-        auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < NT ? tap + 1 : NT - 1) * (TAB_ROWS * 2); };
+        auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < 9 ? tap + 1 : 8) * (TAB_ROWS * 2); };
 
         {
             const unsigned long long c0 = __builtin_readcyclecounter();
             lds_barrier();  // the stage is resident (and the table, on a unit's first stage)
             cyc[0] += __builtin_readcyclecounter() - c0;
         }
-
 #pragma unroll
         for (int j = 0; j < MTW; ++j) row_fetch(j, lds + tab_lane + t0 * (TAB_ROWS * 2));
 #pragma unroll
         for (int j = 0; j < MTW; ++j) row_apply(j);
 #pragma unroll
         for (int j = 0; j < MTW; ++j) frag_load(j, 0);
-        if (KIND == 2) {
-            // two stages per trip (a unit has 4 cin_chunks of them), so that the weight sets alternate at compile time
-            tap_body(I0{}, I0{}, I1{}, next_row(0), wnext_stage);
-            const int cb1 = Wk.cbase();
-            slot_base = lds0 + (uint32_t)((cstart % G::RING) * G::SLOT_BYTES);
-            cstart += slots;
-            more = Wk.next_stage(L);
-            const gfloat* wnext2 = more ? wrow + Wk.cbase() : wrow + cb1;
-            lds_barrier();
-#pragma unroll
-            for (int j = 0; j < MTW; ++j) row_apply(j);   // (the same table row; the next slot)
-#pragma unroll
-            for (int j = 0; j < MTW; ++j) frag_load(j, 0);
-            tap_body(I0{}, I1{}, I0{}, next_row(0), wnext2);
-        } else if (KIND == 1) {
-            tap_body(I2{}, I0{}, I2{}, next_row(0), far_ptr(0));
-            tap_body(I2{}, I1{}, I0{}, next_row(1), far_ptr(1));
-            tap_body(I2{}, I2{}, I1{}, next_row(2), far_ptr(2));
-            tap_body(I0{}, I0{}, I2{}, next_row(3), far_ptr(3));
-            tap_body(I0{}, I1{}, I0{}, next_row(4), far_ptr(4));
-            tap_body(I0{}, I2{}, I1{}, next_row(5), far_ptr(5));
-            tap_body(I1{}, I0{}, I2{}, next_row(6), far_ptr(6));
-            tap_body(I1{}, I1{}, I0{}, next_row(7), far_ptr(7));
-            tap_body(I1{}, I2{}, I1{}, next_row(8), far_ptr(8));
+        if constexpr (WSETS == 3) {
+            if (KIND == 1) {
+                tap_body(I2{}, I0{}, I2{}, next_row(0), far_ptr(0, 2));
+                tap_body(I2{}, I1{}, I0{}, next_row(1), far_ptr(1, 2));
+                tap_body(I2{}, I2{}, I1{}, next_row(2), far_ptr(2, 2));
+                tap_body(I0{}, I0{}, I2{}, next_row(3), far_ptr(3, 2));
+                tap_body(I0{}, I1{}, I0{}, next_row(4), far_ptr(4, 2));
+                tap_body(I0{}, I2{}, I1{}, next_row(5), far_ptr(5, 2));
+                tap_body(I1{}, I0{}, I2{}, next_row(6), far_ptr(6, 2));
+                tap_body(I1{}, I1{}, I0{}, next_row(7), far_ptr(7, 2));
+                tap_body(I1{}, I2{}, I1{}, next_row(8), far_ptr(8, 2));
+            } else {
+                for (int ta = t0; ta < t1; ta += 3) {  // the three taps of a tap row
+                    tap_body(I0{}, I0{}, I2{}, next_row(ta), far_ptr(ta, 2));
+                    tap_body(I0{}, I1{}, I0{}, next_row(ta + 1), far_ptr(ta + 1, 2));
+                    tap_body(I0{}, I2{}, I1{}, next_row(ta + 2), far_ptr(ta + 2, 2));
+                }
+            }
         } else {
-            for (int ta = t0; ta < t1; ta += 3) {  // the three taps of a tap row
-                tap_body(I0{}, I0{}, I2{}, next_row(ta), far_ptr(ta));
-                tap_body(I0{}, I1{}, I0{}, next_row(ta + 1), far_ptr(ta + 1));
-                tap_body(I0{}, I2{}, I1{}, next_row(ta + 2), far_ptr(ta + 2));
+            // two sets: tap k of the stage uses set (par + k) & 1 and requests the tap behind it into the other
+            using SA = integral_constant<int, par>;
+            using SB = integral_constant<int, par ^ 1>;
+            if (KIND == 1) {
+                tap_body(I2{}, SA{}, SB{}, next_row(0), far_ptr(0, 1));
+                tap_body(I2{}, SB{}, SA{}, next_row(1), far_ptr(1, 1));
+                tap_body(I2{}, SA{}, SB{}, next_row(2), far_ptr(2, 1));
+                tap_body(I0{}, SB{}, SA{}, next_row(3), far_ptr(3, 1));
+                tap_body(I0{}, SA{}, SB{}, next_row(4), far_ptr(4, 1));
+                tap_body(I0{}, SB{}, SA{}, next_row(5), far_ptr(5, 1));
+                tap_body(I1{}, SA{}, SB{}, next_row(6), far_ptr(6, 1));
+                tap_body(I1{}, SB{}, SA{}, next_row(7), far_ptr(7, 1));
+                tap_body(I1{}, SA{}, SB{}, next_row(8), far_ptr(8, 1));
+            } else {
+                // (a stage's 9 or 3 taps: 4 or 1 pairs and a last one)
+                int ta = t0;
+                for (; ta + 1 < t1; ta += 2) {
+                    tap_body(I0{}, SA{}, SB{}, next_row(ta), far_ptr(ta, 1));
+                    tap_body(I0{}, SB{}, SA{}, next_row(ta + 1), far_ptr(ta + 1, 1));
+                }
+                tap_body(I0{}, SA{}, SB{}, next_row(ta), far_ptr(ta, 1));
             }
         }
+    };
+    while (more) {
+        stage(I0{});
+        if (WSETS == 2 && more) stage(I1{});  // (an odd number of taps per stage: the next one starts on the other set)
     }
     const unsigned long long c_u = __builtin_readcyclecounter();
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
     const unsigned long long c_e = __builtin_readcyclecounter();
-    if (exist != 0u) epilogue<H, W, TH, MTW>(it, acc, mbase, n0, band, L.out_stride, L.relu, lane, bias4);
+    if (exist != 0u) {
+#pragma unroll
+        for (int n = 0; n < NW; ++n)
+            epilogue<H, W, TH, MTW>(it, acc[n], mbase, n0 + 16 * n, band, L.out_stride, L.relu, lane, bias4[n]);
+    }
     Wk.next_unit(L);
     const unsigned long long c_x = __builtin_readcyclecounter();
     cyc[0] += c_e - c_u;
@@ -746,16 +784,12 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     const unsigned long long c_begin = __builtin_readcyclecounter();
     while (Wk.valid()) {
         // (all uniform over the workgroup)
-        if (L.ntaps == 1) {
-            switch (Wk.split) {
-                case 2: run_unit<H, W, TH, 2, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
-                case 4: run_unit<H, W, TH, 4, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
-                default: run_unit<H, W, TH, 8, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
-            }
-        } else if (G::WHOLE && Wk.dil == 8 && Wk.split == 2) {
-            run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane, cyc);
+        if (G::WHOLE && Wk.dil == 8 && Wk.split <= 2) {
+            if (Wk.split == 1) run_unit<H, W, TH, 1, 1>(Wk, L, lds, cstart, wave, lane, cyc);
+            else run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane, cyc);
         } else {
             switch (Wk.split) {
+                case 1: run_unit<H, W, TH, 1, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
