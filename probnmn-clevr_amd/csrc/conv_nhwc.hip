@@ -175,7 +175,7 @@ __global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_stream_kernel(
 inline bool streamed() {
     static const bool on = [] {
         const char* e = getenv("PNMN_CONV_STREAM");
-        return e && atoi(e) != 0;  // (off until it beats the one-workgroup-per-unit kernel in the step)
+        return !e || atoi(e) != 0;
     }();
     return on;
 }

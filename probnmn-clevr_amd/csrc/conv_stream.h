@@ -75,8 +75,7 @@ struct Geom {
     static constexpr int SLOT_BYTES = 2 * SUB_BYTES;
     static constexpr int RING = WHOLE ? 6 : 4;
     static constexpr int TAB_OFF = RING * SLOT_BYTES;                  // uint16 [9][208]
-    static constexpr int LIVE_OFF = TAB_OFF + 9 * TAB_ROWS * 2;        // uint32 [9] (+ padding to 16 entries)
-    static constexpr int LDS_BYTES = LIVE_OFF + 16 * 4 + 128;          // (+ the table rows of the m-tiles past the 13th)
+    static constexpr int LDS_BYTES = TAB_OFF + 9 * TAB_ROWS * 2 + 128; // (+ the table rows of the m-tiles past the 13th)
     static_assert(LDS_BYTES <= 160 * 1024, "ring + table must fit the CU's LDS");
     static_assert((Z0 + 7) * 64 + 16 < 65536 && SUB_BYTES < 65536, "table entries and the kb offset are 16 bits");
 };
@@ -252,17 +251,15 @@ __device__ __forceinline__ void fixup(char* lds, int slot_x, int slot_g, const f
     }
 }
 
-// row table + live m-tiles of a unit geometry (band, dilation)
+// row table of a unit geometry (band, dilation): wave `w` of `nw` fills its share (one m-tile = 16 lanes)
 template <int H, int W, int TH>
-__device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npass, int ntaps, int lane) {
+__device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npass, int ntaps, int lane, int w, int nw) {
     using G = Geom<H, W, TH>;
     constexpr int HW = TH * W;
     uint16_t* tab = reinterpret_cast<uint16_t*>(lds + G::TAB_OFF);
-    uint32_t* live = reinterpret_cast<uint32_t*>(lds + G::LIVE_OFF);
-    if (lane < 16) live[lane] = 0;
     const int y0 = G::WHOLE ? 0 : band * TH;
     const int ntile = ntaps * MTILES;
-    for (int t4 = 0; t4 < ntile; t4 += 4) {  // four m-tiles per pass of the wave
+    for (int t4 = 4 * w; t4 < ntile; t4 += 4 * nw) {  // four m-tiles per pass of a wave
         const int tile = t4 + (lane >> 4);
         const int tap = tile / MTILES;
         const int m = tile - tap * MTILES;
@@ -277,21 +274,11 @@ __device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npa
         const int qv = rows_ok ? (yy - rs) * W + xx : p;
         const int row = ok ? qv : G::Z0 + (qv & 7);
         if (tile < ntile) tab[tap * TAB_ROWS + p] = (uint16_t)(row * 64 + ((row >> 2) & 1) * 16);
-        const unsigned long long b = __ballot(ok);
-        if ((lane & 15) == 0 && tile < ntile && ((b >> (lane & 48)) & 0xffffull)) atomicOr(&live[tap], 1u << m);
-    }
-    // the contraction's compile-time tile ranges (run_unit, split 1): first half / second half of the m-tiles only
-    if (lane < ntaps) {
-        const uint32_t lv = live[lane];
-        uint32_t variant = 0;
-        if (lv != 0u && (lv >> 7) == 0u) variant = 1;          // tiles [0, 7)
-        else if (lv != 0u && (lv & 0x7fu) == 0u) variant = 2;  // tiles [7, 13)
-        live[lane] = lv | (variant << 16);
     }
 }
 
 template <int H, int W, int TH>
-__device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane) {
+__device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane, int tab_band, int tab_dil) {
     using G = Geom<H, W, TH>;
     lchar* ring = (lchar*)lds;
     // The loader shares its SIMD with a contraction wave whose MFMA stream would otherwise win nearly every issue
@@ -302,8 +289,11 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
     C = P;
     int issued = 0, freed = 0, cstart = 0;  // in slots, cumulative
     const pnmn_conv_item* pit = P.valid() ? items + P.item : nullptr;
-    auto top_up = [&] {
-        while (P.valid() && issued - freed + P.slots <= G::RING) {
+    // `limit`: slots that may be in use.  Before the first hand-over only the first stage is requested: the contraction
+    // waves stand at its barrier, and everything issued in front of it delays it (launches of one unit per workgroup
+    // -- the deep program levels -- spent a quarter of their time there).
+    auto top_up = [&](int limit) {
+        while (P.valid() && issued - freed + P.slots <= limit) {
             const float* src = (pit->in2 != nullptr && P.chunk > 0) ? pit->in2 + P.kq * QC : pit->in + P.cbase();
             // The vector-memory counter holds 63.  With more loads than that in flight (the first top-up used to
             // issue six slots = 156 back to back) the zero rows of the ring came out dirty on the box; a slot is
@@ -322,7 +312,6 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
             }
         }
     };
-    int tab_band = -1, tab_dil = -1;
     bool unit_end = false;   // the contraction waves stand (or will stand) at the end-of-unit barrier
     unsigned long long lc[4] = {0, 0, 0, 0};  // cycles: issuing, waiting for loads, prologue in place, at barriers
     unsigned long long lt = __builtin_readcyclecounter();
@@ -331,7 +320,7 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
         lc[k] += now - lt;
         lt = now;
     };
-    top_up();
+    top_up(P.valid() ? P.slots : 0);
     lap(0);
     while (C.valid()) {
         const pnmn_conv_item* cit = items + C.item;
@@ -353,7 +342,7 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
             lap(3);
         }
         if (C.band != tab_band || C.dil != tab_dil) {
-            fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane);
+            fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane, 0, 1);
             tab_band = C.band, tab_dil = C.dil;
         }
         lap(2);
@@ -365,7 +354,7 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
             C.next_unit(L);
             unit_end = true;
         }
-        top_up();
+        top_up(G::RING);
         lap(0);
     }
     if (unit_end) lds_barrier();
@@ -772,13 +761,15 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
         const int sl = t >> 6, kb = (t >> 5) & 1;
         *reinterpret_cast<f32x4*>(lds + sl * G::SLOT_BYTES + kb * G::SUB_BYTES + G::Z0 * 64 + (t & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    if (wave == LOADER_WAVE) {
-        loader<H, W, TH>(L, items, lds, lane);
-        return;
-    }
     Walker<H, W, TH> Wk;
     Wk.start(L, items);
+    // the row table of the first unit, by all five waves (later geometries are the loader's, behind a unit's end)
+    if (Wk.valid()) fill_table<H, W, TH>(lds, Wk.band, Wk.dil, Wk.npass, L.ntaps, lane, wave, NTHREADS / 64);
+    __syncthreads();
+    if (wave == LOADER_WAVE) {
+        loader<H, W, TH>(L, items, lds, lane, Wk.valid() ? Wk.band : -1, Wk.valid() ? Wk.dil : -1);
+        return;
+    }
     int cstart = 0;
     unsigned long long cyc[4] = {0, 0, 0, 0};  // barrier waits, epilogues, units, unit count
     const unsigned long long c_begin = __builtin_readcyclecounter();
