@@ -87,7 +87,7 @@ int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int H, int W, i
 /* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 or 2: whole rounds of 256
  * workgroups with one K-split, the remainder with a larger one) -- for per-launch accounting. */
 int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks);
-/* Tuning / test hook: every later convolution launch (and executor unit) of this process uses ONE split -- 1, 2, 4, 8
+/* Tuning / test hook: every later convolution launch of this process uses ONE split -- 1, 2, 4, 8
  * (workgroups per item, each 128/split output channels) or 16 (8 x two m-halves); 0 = the launch planner decides again.
  * Also settable as PNMN_CONV_KSPLIT before the first launch. */
 int pnmn_conv_force_split(int split);
@@ -560,7 +560,6 @@ int pnmn_sample_tokens(const float* logits, int64_t* tokens, float* logprobs, in
 #define PNMN_OP_ACCUMULATE        14   /* a items, n                                      (pnmn_accumulate) */
 #define PNMN_OP_ZERO              15   /* a device pointer, b = byte count (as a pointer-sized integer): hipMemsetAsync */
 #define PNMN_OP_FEAT_GATHER       16   /* a items, b gfeat, n = n_items, p = n_examples, HW   (pnmn_feat_grad_gather) */
-#define PNMN_OP_EXEC              17   /* a program (device), n = workgroups, p = H, W        (pnmn_trunk_exec) */
 typedef struct pnmn_launch {
     const void* a;
     const void* b;
@@ -570,57 +569,6 @@ typedef struct pnmn_launch {
     int32_t     p[8];
 } pnmn_launch;             /* 64 bytes */
 int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Trunk executor: the module programs of a batch, forward or data-gradient, as ONE launch       nmn.py:197-238
- *
- * The level-ordered grouped launches above put a kernel boundary between two levels of the module programs although
- * an example's next module only needs that example's previous one.  Here the same work-item records are walked by
- * persistent workgroups: a UNIT is one workgroup's share of one record (a convolution record is `split` units, as the
- * launch planner would have cut it; a one-channel head / Same / And-Or record is one unit).  Every example (`owner`)
- * is pinned to one XCD: its units sit, in launch order, in that XCD's queue; the workgroups running on the XCD
- * (HW_REG_XCC_ID) take the queue's units in order, wait until `need` units of the same owner have completed (all its
- * units of earlier launches), run the unit, and count it in progress[owner].  Producer and consumer share the XCD's
- * L2, so a hand-off needs no L2 write-back / invalidate (csrc/cluster.h measured 6-9 us for the agent-scope pair).
- * A unit only ever waits for units that were taken before it by workgroups that are running: no co-residency of the
- * grid is assumed, the grid size is a speed choice.  `heads` and `progress` must be zero at launch.
- * ------------------------------------------------------------------------------------------- */
-#define PNMN_EXEC_CONV        0   /* pnmn_conv_item: 3x3, one 128-channel chunk, bias + ReLU                    */
-#define PNMN_EXEC_PROJ        1   /* pnmn_conv_item: 1x1 over two chunks (in, in2), bias + ReLU                 */
-#define PNMN_EXEC_DGRAD       2   /* pnmn_conv_item: 3x3 data gradient (gate fused into the load), no ReLU      */
-#define PNMN_EXEC_PDGRAD      3   /* pnmn_conv_item: 1x1 data gradient, one chunk                               */
-#define PNMN_EXEC_DOT_FWD     4   /* pnmn_dot1_item                                                             */
-#define PNMN_EXEC_DOT_BWD     5
-#define PNMN_EXEC_SAME_FWD    6   /* pnmn_same_item                                                             */
-#define PNMN_EXEC_SAME_BWD    7
-#define PNMN_EXEC_MINMAX_FWD  8   /* pnmn_minmax_item                                                           */
-#define PNMN_EXEC_MINMAX_BWD  9
-#define PNMN_EXEC_KINDS      10
-typedef struct pnmn_exec_unit {
-    uint8_t kind;      /* PNMN_EXEC_*                                                        */
-    uint8_t split;     /* workgroups per record: 1, 2, 4, 8 (K-split) or 16 (8 x two m-halves) */
-    uint8_t sub;       /* which of them                                                      */
-    uint8_t band;      /* 28x28 maps: row band 0..3                                          */
-    int32_t record;    /* index into records[kind]                                           */
-    int32_t owner;     /* progress counter (example)                                         */
-    int32_t need;      /* units of `owner` that must have completed                          */
-} pnmn_exec_unit;          /* 16 bytes */
-#define PNMN_EXEC_COUNTER_STRIDE 16   /* ints between two counters (one 64-byte line each) */
-typedef struct pnmn_exec_program {
-    const pnmn_exec_unit* units[8];          /* queue of XCD x */
-    const void*           records[PNMN_EXEC_KINDS];
-    int32_t*              heads;             /* [8][PNMN_EXEC_COUNTER_STRIDE], zero at launch      */
-    int32_t*              progress;          /* [n_owners][PNMN_EXEC_COUNTER_STRIDE], zero at launch */
-    int32_t               n_units[8];
-    int32_t               H, W, n_owners, reserved;
-    int32_t*              debug;             /* NULL, or [workgroups][16] trace words in HOST-visible memory (hang debugging:
-                                                phase, unit index, owner, need, progress seen, XCD, units run, queue length) */
-} pnmn_exec_program;       /* 216 bytes */
-/* `program` is a DEVICE pointer (the planner uploads it with the records); `workgroups` a multiple of 8, <= 256. */
-int pnmn_trunk_exec(const pnmn_exec_program* program, int workgroups, int H, int W, void* stream);
-/* debugging hook: page-locked host block the executor launches of this process trace into when PNMN_EXEC_DEBUG is set
- * (NULL otherwise): [256][16] int32 */
-int pnmn_trunk_exec_debug_block(int32_t** block);
 
 /* ---------------------------------------------------------------------------------------------
  * Trunk planner: sampled programs -> launched module programs in ONE call (host side; replaces the per-example
@@ -667,11 +615,9 @@ typedef struct pnmn_trunk_io {
     int32_t            n_bwd, bwd_piece_cut, n_prims, n_fwd, depth, n_invalid, n_feat_result;
     int32_t            conv_cus;      /* in: CU budget of the module programs' conv launches (0 = all CUs) */
     int32_t            wgrad_cus;     /* in: CU budget of their weight-gradient launches (0 = none) */
-    int32_t            exec;          /* in: 1 = the module programs run as ONE launch each way (pnmn_trunk_exec) instead
-                                         of the level-ordered grouped launches; needs fuse_mask_bwd == 2 */
-    int32_t            n_exec_fwd, n_exec_bwd;   /* out: units of the two executor launches (0 = lists were used)     */
     int32_t            n_conv, n_proj;           /* out: 3x3 / projection records of the batch (FLOP accounting)       */
-} pnmn_trunk_io;           /* 232 bytes */
+    int32_t            reserved;
+} pnmn_trunk_io;           /* 224 bytes */
 int pnmn_trunk_planner_create(const pnmn_trunk_config* config, void** planner);
 int pnmn_trunk_planner_destroy(void* planner);
 int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream);
@@ -717,12 +663,6 @@ typedef struct {
 } pnmn_plan_in;   /* 216 bytes */
 int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int64_t out_capacity, int64_t* meta, int32_t* cuts,
                     int32_t cuts_capacity);
-/* The same, also reporting the example (batch row) of every record of the forward / data-gradient kinds:
- * owners[owner_off[k] + i] for record i of kind k in the output's order; owner_off[12], -1 for the kinds without
- * (weight-gradient items / jobs, the gather's items).  For the trunk executor's units. */
-int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_words, int64_t out_capacity, int64_t* meta, int32_t* cuts,
-                           int32_t cuts_capacity, int32_t* owners, int64_t owners_capacity, int64_t* owner_off);
-
 /* ---------------------------------------------------------------------------------------------
  * Host-side batch program compiler (no device work)        nmn.py:191-238, SURVEY App. C
  *   tokens [n_programs][length] int64 prefix programs; kinds[token] = module class of each
@@ -737,7 +677,7 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
-/* Library self-description (no GPU needed).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* Library self-description (no GPU needed).  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

@@ -137,6 +137,15 @@ int launch_segments(const pnmn_conv_item* items, const LaunchPlan& lp, int first
     return (int)hipGetLastError();
 }
 
+// the 3x3 convolutions run on the streamed kernel (conv_stream.h); PNMN_CONV_STREAM=0: everything on the kernel above
+inline bool streamed() {
+    static const bool on = [] {
+        const char* e = getenv("PNMN_CONV_STREAM");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+
 // (A/B hook: PNMN_CONV_MERGED=0 issues the segments as separate launches, as rounds 1-2 did)
 inline bool merged_launches() {
     static const bool merged = [] {
@@ -150,7 +159,9 @@ template <int H, int W, int TH>
 int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
                 int out_stride, int cout_blocks, int relu, int cus, hipStream_t stream) {
     const int n_units = n_items * (H / TH);
-    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus);
+    // (the forced split pins the STREAMED kernel's split, whose results do not depend on it; this kernel's K-split
+    // changes the summation order, so while the streamed kernel runs the 3x3 convolutions the 1x1 ones keep the plan)
+    const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus, false, !streamed());
     if (merged_launches())
         return launch_segments<H, W, TH>(items, lp, 0, lp.n_seg, 0, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu,
                                          stream);
@@ -172,13 +183,6 @@ __global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_stream_kernel(
     pnmn::stream::conv_stream<H, W, TH>(L, items, smem_raw);
 }
 
-inline bool streamed() {
-    static const bool on = [] {
-        const char* e = getenv("PNMN_CONV_STREAM");
-        return !e || atoi(e) != 0;
-    }();
-    return on;
-}
 
 template <int H, int W, int TH>
 int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride, int out_stride,

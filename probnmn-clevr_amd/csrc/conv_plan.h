@@ -1,5 +1,5 @@
 // Launch planner of the grouped convolution (host side): how a call's units are cut into segments of different splits.
-// Shared by conv_nhwc.hip (one launch per call) and host_trunk.hip (the units of the trunk executor).
+// Used by conv_nhwc.hip (one launch per call).
 #pragma once
 #include <stdlib.h>
 
@@ -43,8 +43,9 @@ inline int default_conv_cus() {
 // streamed: the persistent kernel of conv_stream.h -- staging is hidden behind the contraction (no per-chunk cost); a
 // workgroup computes 128 / split output channels; split 2 halves a wave's channels, split 4 / 8 also share an item's 13
 // m-tiles among 2 / 4 waves per channel tile (7 / 4 tiles on the longest wave); there is no split 16.
-inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0, bool streamed = false) {
-    if (forced_split()) return LaunchPlan{1, {streamed && forced_split() > 8 ? 8 : forced_split(), 0, 0}, {n_items, 0, 0}};
+inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0, bool streamed = false,
+                              bool honour_forced = true) {
+    if (forced_split() && honour_forced) return LaunchPlan{1, {streamed && forced_split() > 8 ? 8 : forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
     static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
         const char* e = getenv("PNMN_CONV_STAGE_COST");

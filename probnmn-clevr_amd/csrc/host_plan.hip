@@ -144,33 +144,7 @@ void wgrad_jobs(const std::vector<int64_t>& key, const std::vector<uint64_t>& dw
 
 extern "C" int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int64_t out_capacity, int64_t* meta,
                                int32_t* cuts, int32_t cuts_capacity) {
-    return pnmn_plan_batch_owners(in, out_words, out_capacity, meta, cuts, cuts_capacity, nullptr, 0, nullptr);
-}
-
-// The same, also reporting which example (batch row) every record of the forward / data-gradient kinds belongs to:
-// owners[owner_off[k] + i] = example of record i of kind k (in the sorted order of the output), owner_off[k] = -1 for
-// the kinds that have none (weight-gradient items and jobs, the gather's items).  The trunk executor pins examples to
-// XCDs and orders an example's units by these.
-extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_words, int64_t out_capacity, int64_t* meta,
-                                      int32_t* cuts, int32_t cuts_capacity, int32_t* owners, int64_t owners_capacity,
-                                      int64_t* owner_off) {
-    if (!in || !out_words || !meta || !cuts || (owners && !owner_off)) return PNMN_EINVAL;
-    int64_t owners_used = 0;
-    bool owners_overflow = false;
-    if (owner_off)
-        for (int k = 0; k < R_COUNT; ++k) owner_off[k] = -1;
-    // owners of kind k: examples[order[i]] (order == nullptr: identity)
-    auto put_owners = [&](int kind, const std::vector<int64_t>& examples, const std::vector<int>* order) {
-        if (!owners) return;
-        const int64_t n = (int64_t)(order ? order->size() : examples.size());
-        owner_off[kind] = owners_used;
-        if (owners_used + n > owners_capacity) {
-            owners_overflow = true;
-            return;
-        }
-        for (int64_t i = 0; i < n; ++i) owners[owners_used + i] = (int32_t)examples[order ? (*order)[i] : i];
-        owners_used += n;
-    };
+    if (!in || !out_words || !meta || !cuts) return PNMN_EINVAL;
     const int nv = in->nv;
     memset(meta, 0, sizeof(int64_t) * (2 + 3 * R_COUNT + 1));
     if (nv <= 0) return 0;
@@ -240,7 +214,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
         KEEP(std::vector<uint64_t>, scratch_v);
         KEEP(std::vector<char>, masked_v);
         KEEP(std::vector<const Prim*>, src);
-        KEEP(std::vector<int64_t>, exs);
         int64_t depth3 = 0;
         for (const Prim& q : prims)
             if (q.r[C_KIND] == K_CONV) depth3 = std::max(depth3, q.r[C_LEVEL]);
@@ -294,17 +267,14 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
             masked_v.push_back(masked);
             scratch_v.push_back(scratch);
             src.push_back(&q);
-            exs.push_back(q.ex);
         }
         if (!lv.empty()) {
             const std::vector<int> idx = order_by(lv, in->sort_by_weight ? &fw : nullptr, 4);
             out.put(R_CONV, fw, &idx);
             out.cut(CUT_CONV, permuted(lv, idx));
-            put_owners(R_CONV, exs, &idx);
             const std::vector<int> didx = order_by(lv, in->sort_by_weight ? &dg : nullptr, 4);
             out.put(R_DGRAD, dg, &didx);
             out.cut(CUT_DGRAD, permuted(lv, didx));
-            put_owners(R_DGRAD, exs, &didx);
             if (in->fuse_mask_bwd == 2) {  // the gather's items: every masked conv, sorted by the d(feats) map it adds into
                 std::vector<std::pair<uint64_t, int>> order;
                 for (int i : idx)
@@ -361,7 +331,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
         KEEP(std::vector<int64_t>, grp);
         KEEP(std::vector<uint64_t>, dw);
         KEEP(std::vector<uint64_t>, db);
-        KEEP(std::vector<int64_t>, exs);
         for (const Prim& q : prims) {
             if (q.r[C_KIND] != K_PROJ) continue;
             const int64_t t = q.tok;
@@ -376,7 +345,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
             g[0] = q.a_f, g[1] = q.b_f, g[3] = q.o_g, g[4] = q.o_f;
             lv.push_back(q.r[C_LEVEL]);
             key.push_back(t);
-            exs.push_back(q.ex);
             grp.push_back(0);
             dw.push_back(G(w_off));
             db.push_back(G(b_off));
@@ -385,7 +353,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
             const std::vector<int> idx = order_by(lv, in->sort_by_weight ? &fw : nullptr, 4);
             out.put(R_PROJ, fw, &idx);
             out.cut(CUT_PROJ, permuted(lv, idx));
-            put_owners(R_PROJ, exs, &idx);
             // two data gradients per projection (one per operand); the halves never share a launch
             KEEP(Mat, pd, 12);
             KEEP(std::vector<int64_t>, lv2);
@@ -394,11 +361,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
             const std::vector<int> pidx = order_by(lv2, in->sort_by_weight ? &pd : nullptr, 4);
             out.put(R_PDGRAD, pd, &pidx);
             out.cut(CUT_PDGRAD, permuted(lv2, pidx));
-            {
-                std::vector<int64_t> exs2(exs);
-                exs2.insert(exs2.end(), exs.begin(), exs.end());  // (first operand's records, then the second's)
-                put_owners(R_PDGRAD, exs2, &pidx);
-            }
             std::vector<int> widx;
             std::vector<int64_t> jgrp;
             wgrad_jobs(key, dw, db, grp, in->wgrad_chunk, widx, jobs, jgrp);
@@ -415,9 +377,6 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
         KEEP(std::vector<int64_t>, ldot);
         KEEP(std::vector<int64_t>, lsame);
         KEEP(std::vector<int64_t>, lmm);
-        KEEP(std::vector<int64_t>, edot);
-        KEEP(std::vector<int64_t>, esame);
-        KEEP(std::vector<int64_t>, emm);
         for (const Prim& q : prims) {
             const int64_t kind = q.r[C_KIND], t = q.tok;
             if (kind == K_DOT) {
@@ -425,14 +384,12 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
                 r[0] = q.a_f, r[1] = P(in->dotw[t]), r[2] = P(in->dotb[t]), r[3] = q.o_f, r[4] = q.o_g, r[5] = q.a_g;
                 r[6] = G(in->dotw[t]), r[7] = G(in->dotb[t]);
                 ldot.push_back(q.r[C_LEVEL]);
-                edot.push_back(q.ex);
             } else if (kind == K_SAME) {
                 uint64_t* r = same.add();
                 r[0] = q.a_f, r[1] = q.r[C_BK] == L_ONES ? in->ones : q.b_f;
                 r[2] = P(in->dotw[t]), r[3] = P(in->dotb[t]), r[4] = q.o_f, r[5] = q.o_g, r[6] = q.a_g, r[7] = q.b_g;
                 r[8] = G(in->dotw[t]), r[9] = G(in->dotb[t]);
                 lsame.push_back(q.r[C_LEVEL]);
-                esame.push_back(q.ex);
             } else if (kind == K_MINMAX) {
                 uint64_t* r = mm.add();
                 r[0] = q.r[C_AK] == L_ONES ? in->ones : q.a_f;
@@ -441,29 +398,25 @@ extern "C" int pnmn_plan_batch_owners(const pnmn_plan_in* in, uint64_t* out_word
                 r[6] = (uint64_t)q.r[C_ACH] | ((uint64_t)q.r[C_BCH] << 32);
                 r[7] = (uint64_t)q.r[C_ISMAX];
                 lmm.push_back(q.r[C_LEVEL]);
-                emm.push_back(q.ex);
             }
         }
         if (!ldot.empty()) {
             const std::vector<int> idx = order_by(ldot, nullptr, 0);
             out.put(R_DOT, dot, &idx);
             out.cut(CUT_DOT, permuted(ldot, idx));
-            put_owners(R_DOT, edot, &idx);
         }
         if (!lsame.empty()) {
             const std::vector<int> idx = order_by(lsame, nullptr, 0);
             out.put(R_SAME, same, &idx);
             out.cut(CUT_SAME, permuted(lsame, idx));
-            put_owners(R_SAME, esame, &idx);
         }
         if (!lmm.empty()) {
             const std::vector<int> idx = order_by(lmm, nullptr, 0);
             out.put(R_MINMAX, mm, &idx);
             out.cut(CUT_MINMAX, permuted(lmm, idx));
-            put_owners(R_MINMAX, emm, &idx);
         }
     }
 #undef KEEP
     meta[2 + 3 * R_COUNT] = out.n_cuts;
-    return (out.overflow || owners_overflow) ? PNMN_EINVAL : 0;
+    return out.overflow ? PNMN_EINVAL : 0;
 }

@@ -73,9 +73,7 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
                 rc = pnmn_feat_grad_gather(static_cast<const pnmn_maskbwd_item*>(l.a),
                                            static_cast<float*>(const_cast<void*>(l.b)), l.n, p[0], p[1], stream);
                 break;
-            case PNMN_OP_EXEC:
-                rc = pnmn_trunk_exec(static_cast<const pnmn_exec_program*>(l.a), l.n, p[0], p[1], stream);
-                break;
+
             case PNMN_OP_ZERO:
                 rc = (int)hipMemsetAsync(const_cast<void*>(l.a), 0, (size_t)reinterpret_cast<uintptr_t>(l.b),
                                          static_cast<hipStream_t>(stream));

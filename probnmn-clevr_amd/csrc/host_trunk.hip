@@ -195,88 +195,7 @@ struct Planner {
     std::vector<uint8_t> cvalid;
     std::vector<int> miss;
     std::vector<int64_t> miss_rows;
-    // trunk executor (io->exec): owners of the records, units per XCD queue, scratch
-    std::vector<int32_t> owners;
-    std::vector<pnmn_exec_unit> queue_fwd[8], queue_bwd[8];
-    std::vector<int32_t> units_done, units_stage;  // per example: units of its finished stages / of the stage at hand
-    std::vector<int8_t> xcd_of;
-    std::vector<int> bucket[8];
-    size_t exec_reserve = 0;  // bytes kept free behind the records for the executor's tables (grows to what a call needed)
 };
-
-// One launch of the grouped path = one STAGE of the executor: records [b, e) of one kind.
-struct Stage {
-    int exec_kind, b, e, cin_chunks, ntaps;
-    const int32_t* owners;  // of record 0 of the kind
-    bool conv;
-};
-
-// Pin every example to an XCD: longest-processing-time first over the examples' matrix work, so that the eight
-// queues carry about the same work and the deep programs are spread out.
-void assign_xcds(Planner& P, int B, const std::vector<std::pair<const int32_t*, std::pair<int64_t, int>>>& weighted) {
-    static thread_local std::vector<int64_t> work;
-    work.assign(B, 0);
-    for (const auto& w : weighted)
-        for (int64_t i = 0; i < w.second.first; ++i) work[w.first[i]] += w.second.second;
-    static thread_local std::vector<std::pair<int64_t, int>> order;
-    order.clear();
-    for (int e = 0; e < B; ++e)
-        if (work[e] > 0) order.emplace_back(-work[e], e);
-    std::sort(order.begin(), order.end());
-    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    P.xcd_of.assign(B, 0);
-    for (const auto& o : order) {
-        int best = 0;
-        for (int x = 1; x < 8; ++x)
-            if (load[x] < load[best]) best = x;
-        P.xcd_of[o.second] = (int8_t)best;
-        load[best] -= o.first;
-    }
-}
-
-// The units of a list of stages, per XCD queue, in stage order.  A convolution stage is cut per XCD by the launch
-// planner (conv_plan.h) for that XCD's share of the CUs: whole rounds at one split, the remainder at larger ones.
-void build_units(Planner& P, const std::vector<Stage>& stages, int B, int bands, int cus_per_xcd,
-                 std::vector<pnmn_exec_unit> (&queue)[8]) {
-    for (auto& q : queue) q.clear();
-    P.units_done.assign(B, 0);
-    P.units_stage.assign(B, 0);
-    for (const Stage& st : stages) {
-        if (!st.conv) {
-            for (int i = st.b; i < st.e; ++i) {
-                const int ex = st.owners[i];
-                queue[P.xcd_of[ex]].push_back(pnmn_exec_unit{(uint8_t)st.exec_kind, 1, 0, 0, i, ex, P.units_done[ex]});
-                ++P.units_stage[ex];
-            }
-        } else {
-            for (auto& b : P.bucket) b.clear();
-            for (int i = st.b; i < st.e; ++i) P.bucket[P.xcd_of[st.owners[i]]].push_back(i);
-            for (int x = 0; x < 8; ++x) {
-                const std::vector<int>& recs = P.bucket[x];
-                if (recs.empty()) continue;
-                const int n_units = (int)recs.size() * bands;
-                const pnmn::LaunchPlan lp = pnmn::plan_launch(n_units, 1, st.cin_chunks, st.ntaps, cus_per_xcd);
-                int at = 0;
-                for (int k = 0; k < lp.n_seg; ++k) {
-                    const int split = lp.split[k];
-                    for (int t = at; t < at + lp.count[k] && t < n_units; ++t) {
-                        const int rec = recs[t / bands], band = t % bands, ex = st.owners[rec];
-                        for (int sub = 0; sub < split; ++sub)
-                            queue[x].push_back(pnmn_exec_unit{(uint8_t)st.exec_kind, (uint8_t)split, (uint8_t)sub, (uint8_t)band,
-                                                              rec, ex, P.units_done[ex]});
-                        P.units_stage[ex] += split;
-                    }
-                    at += lp.count[k] > 0 ? lp.count[k] : 0;
-                }
-            }
-        }
-        for (int i = st.b; i < st.e; ++i) {  // the stage is complete: its units count for the example's later ones
-            const int ex = st.owners[i];
-            P.units_done[ex] += P.units_stage[ex];
-            P.units_stage[ex] = 0;
-        }
-    }
-}
 
 void rebuild_bank(Planner& P) {
     P.pmax = 1;
@@ -517,10 +436,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
     const size_t n_rows = (size_t)io->n_invalid + 2 * (size_t)io->n_feat_result;  // SET_ROWS / ACCUMULATE items
     const size_t row_words = n_rows * 3;
     const size_t plan_words = (size_t)n_total * 48 + 64;
-    const bool want_exec = io->exec != 0 && P.fuse_mask_bwd == 2 && nv > 0 && B > 0;
-    if (want_exec && P.exec_reserve == 0) P.exec_reserve = (size_t)2048 + (size_t)B * 128 + ((size_t)n_total * 8 + 8192) * sizeof(pnmn_exec_unit);
-    const size_t total_bytes = (row_words + plan_words) * 8 + (want_exec ? P.exec_reserve + 256 : 0);
-    io->n_exec_fwd = io->n_exec_bwd = 0;
+    const size_t total_bytes = (row_words + plan_words) * 8;
     uint64_t* words = nullptr;
     Planner::Slot* slot = nullptr;
     const bool on_device = io->launch != 0;
@@ -553,8 +469,6 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
     }
     int64_t meta[2 + 3 * R_COUNT + 1];
     memset(meta, 0, sizeof(meta));
-    const int32_t* owner_at[R_COUNT];
-    for (auto& o : owner_at) o = nullptr;
     P.cuts.resize(4 * 4096);
     int n_cuts = 0;
     if (nv > 0) {
@@ -571,12 +485,8 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
         in.wgrad_chunk = std::min<int>(P.wgrad_chunk, std::max<int>(2, (int)(n_total / 256)));
         in.wgrad_groups = P.wgrad_groups, in.fuse_mask_bwd = P.fuse_mask_bwd;
         in.sole_writer = P.sole_writer, in.sort_by_weight = P.sort_by_weight;
-        int64_t owner_off[R_COUNT];
-        if (want_exec) P.owners.resize((size_t)n_total * 3 + 16);
-        const int rc = pnmn_plan_batch_owners(&in, words + row_words, (int64_t)plan_words, meta, P.cuts.data(), 4096,
-                                              want_exec ? P.owners.data() : nullptr, (int64_t)P.owners.size(), owner_off);
+        const int rc = pnmn_plan_batch(&in, words + row_words, (int64_t)plan_words, meta, P.cuts.data(), 4096);
         if (rc != 0) return rc;
-        for (int k = 0; k < R_COUNT; ++k) owner_at[k] = (want_exec && owner_off[k] >= 0) ? P.owners.data() + owner_off[k] : nullptr;
         n_cuts = (int)meta[2 + 3 * R_COUNT];
     }
     io->depth = (int)meta[1];
@@ -606,80 +516,6 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
     }
     const void* conv_cus = reinterpret_cast<const void*>((uintptr_t)(io->conv_cus > 0 ? io->conv_cus : 0));
 
-    // ---- trunk executor: the same records as units of two launches (trunk_exec.hip) ----------------------------
-    bool use_exec = false;
-    int exec_wgs = 256;
-    uint64_t exec_prog[2] = {0, 0};  // device addresses of the forward / backward program
-    if (want_exec) {
-        exec_wgs = io->conv_cus >= 8 && io->conv_cus <= 256 ? (io->conv_cus / 8) * 8 : 256;
-        const int bands = (H == 28) ? 4 : 1;
-        assign_xcds(P, B, {{owner_at[R_CONV], {meta[3 + 3 * R_CONV], 36}}, {owner_at[R_PROJ], {meta[3 + 3 * R_PROJ], 8}},
-                           {owner_at[R_DOT], {meta[3 + 3 * R_DOT], 1}}, {owner_at[R_SAME], {meta[3 + 3 * R_SAME], 1}},
-                           {owner_at[R_MINMAX], {meta[3 + 3 * R_MINMAX], 1}}});
-        std::vector<Stage> stages;
-        for (int lv = 1; lv <= depth; ++lv) {
-            for (const Cut& c : at[CUT_MINMAX][lv]) stages.push_back(Stage{PNMN_EXEC_MINMAX_FWD, c.b, c.e, 0, 0, owner_at[R_MINMAX], false});
-            for (const Cut& c : at[CUT_SAME][lv]) stages.push_back(Stage{PNMN_EXEC_SAME_FWD, c.b, c.e, 0, 0, owner_at[R_SAME], false});
-            for (const Cut& c : at[CUT_DOT][lv]) stages.push_back(Stage{PNMN_EXEC_DOT_FWD, c.b, c.e, 0, 0, owner_at[R_DOT], false});
-            for (const Cut& c : at[CUT_PROJ][lv]) stages.push_back(Stage{PNMN_EXEC_PROJ, c.b, c.e, 2, 1, owner_at[R_PROJ], true});
-            for (const Cut& c : at[CUT_CONV][lv]) stages.push_back(Stage{PNMN_EXEC_CONV, c.b, c.e, 1, 9, owner_at[R_CONV], true});
-        }
-        build_units(P, stages, B, bands, exec_wgs / 8, P.queue_fwd);
-        if (io->need_backward) {
-            stages.clear();
-            for (int lv = depth; lv >= 1; --lv) {
-                for (const Cut& c : at[CUT_MINMAX][lv]) stages.push_back(Stage{PNMN_EXEC_MINMAX_BWD, c.b, c.e, 0, 0, owner_at[R_MINMAX], false});
-                for (const Cut& c : at[CUT_SAME][lv]) stages.push_back(Stage{PNMN_EXEC_SAME_BWD, c.b, c.e, 0, 0, owner_at[R_SAME], false});
-                for (const Cut& c : at[CUT_DOT][lv]) stages.push_back(Stage{PNMN_EXEC_DOT_BWD, c.b, c.e, 0, 0, owner_at[R_DOT], false});
-                for (const Cut& c : at[CUT_PDGRAD][lv]) stages.push_back(Stage{PNMN_EXEC_PDGRAD, c.b, c.e, 1, 1, owner_at[R_PDGRAD], true});
-                for (const Cut& c : at[CUT_DGRAD][lv]) stages.push_back(Stage{PNMN_EXEC_DGRAD, c.b, c.e, 1, 9, owner_at[R_DGRAD], true});
-            }
-            build_units(P, stages, B, bands, exec_wgs / 8, P.queue_bwd);
-        } else {
-            for (auto& q : P.queue_bwd) q.clear();
-        }
-        // tables behind the records: [program fwd | program bwd | heads fwd, bwd | progress fwd, bwd | units]
-        size_t n_fwd_units = 0, n_bwd_units = 0;
-        for (int x = 0; x < 8; ++x) n_fwd_units += P.queue_fwd[x].size(), n_bwd_units += P.queue_bwd[x].size();
-        const size_t counter_bytes = (size_t)PNMN_EXEC_COUNTER_STRIDE * 4;
-        const size_t need = 512 + 2 * 8 * counter_bytes + 2 * (size_t)B * counter_bytes + (n_fwd_units + n_bwd_units) * sizeof(pnmn_exec_unit);
-        if (need > P.exec_reserve) {
-            // (first call with a list this long: this step runs the grouped launches, the next one has the room)
-            P.exec_reserve = need + need / 2;
-        } else {
-            use_exec = true;
-            const size_t base = (used_words * 8 + 255) / 256 * 256;  // bytes from `words`
-            char* host = reinterpret_cast<char*>(words);
-            pnmn_exec_program prog[2];
-            memset(prog, 0, sizeof(prog));
-            size_t off = base + 512;
-            memset(host + off, 0, 2 * 8 * counter_bytes + 2 * (size_t)B * counter_bytes);  // heads and progress start at zero
-            for (int d = 0; d < 2; ++d) prog[d].heads = reinterpret_cast<int32_t*>(dev_base + off), off += 8 * counter_bytes;
-            for (int d = 0; d < 2; ++d) prog[d].progress = reinterpret_cast<int32_t*>(dev_base + off), off += (size_t)B * counter_bytes;
-            for (int d = 0; d < 2; ++d) {
-                std::vector<pnmn_exec_unit>(&queue)[8] = d == 0 ? P.queue_fwd : P.queue_bwd;
-                for (int x = 0; x < 8; ++x) {
-                    prog[d].units[x] = reinterpret_cast<const pnmn_exec_unit*>(dev_base + off);
-                    prog[d].n_units[x] = (int32_t)queue[x].size();
-                    if (!queue[x].empty()) memcpy(host + off, queue[x].data(), queue[x].size() * sizeof(pnmn_exec_unit));
-                    off += queue[x].size() * sizeof(pnmn_exec_unit);
-                }
-                prog[d].H = H, prog[d].W = W, prog[d].n_owners = B;
-                (void)pnmn_trunk_exec_debug_block(&prog[d].debug);
-            }
-            prog[0].records[PNMN_EXEC_CONV] = rec(R_CONV, 0), prog[0].records[PNMN_EXEC_PROJ] = rec(R_PROJ, 0);
-            prog[0].records[PNMN_EXEC_DOT_FWD] = rec(R_DOT, 0), prog[0].records[PNMN_EXEC_SAME_FWD] = rec(R_SAME, 0);
-            prog[0].records[PNMN_EXEC_MINMAX_FWD] = rec(R_MINMAX, 0);
-            prog[1].records[PNMN_EXEC_DGRAD] = rec(R_DGRAD, 0), prog[1].records[PNMN_EXEC_PDGRAD] = rec(R_PDGRAD, 0);
-            prog[1].records[PNMN_EXEC_DOT_BWD] = rec(R_DOT, 0), prog[1].records[PNMN_EXEC_SAME_BWD] = rec(R_SAME, 0);
-            prog[1].records[PNMN_EXEC_MINMAX_BWD] = rec(R_MINMAX, 0);
-            memcpy(host + base, &prog[0], sizeof(pnmn_exec_program));
-            memcpy(host + base + 256, &prog[1], sizeof(pnmn_exec_program));
-            exec_prog[0] = dev_base + base, exec_prog[1] = dev_base + base + 256;
-            used_words = (off + 7) / 8;
-            io->n_exec_fwd = (int32_t)n_fwd_units, io->n_exec_bwd = (int32_t)n_bwd_units;
-        }
-    }
     if (on_device && used_words) {
         hipError_t e = hipMemcpyAsync(P.dev, words, used_words * 8, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return (int)e;
@@ -689,9 +525,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
     P.fwd.clear();
     const size_t n_zero = (size_t)io->n_invalid, n_copy = (size_t)io->n_feat_result;
     if (n_zero + n_copy) P.fwd.push_back(make_launch(PNMN_OP_SET_ROWS, (int)(n_zero + n_copy), rows_at(0), nullptr, nullptr, {}));
-    if (use_exec && io->n_exec_fwd > 0)
-        P.fwd.push_back(make_launch(PNMN_OP_EXEC, exec_wgs, reinterpret_cast<const void*>(exec_prog[0]), nullptr, nullptr, {H, W}));
-    for (int lv = 1; lv <= depth && !use_exec; ++lv) {
+    for (int lv = 1; lv <= depth; ++lv) {
         for (const Cut& c : at[CUT_MINMAX][lv])
             P.fwd.push_back(make_launch(PNMN_OP_MINMAX_FWD, c.e - c.b, rec(R_MINMAX, c.b), nullptr, nullptr, {HW, C}));
         for (const Cut& c : at[CUT_SAME][lv])
@@ -713,9 +547,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
             bwd.push_back(make_launch(PNMN_OP_ZERO, 0, reinterpret_cast<const void*>(io->gact),
                                       reinterpret_cast<const void*>((uintptr_t)(arena * 4)), nullptr, {}));
         if (n_copy) bwd.push_back(make_launch(PNMN_OP_ACCUMULATE, (int)n_copy, rows_at(n_zero + n_copy), nullptr, nullptr, {}));
-        if (use_exec && io->n_exec_bwd > 0)
-            bwd.push_back(make_launch(PNMN_OP_EXEC, exec_wgs, reinterpret_cast<const void*>(exec_prog[1]), nullptr, nullptr, {H, W}));
-        for (int lv = depth; lv >= 1 && !use_exec; --lv) {
+        for (int lv = depth; lv >= 1; --lv) {
             for (const Cut& c : at[CUT_MINMAX][lv])
                 bwd.push_back(make_launch(PNMN_OP_MINMAX_BWD, c.e - c.b, rec(R_MINMAX, c.b), nullptr, nullptr, {HW, C}));
             for (const Cut& c : at[CUT_SAME][lv])

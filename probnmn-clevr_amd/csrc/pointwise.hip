@@ -22,7 +22,7 @@ constexpr int C = PNMN_CHANNELS;  // 128
 using pnmn::pointwise::dot4;
 using pnmn::pointwise::half_wave_sum;
 
-// One workgroup of 256 threads per item; the bodies are shared with the trunk executor (pointwise_body.h).
+// One workgroup of 256 threads per item (bodies: pointwise_body.h).
 constexpr int NT = 256;
 
 // conv1x1 (128 -> 1) + sigmoid
@@ -490,7 +490,7 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
 
 extern "C" {
 
-int pnmn_abi_version(void) { return 7; }
+int pnmn_abi_version(void) { return 8; }
 
 int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
     if (n_items <= 0) return 0;

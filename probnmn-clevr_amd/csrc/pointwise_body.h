@@ -1,7 +1,7 @@
 // Bodies of the point-wise module kernels (one-channel head, SameModule, And / Or; forward and backward), for a
-// workgroup of NT threads working on ONE item.  pointwise.hip launches them one workgroup of 256 threads per item; the
-// trunk executor (trunk_exec.hip) runs them inside its 512-thread workgroups.  NT / 32 half-waves walk the pixels (a
-// half-wave = 32 lanes x float4 = one 512-byte pixel row); reductions over the pixels go through `scratch` (LDS).
+// workgroup of NT threads working on ONE item (pointwise.hip launches them one workgroup of 256 threads per item).
+// NT / 32 half-waves walk the pixels (a half-wave = 32 lanes x float4 = one 512-byte pixel row); reductions over the
+// pixels go through `scratch` (LDS).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>

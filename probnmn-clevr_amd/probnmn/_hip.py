@@ -99,15 +99,12 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_trunk_last_forward": (_P, _P, _I),
     "pnmn_trunk_last_records_bytes": (_P, _P, ctypes.c_int64),
     "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),
-    "pnmn_plan_batch_owners": (_P, _P, ctypes.c_int64, _P, _P, _I, _P, ctypes.c_int64, _P),
-    "pnmn_trunk_exec": (_P, _I, _I, _I, _P),
-    "pnmn_trunk_exec_debug_block": (_P,),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
 }
 
 
-ABI_VERSION = 7  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 8  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:
@@ -231,12 +228,7 @@ TRUNK_IO = np.dtype([(n, _u64) for n in ("programs", "params", "grads", "wt", "a
                     + [("arena_floats", np.int64)]
                     + [(n, _i32) for n in ("n_programs", "length", "n_fwd_tail", "n_bwd_head", "n_bwd_tail", "bwd_capacity",
                                            "need_backward", "launch", "n_bwd", "bwd_piece_cut", "n_prims", "n_fwd", "depth",
-                                           "n_invalid", "n_feat_result", "conv_cus", "wgrad_cus", "exec", "n_exec_fwd", "n_exec_bwd",
-                                           "n_conv", "n_proj")])
-EXEC_UNIT = np.dtype([("kind", np.uint8), ("split", np.uint8), ("sub", np.uint8), ("band", np.uint8), ("record", _i32),
-                      ("owner", _i32), ("need", _i32)])
-EXEC_PROGRAM = np.dtype([("units", _u64, (8,)), ("records", _u64, (10,)), ("heads", _u64), ("progress", _u64),
-                         ("n_units", _i32, (8,)), ("H", _i32), ("W", _i32), ("n_owners", _i32), ("reserved", _i32), ("debug", _u64)])
+                                           "n_invalid", "n_feat_result", "conv_cus", "wgrad_cus", "n_conv", "n_proj", "reserved")])
 DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "h0", "w_c", "w_hh", "w_p", "b_p", "hs", "cs", "act",
                                                   "ctx", "probs", "tokens", "in_tokens")]
                            + [("in_token_stride", np.int64), ("seed", _u64), ("row_offset", _u64)]
@@ -249,7 +241,7 @@ ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
 (OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
- OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO, OP_FEAT_GATHER, OP_EXEC) = range(18)
+ OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO, OP_FEAT_GATHER) = range(17)
 
 
 class LaunchList:
@@ -292,9 +284,7 @@ ITEM_SIZES = {
     "pnmn_decoder_fwd_job": (DECODER_FWD_JOB, 184),
     "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
-    "pnmn_trunk_io": (TRUNK_IO, 232),
-    "pnmn_exec_unit": (EXEC_UNIT, 16),
-    "pnmn_exec_program": (EXEC_PROGRAM, 216),
+    "pnmn_trunk_io": (TRUNK_IO, 224),
 }
 
 

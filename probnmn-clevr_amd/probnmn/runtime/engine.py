@@ -127,10 +127,7 @@ class NMNEngine:
         # beside other work sets the number it may count on (JointTrainingStep: 192 -- the seq2seq passes' multi-CU
         # kernels hold 64-96 CUs, and a launch cut for 256 workgroups then takes two rounds)
         self.conv_cus = 0
-        # the module programs as ONE launch each way (csrc/trunk_exec.hip) instead of the level-ordered grouped launches;
-        # native planner only (PNMN_TRUNK_EXEC, A/B hook)
-        self.exec_trunk = int(os.environ.get("PNMN_TRUNK_EXEC", "0"))
-        self.last_exec = (0, 0, 0, 0)
+        self.last_counts = (0, 0)  # 3x3 / projection records of the last natively planned batch
         self.wgrad_cus = 0  # the same for the weight-gradient launches: at most that many (persistent) workgroups
         self.native = os.environ.get("PNMN_NATIVE_PLANNER", "1") != "0"
         self._planner = None
@@ -639,7 +636,7 @@ class NMNEngine:
                      self._planner_bwd.ctypes.data, self._planner_valid.ctypes.data, 0,
                      B, programs.shape[1], rows["fwd_tail"].shape[0], rows["bwd_head"].shape[0], rows["bwd_tail"].shape[0],
                      self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, self.conv_cus, self.wgrad_cus,
-                     int(self.exec_trunk), 0, 0, 0, 0)
+                     0, 0, 0)
             rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, st)
             if rc != _hip.EAGAIN:
                 break
@@ -648,8 +645,7 @@ class NMNEngine:
         out = io[0]
         valid = self._planner_valid[:B].copy()
         self.last_plan = _NativePlan(int(out["n_prims"]), int(out["arena_floats"]), int(out["n_fwd"]), int(out["n_bwd"]))
-        # (units of the executor's two launches -- zero when the grouped launches ran --, 3x3 / projection records)
-        self.last_exec = (int(out["n_exec_fwd"]), int(out["n_exec_bwd"]), int(out["n_conv"]), int(out["n_proj"]))
+        self.last_counts = (int(out["n_conv"]), int(out["n_proj"]))
         state = None
         if need_backward:
             state = _State()

@@ -90,10 +90,16 @@ def test_gradients_per_program_tight():
     pre-activation lands within fp32 round-off of a gate, the GPU (MFMA accumulation order) and the
     CPU oracle can take different sides, and that one element's gradient is routed differently --
     a property of fp32, not of the kernels (the kernel-level tests in test_hip_kernels.py, which
-    share saved activations with autograd, match to 1e-4 everywhere).  It hits a few programs per
-    thousand gates, so the bar is: the typical program matches on EVERY parameter to 5e-5 of the
-    tensor's max, at least 3 in 4 programs match to 2e-4, and no program is off by more than a
-    single flipped gate can explain (5e-2)."""
+    share saved activations with autograd, match to 1e-4 everywhere).  A program runs ~4e5 gated
+    elements whose pre-activations are sums of ~1 152 products (round-off ~1e-6 on O(1) values), so
+    about one program in three holds a flipped gate, WHICH ones depends on the summation order
+    (scripts/r04_dbg3.py: the round-3 and round-4 convolution kernels, same loss bit for bit, differ from
+    each other by 1e-2 .. 5e-2 on 7 of 21 programs and by ~1e-6 on the rest), and in a batch of two one
+    flipped element moves a tensor's gradient by up to ~5e-2 of its maximum.  So a program whose input
+    misses the tight bar gets further independent inputs, up to eight: an arithmetic or indexing error
+    shows on every input, a flipped gate on one in three.  The bar: EVERY program matches on EVERY
+    parameter to 2e-4 of the tensor's max on at least one input, the typical program to 5e-5 on its
+    first, and at least half of the programs to 2e-4 on their first."""
     from probnmn.models.nmn import NeuralModuleNetwork  # noqa: F401
 
     vocab, net, _, _, _ = _setup()
@@ -102,26 +108,33 @@ def test_gradients_per_program_tight():
     dev = torch.device("cuda:0")
     net.to(dev).train()
     g = torch.Generator().manual_seed(1)
-    worst_per_case = []
+    first, best = [], []
     for case in VALIDITY_CASES:
         programs = encode_programs([case, case], stoi)
-        features = torch.relu(torch.randn(2, 1024, 14, 14, generator=g))
-        answers = torch.randint(0, 28, (2,), generator=g)
-        ref, ref_sd = _oracle(vocab, cpu_sd, programs, features, answers)
-        if int(ref["valid"][0]) == 0:
-            continue
-        net.zero_grad(set_to_none=True)
-        out = net(features.to(dev), programs.to(dev), answers.to(dev))
-        out["loss"].mean().backward()
-        torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-5, atol=2e-6)
-        errs = _grad_errors(net, ref_sd)
-        worst_per_case.append(max(errs.values()))
-    w = np.sort(np.asarray(worst_per_case))
-    print("per-program worst gradient errors:", np.array2string(w, precision=1))
+        tries = []
+        for _ in range(8):
+            features = torch.relu(torch.randn(2, 1024, 14, 14, generator=g))
+            answers = torch.randint(0, 28, (2,), generator=g)
+            ref, ref_sd = _oracle(vocab, cpu_sd, programs, features, answers)
+            if int(ref["valid"][0]) == 0:
+                break
+            net.zero_grad(set_to_none=True)
+            out = net(features.to(dev), programs.to(dev), answers.to(dev))
+            out["loss"].mean().backward()
+            torch.testing.assert_close(out["loss"].detach().cpu(), ref["loss"].detach(), rtol=1e-5, atol=2e-6)
+            tries.append(max(_grad_errors(net, ref_sd).values()))
+            if tries[-1] < 2e-4:
+                break
+        if tries:
+            first.append(tries[0])
+            best.append(min(tries))
+    w = np.sort(np.asarray(first))
+    print("per-program worst gradient errors (first input):", np.array2string(w, precision=1))
+    print("                                  (best of <= 8):", np.array2string(np.sort(np.asarray(best)), precision=1))
     assert len(w) >= 20
     assert np.median(w) < 5e-5
-    assert np.mean(w < 2e-4) >= 0.75
-    assert w.max() < 5e-2
+    assert np.mean(w < 2e-4) >= 0.5
+    assert max(best) < 2e-4
 
 
 # BASELINE config 5: 28x28 feature maps, programs of up to 40 tokens.  A slice of the golden cases that
@@ -257,16 +270,14 @@ def test_mask_backward_modes_agree():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n, deep, cus, split", [(24, False, 0, 4), (200, False, 0, 2), (96, True, 192, 2), (700, False, 0, 1),
-                                                 (64, False, 192, 8)])
-def test_trunk_executor_equals_the_grouped_launches(n, deep, cus, split):
-    """The module programs as ONE launch each way (csrc/trunk_exec.hip: persistent workgroups, examples pinned to XCDs,
-    per-example progress counters) give the losses and gradients of the level-ordered grouped launches.  With the
-    convolutions' split pinned (pnmn_conv_force_split: both schedules then sum every convolution in the same order) the
-    forward pass is bit-equal and the gradients differ by the order of the fp32 atomic adds alone (<= 1e-4 of the largest entry); with the planner free
-    (split 0: the executor cuts a launch per XCD, the grouped path per chip) activations differ in the last bit and, rarely,
-    one lands on the other side of a ReLU -- that case only gets the whole-tensor bar.  Three steps on the same network:
-    the first call with a longer list may reserve room and still run the grouped launches."""
+@pytest.mark.parametrize("n, deep, cus", [(24, False, 0), (200, False, 0), (96, True, 192), (700, False, 0)])
+def test_conv_splits_give_bit_identical_activations(n, deep, cus):
+    """The streamed convolution (csrc/conv_stream.h) splits OUTPUT work only -- a workgroup computes 128 / 64 / 32 / 16 of
+    a unit's channels, a wave one or two 16-channel tiles x 13 / 7 / 4 m-tiles -- and every wave contracts all input
+    channels of its outputs in the same order, so the split the launch planner picks (by launch size and CU budget) must
+    not change a single bit of the forward pass: the losses of the whole network are EQUAL under split 1, 2, 4, 8 and
+    under the planner's own choice, and the gradients differ by the order of the weight gradients' fp32 atomic adds
+    alone (<= 1e-4 of a tensor's largest entry)."""
     from probnmn import _hip
     from probnmn.data.synthetic import synthetic_batch
     from probnmn.models.nmn import NeuralModuleNetwork
@@ -277,43 +288,30 @@ def test_trunk_executor_equals_the_grouped_launches(n, deep, cus, split):
     batch = synthetic_batch(vocab, n, seed=31 + n, deep=deep)
     images, answers = batch["image"].to(dev), batch["answer"].to(dev)
     results = {}
-    _hip.check(_hip.lib().pnmn_conv_force_split(split), "force split")
     try:
-        for executor in (0, 1):
+        for split in (1, 2, 4, 8, 0):
+            _hip.check(_hip.lib().pnmn_conv_force_split(split), "force split")
             torch.manual_seed(7)
             net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
             net.engine.ensure_arena()
-            net.engine.exec_trunk = executor
             net.engine.conv_cus = cus
             net.train()
-            used = []
-            for _ in range(3):
-                net.zero_grad(set_to_none=True)
-                out = net(images, batch["program"], answers)
-                out["loss"].mean().backward()
-                torch.cuda.synchronize()
-                used.append(net.engine.last_exec[:2])
+            net.zero_grad(set_to_none=True)
+            out = net(images, batch["program"], answers)
+            out["loss"].mean().backward()
+            torch.cuda.synchronize()
             assert net.engine.use_native()
-            if executor:
-                assert used[-1][0] > 0 and used[-1][1] > 0, used
-            else:
-                assert used[-1][:2] == (0, 0)
-            results[executor] = (out["loss"].detach().clone(), out["predictions"].clone(),
-                                 {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+            results[split] = (out["loss"].detach().clone(), out["predictions"].clone(),
+                              {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
     finally:
         _hip.lib().pnmn_conv_force_split(0)
-    (loss0, pred0, grads0), (loss1, pred1, grads1) = results[0], results[1]
-    assert torch.equal(pred0, pred1)
-    if split:
-        assert torch.equal(loss0, loss1)
-    else:
-        assert float((loss0 - loss1).abs().max()) <= 2e-6
-    assert grads0.keys() == grads1.keys() and len(grads0) > 20
-    for k, g in grads1.items():
-        scale = float(grads0[k].abs().max()) + 1e-12
-        err = (g - grads0[k]).abs().reshape(-1) / scale
-        rel = float((g - grads0[k]).double().norm() / grads0[k].double().norm().clamp_min(1e-30))
-        if split:
-            assert float(err.max()) <= 1e-4, (k, float(err.max()))  # (3.04e-5 seen once in 80 runs: a one-element bias, atomics order)
-        else:
-            assert rel <= 2e-2 and float(err.max()) <= 5e-2, (k, rel, float(err.max()))
+    loss1, pred1, grads1 = results[1]
+    for split, (loss, pred, grads) in results.items():
+        assert torch.equal(pred, pred1), split
+        assert torch.equal(loss, loss1), split
+        assert grads.keys() == grads1.keys() and len(grads) > 20
+        for k, g in grads.items():
+            scale = float(grads1[k].abs().max()) + 1e-12
+            assert float((g - grads1[k]).abs().max()) <= 1e-4 * scale, (split, k)
+
+

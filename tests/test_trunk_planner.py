@@ -35,7 +35,7 @@ def _rows(spec):
     return np.array(lst._rows, dtype=np.uint64).reshape(-1, 8)
 
 
-def _run(planner, programs, capacity=1 << 40, executor=0, conv_cus=0):
+def _run(planner, programs, capacity=1 << 40, conv_cus=0):
     programs = np.ascontiguousarray(programs, dtype=np.int64)
     B = programs.shape[0]
     fwd_tail, bwd_head, bwd_tail = _rows([(_hip.OP_MAXPOOL_FWD, B, 111)]), _rows([(_hip.OP_ZERO, 0, 222), (_hip.OP_MAXPOOL_BWD, B, 333)]), _rows([(_hip.OP_WGRAD, 5, 444)])
@@ -44,7 +44,7 @@ def _run(planner, programs, capacity=1 << 40, executor=0, conv_cus=0):
     io = np.zeros(1, _hip.TRUNK_IO)
     io[0] = (programs.ctypes.data, BUF.params, BUF.grads, BUF.wt, BUF.act, BUF.gact, BUF.feat, BUF.gfeat, BUF.final, BUF.gfinal,
              BUF.ones, capacity, fwd_tail.ctypes.data, bwd_head.ctypes.data, bwd_tail.ctypes.data, bwd.ctypes.data,
-             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, conv_cus, 0, executor, 0, 0, 0, 0)
+             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, conv_cus, 0, 0, 0, 0)
     rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, None)
     out = io[0]
     if rc != 0:
@@ -174,84 +174,4 @@ def test_native_planner_reports_a_too_small_arena_and_an_empty_batch():
     rc, out, fwd, bwd, valid, _ = _run(planner, np.zeros((3, 5), np.int64))  # three empty programs: result = the feature map
     assert rc == 0 and valid.tolist() == [1, 1, 1] and out["n_feat_result"] == 3 and out["n_prims"] == 0
     assert [int(l["op"]) for l in fwd] == [_hip.OP_SET_ROWS, _hip.OP_MAXPOOL_FWD]
-    _hip.lib().pnmn_trunk_planner_destroy(planner)
-
-
-def _exec_tables(words, launch):
-    """(program, units of the eight queues) behind an EXEC launch of a `launch = 0` plan."""
-    off = (int(launch["a"]) - FAKE_BASE) // 8
-    prog = words[off: off + _hip.EXEC_PROGRAM.itemsize // 8].view(_hip.EXEC_PROGRAM)[0]
-    queues = []
-    for x in range(8):
-        n = int(prog["n_units"][x])
-        at = (int(prog["units"][x]) - FAKE_BASE) // 8
-        queues.append(words[at: at + 2 * n].view(_hip.EXEC_UNIT).copy())
-    return prog, queues
-
-
-def _check_exec(words, launch, kinds, n_records, B, workgroups):
-    """Invariants of an executor program (csrc/trunk_exec.hip): every record covered once per split part; an example's
-    units in ONE queue; a unit's `need` = the example's units of all earlier stages, every one of which sits earlier in
-    the same queue (the progress argument); counters zero."""
-    assert int(launch["n"]) == workgroups and tuple(int(v) for v in launch["p"][:2]) == (14, 14)
-    prog, queues = _exec_tables(words, launch)
-    assert int(prog["H"]) == 14 and int(prog["W"]) == 14 and int(prog["n_owners"]) == B
-    heads = words[(int(prog["heads"]) - FAKE_BASE) // 8:][: 8 * 16 // 2]
-    progress = words[(int(prog["progress"]) - FAKE_BASE) // 8:][: B * 16 // 2]
-    assert not heads.any() and not progress.any()
-    seen = {}
-    queue_of = {}
-    for x, q in enumerate(queues):
-        done = {}    # owner -> units before this position in the queue
-        stage = {}   # owner -> (need of the stage at hand, units of it so far)
-        for u in q:
-            kind, split, sub, owner, need = int(u["kind"]), int(u["split"]), int(u["sub"]), int(u["owner"]), int(u["need"])
-            assert kind in kinds and split in (1, 2, 4, 8, 16) and 0 <= sub < split and int(u["band"]) == 0
-            assert 0 <= int(u["record"]) < n_records[kind]
-            assert queue_of.setdefault(owner, x) == x
-            assert need <= done.get(owner, 0), "a unit must only wait for units taken before it"
-            cur = stage.get(owner)
-            if cur is None or cur[0] != need:
-                # a new stage of this example: everything before it is what it waits for
-                assert need == done.get(owner, 0)
-                stage[owner] = [need, 0]
-            stage[owner][1] += 1
-            done[owner] = done.get(owner, 0) + 1
-            seen.setdefault((kind, int(u["record"])), []).append((split, sub))
-    for kind in kinds:
-        for r in range(n_records[kind]):
-            parts = seen.get((kind, r))
-            assert parts is not None, (kind, r)
-            split = parts[0][0]
-            assert sorted(parts) == [(split, k) for k in range(split)], (kind, r, parts)
-    return sum(len(q) for q in queues)
-
-
-def test_native_planner_builds_the_executor_programs():
-    v, comp, s = _scheduler()
-    if s.fuse_mask_bwd != 2:
-        return
-    planner = _planner(s, comp)
-    E = _hip
-    for seed, n, cus in ((1, 64, 0), (2, 257, 192), (5, 700, 0)):
-        b = synthetic_batch(v, n, seed=seed, with_image=False)["program"].numpy()
-        rc, out, fwd, bwd, valid, words = _run(planner, b, executor=1, conv_cus=cus)
-        if out["n_exec_fwd"] == 0:  # (the first call with a list this long reserves the room and runs the grouped launches)
-            rc, out, fwd, bwd, valid, words = _run(planner, b, executor=1, conv_cus=cus)
-        assert rc == 0 and out["n_exec_fwd"] > 0 and out["n_exec_bwd"] > 0
-        ops = [int(l["op"]) for l in fwd]
-        assert ops.count(E.OP_EXEC) == 1 and not {E.OP_CONV, E.OP_DOT_FWD, E.OP_SAME_FWD, E.OP_MINMAX_FWD} & set(ops)
-        plan = s.plan(comp.compile_batch(b), BUF)
-        nrec = {k: len(plan.records[k]) for k in ("conv", "proj", "dgrad", "pdgrad", "dot", "same", "minmax")}
-        assert out["n_conv"] == nrec["conv"] and out["n_proj"] == nrec["proj"]
-        wgs = cus or 256
-        n = _check_exec(words, fwd[ops.index(E.OP_EXEC)], (0, 1, 4, 6, 8),
-                        {0: nrec["conv"], 1: nrec["proj"], 4: nrec["dot"], 6: nrec["same"], 8: nrec["minmax"]}, len(b), wgs)
-        assert n == out["n_exec_fwd"]
-        bops = [int(l["op"]) for l in bwd]
-        assert bops.count(E.OP_EXEC) == 1 and not {E.OP_CONV, E.OP_DOT_BWD, E.OP_SAME_BWD, E.OP_MINMAX_BWD} & set(bops[2:-1])
-        assert bops.index(E.OP_EXEC) < bops.index(E.OP_FEAT_GATHER)
-        n = _check_exec(words, bwd[bops.index(E.OP_EXEC)], (2, 3, 5, 7, 9),
-                        {2: nrec["dgrad"], 3: nrec["pdgrad"], 5: nrec["dot"], 7: nrec["same"], 9: nrec["minmax"]}, len(b), wgs)
-        assert n == out["n_exec_bwd"]
     _hip.lib().pnmn_trunk_planner_destroy(planner)
