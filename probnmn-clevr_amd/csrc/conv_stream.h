@@ -1,13 +1,13 @@
 // Streamed grouped NHWC convolution for gfx950 (see conv_nhwc.hip for the launch side).
 //
-// A workgroup is PERSISTENT and WAVE-SPECIALISED: 4 contraction waves (one per SIMD) + 1 loader wave (320 threads, one
-// workgroup per CU).  It walks its share of the launch's units -- unit = (item, band of 196 output pixels, block of 128 / split
+// A workgroup is PERSISTENT and WAVE-SPECIALISED: 4 contraction waves + 4 loader waves, one of each per SIMD (512
+// threads, one workgroup per CU).  It walks its share of the launch's units -- unit = (item, band of 196 output pixels, block of 128 / split
 // output channels) -- and sees the input of every unit as a sequence of STAGES of 32 input channels:
 //
 //     14x14 maps, 28x28 with dilation 1 / 1x1:  stage = one quarter of a 128-channel chunk, all taps
 //     28x28 maps with dilation 2 / 4 / 8:        stage = (tap row ky, quarter): the 7 image rows that tap row reads
 //
-// The loader wave moves stages from global memory straight into a RING of LDS slots with 16-byte direct-to-LDS loads
+// The loader waves move stages from global memory straight into a RING of LDS slots with 16-byte direct-to-LDS loads
 // (global_load_lds_dwordx4: no registers, no ds_write pass), several stages ahead of the contraction waves and ACROSS
 // unit boundaries, applies the fused prologue in place in LDS (attention-mask multiply; ReLU-backward gate, whose map
 // travels through the ring slot behind its stage) and announces a stage with one s_barrier.  The contraction waves
@@ -56,8 +56,9 @@ namespace stream {
 
 constexpr int CB = 128;          // channels of a chunk / of an output block
 constexpr int QC = 32;           // channels of a stage
-constexpr int NTHREADS = 320;    // 4 contraction waves + the loader wave
-constexpr int LOADER_WAVE = 4;
+constexpr int NTHREADS = 512;    // 4 contraction waves + 4 loader waves (one of each per SIMD)
+constexpr int LOADER_WAVE = 4;   // the first loader wave
+constexpr int NLOAD = 4;
 constexpr int MTILES = 13;       // 196 output pixels = 12.25 tiles of 16
 constexpr int TAB_ROWS = 208;    // table entries per tap (13 tiles x 16 pixels)
 
@@ -74,6 +75,16 @@ struct Geom {
     static constexpr int SUB_BYTES = (Z0 + 8) * 64;                    // 13 312 (14x14) / 16 896 (28x28)
     static constexpr int SLOT_BYTES = 2 * SUB_BYTES;
     static constexpr int RING = WHOLE ? 6 : 4;
+    // which loader wave requests (and prepares) piece i of a sub-slot: every fourth one -- except that a LAST piece which
+    // overlaps its predecessor (it starts at Z0 - 16 to end in front of the zero rows) goes to the predecessor's wave:
+    // two waves writing the same rows would let one's late load undo the other's prologue.
+    static constexpr bool OVERLAP = (Z0 % 16) != 0;
+    static constexpr int owner(int i) { return (OVERLAP && i == SUB_PIECES - 1) ? (SUB_PIECES - 2) % NLOAD : i % NLOAD; }
+    static constexpr int owned(int lw) {
+        int n = 0;
+        for (int i = 0; i < SUB_PIECES; ++i) n += owner(i) == lw ? 1 : 0;
+        return n;
+    }
     static constexpr int TAB_OFF = RING * SLOT_BYTES;                  // uint16 [9][208]
     static constexpr int LDS_BYTES = TAB_OFF + 9 * TAB_ROWS * 2 + 128; // (+ the table rows of the m-tiles past the 13th)
     static_assert(LDS_BYTES <= 160 * 1024, "ring + table must fit the CU's LDS");
@@ -189,55 +200,72 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// one stage (32 channels of the rows [rs, re) of one source map) into the slot at LDS byte address `slot`
-template <int H, int W, int TH>
+// one stage (32 channels of the rows [rs, re) of one source map) into the slot at LDS byte address `slot`.
+// The loader shares a SIMD with a contraction wave that keeps the matrix pipe busy, and there every VECTOR-ALU
+// instruction of the loader waits for a gap between MFMAs (measured: ~150 cycles per instruction of the first version,
+// which formed a 64-bit address per piece and lane).  So the per-lane part of the address is formed ONCE: the channel
+// permutation of a lane does not depend on the piece (a piece starts on a multiple of 8 rows, so (row >> 2) & 1 is
+// (lane >> 4) & 1), and a piece advances a wave-uniform base on the scalar unit.
+template <int H, int W, int TH, int LW>
 __device__ __forceinline__ void issue_rows(const float* src, int in_stride, int rs, int re, lchar* slot, int lane) {
     using G = Geom<H, W, TH>;
     const int nr = (re - rs) * W;
-    const gfloat* base = as_global(src) + (size_t)rs * W * in_stride;
-    const int s = lane & 3;
-#pragma unroll 2
+    using gchar = __attribute__((address_space(1))) char;
+    // (the pointer comes out of an item record: uniform, but only the scalar unit can be told so)
+    const uint64_t src64 = (uint64_t)(uintptr_t)src + (uint64_t)rs * W * in_stride * 4;
+    const uint64_t base64 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(src64 >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)src64);
+    const gchar* base = (const gchar*)base64;
+    const int s = lane & 3, lrow = lane >> 2;
+    const int g = (((s & 1) ^ ((lane >> 4) & 1)) << 1) | (s >> 1);
+    const uint32_t voff = (uint32_t)(lrow * in_stride + g * 4) * 4u;  // this lane's row and channels within a piece
+    // the one piece that straddles the end of the region: its rows past the end re-read the last row (never addressed)
+    const int edge = (nr & 15) && nr < G::Z0 ? (nr < G::Z0 - 16 ? nr & ~15 : G::Z0 - 16) : -1;
+    const uint32_t eoff = edge < 0 ? voff : (uint32_t)(((edge + lrow < nr ? edge + lrow : nr - 1) - edge) * in_stride + g * 4) * 4u;
+#pragma unroll
     for (int i = 0; i < G::SUB_PIECES; ++i) {
-        // Every lane of a direct-to-LDS load writes its 16 bytes, whatever EXEC says (measured: a last piece issued
-        // under a partial mask overwrote the zero rows behind it with stale data).  So every piece is 16 full rows,
+        if (G::owner(i) != LW) continue;  // (this loader wave's pieces)
+        // Every lane of a direct-to-LDS load writes its 16 bytes, whatever EXEC says.  So every piece is 16 full rows,
         // and the last one starts early enough to end in front of the zero rows, overlapping its predecessor.
         const int r0 = i * 16 < G::Z0 - 16 ? i * 16 : G::Z0 - 16;
-        const int row = r0 + (lane >> 2);
-        const int g = (((s & 1) ^ ((row >> 2) & 1)) << 1) | (s >> 1);
-        const int rr = row < nr ? row : nr - 1;  // rows past the region re-read its last row (never addressed)
-        const gfloat* gp = base + (size_t)rr * in_stride + g * 4;
-        __builtin_amdgcn_global_load_lds(gp, slot + r0 * 64, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gp + 16, slot + G::SUB_BYTES + r0 * 64, 16, 0, 0);
+        const uint32_t off = r0 == edge ? eoff : voff;
+        const gchar* pb = base + (size_t)(r0 < nr ? r0 : 0) * in_stride * 4;  // (uniform; pieces past the region: any rows)
+        __builtin_amdgcn_global_load_lds((const gfloat*)(pb + off), slot + r0 * 64, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const gfloat*)(pb + (off + 64u)), slot + G::SUB_BYTES + r0 * 64, 16, 0, 0);
     }
 }
 
 // prologue in place: x *= mask[pixel], x = gate > 0 ? x : 0
-template <int H, int W, int TH>
+template <int H, int W, int TH, int LW>
 __device__ __forceinline__ void fixup(char* lds, int slot_x, int slot_g, const float* mask, int rs, int re, bool gated, int lane) {
     using G = Geom<H, W, TH>;
     const int nr = (re - rs) * W;
     const gfloat* msrc = mask ? as_global(mask) + rs * W : nullptr;
     // the mask values of all pieces are requested before the first is used (one round trip, not SUB_PIECES of them:
     // the first version kept the contraction waves waiting 18 % of their time at the hand-over)
+    // this loader wave's pieces (Geom::owner); all their mask values are requested before the first is used
     float mk[G::SUB_PIECES];
 #pragma unroll
     for (int i = 0; i < G::SUB_PIECES; ++i) {
+        if (G::owner(i) != LW) continue;
         const int row = i * 16 + (lane >> 2);
         mk[i] = msrc ? msrc[row < nr ? row : nr - 1] : 1.f;
     }
-    // one sub-slot at a time, all of its pieces read before the first is written back (13-16 LDS round trips in
-    // flight instead of one after the other; the loader has the registers)
+    // one sub-slot at a time, all of its pieces read before the first is written back (LDS round trips in flight
+    // instead of one after the other; the loaders have the registers)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         f32x4 v[G::SUB_PIECES], gt[G::SUB_PIECES];
 #pragma unroll
         for (int i = 0; i < G::SUB_PIECES; ++i) {
+            if (G::owner(i) != LW) continue;
             const int off = kb * G::SUB_BYTES + i * 1024 + lane * 16;
             v[i] = *reinterpret_cast<const f32x4*>(lds + slot_x + off);
             if (gated) gt[i] = *reinterpret_cast<const f32x4*>(lds + slot_g + off);
         }
 #pragma unroll
         for (int i = 0; i < G::SUB_PIECES; ++i) {
+            if (G::owner(i) != LW) continue;
             const int off = kb * G::SUB_BYTES + i * 1024 + lane * 16;
             f32x4 x = v[i] * mk[i];
             if (gated) {
@@ -277,9 +305,13 @@ __device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npa
     }
 }
 
-template <int H, int W, int TH>
+template <int H, int W, int TH, int LW>
 __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane, int tab_band, int tab_dil) {
     using G = Geom<H, W, TH>;
+    // direct-to-LDS loads of THIS wave per slot.  (One loader wave could not feed the ring: a wave keeps few such loads
+    // in flight -- 250-650 cycles per load at the issue, measured -- so four of them, one per SIMD, take every fourth
+    // piece each; a wave prepares exactly the pieces it requested, so its own vmcnt covers them.)
+    constexpr int NP2 = 2 * G::owned(LW);
     lchar* ring = (lchar*)lds;
     // The loader shares its SIMD with a contraction wave whose MFMA stream would otherwise win nearly every issue
     // slot: at the default priority issuing one stage (26 loads and their addresses) took as long as contracting it.
@@ -295,14 +327,9 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
     auto top_up = [&](int limit) {
         while (P.valid() && issued - freed + P.slots <= limit) {
             const float* src = (pit->in2 != nullptr && P.chunk > 0) ? pit->in2 + P.kq * QC : pit->in + P.cbase();
-            // The vector-memory counter holds 63.  With more loads than that in flight (the first top-up used to
-            // issue six slots = 156 back to back) the zero rows of the ring came out dirty on the box; a slot is
-            // therefore issued only once all but the last 63 - PIECES loads have landed.
-            wait_vm<63 - G::PIECES>();
-            issue_rows<H, W, TH>(src, L.in_stride, P.rs, P.re, ring + (issued % G::RING) * G::SLOT_BYTES, lane);
+            issue_rows<H, W, TH, LW>(src, L.in_stride, P.rs, P.re, ring + (issued % G::RING) * G::SLOT_BYTES, lane);
             if (P.slots == 2) {
-                wait_vm<63 - G::PIECES>();
-                issue_rows<H, W, TH>(pit->gate + P.cbase(), L.in_stride, P.rs, P.re,
+                issue_rows<H, W, TH, LW>(pit->gate + P.cbase(), L.in_stride, P.rs, P.re,
                                      ring + ((issued + 1) % G::RING) * G::SLOT_BYTES, lane);
             }
             issued += P.slots;
@@ -320,29 +347,33 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
         lc[k] += now - lt;
         lt = now;
     };
-    top_up(P.valid() ? P.slots : 0);
-    lap(0);
-    while (C.valid()) {
+    // the consumer's stage: its loads (and the gate map's) have landed -- everything issued up to its end -- and the
+    // prologue is applied in place
+    auto prepare = [&] {
         const pnmn_conv_item* cit = items + C.item;
-        // the stage's loads (and the gate map's) have landed: everything issued up to the end of this stage
         const int younger = issued - (cstart + C.slots);
-        // (the counter holds 63: at most two younger slots are told apart at 14x14, one at 28x28)
-        constexpr int TWO = 2 * G::PIECES <= 63 ? 2 * G::PIECES : G::PIECES;
         if (younger == 0) wait_vm<0>();
-        else if (younger == 1) wait_vm<G::PIECES>();
-        else wait_vm<TWO>();
+        else if (younger == 1) wait_vm<NP2>();
+        else if (younger == 2) wait_vm<2 * NP2>();
+        else wait_vm<3 * NP2>();
         lap(1);
         if (cit->mask != nullptr || C.slots == 2)
-            fixup<H, W, TH>(lds, (cstart % G::RING) * G::SLOT_BYTES, ((cstart + 1) % G::RING) * G::SLOT_BYTES, cit->mask, C.rs,
+            fixup<H, W, TH, LW>(lds, (cstart % G::RING) * G::SLOT_BYTES, ((cstart + 1) % G::RING) * G::SLOT_BYTES, cit->mask, C.rs,
                             C.re, C.slots == 2, lane);
         lap(2);
+    };
+    top_up(P.valid() ? P.slots : 0);
+    lap(0);
+    bool prepared = false;
+    while (C.valid()) {
+        if (!prepared) prepare();  // (only the first stage, and the second: requested behind the first hand-over)
         if (unit_end) {  // the previous unit's contraction is over: its table may go
             lds_barrier();
             unit_end = false;
             lap(3);
         }
         if (C.band != tab_band || C.dil != tab_dil) {
-            fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane, 0, 1);
+            fill_table<H, W, TH>(lds, C.band, C.dil, C.npass, L.ntaps, lane, LW, NLOAD);
             tab_band = C.band, tab_dil = C.dil;
         }
         lap(2);
@@ -354,11 +385,16 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
             C.next_unit(L);
             unit_end = true;
         }
+        // The NEXT stage is prepared before anything new is requested: its loads went out a stage ago and have landed,
+        // whereas behind a fresh request the in-place prologue -- whose LDS reads the compiler orders behind every
+        // outstanding direct-to-LDS load -- would wait a full memory round trip per stage.
+        prepared = C.valid() && issued >= cstart + C.slots;
+        if (prepared) prepare();
         top_up(G::RING);
         lap(0);
     }
     if (unit_end) lds_barrier();
-    if (L.dbg && lane == 0) {
+    if (L.dbg && lane == 0 && LW == 0) {
         unsigned long long* d = L.dbg + ((size_t)gridDim.x * 4 + blockIdx.x) * 8;
         d[0] = lc[0], d[1] = lc[1], d[2] = lc[2], d[3] = lc[3];
     }
@@ -766,8 +802,14 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     // the row table of the first unit, by all five waves (later geometries are the loader's, behind a unit's end)
     if (Wk.valid()) fill_table<H, W, TH>(lds, Wk.band, Wk.dil, Wk.npass, L.ntaps, lane, wave, NTHREADS / 64);
     __syncthreads();
-    if (wave == LOADER_WAVE) {
-        loader<H, W, TH>(L, items, lds, lane, Wk.valid() ? Wk.band : -1, Wk.valid() ? Wk.dil : -1);
+    if (wave >= LOADER_WAVE) {
+        const int tb = Wk.valid() ? Wk.band : -1, td = Wk.valid() ? Wk.dil : -1;
+        switch (wave - LOADER_WAVE) {
+            case 0: loader<H, W, TH, 0>(L, items, lds, lane, tb, td); break;
+            case 1: loader<H, W, TH, 1>(L, items, lds, lane, tb, td); break;
+            case 2: loader<H, W, TH, 2>(L, items, lds, lane, tb, td); break;
+            default: loader<H, W, TH, 3>(L, items, lds, lane, tb, td); break;
+        }
         return;
     }
     int cstart = 0;
