@@ -81,11 +81,12 @@ class PinnedFeatureStore:
             out = torch.empty((n, C, H, W), dtype=torch.float32, device=device)
         elif tuple(out.shape) != (n, C, H, W) or not out.is_contiguous():
             raise ValueError("`out` must be a contiguous (n, C, H, W) tensor")
-        code = _hip.lib().pnmn_copy_rows_h2d(self.store.data_ptr(), idx.ctypes.data, out.data_ptr(), n, N, C * H * W * 4,
-                                             _hip.stream_ptr(device))
-        if code == -1:
+        # (checked here: the library queues row by row, so a bad index found there would leave `out` half overwritten, and
+        # its -1 is PNMN_EINVAL for every kind of bad argument)
+        if n and (int(idx.min()) < 0 or int(idx.max()) >= N):
             raise IndexError("feature index out of range [0, %d)" % N)
-        _hip.check(code, "copy_rows_h2d")
+        _hip.check(_hip.lib().pnmn_copy_rows_h2d(self.store.data_ptr(), idx.ctypes.data, out.data_ptr(), n, N, C * H * W * 4,
+                                                 _hip.stream_ptr(device)), "copy_rows_h2d")
         return out
 
 

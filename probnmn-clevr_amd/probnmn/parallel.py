@@ -115,6 +115,12 @@ class EarlyReducer:
                 p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
             return p.grad
         a, lo, hi = self.pieces[slot[1]]
+        for e in getattr(self, "engines", ()):  # (an engine that rebuilt its arena -- .to(), re-pointed parameters --
+            # leaves this reducer holding the old one: reducing it would silently skip the live gradients)
+            if e.arena is not None and e.arena is not a and any(a is q[0] for q in self.pieces):
+                if not any(e.arena is q[0] for q in self.pieces):
+                    raise RuntimeError("the NMN engine rebuilt its parameter arena after this reducer was created: "
+                                       "build the trainer (early_reducer_for) after moving the model")
         return a.grad[lo:hi]
 
     def _start(self, slot) -> None:
@@ -187,6 +193,7 @@ def early_reducer_for(big_params, engines) -> "EarlyReducer":
     for e in r.engines:
         n = len(e.grad_pieces())
         e.on_grad_piece = (lambda k, base=at: r.piece_ready(base + k))
+        e._grad_piece_owner = r
         at += n
     return r
 

@@ -223,9 +223,15 @@ class NMNEngine:
         _hip.lib()
         if self.arena is None or self.arena.device != device or not self.arena.intact():
             self.arena = ParamArena(self.trunk_named_parameters(), device)
+            self.arena_generation = getattr(self, "arena_generation", 0) + 1
             self._build_tables()
             self._ws.clear()
             self._fixed_cache.clear()
+            # everything that holds the old arena's absolute addresses goes with it: the uploaded records and launch rows
+            # of the native path (keyed on workspace pointers the allocator may hand out again) and the planner's offset
+            # tables (a stale hit read and wrote freed memory)
+            self._native_fixed.clear()
+            self._drop_planner()
         return self.arena
 
     def grad_pieces(self):
@@ -550,10 +556,14 @@ class NMNEngine:
             self._planner_valid = np.zeros(4096, np.uint8)
         return self._planner
 
+    def _drop_planner(self) -> None:
+        if getattr(self, "_planner", None):
+            _hip.lib().pnmn_trunk_planner_destroy(self._planner)
+        self._planner = None
+
     def __del__(self):
         try:
-            if getattr(self, "_planner", None):
-                _hip.lib().pnmn_trunk_planner_destroy(self._planner)
+            self._drop_planner()
         except Exception:
             pass
 

@@ -38,7 +38,10 @@ class StepBase:
         if early is not None:
             early.remove()
             for e in getattr(early, "engines", ()):
-                e.on_grad_piece = None
+                # (only if the callback is still this reducer's: a trainer built later over the same NMN owns it now)
+                if getattr(e, "_grad_piece_owner", None) is early:
+                    e.on_grad_piece = None
+                    e._grad_piece_owner = None
             self._early = None
 
     # ---- checkpoint (reference layout) -----------------------------------------------------------
