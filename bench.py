@@ -539,6 +539,81 @@ def config5_side(vocab, prior, dev, rank, world, args):
     return out
 
 
+def dropin_side(vocab, dev, n, joint_ms, steps=10, warmup=4):
+    """What a maintainer of the reference gets from ``probnmn_graft.install()`` with NOTHING else changed: the
+    reference's own ``_Trainer.step`` + ``JointTrainingTrainer._do_iteration``
+    (/root/reference/probnmn/trainers/_trainer.py:135-151, joint_training_trainer.py:128-198) restated against the class
+    surface only -- index the batch by supervision, ``JointTrainingElbo(...)`` on the unsupervised rows (inside it: the
+    generator's sampling pass, the reconstructor, the prior, the NMN), the generator and the reconstructor AGAIN on the
+    supervised rows, one ``backward()``, the Python clamp loop over every parameter, ``torch.optim.Adam`` over all
+    trainable parameters (``_trainer.py:103-108``).  Fresh models (torch's Adam must not step the headline's), same
+    batch shape; reported next to this build's ``JointTrainingStep``, which batches the four seq2seq calls into two,
+    fuses the objective and runs clamp + Adam as one kernel over the parameter arenas."""
+    import itertools
+
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.modules.elbo import JointTrainingElbo
+
+    torch.manual_seed(1)
+    nmn = NeuralModuleNetwork(vocab).to(dev)
+    pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
+    prior = ProgramPrior(vocab, hidden_size=256).to(dev)
+    for p in prior.parameters():
+        p.requires_grad_(False)  # (checkpointed and frozen in this phase: joint_training_trainer.py:91-94)
+    batch = device_batch(vocab, n, 4000, dev)
+    fit_program_generator(pg, vocab, batch, dev, 400, 0.9)  # (an untrained generator samples invalid programs: no NMN work)
+    elbo = JointTrainingElbo(pg, qr, prior, nmn, beta=JOINT["beta"], gamma=JOINT["gamma"], baseline_decay=JOINT["delta"],
+                             objective="ours")
+    params = [p for m in (pg, qr, nmn) for p in m.parameters() if p.requires_grad]
+    optimizer = torch.optim.Adam(params, lr=JOINT["lr"], weight_decay=0.0)
+
+    def step():
+        optimizer.zero_grad()
+        sup = batch["supervision"].nonzero().squeeze()
+        nosup = (1 - batch["supervision"]).nonzero().squeeze()
+        out = elbo(batch["question"][nosup], batch["image"][nosup], batch["answer"][nosup])
+        loss = JOINT["gamma"] * out.pop("nmn_loss") - out["elbo"]
+        pg_sup = pg(batch["question"][sup], batch["program"][sup], decoding_strategy="sampling")
+        qr_sup = qr(batch["program"][sup], batch["question"][sup], decoding_strategy="sampling")
+        loss = loss + JOINT["alpha"] * (pg_sup["loss"].mean() + qr_sup["loss"].mean())
+        loss.backward()
+        for p in itertools.chain(pg.parameters(), qr.parameters(), nmn.parameters()):
+            if p.grad is not None:
+                p.grad.clamp_(min=-5, max=5)
+        optimizer.step()
+
+    e, h, bl = timed(step, steps, warmup, dev, 1)
+    ms = e / steps * 1e3
+    return {"metric": "CLEVR questions/sec (joint_training step, the reference's own iteration over the grafted classes)",
+            "value": round(n * steps / e, 1), "unit": "questions/s", "ms_per_step": round(ms, 3), "global_batch": n,
+            "steps": steps, "warmup": warmup, "host_busy_ms_per_step": round((h - bl) / steps * 1e3, 3),
+            "slowdown_vs_joint_training_step": round(ms / joint_ms, 3),
+            "workload": "the reference's _Trainer.step + JointTrainingTrainer._do_iteration call for call (four separate "
+                        "seq2seq passes, JointTrainingElbo, Python clamp loop, torch.optim.Adam), %d questions" % n}
+
+
+def evaluation_side(vocab, pg, nmn, dev, n=256, num_batches=8):
+    """Validation answer accuracy as the reference's training loop runs it every CHECKPOINT_EVERY iterations
+    (/root/reference/probnmn/evaluators/_evaluator.py:67-115, joint_training_evaluator.py:74-103, scripts/train.py:135-140):
+    eval mode, no gradients, the generator teacher-forced on the ground-truth programs with "greedy" decoding, the NMN on
+    its predictions; ``num_batches + 2`` batches of ``n`` questions (the reference's loop condition)."""
+    from probnmn.evaluators import evaluate_answer_accuracy
+
+    batches = [device_batch(vocab, n, 5000 + i, dev) for i in range(num_batches + 2)]
+    evaluate_answer_accuracy(pg, nmn, batches[:3], 1)  # (program structures, allocator pools)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    metrics = evaluate_answer_accuracy(pg, nmn, batches, num_batches)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    seen = (num_batches + 2) * n
+    return {"metric": "CLEVR questions/sec (validation answer accuracy: forward only)", "value": round(seen / dt, 1),
+            "unit": "questions/s", "ms_per_batch": round(dt / (num_batches + 2) * 1e3, 3), "batch": n,
+            "batches": num_batches + 2, "answer_accuracy": round(float(metrics["nmn"]["answer_accuracy"]), 4),
+            "workload": "evaluate_answer_accuracy: ProgramGenerator teacher-forced greedy + NMN forward, eval mode, no "
+                        "autograd, %d batches of %d questions (num_batches = %d)" % (num_batches + 2, n, num_batches)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per GPU,
     rendezvous on 127.0.0.1) with the same arguments, pass their output through and exit with their status."""
@@ -842,6 +917,11 @@ def main():
         except Exception as exc:
             extras["joint_training_ingest"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     if want_extras:
+        try:  # (before the trainers below re-hook the models)
+            extras["evaluate_answer_accuracy"] = evaluation_side(vocab, pg, nmn, dev)
+            log("evaluate_answer_accuracy: %.1f questions/s" % extras["evaluate_answer_accuracy"]["value"])
+        except Exception as exc:
+            extras["evaluate_answer_accuracy"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         side("joint_training_b128", "CLEVR questions/sec (joint_training step)",
              "joint_training_ours.yml, 128 questions per GPU (configs[3] read as 1024 over 8 GPUs)", 128,
              lambda: trainer, k=40)  # (8 ms steps whose sampled programs differ: 10 of them scatter by +-4 %)
@@ -853,6 +933,11 @@ def main():
         side("module_training", "CLEVR questions/sec (module_training step)",
              "module_training.yml, 256 questions per GPU, ground-truth programs, NMN fwd+bwd+clamp+Adam (configs[1])", 256,
              lambda: ModuleTrainingStep(nmn, lr=1e-4, weight_decay=0.0, report_metrics=False))
+        try:
+            extras["joint_training_dropin"] = dropin_side(vocab, dev, total, elapsed / args.steps * 1e3)
+            log("joint_training_dropin: %.1f questions/s" % extras["joint_training_dropin"]["value"])
+        except Exception as exc:
+            extras["joint_training_dropin"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         try:
             extras["joint_training_28x28"] = config5_side(vocab, prior, dev, rank, world, args)
             if rank == 0:
