@@ -5,6 +5,7 @@ import math
 from collections import Counter
 from typing import Iterable, Optional, Sequence
 
+import numpy as np
 import torch
 
 
@@ -72,6 +73,10 @@ class BLEU:
                  exclude_indices: Optional[Sequence[int]] = None):
         self._ngram_weights = tuple(ngram_weights)
         self._exclude = set(exclude_indices or ())
+        self._exclude_array = np.asarray(sorted(self._exclude), dtype=np.int64)
+        self._base = 1 << 12  # keys: row, then n <= 4 tokens of 12 bits each (vocabularies here: < 100 entries)
+        if len(self._ngram_weights) > 4:
+            raise ValueError("n-grams beyond 4 tokens do not fit the 64-bit keys")
         self.reset()
 
     def reset(self) -> None:
@@ -80,28 +85,43 @@ class BLEU:
         self._prediction_length = 0
         self._reference_length = 0
 
-    def _ngrams(self, row, n: int) -> Counter:
-        out = Counter()
-        for i in range(len(row) - n + 1):
-            gram = tuple(row[i:i + n])
-            if self._exclude and any(t in self._exclude for t in gram):
-                continue
-            out[gram] += 1
-        return out
+    def _keys(self, tokens: np.ndarray, n: int) -> np.ndarray:
+        """One int64 key per n-gram of every row that holds no excluded index: (row, the n tokens)."""
+        B, T = tokens.shape
+        if T < n:
+            return np.empty(0, np.int64)
+        ok = np.ones((B, T - n + 1), bool)
+        h = np.zeros((B, T - n + 1), np.int64)
+        for k in range(n):
+            part = tokens[:, k:T - n + 1 + k]
+            if self._exclude:
+                ok &= ~np.isin(part, self._exclude_array)
+            h = h * self._base + part
+        h += np.arange(B, dtype=np.int64)[:, None] * (self._base ** n)
+        return h[ok]
 
     def __call__(self, predictions: torch.Tensor, gold_targets: torch.Tensor) -> None:
-        pred, gold = predictions.detach().cpu().tolist(), gold_targets.detach().cpu().tolist()
+        # (vectorised over the batch: the per-row Python loops of the first version took 35 ms per 256-row validation
+        # batch -- nine tenths of evaluate_answer_accuracy)
+        pred = predictions.detach().cpu().numpy().astype(np.int64, copy=False)
+        gold = gold_targets.detach().cpu().numpy().astype(np.int64, copy=False)
+        if pred.ndim != 2 or gold.ndim != 2 or pred.shape[0] != gold.shape[0]:
+            raise ValueError("BLEU takes (batch, length) prediction and target matrices")
+        top = int(max(pred.max(initial=0), gold.max(initial=0))) + 1
+        if top > self._base:
+            raise ValueError("token index %d beyond the metric's key base %d" % (top - 1, self._base))
         for n in range(1, len(self._ngram_weights) + 1):
-            for p_row, g_row in zip(pred, gold):
-                p_counts, g_counts = self._ngrams(p_row, n), self._ngrams(g_row, n)
-                self._matches[n] += sum(min(c, g_counts.get(gram, 0)) for gram, c in p_counts.items())
-                self._totals[n] += sum(p_counts.values())
+            pk, pc = np.unique(self._keys(pred, n), return_counts=True)
+            gk, gc = np.unique(self._keys(gold, n), return_counts=True)
+            _, pi, gi = np.intersect1d(pk, gk, assume_unique=True, return_indices=True)
+            self._matches[n] += int(np.minimum(pc[pi], gc[gi]).sum())
+            self._totals[n] += int(pc.sum())
         if not self._exclude:
-            self._prediction_length += sum(len(r) for r in pred)
-            self._reference_length += sum(len(r) for r in gold)
+            self._prediction_length += pred.size
+            self._reference_length += gold.size
         else:
-            self._prediction_length += sum(1 for r in pred for t in r if t not in self._exclude)
-            self._reference_length += sum(1 for r in gold for t in r if t not in self._exclude)
+            self._prediction_length += int((~np.isin(pred, self._exclude_array)).sum())
+            self._reference_length += int((~np.isin(gold, self._exclude_array)).sum())
 
     def _brevity_penalty(self) -> float:
         if self._prediction_length > self._reference_length:

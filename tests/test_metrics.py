@@ -1,6 +1,7 @@
 """Host-side running metrics (probnmn.running_metrics)."""
 import math
 
+import pytest
 import torch
 
 from probnmn.running_metrics import BLEU, Average, BooleanAccuracy
@@ -30,3 +31,40 @@ def test_average_and_boolean_accuracy():
     acc = BooleanAccuracy()
     acc(torch.tensor([1, 2, 3, 28]), torch.tensor([1, 0, 3, 5]))
     assert acc.get_metric() == 0.5
+
+
+def test_bleu_vectorised_over_the_batch_equals_the_per_row_count():
+    """The metric counts n-grams over whole (batch, length) matrices at once (numpy keys); this restates the count one
+    row and one n-gram at a time, as allennlp 0.9.0's BLEU walks them, on ragged content with excluded indices."""
+    import math
+    from collections import Counter
+
+    def per_row(pred, gold, exclude):
+        m, t = Counter(), Counter()
+
+        def grams(row, n):
+            out = Counter()
+            for i in range(len(row) - n + 1):
+                g = tuple(row[i:i + n])
+                if not any(x in exclude for x in g):
+                    out[g] += 1
+            return out
+        for n in range(1, 5):
+            for p, g in zip(pred, gold):
+                pc, gc = grams(p, n), grams(g, n)
+                m[n] += sum(min(c, gc.get(k, 0)) for k, c in pc.items())
+                t[n] += sum(pc.values())
+        pl = sum(1 for r in pred for x in r if x not in exclude)
+        rl = sum(1 for r in gold for x in r if x not in exclude)
+        bp = 1.0 if pl > rl else (0.0 if rl == 0 or pl == 0 else math.exp(1 - rl / pl))
+        return bp * math.exp(sum(0.25 * (math.log(m[n] + 1e-13) - math.log(t[n] + 1e-13)) for n in range(1, 5)))
+
+    g = torch.Generator().manual_seed(0)
+    for exclude in ({0, 2, 3}, set()):
+        pred = torch.randint(0, 12, (37, 26), generator=g)
+        gold = torch.randint(0, 12, (37, 27), generator=g)
+        pred[:, 20:] = 0
+        b = BLEU(exclude_indices=exclude)
+        b(pred[:20], gold[:20])  # (accumulates over calls)
+        b(pred[20:], gold[20:])
+        assert b.get_metric()["BLEU"] == pytest.approx(per_row(pred.tolist(), gold.tolist(), exclude), abs=1e-12)
