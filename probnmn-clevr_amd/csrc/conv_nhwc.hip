@@ -117,7 +117,6 @@ int launch_segments(const pnmn_conv_item* items, const LaunchPlan& lp, int first
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    static const bool round_robin = getenv("PNMN_CONV_XCD_ROUNDROBIN") != nullptr;  // (tuning hook: the former mapping)
     Segments sg{};
     int wgs = 0;
     for (int k = first; k < last; ++k) {
@@ -127,7 +126,7 @@ int launch_segments(const pnmn_conv_item* items, const LaunchPlan& lp, int first
         sg.split[i] = lp.split[k];
         sg.unit0[i] = unit_at;
         sg.n_units[i] = lp.count[k];
-        sg.per_xcd[i] = round_robin ? 0 : (lp.count[k] + 7) / 8;
+        sg.per_xcd[i] = (lp.count[k] + 7) / 8;
         wgs += ((lp.count[k] + 7) / 8) * 8 * lp.split[k];
         unit_at += lp.count[k];
     }
@@ -146,14 +145,6 @@ inline bool streamed() {
     return on;
 }
 
-// (A/B hook: PNMN_CONV_MERGED=0 issues the segments as separate launches, as rounds 1-2 did)
-inline bool merged_launches() {
-    static const bool merged = [] {
-        const char* e = getenv("PNMN_CONV_MERGED");
-        return !e || atoi(e) != 0;
-    }();
-    return merged;
-}
 
 template <int H, int W, int TH>
 int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride,
@@ -162,17 +153,8 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
     // (the forced split pins the STREAMED kernel's split, whose results do not depend on it; this kernel's K-split
     // changes the summation order, so while the streamed kernel runs the 3x3 convolutions the 1x1 ones keep the plan)
     const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus, false, !streamed());
-    if (merged_launches())
-        return launch_segments<H, W, TH>(items, lp, 0, lp.n_seg, 0, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu,
-                                         stream);
-    int at = 0;
-    for (int k = 0; k < lp.n_seg; ++k) {
-        const int rc = launch_segments<H, W, TH>(items, lp, k, k + 1, at, cin_chunks, ntaps, in_stride, out_stride, cout_blocks,
-                                                 relu, stream);
-        if (rc != 0) return rc;
-        at += lp.count[k] > 0 ? lp.count[k] : 0;
-    }
-    return 0;
+    return launch_segments<H, W, TH>(items, lp, 0, lp.n_seg, 0, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu,
+                                     stream);
 }
 
 // ---- streamed kernel (conv_stream.h): persistent workgroups of 8 contraction waves + 1 loader wave ----
@@ -215,10 +197,12 @@ int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int 
     L.wgs_x = wgs;
     L.total = wgs * cout_blocks;
     L.cin_chunks = cin_chunks, L.ntaps = ntaps, L.in_stride = in_stride, L.out_stride = out_stride, L.relu = relu;
+#ifdef PNMN_STREAM_CYCLES  // (cycle accounting build: make cycles, scripts/r04_cycles.py)
     {
         const char* e = getenv("PNMN_CONV_DBGPTR");
         L.dbg = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr;
     }
+#endif
     int grid = (cus >= 8 && cus <= 256) ? (cus & ~7) : pnmn::default_conv_cus();
     if (grid > L.total) grid = L.total;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pnmn::stream::NTHREADS), G::LDS_BYTES, stream, items, L);
@@ -239,11 +223,7 @@ extern "C" int pnmn_conv_force_split(int split) {
 extern "C" int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks) {
     const int nb = bands_of(H, W);
     if (n_items <= 0 || nb == 0) return 0;
-    if (merged_launches() || streamed()) return 1;
-    const LaunchPlan lp = plan_launch(n_items * nb, cout_blocks, cin_chunks, ntaps);
-    int n = 0;
-    for (int k = 0; k < lp.n_seg; ++k) n += lp.count[k] > 0 ? 1 : 0;
-    return n;
+    return 1;  // (a call's segments go out as one launch, on either kernel)
 }
 
 extern "C" int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W,

@@ -47,27 +47,16 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
                               bool honour_forced = true) {
     if (forced_split() && honour_forced) return LaunchPlan{1, {streamed && forced_split() > 8 ? 8 : forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
-    static const double stage_cost = [] {  // (tuning hook; the default is what measurement picked)
-        const char* e = getenv("PNMN_CONV_STAGE_COST");
-        return e ? atof(e) : 0.5;
-    }();
-    static const int max_seg = [] {  // (A/B hook: 2 = the round-2 planner)
-        const char* e = getenv("PNMN_CONV_MAX_LAUNCHES");
-        const int v = e ? atoi(e) : 3;
-        return v >= 1 && v <= 3 ? v : 3;
-    }();
-    static const double seg_cost = [] {  // a further segment: its workgroups start behind a partly drained round
-        const char* e = getenv("PNMN_CONV_SEG_COST");
-        return e ? atof(e) : 0.3;
-    }();
+    constexpr double stage_cost = 0.5;  // (what measurement picked, rounds 2-3)
+    constexpr int max_seg = 3;
+    constexpr double seg_cost = 0.3;    // a further segment: its workgroups start behind a partly drained round
     const double overhead = streamed ? 0.25 : stage_cost * cin_chunks + 0.25;
     // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
     auto round_cost = [&](int s) {
         if (streamed) return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : 2.0 / 13.0) + overhead;
         return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead;
     };
-    static const int s_max_old = getenv("PNMN_CONV_NO_MSPLIT") ? 8 : 16;  // (A/B hook)
-    const int s_max = streamed ? 8 : s_max_old;
+    const int s_max = streamed ? 8 : 16;
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the

@@ -51,6 +51,14 @@
 #include "../../include/probnmn_hip.h"
 #include "global_ptr.h"
 
+// Cycle accounting (make cycles -> lib/libprobnmn_cycles.so; scripts/r04_cycles.py reads the counters): off in the
+// shipped build -- every stamp is an s_memtime the scalar unit waits for.
+#ifdef PNMN_STREAM_CYCLES
+#define PNMN_CYC() __builtin_readcyclecounter()
+#else
+#define PNMN_CYC() 0ull
+#endif
+
 namespace pnmn {
 namespace stream {
 
@@ -341,9 +349,9 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
     };
     bool unit_end = false;   // the contraction waves stand (or will stand) at the end-of-unit barrier
     unsigned long long lc[4] = {0, 0, 0, 0};  // cycles: issuing, waiting for loads, prologue in place, at barriers
-    unsigned long long lt = __builtin_readcyclecounter();
+    unsigned long long lt = PNMN_CYC();
     auto lap = [&](int k) {
-        const unsigned long long now = __builtin_readcyclecounter();
+        const unsigned long long now = PNMN_CYC();
         lc[k] += now - lt;
         lt = now;
     };
@@ -558,7 +566,7 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
                                          unsigned long long (&cyc)[4]) {
     using G = Geom<H, W, TH>;
     using std::integral_constant;
-    const unsigned long long c_unit = __builtin_readcyclecounter();
+    const unsigned long long c_unit = PNMN_CYC();
     static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
     constexpr int NW = SPLIT == 1 ? 2 : 1;                        // 16-channel output tiles of a wave
     constexpr int MW = SPLIT <= 2 ? 1 : SPLIT / 2;                // waves that share a channel tile's m-tiles
@@ -713,9 +721,9 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < 9 ? tap + 1 : 8) * (TAB_ROWS * 2); };
 
         {
-            const unsigned long long c0 = __builtin_readcyclecounter();
+            const unsigned long long c0 = PNMN_CYC();
             lds_barrier();  // the stage is resident (and the table, on a unit's first stage)
-            cyc[0] += __builtin_readcyclecounter() - c0;
+            cyc[0] += PNMN_CYC() - c0;
         }
 #pragma unroll
         for (int j = 0; j < MTW; ++j) row_fetch(j, lds + tab_lane + t0 * (TAB_ROWS * 2));
@@ -770,16 +778,16 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         stage(I0{});
         if (WSETS == 2 && more) stage(I1{});  // (an odd number of taps per stage: the next one starts on the other set)
     }
-    const unsigned long long c_u = __builtin_readcyclecounter();
+    const unsigned long long c_u = PNMN_CYC();
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
-    const unsigned long long c_e = __builtin_readcyclecounter();
+    const unsigned long long c_e = PNMN_CYC();
     if (exist != 0u) {
 #pragma unroll
         for (int n = 0; n < NW; ++n)
             epilogue<H, W, TH, MTW>(it, acc[n], mbase, n0 + 16 * n, band, L.out_stride, L.relu, lane, bias4[n]);
     }
     Wk.next_unit(L);
-    const unsigned long long c_x = __builtin_readcyclecounter();
+    const unsigned long long c_x = PNMN_CYC();
     cyc[0] += c_e - c_u;
     cyc[1] += c_x - c_e;
     cyc[2] += c_x - c_unit;
@@ -814,7 +822,7 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     }
     int cstart = 0;
     unsigned long long cyc[4] = {0, 0, 0, 0};  // barrier waits, epilogues, units, unit count
-    const unsigned long long c_begin = __builtin_readcyclecounter();
+    const unsigned long long c_begin = PNMN_CYC();
     while (Wk.valid()) {
         // (all uniform over the workgroup)
         if (G::WHOLE && Wk.dil == 8 && Wk.split <= 2) {
@@ -831,7 +839,7 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     }
     if (L.dbg && lane == 0) {
         unsigned long long* d = L.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
-        d[0] = cyc[0], d[1] = cyc[1], d[2] = cyc[2], d[3] = cyc[3], d[4] = __builtin_readcyclecounter() - c_begin;
+        d[0] = cyc[0], d[1] = cyc[1], d[2] = cyc[2], d[3] = cyc[3], d[4] = PNMN_CYC() - c_begin;
     }
 }
 

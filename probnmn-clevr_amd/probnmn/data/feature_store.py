@@ -110,7 +110,7 @@ class PrefetchingLoader:
         self.keep_on_host = set(keep_on_host)
         # (high priority: the ingest is a trickle of long-latency PCIe reads -- or copy-engine transfers -- that must
         # not queue behind the step's thousands of workgroups)
-        self.stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("PNMN_INGEST_PRIORITY", "-1")))
+        self.stream = torch.cuda.Stream(device=device, priority=-1)
         self._buffers = [None, None]  # two image buffers: the one in use and the one being filled
 
     def _stage(self, host_batch, slot: int):

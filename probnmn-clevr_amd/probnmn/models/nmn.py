@@ -8,7 +8,6 @@ return dict.  What differs is how ``forward`` gets there: programs are compiled 
 all module calls of the batch run as grouped kernels, and stem / classifier conv / max-pool are
 part of the same explicit forward+backward schedule (``probnmn.runtime.engine``).
 """
-import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -109,14 +108,11 @@ class _WeightGradOnly(torch.autograd.Function):
         return (dy.t() @ x if ctx.needs_input_grad[0] else None, dy.sum(0) if ctx.needs_input_grad[1] else None, None)
 
 
-_SPLIT_FC_BACKWARD = os.environ.get("PNMN_SPLIT_FC_BACKWARD", "1") != "0"  # (A/B hook)
-
-
 def _first_fc(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     K = layer.in_features
     if (x.is_cuda and x.dim() == 2 and x.is_contiguous() and layer.weight.is_contiguous() and layer.bias is not None
             and K % _SplitKLinear.SLABS == 0 and K >= 8192):
-        if _SPLIT_FC_BACKWARD and torch.is_grad_enabled() and x.requires_grad and layer.weight.requires_grad:
+        if torch.is_grad_enabled() and x.requires_grad and layer.weight.requires_grad:
             # (autograd runs the node created LAST first: the weight-gradient node is made before the product)
             from_weights = _WeightGradOnly.apply(layer.weight, layer.bias, x.detach())
             return _SplitKLinear.apply(x, layer.weight.detach(), layer.bias.detach()) + from_weights

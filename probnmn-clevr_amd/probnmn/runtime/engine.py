@@ -109,12 +109,12 @@ class NMNEngine:
         # data-gradient chain.  Measured on MI355X (B=256): no gain -- a wgrad workgroup holds its CU
         # (151 KiB LDS) for ~400 us and delays the chain's critical path as much as it fills its gaps --
         # so the default is one stream, which also keeps per-kernel profiles clean.
-        self.overlap_wgrad = os.environ.get("PNMN_OVERLAP_WGRAD", "0") == "1"
+        self.overlap_wgrad = False
         self._side_stream: Optional[torch.cuda.Stream] = None
         # launches of a pass are collected and issued by ONE library call (pnmn_run_launches) unless they are
         # being timed one by one (event_log) or spread over two streams (overlap_wgrad)
         self._list: Optional[_hip.LaunchList] = None
-        self.launch_lists = os.environ.get("PNMN_LAUNCH_LISTS", "1") != "0"
+        self.launch_lists = True
         # data parallel: called with k when every kernel that writes gradient piece k of the arena has been
         # queued (see grad_pieces); a trainer points it at its EarlyReducer.piece_ready
         self.on_grad_piece = None
@@ -295,8 +295,7 @@ class NMNEngine:
         self._wt_count = len(wt_items)
         self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
         self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT,
-                                        wgrad_chunk=int(os.environ.get("PNMN_WG_CHUNK", "2" if self.banded else "8")),
-                                        wgrad_groups=int(os.environ.get("PNMN_WG_GROUPS", "1")))
+                                        wgrad_chunk=2 if self.banded else 8, wgrad_groups=1)
 
     # ---- workspaces ---------------------------------------------------------------------------
     def _buf(self, name: str, numel: int) -> torch.Tensor:
@@ -547,7 +546,7 @@ class NMNEngine:
             cfg[0] = (kinds.ctypes.data,) + tuple(a.ctypes.data for a in arrs) + (
                 kinds.size, C, self.H, self.W, self.scheduler.wgrad_chunk, self.scheduler.wgrad_groups,
                 int(self.scheduler.fuse_mask_bwd), int(self.scheduler.sole_writer_rmw),
-                int(not os.environ.get("PNMN_NO_WEIGHT_SORT")), 0)
+                int(self.scheduler.sort_by_weight), 0)
             out = np.zeros(1, np.uint64)
             _hip.check(_hip.lib().pnmn_trunk_planner_create(cfg.ctypes.data, out.ctypes.data), "trunk_planner_create")
             self._planner = int(out[0])

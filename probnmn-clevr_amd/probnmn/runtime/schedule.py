@@ -230,8 +230,9 @@ class BatchScheduler:
         # deferred to ONE gather at the end of the backward pass (default); 1 = both fused into the epilogue (fp32
         # atomics / read-modify-write of the 100 KB d(feats) map per masked conv: data gradients ran ~15 % behind
         # the forward convs); 0 = a separate kernel per level
-        self.fuse_mask_bwd = int(os.environ.get("PNMN_MASK_BWD_MODE", "2"))
-        self.sole_writer_rmw = os.environ.get("PNMN_MB_SOLE", "1") != "0"
+        self.fuse_mask_bwd = 2
+        self.sole_writer_rmw = True
+        self.sort_by_weight = True  # (False: a launch's items in batch order -- tests / HBM-traffic experiments)
         self._tables64 = tuple(np.ascontiguousarray(a, dtype=np.int64)
                                for a in (tables.w3, tables.b3, tables.wt3, tables.dotw, tables.dotb))
         self._tables64_ptrs = tuple(a.ctypes.data for a in self._tables64)
@@ -377,7 +378,7 @@ class BatchScheduler:
             launch's items to the XCDs, so each XCD's L2 holds the one or two weights its items use instead of
             every weight of the level -- 3x less HBM read traffic, scripts/pmc_conv.sh), view as records, cut
             launches"""
-            if wcol is None or os.environ.get("PNMN_NO_WEIGHT_SORT"):  # (the variable: a tuning hook)
+            if wcol is None or not self.sort_by_weight:
                 idx = np.argsort(lv, kind="stable")
             else:
                 idx = np.lexsort((mat[:, wcol], lv))
@@ -603,7 +604,7 @@ class BatchScheduler:
             buf.params, buf.grads, buf.wt, buf.act, buf.gact, buf.feat, buf.gfeat, buf.final, buf.gfinal, buf.ones,
             tables.shape[0], tables.shape[1], nv, cmax, self.hw, self.channels, chunk, self.wgrad_groups,
             int(self.fuse_mask_bwd), int(self.sole_writer_rmw),
-            int(not os.environ.get("PNMN_NO_WEIGHT_SORT")), 0)  # (PNMN_NO_WEIGHT_SORT: a tuning hook)
+            int(self.sort_by_weight), 0)
         _hip.check(_hip.lib().pnmn_plan_batch(rec.ctypes.data, words.ctypes.data, words.size, meta.ctypes.data,
                                               cuts.ctypes.data, cuts.shape[0]), "plan_batch")
         jobs = {}

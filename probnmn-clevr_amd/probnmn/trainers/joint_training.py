@@ -52,7 +52,7 @@ def shared_conv_cus(questions: int, banded: bool) -> int:
 
 
 def stem_waits_for_encoder(questions: int) -> int:
-    """PNMN_STEM_AFTER_ENCODE mode of a step of that many questions: 2 (issued behind the generator's encoder pass and
+    """``stem_after_encode`` mode of a step of that many questions: 2 (issued behind the generator's encoder pass and
     waiting for it on the GPU) from 256 questions on, 0 (first thing in the step) below."""
     return 2 if questions >= 256 else 0
 
@@ -155,7 +155,7 @@ class _TrainerBase(StepBase):
         paired = False
         if n_nosup:
             ques_nosup = question[nosup_d]
-            if n_sup and _PAIR_DECODERS and dev.type == "cuda":
+            if n_sup and dev.type == "cuda":
                 # the generator's sampling decode and its supervised (teacher-forced) decode start from the same encoder
                 # pass and are independent: one launch each way for both -- the persistent decoder kernels are latency
                 # bound, so the supervised pass rides along for free while the sampling pass, which the step's critical
@@ -214,13 +214,6 @@ class _TrainerBase(StepBase):
                                    p.get("pg_sup_rows"), w_nosup, w_sup, alpha, gamma, n, m)
 
 
-#: PNMN_PAIR_DECODERS=0: the generator's sampling and supervised decodes as two launches each way (A/B aid)
-_PAIR_DECODERS = os.environ.get("PNMN_PAIR_DECODERS", "1") != "0"
-
-#: PNMN_FUSED_OBJECTIVE=0: the iteration's scalar end as the chain of torch ops it used to be (A/B aid)
-_FUSED_OBJECTIVE = os.environ.get("PNMN_FUSED_OBJECTIVE", "1") != "0"
-
-
 class QuestionCodingStep(_TrainerBase):
     def __init__(self, program_generator, question_reconstructor, program_prior, objective: str = "ours",
                  alpha: float = 100.0, beta: float = 0.1, delta: float = 0.99, lr: float = 1e-3,
@@ -252,7 +245,7 @@ class QuestionCodingStep(_TrainerBase):
         # synchronised on EVERY rank, whatever this rank's shard holds -- a rank without supervised (or
         # without unsupervised) rows must issue the same sequence of collectives as the others.
         w_sup, w_nosup = _dp_weight(sup.numel(), dev), _dp_weight(nosup.numel(), dev)
-        if _FUSED_OBJECTIVE and ours and dev.type == "cuda" and "qr_rows" in p:
+        if ours and dev.type == "cuda" and "qr_rows" in p:
             loss, stats = self._fused_objective(p, None, w_sup, w_nosup, self.alpha, 0.0)
             if p["n_sup"]:
                 out["loss"] = {k: stats[k] for k in ("program_generation_gt", "question_reconstruction_gt")}
@@ -299,41 +292,39 @@ class JointTrainingStep(_TrainerBase):
         # (round 2 kept batches beyond 320 sampled rows on one stream: "either side fills the chip on its own".  Measured
         # again in round 3, profiles/ab/r04i_ab.txt / r04j_ab.txt, one box each: 512 questions 19.37 -> 17.8-18.9 ms,
         # 768: 25.55 -> 23.8, 1024: 32.3-32.4 -> 30.9-31.1 -- the deep program levels' launches of a few dozen items no
-        # longer have the chip to themselves.  The switch stays for A/B.)
-        self.nmn_stream_max_rows = int(os.environ.get("PNMN_NMN_STREAM_MAX_ROWS", str(1 << 30)))
+        # longer have the chip to themselves.  The attribute stays for A/B.)
+        self.nmn_stream_max_rows = 1 << 30
         # the module programs are scheduled and launched between the reconstructor and the prior pass (the prior then runs
         # beside them) -- up to 511 questions; from 512 on after ALL seq2seq passes are issued: 128 questions 7.20-7.27 ms
         # against 7.28-7.42, 256: equal, 512: 17.92 against 17.80, 1024: 30.96 against 30.48-30.55 (the host's planning
         # of ~500 programs would otherwise hold the prior pass back; profiles/ab/r04k_ab.txt, r04l_ab.txt).
-        # PNMN_TRUNK_BEFORE_PRIOR=0 / 1 fixes it.
-        env = os.environ.get("PNMN_TRUNK_BEFORE_PRIOR")
-        self.trunk_before_prior = None if env is None else env != "0"
+        # (None: by batch size; True / False fixes it.)
+        self.trunk_before_prior = None
         # CUs the trunk's conv launches are cut for while it shares the chip with the seq2seq passes (side stream).  Up to
         # 128 questions: what their multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU: 224 at 64
         # questions (5.43-5.54 ms against 5.58-5.64 at 256), 192 at 128 (7.06-7.14 against 7.37-7.42; best of 160-256;
         # profiles/ab/r03x_ab.txt, r03z_ab.txt).  Beyond: the whole chip -- the multi-CU kernels then take (nearly) all of
         # it whenever they run, and the convs run between them: 256 questions 10.28-10.38 ms at 256 against 10.53-10.56 at
         # 192, 512: 17.8-18.9 / 18.5, 1024: 31.0-31.1 against 31.4-31.5 at 224 and 31.8 at 208 (profiles/ab/r04j_ab.txt).
-        # PNMN_SHARED_CONV_CUS fixes it.
-        self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))
+        # (0: by batch size; a number fixes it.)
+        self.shared_conv_cus = 0
         # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
         # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, profiles/ab/r04a_ab.txt)
-        self.shared_wgrad_cus = int(os.environ.get("PNMN_SHARED_WGRAD_CUS", "0"))
+        self.shared_wgrad_cus = 0
         # When the stem (side stream) goes out.  0: first thing in the step (it then never waits for anything) -- below 256
         # questions.  2: issued behind the generator's encoder pass AND made to wait for it on the GPU -- from 256 questions
         # on: the encoder's multi-CU kernels otherwise become resident one workgroup at a time behind the stem's 1 ms conv
         # workgroups (encoder 0.9 -> 3.2 ms beside the stem at 1024 questions), and the sampled programs the module
         # programs wait for arrive that much later: 30.77-30.82 -> 30.43-30.49 ms, 512 questions 17.66 -> 17.31, 256: 10.30 -> 10.07
         # (profiles/ab/r04t_ab.txt, r04u_ab.txt; 128 questions: no difference).  1: issued behind the encoder pass without the wait (measured at 128 questions, r03f_ab.txt:
-        # 7.85-7.89 against 7.83-7.92 ms, and at 1024: 30.78-30.96 -- no difference).  PNMN_STEM_AFTER_ENCODE fixes it.
-        env = os.environ.get("PNMN_STEM_AFTER_ENCODE")
-        self.stem_after_encode = None if env is None else int(env)
+        # 7.85-7.89 against 7.83-7.92 ms, and at 1024: 30.78-30.96 -- no difference).  (None: by batch size.)
+        self.stem_after_encode = None
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
         if self._side is None or self._side.device != dev:
-            # (PNMN_NMN_STREAM_PRIORITY: -1 = high; A/B hook)
-            self._side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("PNMN_NMN_STREAM_PRIORITY", "0")))
+            # (a high-priority stream was measured: no effect, profiles/ab/r04m_ab.txt)
+            self._side = torch.cuda.Stream(device=dev)
         return self._side
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
@@ -428,7 +419,7 @@ class JointTrainingStep(_TrainerBase):
                 copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
                 self.blocked_seconds += time.perf_counter() - t0
                 nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
-            if _FUSED_OBJECTIVE and ours and dev.type == "cuda":
+            if ours and dev.type == "cuda":
                 loss, stats = self._fused_objective(p, nmn_out["loss"], w_sup, w_nosup, self.alpha, self.gamma)
                 _hip.mark("objective combined")
                 out["loss"]["nmn"] = stats["nmn_loss"]

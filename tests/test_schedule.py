@@ -148,5 +148,5 @@ def test_library_planner_equals_the_numpy_planner(monkeypatch):
     s.sole_writer_rmw = True
     s.wgrad_groups, s.wgrad_chunk = 3, 2
     _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
-    monkeypatch.setenv("PNMN_NO_WEIGHT_SORT", "1")
+    s.sort_by_weight = False
     _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
