@@ -90,6 +90,101 @@ class PinnedFeatureStore:
         return out
 
 
+class ResidentRows:
+    """A batch of rows of a :class:`DeviceFeatureStore`: no data of its own -- the store and the HOST indices.  The NMN
+    takes it where it takes an ``image`` tensor (``nmn(batch["image"], programs, answers)``); ``subset(rows)`` is what
+    ``image[rows]`` is for a tensor."""
+
+    def __init__(self, store: "DeviceFeatureStore", index):
+        self.store = store
+        self.index = np.ascontiguousarray(torch.as_tensor(index).to(torch.long).numpy() if not isinstance(index, np.ndarray)
+                                          else index, dtype=np.int64)
+        if self.index.ndim != 1:
+            raise ValueError("a batch of rows takes a 1-d index")
+        if self.index.size and (int(self.index.min()) < 0 or int(self.index.max()) >= len(store)):
+            raise IndexError("feature index out of range [0, %d)" % len(store))
+
+    @property
+    def device(self) -> torch.device:
+        return self.store.device
+
+    @property
+    def shape(self):
+        return (int(self.index.size),) + tuple(self.store.image_feature_size)
+
+    def size(self, d: Optional[int] = None):
+        return self.shape if d is None else self.shape[d]
+
+    def subset(self, rows) -> "ResidentRows":
+        rows = torch.as_tensor(rows).cpu().numpy() if not isinstance(rows, np.ndarray) else rows
+        return ResidentRows(self.store, self.index[rows])
+
+    def pointers(self) -> np.ndarray:
+        """Device address of every row's [H*W][C] map (int64, host)."""
+        return self.store.data_ptr() + self.index * np.int64(self.store.row_bytes)
+
+    def materialize(self) -> torch.Tensor:
+        """The rows as an ordinary (n, C, H, W) ``channels_last`` tensor (a gathered copy: tests, evaluation code that
+        wants a tensor)."""
+        idx = torch.from_numpy(self.index).to(self.store.device)
+        return self.store.rows[idx].permute(0, 3, 1, 2)
+
+
+class DeviceFeatureStore:
+    """ALL features once in HBM, in the layout the stem reads (NHWC: ``rows[N][H][W][C]`` fp32).  70 000 CLEVR train
+    images x 0.8 MB = 56.2 GB at 14x14 (15 000 val images: 12 GB) of the 288 GB of an MI355X; 28x28 maps: 225 GB -- the
+    train set alone still fits.  A step then moves NO feature bytes over PCIe and runs no gather or layout pass: the
+    first stem convolution and its weight gradient take per-example pointers (``pnmn_conv_item.in`` /
+    ``pnmn_wgrad_item.x``), which point straight at the selected rows (:class:`ResidentRows`).  What does not fit keeps
+    the pinned host store (:class:`PinnedFeatureStore`) and its gather kernel.  The reference re-reads float64 rows
+    from HDF5 per item (probnmn/data/readers.py:63-108, datasets.py:137-142).
+
+    Filled in chunks from any array-like (float32 / float64, (N, C, H, W)): a chunk goes through a page-locked staging
+    buffer and the ingest kernel, which writes the NHWC rows."""
+
+    def __init__(self, features, device: torch.device, chunk_rows: int = 512):
+        shape = tuple(int(d) for d in features.shape)
+        if len(shape) != 4:
+            raise ValueError("features must be (N, C, H, W), got %s" % (shape,))
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _hip.HipLibraryError("the resident feature store lives on a ROCm device, got %s" % device)
+        N, C, H, W = shape
+        self.shape, self.device = shape, device
+        self.row_bytes = C * H * W * 4
+        free, _ = torch.cuda.mem_get_info(device)
+        if N * self.row_bytes > free:
+            raise MemoryError("%d rows x %.1f MB = %.1f GB do not fit the %.1f GB free on %s: use PinnedFeatureStore"
+                              % (N, self.row_bytes / 1e6, N * self.row_bytes / 1e9, free / 1e9, device))
+        self.rows = torch.empty((N, H, W, C), dtype=torch.float32, device=device)
+        chunk_rows = max(1, min(chunk_rows, N))
+        stage = torch.empty((chunk_rows, C, H, W), dtype=torch.float32).pin_memory()
+        view = stage.numpy()
+        st = _hip.stream_ptr(device)
+        for lo in range(0, N, chunk_rows):
+            hi = min(N, lo + chunk_rows)
+            torch.cuda.current_stream(device).synchronize()  # (the staging buffer is reused)
+            view[: hi - lo] = np.asarray(features[lo:hi], dtype=np.float32)
+            idx = _hip.small_to_device(list(range(hi - lo)), torch.long, device) if hi - lo <= 4096 else \
+                torch.arange(hi - lo, device=device)
+            _hip.check(_hip.lib().pnmn_gather_features(stage.data_ptr(), idx.data_ptr(), self.rows[lo:hi].data_ptr(), hi - lo,
+                                                       chunk_rows, C, H * W, st), "gather_features")
+        torch.cuda.current_stream(device).synchronize()
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    @property
+    def image_feature_size(self):
+        return self.shape[1:]
+
+    def data_ptr(self) -> int:
+        return self.rows.data_ptr()
+
+    def batch(self, indices) -> ResidentRows:
+        return ResidentRows(self, indices)
+
+
 class PrefetchingLoader:
     """Wraps an iterable of host-side batches ``{"image_index": LongTensor[B], ...other CPU tensors}`` and
     yields device batches with ``"image"`` filled from the store, one batch ahead: while the trainer works
@@ -103,8 +198,10 @@ class PrefetchingLoader:
         the stem uses in place (``PinnedFeatureStore.gather``); "dma": one copy-engine transfer per row into a plain
         NCHW batch (``copy_rows``).  Measured beside the 1024-question joint step (bench.py: joint_training_ingest):
         39.5 ms per step with the kernel, 51.4 with the copy engines, 32.4 with resident features."""
-        if method not in ("dma", "kernel"):
-            raise ValueError("method must be 'dma' or 'kernel'")
+        if isinstance(store, DeviceFeatureStore):
+            method = "resident"  # (no feature bytes move: a batch's "image" is a ResidentRows)
+        if method not in ("dma", "kernel", "resident"):
+            raise ValueError("method must be 'dma', 'kernel' or 'resident'")
         self.method = method
         self.batches, self.store, self.device = batches, store, device
         self.keep_on_host = set(keep_on_host)
@@ -118,7 +215,7 @@ class PrefetchingLoader:
         n = int(idx.numel())
         C, H, W = self.store.image_feature_size
         buf = self._buffers[slot]
-        if buf is None or buf.size(0) < n:
+        if self.method != "resident" and (buf is None or buf.size(0) < n):
             fmt = torch.channels_last if self.method == "kernel" else torch.contiguous_format
             buf = torch.empty((n, C, H, W), dtype=torch.float32, device=self.device, memory_format=fmt)
             self._buffers[slot] = buf
@@ -129,7 +226,9 @@ class PrefetchingLoader:
             # (measured: the ingest-fed 1024-question step 40.3 ms instead of 32.4 + nothing)
             out = {k: (v if k in self.keep_on_host else self._upload(v))
                    for k, v in host_batch.items() if k != "image_index"}
-            if self.method == "kernel":
+            if self.method == "resident":
+                out["image"] = self.store.batch(idx)
+            elif self.method == "kernel":
                 out["image"] = self.store.gather(idx, self.device, out=buf[:n])
             else:
                 out["image"] = self.store.copy_rows(idx, self.device, out=buf[:n])

@@ -74,7 +74,7 @@ class _NativePlan:
 
 
 class _State:
-    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows")
+    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows", "step_pack")
 
 
 class NMNEngine:
@@ -306,12 +306,14 @@ class NMNEngine:
             self._ws[name] = t
         return t
 
-    def _fixed_records(self, B: int, ws: Dict[str, torch.Tensor]) -> Dict[str, np.ndarray]:
-        """Work lists of the stem and classifier convs: depend only on B and buffer addresses."""
+    def _fixed_records(self, B: int, ws: Dict[str, torch.Tensor], xin_ptrs: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+        """Work lists of the stem and classifier convs: depend only on B and buffer addresses.  ``xin_ptrs``: the input
+        maps are rows of a resident feature store (one device address per example, other rows every step): the cached
+        lists are completed with them for the two kernels that read the input, stem conv1 and its weight gradient."""
         key = (B, self.conv_cus) + tuple(ws[k].data_ptr() for k in sorted(ws))
         hit = self._fixed_cache.get(key)
         if hit is not None:
-            return hit
+            return self._with_inputs(hit, xin_ptrs)
         a = self.arena
         HW = self.HW
         e = np.arange(B, dtype=np.int64)
@@ -359,7 +361,8 @@ class NMNEngine:
             j["item_begin"], j["item_end"] = starts, np.minimum(starts + chunk, B)
             return j
 
-        xin, s1, s2 = ws["xin"].data_ptr(), ws["stem1"].data_ptr(), ws["feat"].data_ptr()
+        xin = ws["xin"].data_ptr() if "xin" in ws else 0  # (0: resident rows, filled in per step by _with_inputs)
+        s1, s2 = ws["stem1"].data_ptr(), ws["feat"].data_ptr()
         gs1, gs2 = ws["gstem1"].data_ptr(), ws["gfeat"].data_ptr()
         fin, gfin = ws["final"].data_ptr(), ws["gfinal"].data_ptr()
         cls, gcls = ws["cls"].data_ptr(), ws["gcls"].data_ptr()
@@ -378,6 +381,17 @@ class NMNEngine:
             "stem1_wg_jobs": jobs(go("stem.0.weight"), go("stem.0.bias"), 2 * self.cin // C),
         }
         self._fixed_cache[key] = out
+        return self._with_inputs(out, xin_ptrs)
+
+    @staticmethod
+    def _with_inputs(fixed: Dict[str, np.ndarray], xin_ptrs: Optional[np.ndarray]) -> Dict[str, np.ndarray]:
+        if xin_ptrs is None:
+            return fixed
+        out = dict(fixed)
+        out["stem1"] = fixed["stem1"].copy()
+        out["stem1"]["in"] = xin_ptrs
+        out["stem1_wg"] = fixed["stem1_wg"].copy()
+        out["stem1_wg"]["x"] = xin_ptrs
         return out
 
     # ---- forward --------------------------------------------------------------------------------
@@ -394,6 +408,11 @@ class NMNEngine:
         dev = a.device
         if features.device != dev:
             raise _hip.HipLibraryError("features on %s but the network is on %s" % (features.device, dev))
+        from probnmn.data.feature_store import ResidentRows
+
+        resident = isinstance(features, ResidentRows)
+        if resident and rows is not None:
+            raise ValueError("rows of a resident batch: pass features.subset(rows) instead")
         B = features.size(0) if rows is None else int(rows.numel())
         if rows is not None and (rows.dtype != torch.long or rows.device != dev or not rows.is_contiguous()):
             raise ValueError("rows must be a contiguous int64 tensor on the network's device")
@@ -401,8 +420,10 @@ class NMNEngine:
             raise ValueError("expected features (B,%d,%d,%d), got %s" % (self.cin, self.H, self.W, tuple(features.shape)))
         # features already in the kernels' layout (a `channels_last` tensor, e.g. from
         # probnmn.data.feature_store: the ingest kernel writes NHWC): used in place, no layout pass
-        nhwc = (features.dtype == torch.float32 and not features.is_contiguous()
-                and features.is_contiguous(memory_format=torch.channels_last))
+        # ... or rows of a feature store that lives in HBM in that layout (DeviceFeatureStore): nothing is gathered or
+        # copied, stem conv1 and its weight gradient get one pointer per example
+        nhwc = resident or (features.dtype == torch.float32 and not features.is_contiguous()
+                            and features.is_contiguous(memory_format=torch.channels_last))
         subset = rows is not None
         if nhwc and rows is not None:  # (a row subset of an NHWC batch: gather it, the layout pass is what reads through rows)
             features, rows = features[rows], None
@@ -421,12 +442,12 @@ class NMNEngine:
         if nhwc:
             names, sizes = names[1:], sizes[1:]
         ws = {n: self._buf(n, s) for n, s in zip(names, sizes)}
-        if nhwc:
+        if nhwc and not resident:
             ws["xin"] = features.permute(0, 2, 3, 1).reshape(-1)  # a view of the caller's storage
         if not need_backward:  # records still reference gradient buffers; point them somewhere valid
             for n in ("gstem1", "gfeat", "gfinal", "gcls"):
                 ws[n] = ws["stem1"]
-        fixed = self._fixed_records(B, ws)
+        fixed = self._fixed_records(B, ws, features.pointers() if resident else None)
         pack = _Pack()
         for k in ("stem1", "stem2"):
             pack.add(k, fixed[k])
@@ -440,7 +461,7 @@ class NMNEngine:
         self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2", rec=fixed["stem2"])
         self._flush_list(st, "stem", end=True)
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
-                "features": features, "pack": pack, "rows": rows, "subset": subset}
+                "features": features, "pack": pack, "rows": rows, "subset": subset, "resident": resident}
 
     def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
                     started=None):
@@ -627,6 +648,12 @@ class NMNEngine:
         st = _hip.stream_ptr(dev)
         planner = self._native_planner()
         rows = self._native_fixed_rows(B, ws, fixed, dev)
+        step_pack = None
+        if started.get("resident"):  # (the stem weight gradient's items name this step's rows: uploaded per step)
+            step_pack = _Pack()
+            step_pack.add("stem1_wg", fixed["stem1_wg"])
+            step_pack.upload(dev)
+            rows["bwd_tail"][2, 0] = step_pack.ptr("stem1_wg")
         H, W, HW = self.H, self.W, self.HW
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
         rows["fwd_tail"][1, 1] = pooled.data_ptr()
@@ -660,6 +687,7 @@ class NMNEngine:
             state = _State()
             state.plan, state.pack, state.fixed, state.B = self.last_plan, rows["pack"], fixed, B
             state.features = started["features"]  # (the stem's weight gradient reads the input again)
+            state.step_pack = step_pack
             state.generation = self.generation
             n = int(out["n_bwd"])
             state.backward_rows = (self._planner_bwd[:n].copy(), int(out["bwd_piece_cut"]), rows["dpooled_row"])

@@ -63,6 +63,16 @@ def trunk_before_prior(questions: int) -> bool:
     return questions < 512
 
 
+def _image_rows(images, rows_host, rows_dev):
+    """(features, device row index) of a row subset of a batch's images: a tensor is read THROUGH the index by the
+    layout kernel; rows of a resident feature store are named by their host indices (no device index needed)."""
+    from probnmn.data.feature_store import ResidentRows
+
+    if isinstance(images, ResidentRows):
+        return images.subset(rows_host), None
+    return images, rows_dev
+
+
 class _TrainerBase(StepBase):
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
@@ -369,7 +379,7 @@ class JointTrainingStep(_TrainerBase):
                 # kernels that each wait for their own not-yet-resident workgroups can starve each other of
                 # CUs forever (that is what stalled the side-stream experiment of round 1).
                 side.wait_stream(main)  # the batch and the index tensors were produced on the main stream
-                images = batch["image"]
+                images, rows_d = _image_rows(batch["image"], nosup, nosup_d)
                 token = {}
 
                 stem_mode = (self.stem_after_encode if self.stem_after_encode is not None
@@ -381,7 +391,7 @@ class JointTrainingStep(_TrainerBase):
                     with torch.cuda.stream(side):
                         # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
                         # layout kernel: no gathered copy)
-                        token["started"] = self.nmn.begin(images, rows=nosup_d)
+                        token["started"] = self.nmn.begin(images, rows=rows_d)
 
                 if not stem_mode:
                     launch_stem()
@@ -395,7 +405,7 @@ class JointTrainingStep(_TrainerBase):
                     t0 = time.perf_counter()
                     copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
                     self.blocked_seconds += time.perf_counter() - t0
-                    return self.nmn.forward_trunk(images, host, started=token["started"], trunk_stream=side, rows=nosup_d)
+                    return self.nmn.forward_trunk(images, host, started=token["started"], trunk_stream=side, rows=rows_d)
 
                 before_prior = (self.trunk_before_prior if self.trunk_before_prior is not None
                                 else trunk_before_prior(int(batch["question"].size(0))))
@@ -405,11 +415,11 @@ class JointTrainingStep(_TrainerBase):
                                          after_encode=launch_stem if stem_mode else None)
                 started = token["started"]
             else:
-                images = batch["image"]
+                images, rows_d = _image_rows(batch["image"], nosup, nosup_d)
                 # one stream: the stem is queued right behind the sampling decode and keeps the GPU busy
                 # (with the reconstructor / prior passes) while the host schedules the sampled programs
                 p = self._seq2seq_passes(batch, sup_d, nosup_d, supervised=ours, sampled=True, prior=ours,
-                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images, rows=nosup_d))
+                                         reconstruct=ours, host_programs=True, after_sampling=lambda: self.nmn.begin(images, rows=rows_d))
                 started = p["after_sampling"]
             if "before_prior" in p:
                 nmn_out = self.nmn.forward_head(p["before_prior"], answers)
@@ -418,7 +428,7 @@ class JointTrainingStep(_TrainerBase):
                 t0 = time.perf_counter()
                 copied.synchronize()  # waits for the sampling decode only, not for the work queued after it
                 self.blocked_seconds += time.perf_counter() - t0
-                nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=nosup_d)
+                nmn_out = self.nmn(images, programs_host, answers, started=started, trunk_stream=side, rows=rows_d)
             if ours and dev.type == "cuda":
                 loss, stats = self._fused_objective(p, nmn_out["loss"], w_sup, w_nosup, self.alpha, self.gamma)
                 _hip.mark("objective combined")

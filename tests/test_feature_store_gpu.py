@@ -93,3 +93,67 @@ def test_copy_rows_rejects_an_index_outside_the_store():
         store.copy_rows(torch.tensor([0, 4]), DEV)
     got = store.copy_rows(torch.tensor([3, 0, 3]), DEV)
     assert tuple(got.shape) == (3, 8, 2, 2) and got.is_contiguous()
+
+
+def test_resident_store_feeds_the_network_without_a_copy():
+    """DeviceFeatureStore: all rows in HBM in the stem's NHWC layout; a batch is (store, host indices) and the stem conv1 /
+    stem weight-gradient records point straight at the selected rows.  Exactness: the resident rows equal host indexing
+    bit for bit; a module-training step and a joint-training step fed with ``store.batch(idx)`` give the SAME losses
+    (bit-equal forward) and gradients (up to the order of the weight gradients' atomic adds) as the steps fed with the
+    gathered tensor -- with repeated and out-of-order indices, and a subset taken by the joint step."""
+    from probnmn.data.feature_store import DeviceFeatureStore, ResidentRows
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import NeuralModuleNetwork, ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import JointTrainingStep
+    from probnmn.trainers.module_training import ModuleTrainingStep
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.relu(torch.randn(23, 1024, 14, 14, generator=g))
+    store = DeviceFeatureStore(feats.numpy(), dev, chunk_rows=7)  # (several chunks, a ragged last one)
+    idx = torch.tensor([3, 22, 3, 0, 17, 9, 9, 21, 1, 14, 6, 2])
+    rows = store.batch(idx)
+    assert isinstance(rows, ResidentRows) and rows.shape == (12, 1024, 14, 14)
+    assert torch.equal(rows.materialize().cpu(), feats[idx])
+    with pytest.raises(IndexError):
+        store.batch(torch.tensor([0, 23]))
+
+    batch = synthetic_batch(vocab, 12, seed=8)
+    batch["image"] = feats[idx]
+
+    def module_step(image):
+        torch.manual_seed(0)
+        net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
+        step = ModuleTrainingStep(net, lr=1e-4, report_metrics=False)
+        b = {k: (v.to(dev) if k != "program" else v) for k, v in batch.items() if k != "image"}
+        b["image"] = image
+        out = step.step(b)
+        torch.cuda.synchronize()
+        return out["loss"].detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    loss_t, grads_t = module_step(batch["image"].to(dev))
+    loss_r, grads_r = module_step(rows)
+    assert torch.equal(loss_t, loss_r)
+    for k in grads_t:
+        assert float((grads_t[k] - grads_r[k]).abs().max()) <= 1e-4 * (float(grads_t[k].abs().max()) + 1e-12), k
+
+    def joint_step(image):
+        torch.manual_seed(1)
+        pg, qr = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev)
+        prior = ProgramPrior(vocab, hidden_size=256).to(dev)
+        net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
+        step = JointTrainingStep(pg, qr, prior, net, objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=1e-4)
+        b = {k: v.to(dev) for k, v in batch.items() if k != "image"}
+        b["supervision"] = batch["supervision"]
+        b["image"] = image
+        out = step.step(b)
+        torch.cuda.synchronize()
+        return float(out["objective"]), out["programs"].cpu(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    obj_t, z_t, g_t = joint_step(batch["image"].to(dev))
+    obj_r, z_r, g_r = joint_step(rows)
+    assert torch.equal(z_t, z_r) and obj_t == obj_r
+    for k in g_t:
+        assert float((g_t[k] - g_r[k]).abs().max()) <= 1e-4 * (float(g_t[k].abs().max()) + 1e-12), k
