@@ -470,10 +470,73 @@ static int pool_band(int H, int W) {
     return rb;
 }
 
+// Backward of the ReLU-gated 2x2 max-pool for EVEN maps (14x14, 28x28 -- every shape the engine runs): only the pooled
+// gradient -- a quarter of the bytes, and the one operand whose layout ([channel][position], NCHW-flatten order) does not
+// match the NHWC maps -- goes through LDS; a thread takes one 2x2 window x 4 channels, reads its four input pieces
+// straight from global memory (16 lanes = 256 contiguous bytes of a pixel), picks the first maximum per channel and
+// writes the four gradient pieces.  (The kernel above staged the INPUT: ~3 scalar LDS accesses per element, 0.50 of the
+// HBM peak; bench.py: hbm_bound_kernels.)
+__global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                              float* __restrict__ din, int H, int W, int Cn, int PRB) {
+    extern __shared__ float gt[];  // [pooled positions of the band][65]
+    const int n = blockIdx.y, c0 = blockIdx.x * 64;
+    const int PH = H / 2, PW = W / 2, PS = PH * PW;
+    const int pr0 = blockIdx.z * PRB;                              // first pooled row of the band
+    const int prn = PH - pr0 < PRB ? PH - pr0 : PRB;
+    const int BS = prn * PW;
+    const pnmn::gfloat* g = pnmn::as_global(dout) + ((size_t)n * Cn + c0) * PS + (size_t)pr0 * PW;
+    copy_batched(64 * BS, [&](int i) { const int c = i / BS; return g[(size_t)c * PS + (i - c * BS)]; },
+                 [&](int i, float v) { const int c = i / BS; gt[(i - c * BS) * 65 + c] = v; });
+    __syncthreads();
+    const pnmn::gfloat* src = pnmn::as_global(in) + (size_t)n * H * W * Cn + c0;
+    pnmn::gfloat* dst = pnmn::as_global(din) + (size_t)n * H * W * Cn + c0;
+    constexpr int NB = 2;  // windows in flight per thread (8 pieces of 16 bytes)
+    for (int i0 = threadIdx.x; i0 < BS * 16; i0 += 256 * NB) {
+        f32x4 v[NB][4];
+        size_t at[NB][4];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = i0 + k * 256 < BS * 16 ? i0 + k * 256 : BS * 16 - 1;
+            const int s = i >> 4, c = 4 * (i & 15);
+            const int y = (pr0 + s / PW) * 2, x = (s % PW) * 2;
+            at[k][0] = ((size_t)y * W + x) * Cn + c, at[k][1] = at[k][0] + Cn;
+            at[k][2] = at[k][0] + (size_t)W * Cn, at[k][3] = at[k][2] + Cn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k][q] = pnmn::load4(src + at[k][q]);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = i0 + k * 256;
+            if (i >= BS * 16) continue;
+            const int s = i >> 4, c = 4 * (i & 15);
+            f32x4 o[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float best = v[k][0][e];
+                int bi = 0;
+#pragma unroll
+                for (int q = 1; q < 4; ++q)
+                    if (v[k][q][e] > best) best = v[k][q][e], bi = q;
+                const float gv = best > 0.f ? gt[s * 65 + c + e] : 0.f;  // ReLU gate of the conv output
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q][e] = (q == bi) ? gv : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pnmn::store4(dst + at[k][q], o[q]);
+        }
+    }
+}
+
 template <bool BWD>
 static int launch_pool(const float* in, const float* dout, float* out, int n, int H, int W, int Cn, void* stream) {
     if (n <= 0) return 0;
     if (!in || !out || (BWD && !dout) || (Cn % 64) != 0 || H < 2 || W < 2) return PNMN_EINVAL;
+    if (BWD && (H % 2) == 0 && (W % 2) == 0) {
+        const int PRB = (H / 2) * (W / 2) <= 64 ? H / 2 : 7;  // pooled rows per workgroup: 14x14 all 7, 28x28 two bands of 7
+        hipLaunchKernelGGL(maxpool_bwd_even_kernel, dim3(Cn / 64, n, (H / 2 + PRB - 1) / PRB), dim3(256),
+                           (size_t)PRB * (W / 2) * 65 * sizeof(float), STREAM(stream), in, dout, out, H, W, Cn, PRB);
+        return last_error();
+    }
     const int RB = pool_band(H, W);
     const size_t lds = (size_t)RB * W * 65 * sizeof(float);
     if (lds > 160 * 1024) return PNMN_ESHAPE;

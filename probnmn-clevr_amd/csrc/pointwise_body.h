@@ -209,14 +209,52 @@ __device__ __forceinline__ void same_bwd(const pnmn_same_item& it, int HW, float
 template <int NT>
 __device__ __forceinline__ void minmax_fwd(const pnmn_minmax_item& it, int HW) {
     const int oc = it.a_channels > it.b_channels ? it.a_channels : it.b_channels;
+    // torch.min/max propagate NaN; fminf/fmaxf would not
+    auto pick = [&](float a, float b) { return (a != a || b != b) ? NAN : (it.is_max ? (a > b ? a : b) : (a < b ? a : b)); };
+    if (oc == C) {
+        // a 128-channel result: 16 bytes per thread, eight of them requested before the first is used (the first version
+        // -- one float and one integer division per element -- ran at half the HBM rate)
+        constexpr int NB = 7;  // (196 pixels x 32 pieces = 24.5 per thread of 256: 3.5 rounds of 7)
+        const int n4 = HW * (C / 4);
+        const gfloat* ga = as_global(it.a);
+        const gfloat* gb = as_global(it.b);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += NT * NB) {
+            f32x4 a[NB], b[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = i0 + k * NT;
+                if (i >= n4) continue;
+                const int p = i >> 5, c = (i & 31) * 4;
+                if (it.a_channels == 1) {
+                    const float v = ga[p];
+                    a[k] = f32x4{v, v, v, v};
+                } else {
+                    a[k] = load4(ga + (size_t)p * C + c);
+                }
+                if (it.b_channels == 1) {
+                    const float v = gb[p];
+                    b[k] = f32x4{v, v, v, v};
+                } else {
+                    b[k] = load4(gb + (size_t)p * C + c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = i0 + k * NT;
+                if (i < n4)
+                    store4(as_global(it.out) + (size_t)i * 4,
+                           f32x4{pick(a[k].x, b[k].x), pick(a[k].y, b[k].y), pick(a[k].z, b[k].z), pick(a[k].w, b[k].w)});
+            }
+        }
+        return;
+    }
     const int n = HW * oc;
     for (int i = threadIdx.x; i < n; i += NT) {
         const int p = i / oc;
         const int c = i - p * oc;
         const float a = it.a[it.a_channels == 1 ? p : p * C + c];
         const float b = it.b[it.b_channels == 1 ? p : p * C + c];
-        // torch.min/max propagate NaN; fminf/fmaxf would not
-        it.out[i] = (a != a || b != b) ? NAN : (it.is_max ? (a > b ? a : b) : (a < b ? a : b));
+        it.out[i] = pick(a, b);
     }
 }
 
