@@ -313,8 +313,21 @@ __device__ __forceinline__ void fill_table(char* lds, int band, int dil, int npa
     }
 }
 
+// Start-up work every wave shares: the zero rows of every slot (no load ever writes them) and the row table of the first
+// unit (later geometries are the loaders', behind a unit's end).  Ends at the workgroup's first barrier.
+template <int H, int W, int TH>
+__device__ __forceinline__ void start_up(char* lds, const Walker<H, W, TH>& first, int ntaps, int wave, int lane) {
+    using G = Geom<H, W, TH>;
+    for (int t = wave * 64 + lane; t < G::RING * 64; t += NTHREADS) {  // (8 rows x 64 bytes per sub-slot: 32 lanes each)
+        const int sl = t >> 6, kb = (t >> 5) & 1;
+        *reinterpret_cast<f32x4*>(lds + sl * G::SLOT_BYTES + kb * G::SUB_BYTES + G::Z0 * 64 + (t & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (first.valid()) fill_table<H, W, TH>(lds, first.band, first.dil, first.npass, ntaps, lane, wave, NTHREADS / 64);
+    lds_barrier();
+}
+
 template <int H, int W, int TH, int LW>
-__device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane, int tab_band, int tab_dil) {
+__device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* items, char* lds, int lane) {
     using G = Geom<H, W, TH>;
     // direct-to-LDS loads of THIS wave per slot.  (One loader wave could not feed the ring: a wave keeps few such loads
     // in flight -- 250-650 cycles per load at the issue, measured -- so four of them, one per SIMD, take every fourth
@@ -370,7 +383,10 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
                             C.re, C.slots == 2, lane);
         lap(2);
     };
+    // the first stage is requested BEFORE the start-up work: zero rows and table are written while it travels
     top_up(P.valid() ? P.slots : 0);
+    int tab_band = C.valid() ? C.band : -1, tab_dil = C.valid() ? C.dil : -1;
+    start_up<H, W, TH>(lds, C, L.ntaps, LOADER_WAVE + LW, lane);
     lap(0);
     bool prepared = false;
     while (C.valid()) {
@@ -800,26 +816,18 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    // the zero rows of every slot (no load ever writes them)
-    for (int t = tid; t < G::RING * 64; t += NTHREADS) {  // (8 rows x 64 bytes per sub-slot: 32 lanes each)
-        const int sl = t >> 6, kb = (t >> 5) & 1;
-        *reinterpret_cast<f32x4*>(lds + sl * G::SLOT_BYTES + kb * G::SUB_BYTES + G::Z0 * 64 + (t & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    Walker<H, W, TH> Wk;
-    Wk.start(L, items);
-    // the row table of the first unit, by all five waves (later geometries are the loader's, behind a unit's end)
-    if (Wk.valid()) fill_table<H, W, TH>(lds, Wk.band, Wk.dil, Wk.npass, L.ntaps, lane, wave, NTHREADS / 64);
-    __syncthreads();
     if (wave >= LOADER_WAVE) {
-        const int tb = Wk.valid() ? Wk.band : -1, td = Wk.valid() ? Wk.dil : -1;
         switch (wave - LOADER_WAVE) {
-            case 0: loader<H, W, TH, 0>(L, items, lds, lane, tb, td); break;
-            case 1: loader<H, W, TH, 1>(L, items, lds, lane, tb, td); break;
-            case 2: loader<H, W, TH, 2>(L, items, lds, lane, tb, td); break;
-            default: loader<H, W, TH, 3>(L, items, lds, lane, tb, td); break;
+            case 0: loader<H, W, TH, 0>(L, items, lds, lane); break;
+            case 1: loader<H, W, TH, 1>(L, items, lds, lane); break;
+            case 2: loader<H, W, TH, 2>(L, items, lds, lane); break;
+            default: loader<H, W, TH, 3>(L, items, lds, lane); break;
         }
         return;
     }
+    Walker<H, W, TH> Wk;
+    Wk.start(L, items);
+    start_up<H, W, TH>(lds, Wk, L.ntaps, wave, lane);
     int cstart = 0;
     unsigned long long cyc[4] = {0, 0, 0, 0};  // barrier waits, epilogues, units, unit count
     const unsigned long long c_begin = PNMN_CYC();
