@@ -305,6 +305,26 @@ __device__ __forceinline__ void conv_body(const pnmn_conv_item& it, int band, in
     // EG m-tiles at a time: all of them where the register budget allows (one workgroup per CU), four where
     // two workgroups share a CU (the other workgroup's MFMAs cover the extra round trips)
     constexpr int EG = (MT > 8) ? MT : 4;
+    if (mb == nullptr && !(it.flags & (PNMN_CONV_ACCUMULATE | PNMN_CONV_ATOMIC))) {
+        // plain store, on a path of its own: on gfx9 stores count on vmcnt like loads, and the shared body below -- "add
+        // the previous contents, which may or may not have been loaded" -- makes every m-tile's store wait for the store
+        // of the tile before it (found in the streamed kernel's epilogue, round 4)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = (mbase + mt) * 16 + li;
+            if (p < HW) {
+                f32x4 v = acc[mt] + bias4;
+                if (relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                store4(as_global(it.out) + (size_t)(p_img + p) * out_stride + n0 + 4 * g, v);
+            }
+        }
+        return;
+    }
     if (mb == nullptr || (it.flags & PNMN_CONV_DATTN)) {
         const bool accumulate = (it.flags & PNMN_CONV_ACCUMULATE) && !(it.flags & PNMN_CONV_ATOMIC);
         // PNMN_CONV_DATTN: besides the plain store of dx, d(attention)[p] += sum_c dx[p][c] * feats[p][c] (this wave's
