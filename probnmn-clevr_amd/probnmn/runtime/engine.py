@@ -152,6 +152,24 @@ class NMNEngine:
         extra = self.HW * 4.0 * ((r["mask"] != 0).sum() + 2 * ((mb | ((r["flags"] & _hip.CONV_DATTN) != 0)) & (r["mb_attn"] != 0)).sum())
         return float(maps.sum()) * m + extra + np.unique(r["weight"]).size * wbytes
 
+    #: (tap, m-tile) pairs of the 117 a 3x3 convolution on a 14x14 map does NOT contract, by dilation: their taps fall
+    #: wholly outside the map (csrc/conv_stream.h, KIND 1) -- work that is not done is not counted as done.  (Bodies for
+    #: dilations 1 / 2 / 4 -- 3 / 9 / 21 pairs -- were built and measured in round 4: 3-14 % faster launch by launch, 1.7 %
+    #: SLOWER in the step, where the units of a launch then alternate between five unrolled bodies of ~30 KB each.)
+    SKIPPED_TAP_TILES = {8: 39}
+
+    def _conv_flops(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
+        """Algorithmic FLOPs of one grouped conv call: 2 * pixels * Cout * taps * Cin per item, less the tap rows the
+        streamed kernel skips on 14x14 maps (counted for every item, also where a split launch contracts them)."""
+        full = 2.0 * self.HW * cout_blocks * C * ntaps * cin_chunks * C
+        if ntaps != 9 or self.banded:
+            return n * full
+        dil = np.ones(n, np.int64) if rec is None else rec["dilation"]
+        skipped = np.zeros(len(dil))
+        for d, k in self.SKIPPED_TAP_TILES.items():
+            skipped += (dil == d) * float(k)
+        return float((1.0 - skipped / 117.0).sum()) * full
+
     def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what, rec=None):
         log = self.event_log
         if self._list is not None:  # (collected into one pnmn_run_launches call)
@@ -167,7 +185,7 @@ class NMNEngine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes, kernel launches of this call)
-            log.append(("conv_nhwc", what, 2.0 * n * self.HW * cout_blocks * C * ntaps * cin_chunks * C, e0, e1,
+            log.append(("conv_nhwc", what, self._conv_flops(rec, n, cin_chunks, ntaps, cout_blocks), e0, e1,
                         self._conv_bytes(rec, n, cin_chunks, ntaps, cout_blocks),
                         _hip.lib().pnmn_conv_nhwc_launches(n, self.H, self.W, cin_chunks, ntaps, cout_blocks)))
 
