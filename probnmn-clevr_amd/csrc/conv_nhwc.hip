@@ -136,14 +136,16 @@ int launch_segments(const pnmn_conv_item* items, const LaunchPlan& lp, int first
     return (int)hipGetLastError();
 }
 
-// the 3x3 convolutions run on the streamed kernel (conv_stream.h); PNMN_CONV_STREAM=0: everything on the kernel above
-inline bool streamed() {
-    static const bool on = [] {
+// the convolutions run on the streamed kernel (conv_stream.h); PNMN_CONV_STREAM=1: the 3x3 ones only, 0: everything on
+// the kernel above
+inline int stream_level() {
+    static const int v = [] {
         const char* e = getenv("PNMN_CONV_STREAM");
-        return !e || atoi(e) != 0;
+        return e ? atoi(e) : 2;
     }();
-    return on;
+    return v;
 }
+inline bool streamed() { return stream_level() != 0; }
 
 
 template <int H, int W, int TH>
@@ -158,20 +160,20 @@ int launch_conv(const pnmn_conv_item* items, int n_items, int cin_chunks, int nt
 }
 
 // ---- streamed kernel (conv_stream.h): persistent workgroups of 8 contraction waves + 1 loader wave ----
-template <int H, int W, int TH>
+template <int H, int W, int TH, int TAPS>
 __global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_stream_kernel(const pnmn_conv_item* __restrict__ items,
                                                                                   const pnmn::stream::Launch L) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    pnmn::stream::conv_stream<H, W, TH>(L, items, smem_raw);
+    pnmn::stream::conv_stream<H, W, TH, TAPS>(L, items, smem_raw);
 }
 
 
-template <int H, int W, int TH>
+template <int H, int W, int TH, int TAPS>
 int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride, int out_stride,
                   int cout_blocks, int relu, int cus, hipStream_t stream) {
     using G = pnmn::stream::Geom<H, W, TH>;
     static bool configured = false;
-    auto kern = conv_stream_kernel<H, W, TH>;
+    auto kern = conv_stream_kernel<H, W, TH, TAPS>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)G::LDS_BYTES);
@@ -239,11 +241,18 @@ extern "C" int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int 
     if (!items || cin_chunks < 1 || cout_blocks < 1 || (ntaps != 9 && ntaps != 1)) return PNMN_EINVAL;
     if ((in_stride & 3) || (out_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (streamed() && ntaps == 9) {  // (1x1 convolutions -- two steps per 32-channel stage -- stay on the kernel below)
+    if (stream_level() >= 1 && ntaps == 9) {
         if (H == 14 && W == 14)
-            return launch_stream<14, 14, 14>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+            return launch_stream<14, 14, 14, 9>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
         if (H == 28 && W == 28)
-            return launch_stream<28, 28, 7>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+            return launch_stream<28, 28, 7, 9>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+        return PNMN_ESHAPE;
+    }
+    if (stream_level() >= 2 && ntaps == 1) {
+        if (H == 14 && W == 14)
+            return launch_stream<14, 14, 14, 1>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
+        if (H == 28 && W == 28)
+            return launch_stream<28, 28, 7, 1>(items, n_items, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, cus, s);
         return PNMN_ESHAPE;
     }
     if (H == 14 && W == 14)

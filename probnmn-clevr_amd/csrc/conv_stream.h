@@ -577,6 +577,7 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
 //   0  every tap contracts all of the wave's m-tiles
 //   1  dilation 8 on a 14x14 map: the taps of row -8 see only the m-tiles [7, 13), those of row +8 only [0, 6)
 //      -- 39 of 117 (tap, m-tile) pairs are skipped (the zero rows would contribute exact zeros)
+//   2  1x1 convolution: a stage is ONE tap (two steps); the weight sets rotate per stage
 template <int H, int W, int TH, int SPLIT, int KIND>
 __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, char* lds, int& cstart, int wave, int lane,
                                          unsigned long long (&cyc)[4]) {
@@ -606,8 +607,9 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         for (int j = 0; j < MTW; ++j) acc[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // weight row of this lane: output channel n0 + li (+ 16 for the second tile), channels 4g.. of each 16-block
-    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * 9 * cin_total + 4 * g;
-    const size_t wtile = (size_t)16 * 9 * cin_total;
+    constexpr int NTAPS = KIND == 2 ? 1 : 9;
+    const gfloat* wrow = as_global(it.weight) + (size_t)(n0 + li) * NTAPS * cin_total + 4 * g;
+    const size_t wtile = (size_t)16 * NTAPS * cin_total;
     const uint32_t gconst = (uint32_t)((g >> 1) * 16 | (g & 1) * 32);
     uint32_t tab_lane = (uint32_t)(G::TAB_OFF + (mbase * 16 + li) * 2);
     asm volatile("" : "+v"(tab_lane));  // (keep the table base in a register: the per-tile offsets are immediates)
@@ -636,7 +638,7 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     {
         const gfloat* w0 = wrow + (size_t)Wk.t0 * cin_total + Wk.cbase();
         wload(wq[0], w0);
-        if constexpr (WSETS == 3) wload(wq[1], w0 + cin_total);
+        if constexpr (WSETS == 3) wload(wq[1], KIND == 2 ? w0 + QC : w0 + cin_total);  // (the next tap / the next stage)
     }
 
     uint32_t rb[MTW];
@@ -734,7 +736,7 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
             return more ? wnext_stage + (size_t)(tap + d - t1) * cin_total : wrow + (size_t)tap * cin_total + cb0;
         };
         // table row of the tap behind `tap` (clamped: the fragments requested behind a stage's last tap are discarded)
-        auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < 9 ? tap + 1 : 8) * (TAB_ROWS * 2); };
+        auto next_row = [&](int tap) -> const char* { return lds + tab_lane + (tap + 1 < NTAPS ? tap + 1 : NTAPS - 1) * (TAB_ROWS * 2); };
 
         {
             const unsigned long long c0 = PNMN_CYC();
@@ -747,7 +749,13 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
         for (int j = 0; j < MTW; ++j) row_apply(j);
 #pragma unroll
         for (int j = 0; j < MTW; ++j) frag_load(j, 0);
-        if constexpr (WSETS == 3) {
+        if constexpr (KIND == 2) {
+            // the stage's one tap uses set `par` and requests the stage WSETS - 1 ahead (the unit's last ones their own)
+            using SA = integral_constant<int, par>;
+            using SB = integral_constant<int, (par + WSETS - 1) % WSETS>;
+            const int ahead = cb0 + (WSETS - 1) * QC;
+            tap_body(I0{}, SA{}, SB{}, next_row(0), wrow + (ahead < cin_total ? ahead : cb0));
+        } else if constexpr (WSETS == 3) {
             if (KIND == 1) {
                 tap_body(I2{}, I0{}, I2{}, next_row(0), far_ptr(0, 2));
                 tap_body(I2{}, I1{}, I0{}, next_row(1), far_ptr(1, 2));
@@ -792,7 +800,8 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     };
     while (more) {
         stage(I0{});
-        if (WSETS == 2 && more) stage(I1{});  // (an odd number of taps per stage: the next one starts on the other set)
+        if ((WSETS == 2 || KIND == 2) && more) stage(I1{});  // (an odd number of taps per stage: the next one starts on the other set)
+        if (WSETS == 3 && KIND == 2 && more) stage(I2{});
     }
     const unsigned long long c_u = PNMN_CYC();
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
@@ -810,8 +819,9 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     cyc[3] += 1;
 }
 
-template <int H, int W, int TH>
+template <int H, int W, int TH, int TAPS>
 __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_item* items, char* lds) {
+    static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
     using G = Geom<H, W, TH>;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -833,7 +843,14 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
     const unsigned long long c_begin = PNMN_CYC();
     while (Wk.valid()) {
         // (all uniform over the workgroup)
-        if (G::WHOLE && Wk.dil == 8 && Wk.split <= 2) {
+        if constexpr (TAPS == 1) {
+            switch (Wk.split) {
+                case 1: run_unit<H, W, TH, 1, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 2: run_unit<H, W, TH, 2, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 4: run_unit<H, W, TH, 4, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                default: run_unit<H, W, TH, 8, 2>(Wk, L, lds, cstart, wave, lane, cyc); break;
+            }
+        } else if (G::WHOLE && Wk.dil == 8 && Wk.split <= 2) {
             if (Wk.split == 1) run_unit<H, W, TH, 1, 1>(Wk, L, lds, cstart, wave, lane, cyc);
             else run_unit<H, W, TH, 2, 1>(Wk, L, lds, cstart, wave, lane, cyc);
         } else {

@@ -40,7 +40,8 @@ def test_bench_launches_its_own_ranks_and_reports_the_strong_scaling_line():
     weak = line["weak_scaling"]
     assert weak["scaling"] == "weak" and weak["global_batch"] == 128 and weak["value"] > 0
     ing = line["joint_training_ingest"]
-    assert ing["value"] > 0 and ing["store_rows"] == 256 and ing["pcie_GBs_per_gpu"] > 0
+    assert ing["value"] > 0 and ing["store_rows"] == 256 and ing["method"] == "resident"
+    assert ing["pinned_host"]["value"] > 0 and ing["pinned_host"]["pcie_GBs_per_gpu"] > 0
     roof = line["roofline"]
     assert roof["kernel"] == "conv_nhwc" and roof["passes"] == 4 and len(roof["tflops_per_pass"]) == 4
     assert roof.get("suspect") or (0 < roof["frac"] < 1 and

@@ -189,6 +189,50 @@ def test_conv_stem_chunks_and_two_sources(hip):
     torch.testing.assert_close(from_nhwc(outc, n, 1024), refc, rtol=RT, atol=AT)
 
 
+@pytest.mark.parametrize("n", [3, 41, 300, 520])
+def test_conv1x1_many_items_every_launch_shape(hip, n):
+    """1x1 convolutions over two sources (the ComparisonModule projection) and into four output blocks (the
+    classifier's 128 -> 512) at item counts that take every split of the launch planner; delta weights make the
+    comparison exact (a tap / channel / block mix-up cannot hide in a tolerance)."""
+    g = gen(n)
+    a = torch.relu(torch.randn(n, C, H, W, generator=g))
+    c = torch.relu(torch.randn(n, C, H, W, generator=g))
+    m = torch.sigmoid(torch.randn(n, 1, H, W, generator=g))
+    wp = torch.randn(3, C, 2 * C, 1, 1, generator=g) * (1.0 / (2 * C)) ** 0.5
+    bp = torch.randn(3, C, generator=g) * 0.1
+    ad, cd, md = nhwc(a), nhwc(c), m.reshape(n, HW).to(dev())
+    wpd = [wcl(wp[k]) for k in range(3)]
+    bpd = [bp[k].to(dev()) for k in range(3)]
+    outp = torch.full((n, HW, C), float("nan"), device=dev())
+    recs = np.zeros(n, hip.CONV_ITEM)
+    for i in range(n):
+        recs[i]["in"], recs[i]["in2"] = ptr(ad[i]), ptr(cd[i])
+        recs[i]["weight"], recs[i]["bias"], recs[i]["out"] = ptr(wpd[i % 3]), ptr(bpd[i % 3]), ptr(outp[i])
+        if i % 2:
+            recs[i]["mask"] = ptr(md[i])
+    run(hip, "pnmn_conv_nhwc", recs, H, W, 2, 1, C, C, 1, 1)
+    got = from_nhwc(outp, n, C)
+    for k in range(3):
+        for masked in (0, 1):
+            rows = [i for i in range(n) if i % 3 == k and i % 2 == masked]
+            if rows:
+                x = torch.cat([a[rows], c[rows]], 1) * (m[rows] if masked else 1.0)
+                ref = F.relu(F.conv2d(x.to(dev()), wp[k].to(dev()), bp[k].to(dev()))).cpu()
+                torch.testing.assert_close(got[rows], ref, rtol=RT, atol=AT)
+
+    # 128 -> 512 with a permutation matrix: out channel o copies in channel (o * 37 + 5) % 128, exactly
+    wc = torch.zeros(4 * C, C, 1, 1)
+    for o in range(4 * C):
+        wc[o, (o * 37 + 5) % C, 0, 0] = 1.0
+    wcd = wcl(wc)
+    outc = torch.full((n, HW, 4 * C), float("nan"), device=dev())
+    recs = np.zeros(n, hip.CONV_ITEM)
+    for i in range(n):
+        recs[i]["in"], recs[i]["weight"], recs[i]["out"] = ptr(ad[i]), ptr(wcd), ptr(outc[i])
+    run(hip, "pnmn_conv_nhwc", recs, H, W, 1, 1, C, 4 * C, 4, 0)
+    assert torch.equal(from_nhwc(outc, n, 4 * C).cpu(), F.conv2d(a, wc))
+
+
 @pytest.mark.parametrize("dilation", [1, 2, 4, 8])
 def test_conv_dgrad_and_wgrad_match_autograd(hip, dilation):
     g = gen(20 + dilation)
