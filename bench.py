@@ -225,7 +225,7 @@ def kernel_rooflines(engine, step_fn, passes, trainer=None):
     return out
 
 
-KERNEL_FAMILY = {"conv_nhwc": ("conv_nhwc_kernel", "conv_stream_kernel")}
+KERNEL_FAMILY = {"conv_nhwc": ("conv_stream_kernel",)}
 
 
 def pmc_traffic(kernel):
@@ -253,8 +253,7 @@ def pmc_traffic(kernel):
             if m:
                 sha = m.group(1)
             m = re.match(r"(\S+)\s+%s\s+(\d+)\s+([0-9.]+)" % counter, line)
-            # (the conv_nhwc family is two kernels since round 4: conv_stream_kernel runs the 3x3 convolutions,
-            # conv_nhwc_kernel the 1x1 ones; a call is one launch of either)
+            # (the conv_nhwc family -- pnmn_conv_nhwc calls -- is conv_stream_kernel since round 4; a call is one launch)
             if m and any(name in m.group(1) for name in KERNEL_FAMILY.get(kernel, (kernel,))):
                 n += int(m.group(2))
                 total += factor * 1024.0 * float(m.group(3))

@@ -84,11 +84,12 @@ int pnmn_conv_nhwc(const pnmn_conv_item* items, int n_items, int H, int W, int c
  * beside the seq2seq passes).  In a pnmn_launch entry the `c` field of a CONV carries it. */
 int pnmn_conv_nhwc_cus(const pnmn_conv_item* items, int n_items, int H, int W, int cin_chunks, int ntaps, int in_stride,
                        int out_stride, int cout_blocks, int relu, int cus, void* stream);
-/* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 or 2: whole rounds of 256
- * workgroups with one K-split, the remainder with a larger one) -- for per-launch accounting. */
+/* Kernel launches one pnmn_conv_nhwc call with these sizes makes (1 since round 3: the segments of different splits
+ * go out as one launch; 0 for an empty call or an unsupported map size) -- for per-launch accounting. */
 int pnmn_conv_nhwc_launches(int n_items, int H, int W, int cin_chunks, int ntaps, int cout_blocks);
-/* Tuning / test hook: every later convolution launch of this process uses ONE split -- 1, 2, 4, 8
- * (workgroups per item, each 128/split output channels) or 16 (8 x two m-halves); 0 = the launch planner decides again.
+/* Tuning / test hook: every later convolution launch of this process uses ONE split -- 1, 2, 4 or 8 workgroups per
+ * (item, 128-channel output block), each computing 128/split output channels; the results do not depend on it (every
+ * output sums all its input channels in one wave, in one order).  0 = the launch planner decides again.
  * Also settable as PNMN_CONV_KSPLIT before the first launch. */
 int pnmn_conv_force_split(int split);
 

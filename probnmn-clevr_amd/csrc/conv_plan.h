@@ -5,27 +5,25 @@
 
 namespace pnmn {
 
-// Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round
-// that holds 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of
-// work).  So the units are cut into up to THREE segments of one launch (conv_nhwc_kernel), of non-decreasing split: as many as fill whole rounds
-// go out with the first split, the remainder follows with larger splits -- whose rounds are s times shorter --
-// again in whole rounds first (667 module-conv items: 512 at split 1, 128 at split 2 -- exactly one round of half
-// the work -- and 27 at split 8, instead of 512 + 155 at split 4 = three quarter rounds: round 3, -5 % on such a
-// launch).  Relative costs only: one tap of one 128-channel chunk = 1 unit, staging a chunk ~ 0.5 unit, every
-// further segment ~ 0.3 unit.
+// Launch plan (in units).  A launch of n workgroups on 256 CUs costs ceil(n / 256) rounds, and a last round that holds
+// 8 workgroups costs as much as a full one (520 stem items = 3 rounds for 2.03 rounds of work).  So the units are cut
+// into up to THREE segments of one launch, of non-decreasing split: as many as fill whole rounds go out with the first
+// split, the remainder follows with larger splits -- whose rounds are shorter -- again in whole rounds first (667
+// module-conv items: 512 at split 1, 128 at split 2 -- exactly one round of half the work -- and 27 at split 8).
+// Relative costs only: one tap of one 128-channel chunk = 1 unit, every further segment ~ 0.3 unit.
 struct LaunchPlan {
     int n_seg;
     int split[3], count[3];
 };
 
-// One split for every launch (0 = the planner decides): PNMN_CONV_KSPLIT=<1|2|4|8|16> or pnmn_conv_force_split() --
-// scripts/conv_modes.py measures the splits with it, and tests that compare two schedules of the same convolutions pin
-// it so that both sum in the same order.  One instance per library (inline, C++17).
+// One split for every launch (0 = the planner decides): PNMN_CONV_KSPLIT=<1|2|4|8> or pnmn_conv_force_split() --
+// scripts/conv_modes.py measures the splits with it, and tests/test_nmn_gpu.py pins each to show that the results do not
+// depend on the split.  One instance per library (inline, C++17).
 inline int& forced_split() {
     static int forced = [] {
         const char* e = getenv("PNMN_CONV_KSPLIT");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
     }();
     return forced;
 }
@@ -40,23 +38,17 @@ inline int default_conv_cus() {
     return v;
 }
 
-// streamed: the persistent kernel of conv_stream.h -- staging is hidden behind the contraction (no per-chunk cost); a
-// workgroup computes 128 / split output channels; split 2 halves a wave's channels, split 4 / 8 also share an item's 13
-// m-tiles among 2 / 4 waves per channel tile (7 / 4 tiles on the longest wave); there is no split 16.
-inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0, bool streamed = false,
-                              bool honour_forced = true) {
-    if (forced_split() && honour_forced) return LaunchPlan{1, {streamed && forced_split() > 8 ? 8 : forced_split(), 0, 0}, {n_items, 0, 0}};
+// Staging is hidden behind the contraction (no per-chunk cost); a workgroup computes 128 / split output channels;
+// split 2 halves a wave's channels, split 4 / 8 also share an item's 13 m-tiles among 2 / 4 waves per channel tile
+// (7 / 4 tiles on the longest wave).
+inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0) {
+    if (forced_split()) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
-    constexpr double stage_cost = 0.5;  // (what measurement picked, rounds 2-3)
     constexpr int max_seg = 3;
     constexpr double seg_cost = 0.3;    // a further segment: its workgroups start behind a partly drained round
-    const double overhead = streamed ? 0.25 : stage_cost * cin_chunks + 0.25;
-    // (split 16 = K-split 8 x two m-halves: 14 instead of 13 m-tiles of matrix work per item)
-    auto round_cost = [&](int s) {
-        if (streamed) return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : 2.0 / 13.0) + overhead;
-        return (s == 16 ? work * (14.0 / 13.0) : work) / s + overhead;
-    };
-    const int s_max = streamed ? 8 : 16;
+    constexpr double overhead = 0.25;   // start-up, epilogue
+    auto round_cost = [&](int s) { return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : 2.0 / 13.0) + overhead; };
+    constexpr int s_max = 8;
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
@@ -65,10 +57,9 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
     // CUs takes one: 128-question step 7.33 -> 7.06 ms at 192, gpurun_out/r03w_ab.txt).  PNMN_CONV_CUS overrides the
     // default of launches that do not say (tuning hook).
     const long cus = (cu_budget >= 8 && cu_budget <= 256) ? cu_budget : default_conv_cus();
-    const int wg_per = 1;
-    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s * wg_per + cus - 1) / cus; };
+    auto rounds_of = [&](long n, int s) { return (n * cout_blocks * s + cus - 1) / cus; };
     auto full_of = [&](long n, int s) {  // items that fill whole rounds at split s
-        const long per_item = (long)cout_blocks * s * wg_per;
+        const long per_item = (long)cout_blocks * s;
         const long m = ((long)n * per_item / cus) * cus / per_item;
         return m > n ? n : m;
     };

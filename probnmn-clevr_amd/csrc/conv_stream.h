@@ -32,7 +32,7 @@
 // one register address + an immediate offset.  In a sub-slot pixel row r = 4 pieces of 16 bytes; piece g -- channels
 // [4 g, +4) of the block -- sits at piece position
 //     (g & 1) << 1  |  (((r >> 2) & 1) ^ (g >> 1))
-// ds_read_b128 is served in groups of 16 lanes (conv_body.h of rounds 1-3 measured the grouping): eight lanes of lane
+// ds_read_b128 is served in groups of 16 lanes (measured in rounds 1-3): eight lanes of lane
 // group g (pixels li in {0-3, 12-15}) and eight of g ^ 1 (li in {4-11}), sixteen different pixel rows.  Rows of equal
 // r & 3 share banks: of each lane group two lanes fall into one such class, their rows 4 or 12 apart, so (r >> 2) & 1
 // separates them and bit 1 separates g from g ^ 1: no bank conflicts for any tap or dilation.  A direct-to-LDS load

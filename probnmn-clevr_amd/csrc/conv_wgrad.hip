@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(
     for (int ii = job.item_begin; ii < job.item_end; ++ii) {
         const pnmn_wgrad_item it = items[ii];
         const int dil = it.dilation;
-        // (global, not flat, loads: see conv_body.h)
+        // (global, not flat, loads: see global_ptr.h)
         const pnmn::gfloat* xsrc = pnmn::as_global((it.x2 != nullptr && cib > 0) ? it.x2 : it.x + cib * CB);
         const pnmn::gfloat* xmask = pnmn::as_global(it.xmask);
         const pnmn::gfloat* dysrc = pnmn::as_global(it.dy);

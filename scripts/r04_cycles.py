@@ -7,7 +7,6 @@ import numpy as np, torch
 dev = torch.device("cuda:0")
 dbg = torch.zeros(256 * 5 * 8, dtype=torch.int64, device=dev)
 os.environ["PNMN_CONV_DBGPTR"] = str(dbg.data_ptr())
-os.environ.setdefault("PNMN_CONV_STREAM", "1")
 os.environ.setdefault("PNMN_LIB", os.path.join(ROOT, "probnmn-clevr_amd", "lib", "libprobnmn_cycles.so"))  # (make -C probnmn-clevr_amd/csrc cycles)
 from probnmn import _hip
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
