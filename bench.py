@@ -154,16 +154,15 @@ def source_sha():
 
 
 def kernel_rooflines(engine, step_fn, passes, trainer=None):
-    """Instrumented steps: events around every conv / wgrad launch on the launch stream.  ONE stream, so
-    that each kernel's duration is its own and not that of two kernels sharing the chip: a trainer that
-    runs the NMN beside the seq2seq passes (small batches) is switched to its single-stream schedule for
-    these passes.
+    """Instrumented steps: the library brackets every conv / wgrad launch with events on the launch stream
+    (pnmn_launch_trace_begin / _end: the shipped host path -- trunk planner, launch lists -- runs unchanged).
+    ONE stream, so that each kernel's duration is its own and not that of two kernels sharing the chip: a trainer
+    that runs the NMN beside the seq2seq passes is switched to its single-stream schedule for these passes.
 
     Every pass is aggregated on its own and the MEDIAN pass is reported (per kernel family: the pass with the
     median FLOP/s; per call site: the median over passes) -- a stalled event interval or an allocator refill in
     one pass then moves nothing.  Each pass's whole step is timed on the same stream; a kernel family whose summed
     launch time exceeds the single-stream step it ran in cannot be right, and the result is marked suspect."""
-    overlap, engine.overlap_wgrad = engine.overlap_wgrad, False
     side_stream = getattr(trainer, "nmn_stream", None)
     if side_stream is not None:
         trainer.nmn_stream = False
@@ -172,17 +171,16 @@ def kernel_rooflines(engine, step_fn, passes, trainer=None):
     try:
         step_fn()  # (the single-stream schedule's first step allocates)
         for _ in range(passes):
-            engine.event_log = []
+            engine.begin_trace()
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s0.record()
             step_fn()
             s1.record()
             torch.cuda.synchronize()
-            events, engine.event_log = engine.event_log, None
+            events = engine.end_trace()
             step_ms.append(s0.elapsed_time(s1))
             agg = {}
-            for kern, what, flops, e0, e1, nbytes, launches in events:
-                ms = e0.elapsed_time(e1)
+            for kern, what, flops, ms, nbytes, launches in events:
                 a = agg.setdefault(kern, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0, "by": {}})
                 a["flops"] += flops
                 a["bytes"] += nbytes
@@ -197,8 +195,10 @@ def kernel_rooflines(engine, step_fn, passes, trainer=None):
                         f.write("%-11s %-20s %9.3f GFLOP %8.4f ms %7.1f TF  %d launches\n" % (kern, what, flops / 1e9, ms, flops / ms / 1e9, launches))
             per_pass.append(agg)
     finally:
-        engine.event_log = None
-        engine.overlap_wgrad = overlap
+        try:
+            engine.end_trace()  # (a step that raised leaves the trace on)
+        except Exception:
+            pass
         if side_stream is not None:
             trainer.nmn_stream = side_stream
 

@@ -571,6 +571,22 @@ typedef struct pnmn_launch {
 } pnmn_launch;             /* 64 bytes */
 int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
 
+/* Launch trace (measurement only: bench.py's roofline passes, scripts/conv_launch_table.py).  Between _begin and _end
+ * every CONV / WGRAD entry that pnmn_run_launches issues -- the trunk planner's lists included, i.e. the SHIPPED host
+ * path -- is bracketed by two events on its stream.  _end waits for them and reports, per traced entry in issue order,
+ * the launch duration and the algorithmic work of the call (the items are read back from the
+ * device).  Returns PNMN_EAGAIN when more than `capacity` entries were traced (*n_out = how many).  The reference has
+ * no counterpart: its per-module timing is whatever torch.profiler shows around nmn.py:191-241. */
+typedef struct pnmn_launch_timing {
+    int32_t op, n;          /* PNMN_OP_CONV / PNMN_OP_WGRAD; items (CONV) or jobs (WGRAD) of the call */
+    int32_t p[8];           /* the entry's parameters */
+    int32_t n_items;        /* items of the call (WGRAD: over all jobs) */
+    float   ms;             /* launch duration */
+    double  flops, bytes;   /* algorithmic FLOPs and HBM bytes */
+} pnmn_launch_timing;      /* 64 bytes */
+int pnmn_launch_trace_begin(void);
+int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int* n_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Trunk planner: sampled programs -> launched module programs in ONE call (host side; replaces the per-example
  * interpreter loop nmn.py:191-241 together with the Python half of the scheduler that used to sit between the

@@ -7,15 +7,142 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/probnmn_hip.h"
+
+// ---- launch trace (pnmn_launch_trace_begin / _end): events around the CONV / WGRAD rows of every list run in between ----
+namespace {
+
+struct Traced {
+    pnmn_launch row;
+    hipEvent_t e0, e1;
+};
+struct Trace {
+    std::mutex mu;
+    bool on = false;
+    std::vector<Traced> rows;
+    std::vector<hipEvent_t> pool;  // events are kept from trace to trace
+    hipEvent_t event() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+};
+Trace& trace() {
+    static Trace t;
+    return t;
+}
+
+// (tap, m-tile) pairs of the 117 a 3x3 convolution on a 14x14 map does not contract (conv_stream.h, KIND 1): work that
+// is not done is not counted as done
+inline double skipped_tap_tiles(int dilation) { return dilation == 8 ? 39.0 : 0.0; }
+
+// Algorithmic work of one grouped convolution call: FLOPs = 2 * pixels * Cout * taps * Cin per item,
+// less the skipped tap rows; bytes = every map an item must read (input chunks, the ReLU gate of a data gradient, the
+// attention mask, the forward features and the accumulated gradient of the fused mask backward, the previous contents of
+// an accumulating output) and write once, plus ONE pass over each distinct weight of the call.
+int conv_work(const pnmn_launch& l, pnmn_launch_timing* t) {
+    const int H = l.p[0], W = l.p[1], cin_chunks = l.p[2], ntaps = l.p[3], cout_blocks = l.p[6];
+    const double HW = (double)H * W, C = 128.0;
+    std::vector<pnmn_conv_item> items((size_t)l.n);
+    const hipError_t e = hipMemcpy(items.data(), l.a, items.size() * sizeof(pnmn_conv_item), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    const double full = 2.0 * HW * cout_blocks * C * ntaps * cin_chunks * C;
+    const double map = HW * C * 4.0, wbytes = cout_blocks * C * ntaps * cin_chunks * C * 4.0;
+    double flops = 0.0, maps = 0.0, extra = 0.0;
+    std::vector<const float*> weights;
+    for (const pnmn_conv_item& it : items) {
+        flops += full * ((ntaps == 9 && H == 14 && W == 14) ? 1.0 - skipped_tap_tiles(it.dilation) / 117.0 : 1.0);
+        const bool mb = (it.flags & PNMN_CONV_MASKBWD) != 0, da = (it.flags & PNMN_CONV_DATTN) != 0;
+        maps += cin_chunks + cout_blocks;
+        if (it.gate) maps += cin_chunks;
+        if (it.flags & PNMN_CONV_ACCUMULATE) maps += cout_blocks;
+        if (mb) maps += 1.0 + (it.mb_attn ? 1.0 : 0.0);
+        if (da) maps += 1.0;
+        extra += HW * 4.0 * ((it.mask ? 1.0 : 0.0) + (((mb || da) && it.mb_attn) ? 2.0 : 0.0));
+        bool seen = false;
+        for (const float* w : weights) seen = seen || w == it.weight;
+        if (!seen) weights.push_back(it.weight);
+    }
+    t->flops = flops;
+    t->bytes = maps * map + extra + (double)weights.size() * wbytes;
+    t->n_items = l.n;
+    return 0;
+}
+
+int wgrad_work(const pnmn_launch& l, pnmn_launch_timing* t) {
+    const int H = l.p[0], W = l.p[1], ntaps = l.p[2], cin_blocks = l.p[3], cout_blocks = l.p[4];
+    const double HW = (double)H * W, C = 128.0;
+    std::vector<pnmn_wgrad_job> jobs((size_t)l.n);
+    const hipError_t e = hipMemcpy(jobs.data(), l.b, jobs.size() * sizeof(pnmn_wgrad_job), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int)e;
+    long n_items = 0;
+    for (const pnmn_wgrad_job& j : jobs) n_items += j.item_end - j.item_begin;
+    t->n_items = (int32_t)n_items;
+    t->flops = 2.0 * n_items * HW * cout_blocks * C * ntaps * cin_blocks * C;
+    t->bytes = 4.0 * (n_items * HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pnmn_launch_trace_begin(void) {
+    Trace& T = trace();
+    std::lock_guard<std::mutex> g(T.mu);
+    for (Traced& r : T.rows) T.pool.push_back(r.e0), T.pool.push_back(r.e1);  // (a trace that was never collected)
+    T.rows.clear();
+    T.on = true;
+    return 0;
+}
+
+extern "C" int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int* n_out) {
+    Trace& T = trace();
+    std::lock_guard<std::mutex> g(T.mu);
+    T.on = false;
+    if (!n_out || (capacity > 0 && !out)) return PNMN_EINVAL;
+    *n_out = (int)T.rows.size();
+    int rc = 0;
+    for (size_t i = 0; i < T.rows.size(); ++i) {
+        Traced& r = T.rows[i];
+        if (rc == 0 && (int)i < capacity) {
+            pnmn_launch_timing* t = out + i;
+            *t = pnmn_launch_timing{};
+            t->op = r.row.op, t->n = r.row.n;
+            for (int k = 0; k < 8; ++k) t->p[k] = r.row.p[k];
+            hipError_t e = hipEventSynchronize(r.e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&t->ms, r.e0, r.e1);
+            rc = (int)e;
+            if (rc == 0) rc = r.row.op == PNMN_OP_CONV ? conv_work(r.row, t) : wgrad_work(r.row, t);
+        }
+        T.pool.push_back(r.e0), T.pool.push_back(r.e1);
+    }
+    T.rows.clear();
+    return rc != 0 ? rc : (*n_out > capacity ? PNMN_EAGAIN : 0);
+}
 
 extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
     if (n <= 0) return 0;
     if (!list) return PNMN_EINVAL;
+    Trace& T = trace();
+    const bool tracing = T.on;  // (set and cleared by the thread that runs the instrumented step)
     for (int i = 0; i < n; ++i) {
         const pnmn_launch& l = list[i];
         const int32_t* p = l.p;
         int rc;
+        Traced tr{};
+        const bool timed = tracing && (l.op == PNMN_OP_CONV || l.op == PNMN_OP_WGRAD) && l.n > 0;
+        if (timed) {
+            std::lock_guard<std::mutex> g(T.mu);
+            tr.row = l, tr.e0 = T.event(), tr.e1 = T.event();
+            if (!tr.e0 || !tr.e1) return PNMN_EINVAL;
+            if (hipEventRecord(tr.e0, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
+        }
         switch (l.op) {
             case PNMN_OP_CONV:
                 rc = pnmn_conv_nhwc_cus(static_cast<const pnmn_conv_item*>(l.a), l.n, p[0], p[1], p[2], p[3], p[4], p[5], p[6],
@@ -80,6 +207,11 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
                 break;
             default:
                 return PNMN_EINVAL;
+        }
+        if (timed) {
+            std::lock_guard<std::mutex> g(T.mu);
+            if (hipEventRecord(tr.e1, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
+            T.rows.push_back(tr);
         }
         if (rc != 0) return rc;
     }

@@ -92,6 +92,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_conv_force_split": (_I,),
     "pnmn_run_launches": (_P, _I, _P),
+    "pnmn_launch_trace_begin": (),
+    "pnmn_launch_trace_end": (_P, _I, _P),
     "pnmn_set_rows": (_P, _I, _P),
     "pnmn_trunk_planner_create": (_P, _P),
     "pnmn_trunk_planner_destroy": (_P,),
@@ -240,6 +242,8 @@ EAGAIN = -3
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
+LAUNCH_TIMING = np.dtype([("op", _i32), ("n", _i32), ("p", _i32, (8,)), ("n_items", _i32), ("ms", np.float32),
+                          ("flops", np.float64), ("bytes", np.float64)])  # pnmn_launch_timing
 (OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
  OP_MASK_BWD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_NCHW_TO_NHWC, OP_SET_ROWS, OP_ACCUMULATE, OP_ZERO, OP_FEAT_GATHER) = range(17)
 

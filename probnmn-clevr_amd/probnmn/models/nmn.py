@@ -46,10 +46,8 @@ class _Trunk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, engine, compiled, started, *params):
         need_backward = any(ctx.needs_input_grad)  # false under torch.no_grad()
-        if isinstance(compiled, _Tokens):  # the library compiles, plans and launches from the token matrix
-            pooled, state, compiled.valid = engine.run_forward_tokens(features, compiled.tokens, need_backward, started)
-        else:
-            pooled, state = engine.run_forward(features, compiled, need_backward, started)
+        # the library compiles, plans and launches from the token matrix
+        pooled, state, compiled.valid = engine.run_forward_tokens(features, compiled.tokens, need_backward, started)
         ctx.engine, ctx.state, ctx.n_params = engine, state, len(params)
         return pooled
 
@@ -251,7 +249,7 @@ class NeuralModuleNetwork(nn.Module):
         # also reads them back, once per example: nmn.py:203)
         # (a CPU ``programs`` tensor costs nothing; a device tensor costs one device->host sync)
         tokens = programs.detach().cpu().numpy()
-        compiled = _Tokens(tokens) if engine.use_native() else engine.compiler.compile_batch(tokens)
+        compiled = _Tokens(tokens)
 
         # the trunk's parameters as inputs of its autograd node -- all of them when autograd is to receive
         # their gradients; ONE anchor when a trainer reads the gradients straight from the arena
@@ -274,10 +272,7 @@ class NeuralModuleNetwork(nn.Module):
         pooled, compiled, trunk_stream = trunk
         # (staged here, not in forward_trunk: the host's time between the sampled programs' arrival and the trunk's
         # launch is on the critical path of a small-batch step)
-        if isinstance(compiled, _Tokens):
-            valid_host = compiled.valid.tolist()
-        else:
-            valid_host = [int(p.valid) for p in compiled]
+        valid_host = compiled.valid.tolist()
         valid = _hip.small_to_device(valid_host, torch.int32, pooled.device)
         if trunk_stream is not None:
             current = torch.cuda.current_stream(pooled.device)

@@ -11,9 +11,14 @@ Forward and backward are both explicit kernel schedules (no autograd inside): ba
 forward levels in reverse; every weight gradient of the module convs is deferred into one big
 grouped launch at the end, where all (example, conv) pairs that share a weight are accumulated by
 the same workgroups.
+
+The module programs are planned and launched by the library's trunk planner (csrc/host_trunk.hip:
+programs -> compiled -> templates -> records -> upload -> launches in ONE call); this file puts the
+program-independent launches around them (stem, classifier conv, pooling) and owns the buffers.
+``probnmn.runtime.schedule`` is the planner's specification in numpy: tests/test_trunk_planner.py
+compares the two word for word; nothing here launches from it.
 """
-import os
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -21,7 +26,7 @@ import torch
 from probnmn import _hip
 from probnmn.runtime import program_compiler as pc
 from probnmn.runtime.arena import ParamArena
-from probnmn.runtime.schedule import BatchScheduler, Buffers, StepPlan, WeightTables
+from probnmn.runtime.schedule import BatchScheduler, WeightTables
 
 C = _hip.CHANNELS
 
@@ -101,131 +106,89 @@ class NMNEngine:
         self._fixed_cache: Dict[int, Dict[str, np.ndarray]] = {}
         self.compiler = pc.ProgramCompiler(
             net.vocabulary.get_index_to_token_vocabulary("programs"), module_channels)
-        self.last_plan: Optional[StepPlan] = None
-        # when a list, every conv / wgrad launch is bracketed by events on the launch stream and
-        # (kernel, algorithmic flops, start, end) is appended -- used by bench.py's roofline pass
-        self.event_log: Optional[list] = None
-        # True: weight gradients run on a second stream, concurrently with the level-by-level
-        # data-gradient chain.  Measured on MI355X (B=256): no gain -- a wgrad workgroup holds its CU
-        # (151 KiB LDS) for ~400 us and delays the chain's critical path as much as it fills its gaps --
-        # so the default is one stream, which also keeps per-kernel profiles clean.
-        self.overlap_wgrad = False
-        self._side_stream: Optional[torch.cuda.Stream] = None
-        # launches of a pass are collected and issued by ONE library call (pnmn_run_launches) unless they are
-        # being timed one by one (event_log) or spread over two streams (overlap_wgrad)
+        self.last_plan: Optional[_NativePlan] = None
+        # launches of a pass are collected and issued by ONE library call (pnmn_run_launches)
         self._list: Optional[_hip.LaunchList] = None
-        self.launch_lists = True
         # data parallel: called with k when every kernel that writes gradient piece k of the arena has been
         # queued (see grad_pieces); a trainer points it at its EarlyReducer.piece_ready
         self.on_grad_piece = None
-        # The trunk planner of the library (csrc/host_trunk.hip): programs -> compiled -> templates -> records ->
-        # upload -> launches in ONE call.  The Python planner below (BatchScheduler / _Pack / LaunchList) stays as the
-        # instrumented path: per-launch events for bench.py's roofline pass (event_log), weight gradients on a second
-        # stream (overlap_wgrad), PNMN_NATIVE_PLANNER=0 -- same kernels, same pnmn_plan_batch, same launch order
-        # (tests/test_trunk_planner.py compares the two lists entry for entry).
         # CUs the trunk's conv launches are planned for: 0 = all of them; a trainer that runs the trunk on its own stream
         # beside other work sets the number it may count on (JointTrainingStep: 192 -- the seq2seq passes' multi-CU
         # kernels hold 64-96 CUs, and a launch cut for 256 workgroups then takes two rounds)
         self.conv_cus = 0
         self.last_counts = (0, 0)  # 3x3 / projection records of the last natively planned batch
         self.wgrad_cus = 0  # the same for the weight-gradient launches: at most that many (persistent) workgroups
-        self.native = os.environ.get("PNMN_NATIVE_PLANNER", "1") != "0"
         self._planner = None
         self._native_fixed: Dict[tuple, dict] = {}
 
-    def _conv_bytes(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
-        """Algorithmic HBM bytes of one grouped conv call (roofline accounting only): every map an item must
-        read (input chunks, the ReLU gate of a data gradient, the attention mask, the forward features and the
-        accumulated gradient of the fused mask backward, the previous contents of an accumulating output) and
-        write once, plus ONE pass over each distinct weight of the call."""
-        m = self.HW * C * 4.0
-        wbytes = cout_blocks * C * ntaps * cin_chunks * C * 4.0
-        if rec is None:
-            return n * m * (cin_chunks + cout_blocks) + wbytes
-        r = rec
-        maps = np.full(n, float(cin_chunks + cout_blocks))
-        maps += (r["gate"] != 0) * cin_chunks
-        maps += ((r["flags"] & _hip.CONV_ACCUMULATE) != 0) * cout_blocks
-        mb = (r["flags"] & _hip.CONV_MASKBWD) != 0
-        maps += mb * (1.0 + (r["mb_attn"] != 0))  # dFEAT read-modify-write (+ FEAT when an attention multiplies it)
-        maps += ((r["flags"] & _hip.CONV_DATTN) != 0) * 1.0  # d(attention) only: FEAT is read, dx is the plain output
-        extra = self.HW * 4.0 * ((r["mask"] != 0).sum() + 2 * ((mb | ((r["flags"] & _hip.CONV_DATTN) != 0)) & (r["mb_attn"] != 0)).sum())
-        return float(maps.sum()) * m + extra + np.unique(r["weight"]).size * wbytes
+    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu):
+        self._list.add(_hip.OP_CONV, n, ptr, c=self.conv_cus,
+                       p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
 
-    #: (tap, m-tile) pairs of the 117 a 3x3 convolution on a 14x14 map does NOT contract, by dilation: their taps fall
-    #: wholly outside the map (csrc/conv_stream.h, KIND 1) -- work that is not done is not counted as done.  (Bodies for
-    #: dilations 1 / 2 / 4 -- 3 / 9 / 21 pairs -- were built and measured in round 4: 3-14 % faster launch by launch, 1.7 %
-    #: SLOWER in the step, where the units of a launch then alternate between five unrolled bodies of ~30 KB each.)
-    SKIPPED_TAP_TILES = {8: 39}
-
-    def _conv_flops(self, rec, n, cin_chunks, ntaps, cout_blocks) -> float:
-        """Algorithmic FLOPs of one grouped conv call: 2 * pixels * Cout * taps * Cin per item, less the tap rows the
-        streamed kernel skips on 14x14 maps (counted for every item, also where a split launch contracts them)."""
-        full = 2.0 * self.HW * cout_blocks * C * ntaps * cin_chunks * C
-        if ntaps != 9 or self.banded:
-            return n * full
-        dil = np.ones(n, np.int64) if rec is None else rec["dilation"]
-        skipped = np.zeros(len(dil))
-        for d, k in self.SKIPPED_TAP_TILES.items():
-            skipped += (dil == d) * float(k)
-        return float((1.0 - skipped / 117.0).sum()) * full
-
-    def _conv(self, ptr, n, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu, st, what, rec=None):
-        log = self.event_log
-        if self._list is not None:  # (collected into one pnmn_run_launches call)
-            self._list.add(_hip.OP_CONV, n, ptr, c=self.conv_cus,
-                           p=(self.H, self.W, cin_chunks, ntaps, in_stride, out_stride, cout_blocks, relu))
-            return
-        if log is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _hip.check(_hip.lib().pnmn_conv_nhwc_cus(ptr, n, self.H, self.W, cin_chunks, ntaps, in_stride, out_stride,
-                                                 cout_blocks, relu, self.conv_cus, st), what)
-        if log is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record()
-            # (kernel, call site, algorithmic FLOPs, start, end, algorithmic bytes, kernel launches of this call)
-            log.append(("conv_nhwc", what, self._conv_flops(rec, n, cin_chunks, ntaps, cout_blocks), e0, e1,
-                        self._conv_bytes(rec, n, cin_chunks, ntaps, cout_blocks),
-                        _hip.lib().pnmn_conv_nhwc_launches(n, self.H, self.W, cin_chunks, ntaps, cout_blocks)))
-
-    def _wgrad(self, items, jobs, n_jobs, n_items, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, stream, what):
-        """``stream``: the torch.cuda.Stream to launch on (weight gradients may run on the side stream)."""
-        log = self.event_log
-        st = stream.cuda_stream
-        if self._list is not None:
-            self._list.add(_hip.OP_WGRAD, n_jobs, items, jobs,
-                           p=(self.H, self.W, ntaps, cin_blocks, cout_blocks, x_stride, dy_stride, self.wgrad_cus))
-            return
-        if log is not None:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        _hip.check(_hip.lib().pnmn_conv_wgrad_cus(items, jobs, n_jobs, self.H, self.W, ntaps, cin_blocks, cout_blocks,
-                                                  x_stride, dy_stride, self.wgrad_cus, st), what)
-        if log is not None:
-            e1 = torch.cuda.Event(enable_timing=True)
-            e1.record(stream)
-            log.append(("conv_wgrad", what, 2.0 * n_items * self.HW * cout_blocks * C * ntaps * cin_blocks * C, e0, e1,
-                        4.0 * (n_items * self.HW * (cin_blocks + cout_blocks) * C + cout_blocks * C * ntaps * cin_blocks * C), 1))
-
-    def _op(self, op: int, name: str, n: int, a: int, st: int, what: str, b: int = 0, c: int = 0, p=()) -> None:
-        """One grouped launch of a non-conv kernel: into the pass's launch list, or directly."""
-        if self._list is not None:
-            self._list.add(op, n, a, b, c, p)
-            return
-        fn = getattr(_hip.lib(), name)
-        args = [x for x in (a, b, c) if x]
-        _hip.check(fn(*args, n, *p, st), what)
+    def _op(self, op: int, n: int, a: int, b: int = 0, c: int = 0, p=()) -> None:
+        self._list.add(op, n, a, b, c, p)
 
     def _begin_list(self) -> None:
         # (a list left over from a pass that raised is dropped here)
-        self._list = _hip.LaunchList() if (self.event_log is None and not self.overlap_wgrad and self.launch_lists) else None
+        self._list = _hip.LaunchList()
 
-    def _flush_list(self, st: int, what: str, end: bool = False) -> None:
-        if self._list is not None:
-            self._list.run(st, what)
-            if end:
-                self._list = None
+    # ---- launch trace (measurement: bench.py's roofline passes, scripts/conv_launch_table.py) ----------
+    def begin_trace(self) -> None:
+        """From here to ``end_trace`` the library brackets every conv / weight-gradient launch it issues -- the stem's
+        list, the trunk planner's forward list, the backward list: the shipped host path -- with events on its stream
+        (``pnmn_launch_trace_begin``)."""
+        _hip.check(_hip.lib().pnmn_launch_trace_begin(), "launch_trace_begin")
+
+    def end_trace(self) -> list:
+        """[(kernel family, call site, algorithmic FLOPs, ms, algorithmic bytes, kernel launches)] of the traced
+        launches, in issue order.  FLOPs and bytes are the library's (csrc/host_run.hip reads the items back); the call
+        site is named here from the call's shape and place in the step."""
+        lib = _hip.lib()
+        cap = 4096
+        out = np.zeros(cap, _hip.LAUNCH_TIMING)
+        n = np.zeros(1, np.int32)
+        rc = lib.pnmn_launch_trace_end(out.ctypes.data, cap, n.ctypes.data)
+        if rc == _hip.EAGAIN:
+            raise _hip.HipLibraryError("launch trace held %d entries, more than %d: trace one step at a time" % (int(n[0]), cap))
+        _hip.check(rc, "launch_trace_end")
+        t = out[: int(n[0])]
+        cin_chunks, cls_blocks = self.cin // C, self.cproj // C
+        sites = []
+        for r in t:
+            p = r["p"]
+            if r["op"] == _hip.OP_CONV:
+                chunks, ntaps, in_stride, out_stride, relu = int(p[2]), int(p[3]), int(p[4]), int(p[5]), int(p[7])
+                if ntaps == 9:
+                    what = "stem conv1" if chunks == cin_chunks and chunks > 1 else ("module conv" if relu else "module dgrad")
+                elif chunks == 2 and relu:
+                    what = "projection"
+                elif relu:
+                    what = "classifier conv"
+                else:
+                    what = "classifier dgrad" if in_stride == self.cproj and chunks == cls_blocks and (cls_blocks > 1 or not sites or sites[-1] == "classifier wgrad") else "projection dgrad"
+                if what == "module conv" and sites and sites[-1] == "stem conv1":
+                    what = "stem conv2"
+                if what == "module dgrad" and sites and sites[-1] == "stem conv2 wgrad":
+                    what = "stem conv2 dgrad"
+            else:
+                ntaps, blocks, out_blocks = int(p[2]), int(p[3]), int(p[4])
+                if ntaps == 1:
+                    what = "projection wgrad" if blocks == 2 else "classifier wgrad"
+                elif blocks == cin_chunks and blocks > 1:
+                    what = "stem conv1 wgrad"
+                else:
+                    what = "module wgrad"
+            sites.append(what)
+        # the backward's tail is [stem conv2 wgrad, stem conv2 dgrad, stem conv1 wgrad]: same shapes as the modules'
+        for i in range(2, len(sites)):
+            if sites[i] == "stem conv1 wgrad" and sites[i - 1] == "module dgrad" and sites[i - 2] == "module wgrad":
+                sites[i - 1], sites[i - 2] = "stem conv2 dgrad", "stem conv2 wgrad"
+        return [("conv_nhwc" if r["op"] == _hip.OP_CONV else "conv_wgrad", w, float(r["flops"]), float(r["ms"]), float(r["bytes"]), 1)
+                for r, w in zip(t, sites)]
+
+    def _flush_list(self, st: int, what: str) -> None:
+        self._list.run(st, what)
+        self._list = None
 
     # ---- parameters ---------------------------------------------------------------------------
     def trunk_named_parameters(self):
@@ -417,12 +380,11 @@ class NMNEngine:
         """The part of the forward pass that does not depend on the programs: layout change of the
         input features and the two stem convolutions.  A trainer whose programs are still being
         produced (joint training: sampled on the device, scheduled on the host) launches this first
-        and hands the returned token to ``run_forward`` -- the GPU then has ~3 ms more work queued
+        and hands the returned token to ``run_forward_tokens`` -- the GPU then has ~3 ms more work queued
         while the host compiles and schedules the sampled programs.  ``rows`` (int64, on the device): run on
         examples ``features[rows]`` without materialising that gather (0.8 MB per example): the layout kernel reads
         through the index."""
         a = self.ensure_arena()
-        lib = _hip.lib()
         dev = a.device
         if features.device != dev:
             raise _hip.HipLibraryError("features on %s but the network is on %s" % (features.device, dev))
@@ -472,110 +434,15 @@ class NMNEngine:
         pack.upload(dev)
         self._begin_list()
         if not nhwc:
-            self._op(_hip.OP_NCHW_TO_NHWC, "pnmn_nchw_to_nhwc" if rows is None else "pnmn_nchw_to_nhwc_rows", B,
-                     features.data_ptr(), st, "nchw_to_nhwc", b=ws["xin"].data_ptr(),
-                     c=0 if rows is None else rows.data_ptr(), p=(self.cin, HW))
-        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1, st, "stem conv1", rec=fixed["stem1"])
-        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1, st, "stem conv2", rec=fixed["stem2"])
-        self._flush_list(st, "stem", end=True)
+            self._op(_hip.OP_NCHW_TO_NHWC, B, features.data_ptr(), b=ws["xin"].data_ptr(),
+                     c=0 if rows is None else rows.data_ptr(), p=(self.cin, HW))  # (c: the layout kernel reads through rows)
+        self._conv(pack.ptr("stem1"), B, self.cin // C, 9, self.cin, C, 1, 1)
+        self._conv(pack.ptr("stem2"), B, 1, 9, C, C, 1, 1)
+        self._flush_list(st, "stem")
         return {"B": B, "ws": ws, "fixed": fixed, "need_backward": need_backward, "generation": self.generation,
                 "features": features, "pack": pack, "rows": rows, "subset": subset, "resident": resident}
 
-    def run_forward(self, features: torch.Tensor, compiled: Sequence[pc.CompiledProgram], need_backward: bool,
-                    started=None):
-        if started is None:
-            started = self.begin_forward(features, need_backward)
-        elif (started["generation"] != self.generation or started["need_backward"] != need_backward
-              or (not started["subset"] and started["B"] != features.size(0))):
-            raise ValueError("begin_forward token does not belong to this forward pass")
-        a = self.ensure_arena()
-        lib = _hip.lib()
-        dev = a.device
-        B, ws, fixed = started["B"], started["ws"], started["fixed"]
-        HW = self.HW
-        st = _hip.stream_ptr(dev)
-
-        floats = self.scheduler.arena_floats(compiled)
-        act = self._buf("act", max(floats, 1))
-        gact = self._buf("gact", max(floats, 1)) if need_backward else act
-        bufs = Buffers(
-            params=a.flat.data_ptr(), grads=a.grad.data_ptr(), wt=self.wt.data_ptr(),
-            act=act.data_ptr(), gact=gact.data_ptr(), feat=ws["feat"].data_ptr(),
-            gfeat=ws["gfeat"].data_ptr(), final=ws["final"].data_ptr(), gfinal=ws["gfinal"].data_ptr(),
-            ones=self.ones.data_ptr())
-        plan = self.scheduler.plan(compiled, bufs)
-        assert plan.arena_floats == floats, (plan.arena_floats, floats)
-        self.last_plan = plan
-
-        pack = _Pack()
-        for k, rec in fixed.items():
-            pack.add(k, rec)
-        for k, rec in plan.records.items():
-            pack.add(k, rec)
-        for k, rec in plan.wgrad_jobs.items():
-            pack.add(k + "_jobs", rec)
-        pack.upload(dev)
-
-        H, W = self.H, self.W
-        chk = _hip.check
-
-        final = ws["final"][: B * HW * C].view(B, HW * C)
-        feat = ws["feat"][: B * HW * C].view(B, HW * C)
-        valid = [p.valid for p in compiled]
-        if not all(valid):
-            inv = _hip.small_to_device([i for i, v in enumerate(valid) if not v], torch.long, dev)
-            final.index_fill_(0, inv, 0.0)  # reference: zeros_like(feat_input) for invalid programs
-        if plan.feat_result_examples.size:
-            idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
-            final.index_copy_(0, idx, feat.index_select(0, idx))
-
-        pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
-        self._begin_list()
-        self._run_forward_launches(plan, pack, st)
-        self._conv(pack.ptr("cls"), B, 1, 1, C, self.cproj, self.cproj // C, 1, st, "classifier conv", rec=fixed["cls"])
-        self._op(_hip.OP_MAXPOOL_FWD, "pnmn_maxpool2_flatten_fwd", B, ws["cls"].data_ptr(), st, "maxpool",
-                 b=pooled.data_ptr(), p=(H, W, self.cproj))
-        self._flush_list(st, "module programs (forward)", end=True)
-
-        state = None
-        if need_backward:
-            state = _State()
-            state.plan, state.pack, state.fixed, state.B = plan, pack, fixed, B
-            state.features = started["features"]  # (the stem's weight gradient reads the input again)
-            state.generation = self.generation
-            state.backward_rows = None
-            if self.event_log is None and not self.overlap_wgrad and self.launch_lists:
-                # the backward pass's launch list, put together now: the forward launches are out and the GPU is busy
-                # with them, whereas in run_backward nothing runs on this stream until the list is complete
-                # (0.4 ms of host time per step on the critical path of a small batch)
-                self._begin_list()
-                cuts, where = self._queue_backward(state, 0, st, live=False)
-                state.backward_rows = (np.array(self._list._rows, dtype=np.uint64), cuts, where)
-                self._list = None
-        return pooled, state
-
-    def _run_forward_launches(self, plan: StepPlan, pack: _Pack, st: int) -> None:
-        lib, chk, H, W, HW = _hip.lib(), _hip.check, self.H, self.W, self.HW
-        for l in plan.forward:
-            n = l.end - l.begin
-            if l.kind == "conv":
-                self._conv(pack.ptr("conv", l.begin), n, 1, 9, C, C, 1, 1, st, "module conv", rec=plan.records["conv"][l.begin:l.end])
-            elif l.kind == "proj":
-                self._conv(pack.ptr("proj", l.begin), n, 2, 1, C, C, 1, 1, st, "projection", rec=plan.records["proj"][l.begin:l.end])
-            elif l.kind == "dot":
-                self._op(_hip.OP_DOT_FWD, "pnmn_dot1_sigmoid_fwd", n, pack.ptr("dot", l.begin), st, "dot1", p=(HW,))
-            elif l.kind == "same":
-                self._op(_hip.OP_SAME_FWD, "pnmn_same_fwd", n, pack.ptr("same", l.begin), st, "same", p=(HW,))
-            elif l.kind == "minmax":
-                self._op(_hip.OP_MINMAX_FWD, "pnmn_minmax_fwd", n, pack.ptr("minmax", l.begin), st, "minmax", p=(HW, C))
-            else:
-                raise AssertionError(l.kind)
-
-
     # ---- the library's trunk planner ------------------------------------------------------------------
-    def use_native(self) -> bool:
-        return self.native and self.event_log is None and not self.overlap_wgrad and self.launch_lists
-
     def _native_planner(self) -> int:
         if self._planner is None:
             t = self.tables
@@ -712,141 +579,15 @@ class NMNEngine:
         return pooled, state, valid
 
     # ---- backward -------------------------------------------------------------------------------
-    def _feat_result_backward(self, plan, ws, B, dev) -> None:
-        """Programs whose result is the stem's feature map itself: d(final) goes straight to d(features)."""
-        HW = self.HW
-        idx = _hip.small_to_device(plan.feat_result_examples.tolist(), torch.long, dev)
-        gfeat = ws["gfeat"][: B * HW * C].view(B, HW * C)
-        gfinal = ws["gfinal"][: B * HW * C].view(B, HW * C)
-        gfeat.index_add_(0, idx, gfinal.index_select(0, idx))
-
-    def _queue_backward(self, state: _State, dpooled_ptr: int, st: int, live: bool):
-        """The trunk's backward launches, appended to the current launch list (or issued one by one when there is
-        none).  ``live``: called from run_backward -- the list is flushed where a torch op has to go in between;
-        otherwise (run_forward putting the list together ahead of time) returns (rows before that op, index of the
-        row that carries d(pooled))."""
-        a = self.arena
-        dev = a.device
-        plan, pack, B = state.plan, state.pack, state.B
-        H, W, HW = self.H, self.W, self.HW
-        ws = self._ws
-        cuts = []  # (rows queued before it, what the host does there): "feat" = the torch op, ("piece", k) = on_grad_piece(k)
-
-        def host_action(what):
-            if live:
-                self._flush_list(st, "trunk backward")  # (everything before it must be queued)
-                self._host_action(what, plan, ws, B, dev)
-            else:
-                cuts.append((len(self._list), what))
-
-        self._op(_hip.OP_TRANSPOSE_WEIGHTS, "pnmn_transpose_weights", self._wt_count, self._wt_records.data_ptr(), st,
-                 "transpose weights")
-
-        main = torch.cuda.current_stream(dev)
-        if self.overlap_wgrad:
-            if self._side_stream is None or self._side_stream.device != dev:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            side = self._side_stream
-        else:
-            side = main
-
-        def fork():
-            """work queued on `side` from here on may read everything `main` has produced so far"""
-            if side is not main:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-
-        # classifier conv
-        where = len(self._list) if self._list is not None else -1
-        self._op(_hip.OP_MAXPOOL_BWD, "pnmn_maxpool2_flatten_bwd", B, ws["cls"].data_ptr(), st, "maxpool bwd",
-                 b=dpooled_ptr, c=ws["gcls"].data_ptr(), p=(H, W, self.cproj))
-        fork()
-        nj = len(state.fixed["cls_wg_jobs"])
-        self._wgrad(pack.ptr("cls_wg"), pack.ptr("cls_wg_jobs"), nj, B, 1, 1, self.cproj // C, C, self.cproj, side,
-                    "classifier wgrad")
-        self._conv(pack.ptr("cls_dgrad"), B, self.cproj // C, 1, self.cproj, C, 1, 0, st, "classifier dgrad", rec=state.fixed["cls_dgrad"])
-        if plan.feat_result_examples.size:
-            host_action("feat")
-
-        # module programs, levels in reverse; each group of module-conv weight gradients is released
-        # to the side stream as soon as the data-gradient chain has passed its lowest level
-        groups = list(plan.wgrad_groups or [])
-        n_items3 = len(plan.records["wg3"])
-        n_jobs3 = max(1, len(plan.wgrad_jobs["wg3"]))
-        for phase in plan.backward:
-            for l in phase:
-                n = l.end - l.begin
-                if l.kind == "dot_bwd":
-                    self._op(_hip.OP_DOT_BWD, "pnmn_dot1_sigmoid_bwd", n, pack.ptr("dot", l.begin), st, "dot1 bwd", p=(HW,))
-                elif l.kind == "same_bwd":
-                    self._op(_hip.OP_SAME_BWD, "pnmn_same_bwd", n, pack.ptr("same", l.begin), st, "same bwd", p=(HW,))
-                elif l.kind == "minmax_bwd":
-                    self._op(_hip.OP_MINMAX_BWD, "pnmn_minmax_bwd", n, pack.ptr("minmax", l.begin), st, "minmax bwd", p=(HW, C))
-                elif l.kind == "dgrad":
-                    self._conv(pack.ptr("dgrad", l.begin), n, 1, 9, C, C, 1, 0, st, "module dgrad", rec=plan.records["dgrad"][l.begin:l.end])
-                elif l.kind == "pdgrad":
-                    self._conv(pack.ptr("pdgrad", l.begin), n, 1, 1, C, C, 1, 0, st, "projection dgrad", rec=plan.records["pdgrad"][l.begin:l.end])
-                elif l.kind == "maskbwd":
-                    self._op(_hip.OP_MASK_BWD, "pnmn_mask_bwd", n, pack.ptr("maskbwd", l.begin), st, "mask bwd", p=(HW,))
-                else:
-                    raise AssertionError(l.kind)
-            level = phase[0].level
-            ready = [g for g in groups if g[0] >= level]
-            if ready:
-                groups = [g for g in groups if g[0] < level]
-                fork()
-                for _, jb, je in ready:
-                    self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3,
-                                9, 1, 1, C, C, side, "module wgrad")
-        if self.scheduler.fuse_mask_bwd == 2 and len(plan.records["maskbwd"]):
-            # deferred d(feats) of the masked convs: one gather over all of them (pnmn_feat_grad_gather)
-            self._op(_hip.OP_FEAT_GATHER, "pnmn_feat_grad_gather", len(plan.records["maskbwd"]), pack.ptr("maskbwd"), st,
-                     "feat grad gather", b=ws["gfeat"].data_ptr(), p=(B, HW))
-        fork()
-        for _, jb, je in groups:
-            self._wgrad(pack.ptr("wg3"), pack.ptr("wg3_jobs", jb), je - jb, n_items3 * (je - jb) // n_jobs3, 9, 1, 1,
-                        C, C, side, "module wgrad")
-        nj = len(plan.wgrad_jobs["wgp"])
-        if nj:
-            self._wgrad(pack.ptr("wgp"), pack.ptr("wgp_jobs"), nj, len(plan.records["wgp"]), 1, 2, 1, C, C, side,
-                        "projection wgrad")
-        if self.on_grad_piece is not None and side is main:
-            host_action(("piece", 0))  # classifier conv + all module gradients are final behind these launches
-
-        # stem: gfeat is complete here
-        nj = len(state.fixed["stem2_wg_jobs"])
-        self._wgrad(pack.ptr("stem2_wg"), pack.ptr("stem2_wg_jobs"), nj, B, 9, 1, 1, C, C, side, "stem conv2 wgrad")
-        self._conv(pack.ptr("stem2_dgrad"), B, 1, 9, C, C, 1, 0, st, "stem conv2 dgrad", rec=state.fixed["stem2_dgrad"])
-        fork()
-        nj = len(state.fixed["stem1_wg_jobs"])
-        self._wgrad(pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"), nj, B, 9, self.cin // C, 1, self.cin, C, side,
-                    "stem conv1 wgrad")
-        if side is not main:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            main.wait_event(ev)
-        return cuts, where
-
-    def _host_action(self, what, plan, ws, B, dev) -> None:
-        if what == "feat":
-            self._feat_result_backward(plan, ws, B, dev)
-        elif self.on_grad_piece is not None:
-            self.on_grad_piece(what[1])
-
-
     def run_backward(self, state: _State, dpooled: torch.Tensor):
         if state.generation != self.generation:
             raise RuntimeError(
                 "NeuralModuleNetwork.forward was called again before backward of the previous call: "
                 "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
         a = self.arena
-        lib, chk = _hip.lib(), _hip.check
+        chk = _hip.check
         dev = a.device
         st = _hip.stream_ptr(dev)
-        plan, pack, B = state.plan, state.pack, state.B
-        H, W, HW = self.H, self.W, self.HW
-        ws = self._ws
         dpooled = dpooled.contiguous()
         # d(pooled) was produced (and is owned) by the stream of the fully connected layers; when the trunk runs on its own
         # stream the launches below read it there AFTER this function has returned and autograd has dropped the tensor --
@@ -854,53 +595,22 @@ class NMNEngine:
         # has not run yet (seen as NMN gradients off by ~1e-3 in one run in four of the 1024-row side-stream test)
         dpooled.record_stream(torch.cuda.current_stream(dev))
 
-        if isinstance(plan, _NativePlan):
-            # the whole list came out of the planner (zeroing of the gradient buffers included): d(pooled) is the only
-            # thing that was not known then
-            rows, piece_cut, where = state.backward_rows
-            rows[where, 1] = dpooled.data_ptr()
-            lib_run = _hip.lib().pnmn_run_launches
-            _hip.mark("trunk backward begins (dpooled ready)")
-            if self.on_grad_piece is not None and 0 < piece_cut < rows.shape[0]:
-                chk(lib_run(rows.ctypes.data, piece_cut, st), "trunk backward")
-                self.on_grad_piece(0)  # classifier conv + all module gradients are final behind these launches
-                chk(lib_run(rows[piece_cut:].ctypes.data, rows.shape[0] - piece_cut, st), "trunk backward (stem)")
-            else:
-                chk(lib_run(rows.ctypes.data, rows.shape[0], st), "trunk backward")
-            if self.on_grad_piece is not None:
-                if not 0 < piece_cut < rows.shape[0]:
-                    self.on_grad_piece(0)
-                self.on_grad_piece(1)
-            if self.direct_grads:
-                a.attach_grads()
-                return [None] * len(a.names)
-            return [a.grad_view(n) for n in a.names]
+        # the whole list came out of the planner (zeroing of the gradient buffers included): d(pooled) is the only
+        # thing that was not known then
+        rows, piece_cut, where = state.backward_rows
+        rows[where, 1] = dpooled.data_ptr()
+        lib_run = _hip.lib().pnmn_run_launches
         _hip.mark("trunk backward begins (dpooled ready)")
-        a.grad.zero_()
-        if plan.arena_floats:
-            ws["gact"][: plan.arena_floats].zero_()
-        ws["gfeat"][: B * HW * C].zero_()
-        _hip.mark("gradient buffers zeroed")
-        pre = state.backward_rows
-        if pre is not None and self.event_log is None and not self.overlap_wgrad and self.launch_lists:
-            # the launch list was put together behind the forward pass (run_forward): only d(pooled) is new
-            rows, cuts, where = pre
-            rows[where, 1] = dpooled.data_ptr()
-            lib_run = _hip.lib().pnmn_run_launches
-            at = 0
-            for upto, what in cuts + [(rows.shape[0], None)]:
-                if upto > at:
-                    chk(lib_run(rows[at:upto].ctypes.data, upto - at, st), "trunk backward")
-                    at = upto
-                if what is not None:
-                    self._host_action(what, plan, ws, B, dev)
+        if self.on_grad_piece is not None and 0 < piece_cut < rows.shape[0]:
+            chk(lib_run(rows.ctypes.data, piece_cut, st), "trunk backward")
+            self.on_grad_piece(0)  # classifier conv + all module gradients are final behind these launches
+            chk(lib_run(rows[piece_cut:].ctypes.data, rows.shape[0] - piece_cut, st), "trunk backward (stem)")
         else:
-            self._begin_list()
-            self._queue_backward(state, dpooled.data_ptr(), st, live=True)
-            self._flush_list(st, "trunk backward", end=True)
+            chk(lib_run(rows.ctypes.data, rows.shape[0], st), "trunk backward")
         if self.on_grad_piece is not None:
-            self.on_grad_piece(1)  # the stem's gradients: the last kernels of the trunk backward are queued
-
+            if not 0 < piece_cut < rows.shape[0]:
+                self.on_grad_piece(0)
+            self.on_grad_piece(1)
         if self.direct_grads:
             a.attach_grads()
             return [None] * len(a.names)

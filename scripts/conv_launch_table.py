@@ -20,12 +20,12 @@ step = ModuleTrainingStep(nmn, lr=1e-4, report_metrics=False)
 for _ in range(3):
     step.step(batch)
 torch.cuda.synchronize()
-nmn.engine.event_log = []
+nmn.engine.begin_trace()
 step.step(batch)
 torch.cuda.synchronize()
 rows = []
-for kern, what, flops, e0, e1, _, _ in nmn.engine.event_log:
-    rows.append((kern, what, flops, e0.elapsed_time(e1)))
+for kern, what, flops, ms, _, _ in nmn.engine.end_trace():
+    rows.append((kern, what, flops, ms))
 tot = {}
 print("%-11s %-22s %9s %9s %8s" % ("kernel", "site", "GFLOP", "ms", "TF"))
 for kern, what, flops, ms in rows:

@@ -239,7 +239,7 @@ def test_row_subset_equals_the_gathered_batch(size):
 def test_mask_backward_modes_agree():
     """The three ways the backward of `feats * attn` is scheduled (probnmn.runtime.schedule: 2 = d(attention) in the data
     gradient's epilogue + ONE deferred gather of d(feats), the default; 1 = both fused into the epilogue; 0 = a separate
-    kernel per level) give the same gradients -- through the library's trunk planner AND through the Python planner."""
+    kernel per level) give the same gradients."""
     from probnmn.data.synthetic import synthetic_batch
     from probnmn.models.nmn import NeuralModuleNetwork
     from probnmn.vocabulary import Vocabulary
@@ -250,18 +250,16 @@ def test_mask_backward_modes_agree():
     images, answers = batch["image"].to(dev), batch["answer"].to(dev)
     results = {}
     for mode in (2, 1, 0):
-        for native in (True, False):
-            torch.manual_seed(7)
-            net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
-            net.engine.ensure_arena()
-            net.engine.scheduler.fuse_mask_bwd = mode
-            net.engine.native = native
-            net.train()
-            out = net(images, batch["program"], answers)
-            out["loss"].mean().backward()
-            torch.cuda.synchronize()
-            results[(mode, native)] = (out["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
-    loss0, grads0 = results[(2, True)]
+        torch.manual_seed(7)
+        net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
+        net.engine.ensure_arena()
+        net.engine.scheduler.fuse_mask_bwd = mode
+        net.train()
+        out = net(images, batch["program"], answers)
+        out["loss"].mean().backward()
+        torch.cuda.synchronize()
+        results[mode] = (out["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+    loss0, grads0 = results[2]
     for key, (loss, grads) in results.items():
         assert torch.equal(loss, loss0), key
         for n, g in grads.items():
@@ -300,7 +298,6 @@ def test_conv_splits_give_bit_identical_activations(n, deep, cus):
             out = net(images, batch["program"], answers)
             out["loss"].mean().backward()
             torch.cuda.synchronize()
-            assert net.engine.use_native()
             results[split] = (out["loss"].detach().clone(), out["predictions"].clone(),
                               {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
     finally:
