@@ -618,6 +618,30 @@ def evaluation_side(vocab, pg, nmn, dev, n=256, num_batches=8):
                         "autograd, %d batches of %d questions (num_batches = %d)" % (num_batches + 2, n, num_batches)}
 
 
+def extraction_side(dev, n=64, k=5):
+    """The offline feature extractor the reference runs before any training (/root/reference/scripts/preprocess/
+    extract_features.py:98-131: torchvision ResNet-101 up to stage 3 on 224x224 images) on csrc/resnet.hip: images / s and
+    the fraction of the fp32 matrix roof of its 94 convolutions, random weights, one batch of synthetic images."""
+    from probnmn.data.feature_extractor import ResNet101Stage3
+
+    model = ResNet101Stage3().to(dev)
+    images = torch.randn(n, 3, 224, 224, device=dev)
+    for _ in range(2):
+        feats = model(images)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        feats = model(images)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    tf = model.flops_per_image() * n / dt / 1e12
+    return {"metric": "CLEVR images/sec (ResNet-101 stage-3 feature extraction)", "value": round(n / dt, 1), "unit": "images/s",
+            "ms_per_batch": round(dt * 1e3, 3), "batch": n, "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / 157.3, 4),
+            "features": list(feats.shape[1:]), "dtype": "f32",
+            "workload": "ResNet101Stage3.forward (94 x pnmn_conv2d_nhwc + max pool), %d synthetic 224x224 images, random weights; "
+                        "70 000 training images = %.0f s" % (n, 70000 * dt / n)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per GPU,
     rendezvous on 127.0.0.1) with the same arguments, pass their output through and exit with their status."""
@@ -937,6 +961,11 @@ def main():
             log("evaluate_answer_accuracy: %.1f questions/s" % extras["evaluate_answer_accuracy"]["value"])
         except Exception as exc:
             extras["evaluate_answer_accuracy"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        try:
+            extras["feature_extraction"] = extraction_side(dev)
+            log("feature_extraction: %.1f images/s" % extras["feature_extraction"]["value"])
+        except Exception as exc:
+            extras["feature_extraction"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         side("joint_training_b128", "CLEVR questions/sec (joint_training step)",
              "joint_training_ours.yml, 128 questions per GPU (configs[3] read as 1024 over 8 GPUs)", 128,
              lambda: trainer, k=40)  # (8 ms steps whose sampled programs differ: 10 of them scatter by +-4 %)

@@ -694,6 +694,33 @@ int pnmn_compile_programs(const int64_t* tokens, int n_programs, int length, con
                           int n_kinds, int channels, uint8_t* valid, int32_t* n_calls,
                           int32_t* calls, int32_t* result);
 
+/* ---------------------------------------------------------------------------------------------
+ * Feature extractor (csrc/resnet.hip): the convolutions of torchvision's ResNet-101 up to stage 3, which the reference
+ * runs offline to produce the NMN's input features (/root/reference/scripts/preprocess/extract_features.py:98-105 build
+ * resnet101(pretrained=True) with layer4 / avgpool / fc replaced by Identity, eval mode; :124-131 run it under no_grad).
+ * Tensors are NHWC fp32 on the device.
+ *
+ * pnmn_conv2d_nhwc: y[n][oy][ox][co] = act( scale[co] * sum_{ky,kx,ci} x[n][oy*stride-pad+ky][ox*stride-pad+kx][ci] *
+ *                   w[co][(ky*kw+kx)*Cin+ci] + shift[co] (+ residual[n][oy][ox][co]) ),  act = ReLU if `relu`.
+ *   Replaces nn.Conv2d(bias=False) + nn.BatchNorm2d in eval mode (+ the block's `out += identity; relu`) of
+ *   torchvision.models.resnet (0.5.0: Bottleneck.forward, ResNet._forward_impl); scale = gamma / sqrt(var + eps),
+ *   shift = beta - mean * scale are folded by the host.  Cin a multiple of 4 (the image is padded from 3 to 4 channels),
+ *   Cout a multiple of 64; w is [Cout][Kpad] with K = kh*kw*Cin padded with zeros to pnmn_conv2d_weight_floats / Cout.
+ *   Ho / Wo must equal floor((H + 2 pad - k) / stride) + 1 (PNMN_ESHAPE otherwise).
+ * pnmn_maxpool3x3s2_nhwc: nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (ResNet.maxpool); C a multiple of 4. */
+typedef struct pnmn_conv2d_desc {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;  /* or NULL */
+    float*       y;
+    int32_t      N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, relu;
+} pnmn_conv2d_desc;         /* 96 bytes */
+int pnmn_conv2d_nhwc(const pnmn_conv2d_desc* desc, void* stream);
+int pnmn_conv2d_weight_floats(int Cout, int Cin, int kh, int kw);
+int pnmn_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
 /* Library self-description (no GPU needed).  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */

@@ -800,8 +800,12 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     };
     while (more) {
         stage(I0{});
-        if ((WSETS == 2 || KIND == 2) && more) stage(I1{});  // (an odd number of taps per stage: the next one starts on the other set)
-        if (WSETS == 3 && KIND == 2 && more) stage(I2{});
+        if constexpr (WSETS == 2 || KIND == 2) {  // (an odd number of taps per stage: the next one starts on the other set)
+            if (more) stage(I1{});
+        }
+        if constexpr (WSETS == 3 && KIND == 2) {
+            if (more) stage(I2{});
+        }
     }
     const unsigned long long c_u = PNMN_CYC();
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table

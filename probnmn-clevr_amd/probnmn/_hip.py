@@ -92,6 +92,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_conv_force_split": (_I,),
     "pnmn_run_launches": (_P, _I, _P),
+    "pnmn_conv2d_nhwc": (_P, _P),
+    "pnmn_conv2d_weight_floats": (_I, _I, _I, _I),
+    "pnmn_maxpool3x3s2_nhwc": (_P, _P, _I, _I, _I, _I, _P),
     "pnmn_launch_trace_begin": (),
     "pnmn_launch_trace_end": (_P, _I, _P),
     "pnmn_set_rows": (_P, _I, _P),
@@ -238,10 +241,13 @@ DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "
 DECODER_BWD_JOB = np.dtype([(n, _u64) for n in ("dhs", "act", "cs", "hs", "probs", "enc", "mask", "h0", "w_c_t", "w_hh_t", "dgates",
                                                   "dctx", "dscore", "weights", "dh0")]
                            + [(n, _i32) for n in ("B", "T", "S", "reserved")])
-EAGAIN = -3
+EINVAL, ESHAPE, EAGAIN = -1, -2, -3  # PNMN_EINVAL / PNMN_ESHAPE / PNMN_EAGAIN
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
+CONV2D_DESC = np.dtype([("x", _u64), ("w", _u64), ("scale", _u64), ("shift", _u64), ("residual", _u64), ("y", _u64),
+                        ("N", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
+                        ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32), ("relu", _i32)])  # pnmn_conv2d_desc
 LAUNCH_TIMING = np.dtype([("op", _i32), ("n", _i32), ("p", _i32, (8,)), ("n_items", _i32), ("ms", np.float32),
                           ("flops", np.float64), ("bytes", np.float64)])  # pnmn_launch_timing
 (OP_CONV, OP_WGRAD, OP_TRANSPOSE_WEIGHTS, OP_DOT_FWD, OP_DOT_BWD, OP_SAME_FWD, OP_SAME_BWD, OP_MINMAX_FWD, OP_MINMAX_BWD,
@@ -273,6 +279,8 @@ class LaunchList:
 
 ITEM_SIZES = {
     "pnmn_launch": (LAUNCH, 64),
+    "pnmn_launch_timing": (LAUNCH_TIMING, 64),
+    "pnmn_conv2d_desc": (CONV2D_DESC, 96),
     "pnmn_conv_item": (CONV_ITEM, 96),
     "pnmn_wgrad_item": (WGRAD_ITEM, 48),
     "pnmn_wgrad_job": (WGRAD_JOB, 24),

@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert handle.pnmn_abi_version() == _hip.ABI_VERSION == 8
 
 
+def test_launch_trace_without_launches_is_empty():
+    """pnmn_launch_trace_begin / _end around nothing: zero entries, no device needed; a second _end is harmless."""
+    handle = _hip.lib()
+    import numpy as np
+    out, n = np.zeros(4, _hip.LAUNCH_TIMING), np.full(1, -1, np.int32)
+    assert handle.pnmn_launch_trace_begin() == 0
+    assert handle.pnmn_launch_trace_end(out.ctypes.data, 4, n.ctypes.data) == 0 and n[0] == 0
+    assert handle.pnmn_launch_trace_end(out.ctypes.data, 4, n.ctypes.data) == 0 and n[0] == 0
+    assert handle.pnmn_launch_trace_end(0, 0, 0) == _hip.EINVAL
+
+
 def test_record_layouts_match_c_structs():
     """Compile a tiny C program against the header and compare sizeof/offsetof with numpy."""
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "probnmn_hip.h"', "int main(){"]

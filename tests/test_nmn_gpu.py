@@ -183,6 +183,46 @@ def test_config5_28x28_long_programs_match_oracle():
     torch.testing.assert_close(ev["loss"].cpu(), ref_ev["loss"].detach(), rtol=1e-4, atol=1e-4)
 
 
+def test_launch_trace_reports_the_shipped_path():
+    """engine.begin_trace / end_trace (pnmn_launch_trace_*): the library times the conv / weight-gradient launches of its own
+    lists -- stem, planner forward, backward -- and accounts their algorithmic work; the step's results do not change."""
+    vocab, net, programs, features, answers = _setup(seed=5, cases=VALIDITY_CASES[:16])
+    dev = torch.device("cuda:0")
+    net.to(dev).train()
+    B = features.size(0)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        out = net(features.to(dev), programs.to(dev), answers.to(dev))
+        out["loss"].mean().backward()
+        torch.cuda.synchronize()
+        return out["loss"].detach().clone()
+
+    loss0 = step()
+    net.engine.begin_trace()
+    loss1 = step()
+    events = net.engine.end_trace()
+    assert torch.equal(loss0, loss1)
+    assert net.engine.end_trace() == []  # (collected: the trace is off and empty)
+    sites = [e[1] for e in events]
+    assert sites[:2] == ["stem conv1", "stem conv2"] and sites[-3:] == ["stem conv2 wgrad", "stem conv2 dgrad", "stem conv1 wgrad"]
+    assert sites.count("classifier conv") == 1 and sites.count("classifier dgrad") == 1 and sites.count("classifier wgrad") == 1
+    n_conv, n_proj = net.engine.last_counts
+    assert n_conv > 0 and ("module conv" in sites) and ("module dgrad" in sites) and ("module wgrad" in sites)
+    by = {w: [e for e in events if e[1] == w] for w in set(sites)}
+    hw, c = 14 * 14, 128
+    cin = features.size(1)
+    assert by["stem conv1"][0][2] == 2.0 * B * hw * c * 9 * cin and by["stem conv1 wgrad"][0][2] == 2.0 * B * hw * c * 9 * cin
+    assert by["stem conv2"][0][2] == 2.0 * B * hw * c * 9 * c
+    # every module conv once forward, once as a data gradient (or not at all where its input needs none), once in the
+    # deferred weight gradient; dilation-8 items count 78 / 117 of the taps, so compare with the record count only from above
+    full = 2.0 * hw * c * 9 * c
+    fwd = sum(e[2] for e in by["module conv"])
+    assert 0.6 * n_conv * full <= fwd <= n_conv * full
+    assert sum(e[2] for e in by["module wgrad"]) == n_conv * full
+    assert all(e[3] > 0 and e[4] > 0 and e[0] in ("conv_nhwc", "conv_wgrad") for e in events)
+
+
 def test_eval_without_answers_and_repeat_is_deterministic():
     vocab, net, programs, features, _ = _setup(seed=3, cases=VALIDITY_CASES[:12])
     cpu_sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
