@@ -618,7 +618,7 @@ def evaluation_side(vocab, pg, nmn, dev, n=256, num_batches=8):
                         "autograd, %d batches of %d questions (num_batches = %d)" % (num_batches + 2, n, num_batches)}
 
 
-def extraction_side(dev, n=64, k=5):
+def extraction_side(dev, n=128, k=5):
     """The offline feature extractor the reference runs before any training (/root/reference/scripts/preprocess/
     extract_features.py:98-131: torchvision ResNet-101 up to stage 3 on 224x224 images) on csrc/resnet.hip: images / s and
     the fraction of the fp32 matrix roof of its 94 convolutions, random weights, one batch of synthetic images."""
