@@ -171,6 +171,21 @@ class DeviceFeatureStore:
                                                        chunk_rows, C, H * W, st), "gather_features")
         torch.cuda.current_stream(device).synchronize()
 
+    @classmethod
+    def from_device(cls, features: torch.Tensor) -> "DeviceFeatureStore":
+        """Adopt features that are already in HBM in the stem's layout -- an (N, C, H, W) fp32 ``channels_last`` tensor,
+        which is what ``probnmn.data.feature_extractor`` writes -- without a copy."""
+        if features.dim() != 4 or features.dtype != torch.float32 or features.device.type != "cuda":
+            raise ValueError("expected an (N, C, H, W) fp32 tensor on a ROCm device")
+        rows = features.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            raise ValueError("features must be in channels_last memory format (NHWC storage)")
+        self = cls.__new__(cls)
+        self.shape, self.device = tuple(int(d) for d in features.shape), features.device
+        self.row_bytes = self.shape[1] * self.shape[2] * self.shape[3] * 4
+        self.rows = rows
+        return self
+
     def __len__(self) -> int:
         return self.shape[0]
 

@@ -23,3 +23,8 @@ done
 PNMN_NMN_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_pmc_MFMA.log 2>&1
 python profiles/summarize.py --mfma $(find /tmp/pmc_mfma -name '*_results.db' | head -1) > gpurun_out/${TAG}_pmc_MFMA.txt 2>&1
 cut -c1-400 gpurun_out/${TAG}_prof_bench.json
+# 4) the timed steps alone, single-stream schedule: per-iteration table of the last 20 iterations (= the timed region when
+#    nothing runs behind it), whose conv launch durations are what bench.py's instrumented passes must agree with -- the
+#    whole-process table of 1) also averages the settle / warm-up steps, whose generator samples fewer valid programs
+PNMN_NMN_STREAM=0 timeout 900 rocprofv3 --kernel-trace -d /tmp/prof3_$TAG -o $TAG -- python bench.py --no-cpu-baseline --no-extras --no-roofline > gpurun_out/${TAG}_prof3_bench.log 2>&1
+python profiles/summarize.py --steady 20 $(find /tmp/prof3_$TAG -name '*_results.db' | head -1) > gpurun_out/${TAG}_steady_single_stream.txt 2>&1

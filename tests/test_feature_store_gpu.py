@@ -157,3 +157,21 @@ def test_resident_store_feeds_the_network_without_a_copy():
     assert torch.equal(z_t, z_r) and obj_t == obj_r
     for k in g_t:
         assert float((g_t[k] - g_r[k]).abs().max()) <= 1e-4 * (float(g_t[k].abs().max()) + 1e-12), k
+
+
+@pytest.mark.gpu
+def test_resident_store_adopts_device_features_in_place():
+    """DeviceFeatureStore.from_device: the feature extractor's channels_last output becomes the store without a copy; rows
+    read through it equal the tensor's."""
+    from probnmn.data.feature_store import DeviceFeatureStore
+
+    dev = torch.device("cuda:0")
+    feats = torch.randn(12, 1024, 14, 14, device=dev).contiguous(memory_format=torch.channels_last)
+    store = DeviceFeatureStore.from_device(feats)
+    assert len(store) == 12 and store.data_ptr() == feats.data_ptr() and store.image_feature_size == (1024, 14, 14)
+    rows = store.batch([7, 0, 7, 11])
+    assert rows.shape == (4, 1024, 14, 14)
+    assert torch.equal(rows.materialize(), feats[[7, 0, 7, 11]])
+    assert rows.pointers().tolist() == [feats.data_ptr() + i * 1024 * 196 * 4 for i in (7, 0, 7, 11)]
+    with pytest.raises(ValueError):
+        DeviceFeatureStore.from_device(torch.randn(2, 1024, 14, 14, device=dev))  # NCHW storage
