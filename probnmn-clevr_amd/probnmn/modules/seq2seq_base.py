@@ -995,9 +995,12 @@ class Seq2SeqBase(nn.Module):
         target_tokens: Optional[torch.LongTensor] = None,
         decoding_strategy: str = "sampling",
         need_predictions: bool = True,
+        seed: Optional[int] = None,
     ) -> Dict[str, torch.Tensor]:
         """``need_predictions=False`` (teacher forcing only): skip drawing the per-step predictions from the
-        teacher-forced distributions (reference :196-220) -- training iterations never read them."""
+        teacher-forced distributions (reference :196-220) -- training iterations never read them.  ``seed``: the sampler
+        seed a ``decode_prepare`` of this pass already drew (its pairing fell through): one draw per pass either way, so
+        paired and unpaired schedules sample the same programs from the same torch seed."""
         if decoding_strategy not in ("sampling", "greedy"):
             raise ValueError("decoding_strategy must be 'sampling' or 'greedy'")
         pad, bos, eos = self._pad_index, self._start_index, self._end_index
@@ -1009,7 +1012,8 @@ class Seq2SeqBase(nn.Module):
 
         steps = tgt.size(1) - 1 if tgt is not None else self._max_decoding_steps
         greedy = decoding_strategy == "greedy"
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
         Hd = h.size(1)
         w_ih = self._decoder_cell.weight_ih
         # the cell's input is cat(attended, embedding)
@@ -1077,6 +1081,11 @@ class Seq2SeqBase(nn.Module):
         Hd = h.size(1)
         if not (self.training and torch.is_grad_enabled() and enc.is_cuda and Hd == 256 and enc.size(1) <= 64 and w_p.size(0) <= 128):
             return None
+        # the pair kernels are multi-CU only: PNMN_DECODER_CLUSTER=0, or a device that cannot host eight resident
+        # workgroups per tile (the library then reports no workspace), leave both passes to decode()
+        if os.environ.get("PNMN_DECODER_CLUSTER", "1") == "0" or \
+                int(_hip.lib().pnmn_attn_lstm_multi_workspace_bytes(enc.size(0), 0)) <= 0:
+            return None
         derived = self._derived()
         if derived is None:
             return None
@@ -1091,6 +1100,7 @@ class Seq2SeqBase(nn.Module):
             tgt = _TokenPrep.run(target_tokens, pad, bos, eos, drop_first=False, want_mask=False)[0]
             steps = tgt.size(1) - 1
             etable = _TokenTable.apply(emb.weight, w_e, bias, emb.padding_idx)
+            torch.randint(0, 2 ** 62, (1,))  # (decode() draws one seed per pass, used or not: keep the generator in step)
             meta.update(mode=0, in_tokens=tgt[:, :steps], T=steps)
         else:
             steps = self._max_decoding_steps

@@ -165,6 +165,7 @@ class _TrainerBase(StepBase):
         paired = False
         if n_nosup:
             ques_nosup = question[nosup_d]
+            prep_s = None
             if n_sup and dev.type == "cuda":
                 # the generator's sampling decode and its supervised (teacher-forced) decode start from the same encoder
                 # pass and are independent: one launch each way for both -- the persistent decoder kernels are latency
@@ -179,7 +180,8 @@ class _TrainerBase(StepBase):
                     out["pg_sup_rows"] = o_sup["loss"]
                     paired = True
             if not paired:
-                out["pg"] = self.pg.decode(state_nosup, None, "sampling")
+                drawn = prep_s["meta"]["seed"] if prep_s is not None else None  # (a prepared pass has drawn its seed)
+                out["pg"] = self.pg.decode(state_nosup, None, "sampling", seed=drawn)
             z = out["pg"]["predictions"]
             out["programs"] = z
             if host_programs:

@@ -625,17 +625,45 @@ def test_paired_sampling_and_teacher_forced_decodes_equal_two_single_ones(rows_s
         else:
             o_s = pg.decode(st_s, None, "sampling")
             o_t = pg.decode(st_t, p[idx_t], "sampling", need_predictions=False)
+        after = int(torch.randint(0, 2 ** 62, (1,)).item())  # where the CPU generator stands behind the two passes
         ((o_s["loss"] * ws).sum() + (o_t["loss"] * wt).sum()).backward()
         torch.cuda.synchronize()
         return (o_s["predictions"].clone(), o_s["loss"].detach().clone(), o_t["loss"].detach().clone(),
-                {n: t.grad.clone() for n, t in pg.named_parameters()})
+                {n: t.grad.clone() for n, t in pg.named_parameters()}, after)
 
-    z0, ls0, lt0, g0 = run(False)
-    z1, ls1, lt1, g1 = run(True)
+    z0, ls0, lt0, g0, after0 = run(False)
+    z1, ls1, lt1, g1, after1 = run(True)
     assert torch.equal(z0, z1) and torch.equal(ls0, ls1) and torch.equal(lt0, lt1)
+    assert after0 == after1  # (one seed draw per pass in either schedule -- the next iteration samples alike)
     assert int((z0 != 0).sum()) > rows_s  # real programs were sampled
     for n in g0:
         torch.testing.assert_close(g1[n], g0[n], rtol=1e-6, atol=1e-7, msg=lambda m, n=n: "%s: %s" % (n, m))
+
+
+def test_pairing_falls_back_without_the_cluster_kernels(monkeypatch):
+    """decode_prepare declines when the multi-CU decoder kernels are switched off (PNMN_DECODER_CLUSTER=0; the same
+    branch serves a device too small for them) so the iteration falls back to decode(), and a pass that was prepared but
+    not paired hands its drawn seed on: same sampled programs as the prepared pass would have produced."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    torch.manual_seed(6)
+    pg = ProgramGenerator(vocab).to(dev)
+    pg.train()
+    q = synthetic_batch(vocab, 32, seed=43, with_image=False)["question"].to(dev)
+    state = pg.encode(q)
+    torch.manual_seed(9)
+    prep = pg.decode_prepare(state, None, "sampling")
+    assert prep is not None
+    handed_on = pg.decode(state, None, "sampling", seed=prep["meta"]["seed"])["predictions"]
+    torch.manual_seed(9)
+    drawn = pg.decode(state, None, "sampling")["predictions"]
+    assert torch.equal(handed_on, drawn)
+    monkeypatch.setenv("PNMN_DECODER_CLUSTER", "0")
+    assert pg.decode_prepare(state, None, "sampling") is None
 
 
 def test_other_widths_run_step_by_step_and_say_so():
