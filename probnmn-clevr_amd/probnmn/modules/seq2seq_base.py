@@ -176,6 +176,27 @@ class _Alias(torch.autograd.Function):
         return g, g, None
 
 
+class _SplitRows(torch.autograd.Function):
+    """``(x[:n], x[n:])`` as views whose backward is ONE concatenation (a missing side: zeros).  For an encoder state that
+    two decodes share (``Seq2SeqBase.split_rows``): gathering the two row sets with ``index_select`` costs a copy per tensor
+    and set forward, and a zero-filled full-size gradient, an ``index_add_`` and an addition each backward."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.rest = n, x.size(0) - n
+        ctx.tail, ctx.kind = tuple(x.shape[1:]), (x.dtype, x.device)
+        return x.narrow(0, 0, n), x.narrow(0, n, x.size(0) - n)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        dtype, device = ctx.kind
+        if da is None:
+            da = torch.zeros((ctx.n,) + ctx.tail, dtype=dtype, device=device)
+        if db is None:
+            db = torch.zeros((ctx.rest,) + ctx.tail, dtype=dtype, device=device)
+        return torch.cat((da, db), 0), None
+
+
 class _SplitColumns(torch.autograd.Function):
     """``(w[:, :k], w[:, k:])`` whose backward is ONE concatenation: two slices of a parameter otherwise cost two
     zero-filled full-size gradients, two copies into them and an addition per use."""
@@ -988,6 +1009,18 @@ class Seq2SeqBase(nn.Module):
     @staticmethod
     def select_rows(state: Dict[str, torch.Tensor], rows: torch.LongTensor) -> Dict[str, torch.Tensor]:
         return {k: v.index_select(0, rows) for k, v in state.items()}
+
+    @staticmethod
+    def split_rows(state: Dict[str, torch.Tensor], n: int):
+        """The state of rows ``[0, n)`` and of rows ``[n, B)`` -- views, no copies (a trainer that wants two row SETS
+        decoded differently encodes the batch in that order: rows are independent)."""
+        first, rest = {}, {}
+        for k, v in state.items():
+            if v.requires_grad:
+                first[k], rest[k] = _SplitRows.apply(v, n)
+            else:
+                first[k], rest[k] = v[:n], v[n:]
+        return first, rest
 
     def decode(
         self,
