@@ -837,7 +837,9 @@ def main():
     ap.add_argument("--fit-iters", type=int, default=1500, help="cap on the generator's pre-fit iterations")
     ap.add_argument("--fit-target", type=float, default=0.95)
     ap.add_argument("--ingest-rows", type=int, default=8192, help="rows of the pinned host feature store of the ingest side measurement")
-    ap.add_argument("--roofline-passes", type=int, default=4)
+    ap.add_argument("--roofline-passes", type=int, default=12,
+                    help="instrumented steps of the roofline object (every step samples fresh programs: 73-89 conv launches per step, "
+                         "the deep programs adding tiny ones -- the median of a dozen steps does not hang on which four were taken)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
