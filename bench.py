@@ -219,6 +219,10 @@ def kernel_rooflines(engine, step_fn, passes, trainer=None):
             by[what] = [tf * ms, ms, median([x[2] for x in site])]
         chosen["by"] = by
         chosen["tflops_per_pass"] = [round(r["flops"] / r["ms"] / 1e9, 2) for r in runs]
+        # per LAUNCH figures over all passes: the launch count of a step varies with its sampled programs (the deep ones
+        # add tiny launches), and the PMC summaries these are compared with average over their own run's steps
+        chosen["bytes_per_launch_all"] = sum(r["bytes"] for r in runs) / max(1, sum(r["launches"] for r in runs))
+        chosen["launches_per_pass"] = [r["launches"] for r in runs]
         out[kern] = chosen
     out["_step_ms"] = median(step_ms)
     out["_passes"] = len(per_pass)
@@ -279,7 +283,8 @@ def roofline_object(agg, kernel=None):
         "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
         "traffic": pmc["bytes_per_launch"] if pmc else None,
         "traffic_unit": "HBM bytes per launch (PMC, %s)" % pmc["source"] if pmc else None,
-        "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"]),
+        "algorithmic_bytes_per_launch": round(a["bytes_per_launch_all"]),
+        "launches_per_pass": a["launches_per_pass"],
         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
         "launches_per_step": a["launches"],
         "passes": agg["_passes"],
