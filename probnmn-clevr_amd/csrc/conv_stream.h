@@ -153,8 +153,13 @@ struct Walker {
     __device__ __forceinline__ bool valid() const { return vid < total; }
 
     __device__ __forceinline__ bool decode(const Launch& L) {
-        const int cbi = vid / L.wgs_x;
-        const int x = vid - cbi * L.wgs_x;
+        // the output-channel blocks of a unit take CONSECUTIVE ids on one XCD (id & 7): they stream the same input, which
+        // then comes out of that XCD's L2 for all but the first (block-major ids re-fetched the classifier conv's input
+        // from HBM once per block: 841 MB fetched for 103 MB of input at 1024 items, scripts/r04_pmc_dispatch.sh)
+        const int cout_blocks = L.total / L.wgs_x;
+        const int s8 = vid >> 3;
+        const int cbi = s8 % cout_blocks;
+        const int x = (s8 / cout_blocks) * 8 + (vid & 7);
         int wb = L.wg_begin[0], sp = L.split[0], u0 = L.unit0[0], nu = L.n_units[0], per = L.per_xcd[0];
         if (L.n_seg > 1 && x >= L.wg_begin[1]) wb = L.wg_begin[1], sp = L.split[1], u0 = L.unit0[1], nu = L.n_units[1], per = L.per_xcd[1];
         if (L.n_seg > 2 && x >= L.wg_begin[2]) wb = L.wg_begin[2], sp = L.split[2], u0 = L.unit0[2], nu = L.n_units[2], per = L.per_xcd[2];
@@ -568,6 +573,40 @@ __device__ __forceinline__ void epilogue(const pnmn_conv_item& it, const f32x4* 
     }
 }
 
+// Plain-store epilogue of a wave with TWO channel tiles (split 1): the tiles are the two 64-byte halves of one 128-byte
+// line per pixel, stored back to back.  Tile after tile (all of tile 0's m-tiles, then tile 1's) the halves of a line
+// reach L2 hundreds of cycles apart, and per-dispatch PMC (scripts/r04_pmc_dispatch.sh) showed such launches writing
+// 2.5-2.75x and fetching up to 4x their algorithmic bytes.
+template <int H, int W, int TH, int MTW>
+__device__ __forceinline__ void epilogue_plain_pair(const pnmn_conv_item& it, const f32x4* acc0, const f32x4* acc1, int mbase, int n0,
+                                                    int band, int out_stride, int relu, int lane, const f32x4 bias0, const f32x4 bias1) {
+    constexpr int HW = TH * W;
+    asm volatile("" : "+v"(lane));  // (see epilogue())
+    const int li = lane & 15, g = lane >> 4;
+    const int p_img = Geom<H, W, TH>::WHOLE ? 0 : band * TH * W;
+    auto act = [&](f32x4 v, const f32x4 b) {
+        v += b;
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        return v;
+    };
+    float* const out0 = it.out + (size_t)p_img * out_stride + n0 + 4 * g;
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int p = (mbase + j) * 16 + li;
+        const f32x4 v0 = act(acc0[j], bias0), v1 = act(acc1[j], bias1);
+        if (p < HW) {
+            store4(as_global(out0 + (size_t)p * out_stride), v0);
+            store4(as_global(out0 + (size_t)p * out_stride + 16), v1);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (left alone, the compiler issues all of tile 0's stores, then all of tile 1's)
+    }
+}
+
 // One unit at SPLIT workgroups per 128-channel block: all its stages, then the epilogue.  Leaves the walker at the next
 // unit.  `cstart`: cumulative ring slots consumed by this workgroup so far (the same count the loader keeps).
 //   SPLIT 1: a wave owns 32 output channels (two 16-channel tiles that share every A fragment and table row) x 13 m-tiles
@@ -811,9 +850,19 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     lds_barrier();  // end of the unit's contraction: the loader may rewrite the row table
     const unsigned long long c_e = PNMN_CYC();
     if (exist != 0u) {
+        if constexpr (NW == 2) {
+            if (!(it.flags & (PNMN_CONV_ACCUMULATE | PNMN_CONV_MASKBWD | PNMN_CONV_DATTN))) {
+                epilogue_plain_pair<H, W, TH, MTW>(it, acc[0], acc[1], mbase, n0, band, L.out_stride, L.relu, lane, bias4[0], bias4[NW - 1]);
+            } else {
 #pragma unroll
-        for (int n = 0; n < NW; ++n)
-            epilogue<H, W, TH, MTW>(it, acc[n], mbase, n0 + 16 * n, band, L.out_stride, L.relu, lane, bias4[n]);
+                for (int n = 0; n < NW; ++n)
+                    epilogue<H, W, TH, MTW>(it, acc[n], mbase, n0 + 16 * n, band, L.out_stride, L.relu, lane, bias4[n]);
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+                epilogue<H, W, TH, MTW>(it, acc[n], mbase, n0 + 16 * n, band, L.out_stride, L.relu, lane, bias4[n]);
+        }
     }
     Wk.next_unit(L);
     const unsigned long long c_x = PNMN_CYC();
