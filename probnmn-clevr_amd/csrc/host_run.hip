@@ -18,6 +18,8 @@ namespace {
 struct Traced {
     pnmn_launch row;
     hipEvent_t e0, e1;
+    void* records;  // page-locked copy of the call's items (CONV) / jobs (WGRAD), taken in stream order in front of the launch:
+                    // by the time the trace is collected the device buffer may hold the next upload
 };
 struct Trace {
     std::mutex mu;
@@ -47,12 +49,11 @@ inline double skipped_tap_tiles(int dilation) { return dilation == 8 ? 39.0 : 0.
 // less the skipped tap rows; bytes = every map an item must read (input chunks, the ReLU gate of a data gradient, the
 // attention mask, the forward features and the accumulated gradient of the fused mask backward, the previous contents of
 // an accumulating output) and write once, plus ONE pass over each distinct weight of the call.
-int conv_work(const pnmn_launch& l, pnmn_launch_timing* t) {
+int conv_work(const pnmn_launch& l, const void* records, pnmn_launch_timing* t) {
     const int H = l.p[0], W = l.p[1], cin_chunks = l.p[2], ntaps = l.p[3], cout_blocks = l.p[6];
     const double HW = (double)H * W, C = 128.0;
-    std::vector<pnmn_conv_item> items((size_t)l.n);
-    const hipError_t e = hipMemcpy(items.data(), l.a, items.size() * sizeof(pnmn_conv_item), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return (int)e;
+    const pnmn_conv_item* first = static_cast<const pnmn_conv_item*>(records);
+    const std::vector<pnmn_conv_item> items(first, first + l.n);
     const double full = 2.0 * HW * cout_blocks * C * ntaps * cin_chunks * C;
     const double map = HW * C * 4.0, wbytes = cout_blocks * C * ntaps * cin_chunks * C * 4.0;
     double flops = 0.0, maps = 0.0, extra = 0.0;
@@ -76,12 +77,11 @@ int conv_work(const pnmn_launch& l, pnmn_launch_timing* t) {
     return 0;
 }
 
-int wgrad_work(const pnmn_launch& l, pnmn_launch_timing* t) {
+int wgrad_work(const pnmn_launch& l, const void* records, pnmn_launch_timing* t) {
     const int H = l.p[0], W = l.p[1], ntaps = l.p[2], cin_blocks = l.p[3], cout_blocks = l.p[4];
     const double HW = (double)H * W, C = 128.0;
-    std::vector<pnmn_wgrad_job> jobs((size_t)l.n);
-    const hipError_t e = hipMemcpy(jobs.data(), l.b, jobs.size() * sizeof(pnmn_wgrad_job), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return (int)e;
+    const pnmn_wgrad_job* first = static_cast<const pnmn_wgrad_job*>(records);
+    const std::vector<pnmn_wgrad_job> jobs(first, first + l.n);
     long n_items = 0;
     for (const pnmn_wgrad_job& j : jobs) n_items += j.item_end - j.item_begin;
     t->n_items = (int32_t)n_items;
@@ -95,7 +95,10 @@ int wgrad_work(const pnmn_launch& l, pnmn_launch_timing* t) {
 extern "C" int pnmn_launch_trace_begin(void) {
     Trace& T = trace();
     std::lock_guard<std::mutex> g(T.mu);
-    for (Traced& r : T.rows) T.pool.push_back(r.e0), T.pool.push_back(r.e1);  // (a trace that was never collected)
+    for (Traced& r : T.rows) {  // (a trace that was never collected)
+        T.pool.push_back(r.e0), T.pool.push_back(r.e1);
+        if (r.records) (void)hipHostFree(r.records);
+    }
     T.rows.clear();
     T.on = true;
     return 0;
@@ -118,9 +121,10 @@ extern "C" int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int*
             hipError_t e = hipEventSynchronize(r.e1);
             if (e == hipSuccess) e = hipEventElapsedTime(&t->ms, r.e0, r.e1);
             rc = (int)e;
-            if (rc == 0) rc = r.row.op == PNMN_OP_CONV ? conv_work(r.row, t) : wgrad_work(r.row, t);
+            if (rc == 0) rc = r.row.op == PNMN_OP_CONV ? conv_work(r.row, r.records, t) : wgrad_work(r.row, r.records, t);
         }
         T.pool.push_back(r.e0), T.pool.push_back(r.e1);
+        if (r.records) (void)hipHostFree(r.records);
     }
     T.rows.clear();
     return rc != 0 ? rc : (*n_out > capacity ? PNMN_EAGAIN : 0);
@@ -141,6 +145,11 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
             std::lock_guard<std::mutex> g(T.mu);
             tr.row = l, tr.e0 = T.event(), tr.e1 = T.event();
             if (!tr.e0 || !tr.e1) return PNMN_EINVAL;
+            const bool conv = l.op == PNMN_OP_CONV;
+            const size_t bytes = (size_t)l.n * (conv ? sizeof(pnmn_conv_item) : sizeof(pnmn_wgrad_job));
+            if (hipHostMalloc(&tr.records, bytes, hipHostMallocDefault) != hipSuccess) return PNMN_EINVAL;
+            if (hipMemcpyAsync(tr.records, conv ? l.a : l.b, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)) != hipSuccess)
+                return PNMN_EINVAL;
             if (hipEventRecord(tr.e0, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
         }
         switch (l.op) {

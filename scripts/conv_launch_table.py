@@ -24,12 +24,12 @@ nmn.engine.begin_trace()
 step.step(batch)
 torch.cuda.synchronize()
 rows = []
-for kern, what, flops, ms, _, _ in nmn.engine.end_trace():
-    rows.append((kern, what, flops, ms))
+for kern, what, flops, ms, nbytes, _ in nmn.engine.end_trace():
+    rows.append((kern, what, flops, ms, nbytes))
 tot = {}
-print("%-11s %-22s %9s %9s %8s" % ("kernel", "site", "GFLOP", "ms", "TF"))
-for kern, what, flops, ms in rows:
-    print("%-11s %-22s %9.2f %9.4f %8.1f" % (kern, what, flops / 1e9, ms, flops / ms / 1e9))
+print("%-11s %-22s %9s %9s %8s %10s" % ("kernel", "site", "GFLOP", "ms", "TF", "alg MB"))
+for kern, what, flops, ms, nbytes in rows:
+    print("%-11s %-22s %9.2f %9.4f %8.1f %10.1f" % (kern, what, flops / 1e9, ms, flops / ms / 1e9, nbytes / 1e6))
     t = tot.setdefault(kern, [0.0, 0.0]); t[0] += flops; t[1] += ms
 for k, (f, ms) in tot.items():
     print("TOTAL %-11s %9.2f GFLOP %9.3f ms %8.1f TF" % (k, f / 1e9, ms, f / ms / 1e9))

@@ -28,4 +28,4 @@ for (name, a, b), v in sorted(last, key=lambda kv: -kv[1])[:12]:
 print("  in issue order (dispatch index: MB):", " ".join("%d%s:%.0f" % (i, "*" if "ELi1EEE" in k[0] else "", v * f * 1024 / 1e6) for i, (k, v) in enumerate(last)))
 PY
 done
-grep "stem\|classifier\|TOTAL" gpurun_out/r04_pmcd_FETCH_SIZE.log | head -12
+grep "^conv_nhwc" gpurun_out/r04_pmcd_FETCH_SIZE.log | awk '{print NR-1": "$0}' | cut -c1-90

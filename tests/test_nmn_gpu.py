@@ -214,6 +214,10 @@ def test_launch_trace_reports_the_shipped_path():
     cin = features.size(1)
     assert by["stem conv1"][0][2] == 2.0 * B * hw * c * 9 * cin and by["stem conv1 wgrad"][0][2] == 2.0 * B * hw * c * 9 * cin
     assert by["stem conv2"][0][2] == 2.0 * B * hw * c * 9 * c
+    # algorithmic bytes: every input chunk and the output once per item, each distinct weight once per call (the items are
+    # the ones the launch saw: copied in stream order, not read back after the step has re-used their buffer)
+    assert by["stem conv1"][0][4] == B * (cin // c + 1) * hw * c * 4.0 + c * 9 * cin * 4.0
+    assert by["stem conv2"][0][4] == B * 2 * hw * c * 4.0 + c * 9 * c * 4.0
     # every module conv once forward, once as a data gradient (or not at all where its input needs none), once in the
     # deferred weight gradient; dilation-8 items count 78 / 117 of the taps, so compare with the record count only from above
     full = 2.0 * hw * c * 9 * c
