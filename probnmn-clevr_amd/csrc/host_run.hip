@@ -26,6 +26,21 @@ struct Trace {
     bool on = false;
     std::vector<Traced> rows;
     std::vector<hipEvent_t> pool;  // events are kept from trace to trace
+    // page-locked arena the record copies are cut from (one allocation, kept: a hipHostMalloc per traced launch cost the
+    // host ~0.1 ms each and the launches behind it started on an idling chip)
+    char* arena = nullptr;
+    size_t arena_size = 0, arena_used = 0;
+    void* cut(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!arena) {
+            arena_size = (size_t)64 << 20;
+            if (hipHostMalloc(reinterpret_cast<void**>(&arena), arena_size, hipHostMallocDefault) != hipSuccess) arena = nullptr;
+        }
+        if (!arena || arena_used + bytes > arena_size) return nullptr;
+        void* p = arena + arena_used;
+        arena_used += bytes;
+        return p;
+    }
     hipEvent_t event() {
         if (!pool.empty()) {
             hipEvent_t e = pool.back();
@@ -95,10 +110,8 @@ int wgrad_work(const pnmn_launch& l, const void* records, pnmn_launch_timing* t)
 extern "C" int pnmn_launch_trace_begin(void) {
     Trace& T = trace();
     std::lock_guard<std::mutex> g(T.mu);
-    for (Traced& r : T.rows) {  // (a trace that was never collected)
-        T.pool.push_back(r.e0), T.pool.push_back(r.e1);
-        if (r.records) (void)hipHostFree(r.records);
-    }
+    for (Traced& r : T.rows) T.pool.push_back(r.e0), T.pool.push_back(r.e1);  // (a trace that was never collected)
+    T.arena_used = 0;
     T.rows.clear();
     T.on = true;
     return 0;
@@ -124,9 +137,9 @@ extern "C" int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int*
             if (rc == 0) rc = r.row.op == PNMN_OP_CONV ? conv_work(r.row, r.records, t) : wgrad_work(r.row, r.records, t);
         }
         T.pool.push_back(r.e0), T.pool.push_back(r.e1);
-        if (r.records) (void)hipHostFree(r.records);
     }
     T.rows.clear();
+    T.arena_used = 0;
     return rc != 0 ? rc : (*n_out > capacity ? PNMN_EAGAIN : 0);
 }
 
@@ -147,7 +160,8 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
             if (!tr.e0 || !tr.e1) return PNMN_EINVAL;
             const bool conv = l.op == PNMN_OP_CONV;
             const size_t bytes = (size_t)l.n * (conv ? sizeof(pnmn_conv_item) : sizeof(pnmn_wgrad_job));
-            if (hipHostMalloc(&tr.records, bytes, hipHostMallocDefault) != hipSuccess) return PNMN_EINVAL;
+            tr.records = T.cut(bytes);
+            if (!tr.records) return PNMN_EAGAIN;  // (more than 64 MB of records in one trace: collect it more often)
             if (hipMemcpyAsync(tr.records, conv ? l.a : l.b, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)) != hipSuccess)
                 return PNMN_EINVAL;
             if (hipEventRecord(tr.e0, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
