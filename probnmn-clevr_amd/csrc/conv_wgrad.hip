@@ -29,6 +29,8 @@
 #include <type_traits>
 
 #include "../../include/probnmn_hip.h"
+#include "conv_plan.h"
+#include "conv_wgrad_stream.h"
 #include "global_ptr.h"
 
 
@@ -422,6 +424,31 @@ int launch_wgrad_band(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, 
     return (int)hipGetLastError();
 }
 
+// 3x3 on 14x14 maps: the streamed kernel (conv_wgrad_stream.h)
+__global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_wgrad_stream_kernel(const pnmn_wgrad_item* __restrict__ items,
+                                                                                     const pnmn_wgrad_job* __restrict__ jobs,
+                                                                                     const pnmn::wstream::Launch L) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    pnmn::wstream::wgrad_stream(L, items, jobs, smem_raw);
+}
+
+int launch_wgrad_stream(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int cin_blocks, int cout_blocks,
+                        int x_stride, int dy_stride, int cus, hipStream_t stream) {
+    using G = pnmn::wstream::G;
+    auto kern = conv_wgrad_stream_kernel;
+    // (per device, and cheap: ADVICE r4 -- a process-wide flag would skip the opt-in on a second GPU)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    pnmn::wstream::Launch L{};
+    L.n_jobs = n_jobs, L.cin64 = cin_blocks * 2, L.ny = cout_blocks * 2 * L.cin64;
+    L.total = ((n_jobs + 7) / 8) * 8 * L.ny;
+    L.x_stride = x_stride, L.dy_stride = dy_stride, L.cin_total = cin_blocks * CB;
+    int grid = (cus >= 1 && cus <= 256) ? cus : pnmn::default_conv_cus();
+    if (grid > L.total) grid = L.total;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pnmn::stream::NTHREADS), G::LDS_BYTES, stream, items, jobs, L);
+    return (int)hipGetLastError();
+}
+
 template <int H, int W, int TAPS>
 int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int cin_blocks,
                  int cout_blocks, int x_stride, int dy_stride, int cus, hipStream_t stream) {
@@ -461,9 +488,11 @@ extern "C" int pnmn_conv_wgrad_cus(const pnmn_wgrad_item* items, const pnmn_wgra
     if ((x_stride & 3) || (dy_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (H == 14 && W == 14) {
-        if (ntaps == 9)
-            return launch_wgrad<14, 14, 9>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride,
-                                           dy_stride, cus, s);
+        if (ntaps == 9) {
+            static const bool old_kernel = getenv("PNMN_WGRAD_OLD") != nullptr;  // (A/B hook of round 5; goes with the old kernel)
+            if (old_kernel) return launch_wgrad<14, 14, 9>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride, dy_stride, cus, s);
+            return launch_wgrad_stream(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride, dy_stride, cus, s);
+        }
         return launch_wgrad<14, 14, 1>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride,
                                        dy_stride, cus, s);
     }

@@ -157,6 +157,7 @@ class DeviceFeatureStore:
             raise MemoryError("%d rows x %.1f MB = %.1f GB do not fit the %.1f GB free on %s: use PinnedFeatureStore"
                               % (N, self.row_bytes / 1e6, N * self.row_bytes / 1e9, free / 1e9, device))
         self.rows = torch.empty((N, H, W, C), dtype=torch.float32, device=device)
+        self.device = device = self.rows.device  # ('cuda' resolved to 'cuda:<current>': compared with parameter devices)
         chunk_rows = max(1, min(chunk_rows, N))
         stage = torch.empty((chunk_rows, C, H, W), dtype=torch.float32).pin_memory()
         view = stage.numpy()
@@ -218,6 +219,11 @@ class PrefetchingLoader:
         if method not in ("dma", "kernel", "resident"):
             raise ValueError("method must be 'dma', 'kernel' or 'resident'")
         self.method = method
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if method == "resident" and store.device != device:
+            raise _hip.HipLibraryError("the resident feature store lives on %s, the loader feeds %s" % (store.device, device))
         self.batches, self.store, self.device = batches, store, device
         self.keep_on_host = set(keep_on_host)
         # (high priority: the ingest is a trickle of long-latency PCIe reads -- or copy-engine transfers -- that must

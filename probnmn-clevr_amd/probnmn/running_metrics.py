@@ -110,6 +110,15 @@ class BLEU:
         top = int(max(pred.max(initial=0), gold.max(initial=0))) + 1
         if top > self._base:
             raise ValueError("token index %d beyond the metric's key base %d" % (top - 1, self._base))
+        low = int(min(pred.min(initial=0), gold.min(initial=0)))
+        if low < 0:  # (a negative id -- a -1 padding value, say -- would alias other n-grams' keys)
+            raise ValueError("negative token index %d: the n-gram keys pack non-negative indices" % low)
+        if pred.shape[0] * self._base ** len(self._ngram_weights) >= 1 << 63:
+            # (row * base**n overflows int64 from 32 768 rows on: count such a batch in pieces)
+            step = (1 << 62) // self._base ** len(self._ngram_weights)
+            for lo in range(0, pred.shape[0], step):
+                self(predictions[lo:lo + step], gold_targets[lo:lo + step])
+            return
         for n in range(1, len(self._ngram_weights) + 1):
             pk, pc = np.unique(self._keys(pred, n), return_counts=True)
             gk, gc = np.unique(self._keys(gold, n), return_counts=True)

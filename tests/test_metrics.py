@@ -68,3 +68,19 @@ def test_bleu_vectorised_over_the_batch_equals_the_per_row_count():
         b(pred[:20], gold[:20])  # (accumulates over calls)
         b(pred[20:], gold[20:])
         assert b.get_metric()["BLEU"] == pytest.approx(per_row(pred.tolist(), gold.tolist(), exclude), abs=1e-12)
+
+
+def test_bleu_key_limits():
+    """The packed int64 keys: a negative index is refused (it would alias another n-gram), and a batch whose
+    row * base**4 would overflow is counted in pieces with the same result as row-sized calls."""
+    b = BLEU(exclude_indices={0})
+    with pytest.raises(ValueError):
+        b(torch.tensor([[1, -1, 2]]), torch.tensor([[1, 2, 2]]))
+    g = torch.Generator().manual_seed(1)
+    pred = torch.randint(0, 6, (40000, 5), generator=g)
+    gold = torch.randint(0, 6, (40000, 5), generator=g)
+    whole, parts = BLEU(exclude_indices={0}), BLEU(exclude_indices={0})
+    whole(pred, gold)
+    for lo in range(0, 40000, 10000):
+        parts(pred[lo:lo + 10000], gold[lo:lo + 10000])
+    assert whole.get_metric()["BLEU"] == pytest.approx(parts.get_metric()["BLEU"], abs=1e-12)
