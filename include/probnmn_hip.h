@@ -575,7 +575,7 @@ int pnmn_run_launches(const pnmn_launch* list, int n, void* stream);
  * every CONV / WGRAD entry that pnmn_run_launches issues -- the trunk planner's lists included, i.e. the SHIPPED host
  * path -- is bracketed by two events on its stream.  _end waits for them and reports, per traced entry in issue order,
  * the launch duration and the algorithmic work of the call (the call's items are copied to the host
- * in stream order in front of the launch -- outside the bracket -- since a step re-uses its record buffers).  Returns PNMN_EAGAIN when more than `capacity` entries were traced (*n_out = how many).  The reference has
+ * in stream order in front of the launch -- outside the bracket -- since a step re-uses its record buffers).  Returns PNMN_EAGAIN when more than `capacity` entries were traced (*n_out = how many; the trace is KEPT: call again with room for them -- it is dropped by a successful _end or the next _begin).  The reference has
  * no counterpart: its per-module timing is whatever torch.profiler shows around nmn.py:191-241. */
 typedef struct pnmn_launch_timing {
     int32_t op, n;          /* PNMN_OP_CONV / PNMN_OP_WGRAD; items (CONV) or jobs (WGRAD) of the call */

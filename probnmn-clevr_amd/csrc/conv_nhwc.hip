@@ -26,6 +26,7 @@
 
 #include "conv_plan.h"
 #include "conv_stream.h"
+#include "lds_optin.h"
 
 namespace {
 
@@ -44,14 +45,9 @@ template <int H, int W, int TH, int TAPS>
 int launch_stream(const pnmn_conv_item* items, int n_items, int cin_chunks, int ntaps, int in_stride, int out_stride,
                   int cout_blocks, int relu, int cus, hipStream_t stream) {
     using G = pnmn::stream::Geom<H, W, TH>;
-    static bool configured = false;
+    static std::atomic<uint64_t> configured{0};  // (per device: lds_optin.h)
     auto kern = conv_stream_kernel<H, W, TH, TAPS>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)G::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, configured)) return e;
     const int n_units = n_items * (H / TH);
     const LaunchPlan lp = plan_launch(n_units, cout_blocks, cin_chunks, ntaps, cus);
     pnmn::stream::Launch L{};

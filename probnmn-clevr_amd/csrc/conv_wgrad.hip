@@ -32,6 +32,7 @@
 #include "conv_plan.h"
 #include "conv_wgrad_stream.h"
 #include "global_ptr.h"
+#include "lds_optin.h"
 
 
 namespace {
@@ -411,14 +412,9 @@ int launch_wgrad_band(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, 
                       int cout_blocks, int x_stride, int dy_stride, hipStream_t stream) {
     constexpr size_t lds_bytes = ((size_t)((TH + 2) * W + 2) * CK + (size_t)TH * W * CK + (size_t)TAPS * TH * W) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "tiles must fit the CU's LDS");
-    static bool configured = false;
+    static std::atomic<uint64_t> configured{0};  // (per device: lds_optin.h)
     auto kern = conv_wgrad_band_kernel<H, W, TH, TAPS>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(kern), lds_bytes, configured)) return e;
     dim3 grid(n_jobs, cout_blocks * 2 * cin_blocks * 2);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds_bytes, stream, items, jobs, cin_blocks, x_stride, dy_stride);
     return (int)hipGetLastError();
@@ -436,9 +432,8 @@ int launch_wgrad_stream(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs
                         int x_stride, int dy_stride, int cus, hipStream_t stream) {
     using G = pnmn::wstream::G;
     auto kern = conv_wgrad_stream_kernel;
-    // (per device, and cheap: ADVICE r4 -- a process-wide flag would skip the opt-in on a second GPU)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    static std::atomic<uint64_t> configured{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, configured)) return e;
     pnmn::wstream::Launch L{};
     L.n_jobs = n_jobs, L.cin64 = cin_blocks * 2, L.ny = cout_blocks * 2 * L.cin64;
     L.total = ((n_jobs + 7) / 8) * 8 * L.ny;
@@ -455,14 +450,9 @@ int launch_wgrad(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n
     constexpr int HW = H * W;
     constexpr size_t lds_bytes = ((size_t)(HW + 2) * CB + (size_t)HW * CH + (size_t)TAPS * HW) * sizeof(float);
     static_assert(lds_bytes <= 160 * 1024, "tiles must fit the CU's LDS");
-    static bool configured = false;
+    static std::atomic<uint64_t> configured{0};  // (per device: lds_optin.h)
     auto kern = conv_wgrad_kernel<H, W, TAPS>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(kern), lds_bytes, configured)) return e;
     const int ny = cout_blocks * 2 * cin_blocks;
     const long units = (long)n_jobs * ny;
     const long wgs = (cus >= 1 && cus < units) ? cus : units;

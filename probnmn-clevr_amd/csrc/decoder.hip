@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "lds_optin.h"
 #include "sampling.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -455,13 +456,8 @@ int pnmn_attn_lstm_bwd(const float* dhs, const float* act, const float* cs, cons
         return PNMN_EINVAL;
     if (hidden != H || S < 1 || S > MAXS) return PNMN_ESHAPE;
     constexpr size_t lds = sizeof(float) * (ROWS * (G4 + 4) + 2 * ROWS * LD);
-    static bool cfg = false;
-    if (!cfg) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_lstm_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        cfg = true;
-    }
+    static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_bwd_kernel), lds, cfg)) return e;
     BwdArgs a{dhs, act, cs, hs, ctx, probs, enc, mask, h0, w_c_t, w_hh_t, dgates, denc, dh0, B, T, S};
     hipLaunchKernelGGL(attn_lstm_bwd_kernel, dim3((B + ROWS - 1) / ROWS), dim3(512), lds,
                        static_cast<hipStream_t>(stream), a);

@@ -27,6 +27,7 @@
 
 #include "../../include/probnmn_hip.h"
 #include "cluster.h"
+#include "lds_optin.h"
 #include "sampling.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -637,11 +638,6 @@ int rows_per_launch() {
     return cus >= 8 * MEMBERS ? (cus / (8 * MEMBERS)) * 8 * ROWS : 0;
 }
 
-template <typename K>
-hipError_t allow_lds(K kernel, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 }  // namespace
 
 extern "C" {
@@ -671,11 +667,11 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
     constexpr size_t LDS_LIMIT = 160 * 1024;
     const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * S * H + ALL_PARTS_LDS <= LDS_LIMIT;
     const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H + (all_parts ? ALL_PARTS_LDS : 0);
-    static size_t allowed[2] = {0, 0};
-    if (lds > allowed[all_parts]) {
-        hipError_t e = all_parts ? allow_lds(attn_lstm_fwd_multi_kernel<true>, lds) : allow_lds(attn_lstm_fwd_multi_kernel<false>, lds);
-        if (e != hipSuccess) return (int)e;
-        allowed[all_parts] = lds;
+    {   // (the opt-in is per device and per kernel: lds_optin.h; the limit itself, whatever this launch uses)
+        static std::atomic<uint64_t> cfg[2] = {{0}, {0}};
+        const int e = all_parts ? pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<true>), LDS_LIMIT, cfg[1])
+                                : pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<false>), LDS_LIMIT, cfg[0]);
+        if (e) return e;
     }
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
@@ -711,11 +707,9 @@ int pnmn_attn_lstm_bwd_multi(const float* dhs, const float* act, const float* cs
     if (chunk <= 0) return PNMN_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = BWD_FIXED_LDS + sizeof(float) * RW * S * H;
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        hipError_t e = allow_lds(attn_lstm_bwd_multi_kernel, lds);
-        if (e != hipSuccess) return (int)e;
-        allowed = lds;
+    {
+        static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+        if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_bwd_multi_kernel), 160 * 1024, cfg)) return e;
     }
     char* ws = static_cast<char*>(workspace);
     float* x1 = reinterpret_cast<float*>(ws + pnmn::CLUSTER_SYNC_BYTES);
@@ -785,11 +779,11 @@ int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* ja, const pnmn_dec
     const int smax = ja->S > jb->S ? ja->S : jb->S;
     const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + ALL_PARTS_LDS <= LDS_LIMIT;
     const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + (all_parts ? ALL_PARTS_LDS : 0);
-    static size_t allowed[2] = {0, 0};
-    if (lds > allowed[all_parts]) {
-        hipError_t e = all_parts ? allow_lds(attn_lstm_fwd_pair_kernel<true>, lds) : allow_lds(attn_lstm_fwd_pair_kernel<false>, lds);
-        if (e != hipSuccess) return (int)e;
-        allowed[all_parts] = lds;
+    {   // (the opt-in is per device and per kernel: lds_optin.h; the limit itself, whatever this launch uses)
+        static std::atomic<uint64_t> cfg[2] = {{0}, {0}};
+        const int e = all_parts ? pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<true>), LDS_LIMIT, cfg[1])
+                                : pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<false>), LDS_LIMIT, cfg[0]);
+        if (e) return e;
     }
     int* sync = nullptr;
     hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
@@ -829,11 +823,9 @@ int pnmn_attn_lstm_bwd_multi_pair(const pnmn_decoder_bwd_job* ja, const pnmn_dec
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int smax = ja->S > jb->S ? ja->S : jb->S;
     const size_t lds = BWD_FIXED_LDS + sizeof(float) * RW * smax * H;
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        hipError_t e = allow_lds(attn_lstm_bwd_pair_kernel, lds);
-        if (e != hipSuccess) return (int)e;
-        allowed = lds;
+    {
+        static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+        if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_bwd_pair_kernel), 160 * 1024, cfg)) return e;
     }
     int* sync = nullptr;
     hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);

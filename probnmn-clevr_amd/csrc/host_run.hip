@@ -7,10 +7,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
 #include "../../include/probnmn_hip.h"
+#include "conv_plan.h"
 
 // ---- launch trace (pnmn_launch_trace_begin / _end): events around the CONV / WGRAD rows of every list run in between ----
 namespace {
@@ -23,7 +25,7 @@ struct Traced {
 };
 struct Trace {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};  // (read by pnmn_run_launches without the mutex)
     std::vector<Traced> rows;
     std::vector<hipEvent_t> pool;  // events are kept from trace to trace
     // page-locked arena the record copies are cut from (one allocation, kept: a hipHostMalloc per traced launch cost the
@@ -73,8 +75,25 @@ int conv_work(const pnmn_launch& l, const void* records, pnmn_launch_timing* t) 
     const double map = HW * C * 4.0, wbytes = cout_blocks * C * ntaps * cin_chunks * C * 4.0;
     double flops = 0.0, maps = 0.0, extra = 0.0;
     std::vector<const float*> weights;
+    // the kernel skips the out-of-map tap rows of dilation 8 only in its split-1 / split-2 bodies (conv_stream.h, KIND 1):
+    // the launch is planned again here, as conv_nhwc.hip plans it, to know which items those are
+    const pnmn::LaunchPlan lp = pnmn::plan_launch(l.n, cout_blocks, cin_chunks, ntaps, (int)reinterpret_cast<uintptr_t>(l.c));
+    size_t index = 0;
     for (const pnmn_conv_item& it : items) {
-        flops += full * ((ntaps == 9 && H == 14 && W == 14) ? 1.0 - skipped_tap_tiles(it.dilation) / 117.0 : 1.0);
+        int split = 8;
+        {
+            size_t at = 0;
+            for (int k = 0; k < lp.n_seg; ++k) {
+                if (index < at + (size_t)lp.count[k]) {
+                    split = lp.split[k];
+                    break;
+                }
+                at += (size_t)lp.count[k];
+            }
+        }
+        ++index;
+        const bool skips = ntaps == 9 && H == 14 && W == 14 && split <= 2;
+        flops += full * (skips ? 1.0 - skipped_tap_tiles(it.dilation) / 117.0 : 1.0);
         const bool mb = (it.flags & PNMN_CONV_MASKBWD) != 0, da = (it.flags & PNMN_CONV_DATTN) != 0;
         maps += cin_chunks + cout_blocks;
         if (it.gate) maps += cin_chunks;
@@ -123,6 +142,7 @@ extern "C" int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int*
     T.on = false;
     if (!n_out || (capacity > 0 && !out)) return PNMN_EINVAL;
     *n_out = (int)T.rows.size();
+    if (*n_out > capacity) return PNMN_EAGAIN;  // (nothing is dropped: call again with room for *n_out rows)
     int rc = 0;
     for (size_t i = 0; i < T.rows.size(); ++i) {
         Traced& r = T.rows[i];
@@ -140,7 +160,7 @@ extern "C" int pnmn_launch_trace_end(pnmn_launch_timing* out, int capacity, int*
     }
     T.rows.clear();
     T.arena_used = 0;
-    return rc != 0 ? rc : (*n_out > capacity ? PNMN_EAGAIN : 0);
+    return rc;
 }
 
 extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
@@ -157,14 +177,19 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
         if (timed) {
             std::lock_guard<std::mutex> g(T.mu);
             tr.row = l, tr.e0 = T.event(), tr.e1 = T.event();
-            if (!tr.e0 || !tr.e1) return PNMN_EINVAL;
+            auto give_back = [&](int code) {  // (an error path keeps the pool whole)
+                if (tr.e0) T.pool.push_back(tr.e0);
+                if (tr.e1) T.pool.push_back(tr.e1);
+                return code;
+            };
+            if (!tr.e0 || !tr.e1) return give_back(PNMN_EINVAL);
             const bool conv = l.op == PNMN_OP_CONV;
             const size_t bytes = (size_t)l.n * (conv ? sizeof(pnmn_conv_item) : sizeof(pnmn_wgrad_job));
             tr.records = T.cut(bytes);
-            if (!tr.records) return PNMN_EAGAIN;  // (more than 64 MB of records in one trace: collect it more often)
+            if (!tr.records) return give_back(PNMN_EAGAIN);  // (more than 64 MB of records in one trace: collect it more often)
             if (hipMemcpyAsync(tr.records, conv ? l.a : l.b, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)) != hipSuccess)
-                return PNMN_EINVAL;
-            if (hipEventRecord(tr.e0, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
+                return give_back(PNMN_EINVAL);
+            if (hipEventRecord(tr.e0, static_cast<hipStream_t>(stream)) != hipSuccess) return give_back(PNMN_EINVAL);
         }
         switch (l.op) {
             case PNMN_OP_CONV:
@@ -233,7 +258,10 @@ extern "C" int pnmn_run_launches(const pnmn_launch* list, int n, void* stream) {
         }
         if (timed) {
             std::lock_guard<std::mutex> g(T.mu);
-            if (hipEventRecord(tr.e1, static_cast<hipStream_t>(stream)) != hipSuccess) return PNMN_EINVAL;
+            if (hipEventRecord(tr.e1, static_cast<hipStream_t>(stream)) != hipSuccess) {
+                T.pool.push_back(tr.e0), T.pool.push_back(tr.e1);
+                return PNMN_EINVAL;
+            }
             T.rows.push_back(tr);
         }
         if (rc != 0) return rc;

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "lds_optin.h"
 #include "global_ptr.h"
 #include "pointwise_body.h"
 
@@ -452,12 +453,8 @@ static int launch_layout(const float* src, float* dst, int n, int Cn, int HW, vo
     if (!src || !dst || Cn <= 0 || HW <= 0) return PNMN_EINVAL;
     const int PT = layout_chunk(HW);
     const size_t lds = (size_t)64 * (PT + 1) * sizeof(float);
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(layout_kernel<TO_NHWC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
+    static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(layout_kernel<TO_NHWC>), 160 * 1024, cfg)) return e;
     hipLaunchKernelGGL(layout_kernel<TO_NHWC>, dim3((Cn + 63) / 64, n, (HW + PT - 1) / PT), dim3(256), lds,
                        STREAM(stream), src, dst, Cn, HW, PT, rows);
     return last_error();
@@ -540,12 +537,8 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
     const int RB = pool_band(H, W);
     const size_t lds = (size_t)RB * W * 65 * sizeof(float);
     if (lds > 160 * 1024) return PNMN_ESHAPE;
-    static bool cfg = false;
-    if (!cfg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_kernel<BWD>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        cfg = true;
-    }
+    static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(maxpool_kernel<BWD>), 160 * 1024, cfg)) return e;
     hipLaunchKernelGGL(maxpool_kernel<BWD>, dim3(Cn / 64, n, (H + RB - 1) / RB), dim3(256), lds, STREAM(stream), in,
                        dout, out, H, W, Cn, RB);
     return last_error();

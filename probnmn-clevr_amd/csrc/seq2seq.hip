@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/probnmn_hip.h"
+#include "lds_optin.h"
 #include "cluster.h"
 #include "sampling.h"
 
@@ -779,13 +780,8 @@ int pnmn_lstm_seq_bwd(const float* dhs, const float* act, const float* cs, const
         return 0;
     }
     constexpr size_t lds = (size_t)LROWS * (4 * LH + 4) * sizeof(float);
-    static bool cfg = false;
-    if (!cfg) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        cfg = true;
-    }
+    static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(lstm_seq_bwd_kernel), lds, cfg)) return e;
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(tiles), dim3(512), lds, st, dhs, act, cs, w_hh_t, dgates, B, T);
     return (int)hipGetLastError();
 }

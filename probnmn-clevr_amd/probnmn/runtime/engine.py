@@ -148,8 +148,10 @@ class NMNEngine:
         out = np.zeros(cap, _hip.LAUNCH_TIMING)
         n = np.zeros(1, np.int32)
         rc = lib.pnmn_launch_trace_end(out.ctypes.data, cap, n.ctypes.data)
-        if rc == _hip.EAGAIN:
-            raise _hip.HipLibraryError("launch trace held %d entries, more than %d: trace one step at a time" % (int(n[0]), cap))
+        if rc == _hip.EAGAIN:  # (the library keeps the trace: read it again with room for all of it)
+            cap = int(n[0])
+            out = np.zeros(cap, _hip.LAUNCH_TIMING)
+            rc = lib.pnmn_launch_trace_end(out.ctypes.data, cap, n.ctypes.data)
         _hip.check(rc, "launch_trace_end")
         t = out[: int(n[0])]
         cin_chunks, cls_blocks = self.cin // C, self.cproj // C
@@ -324,7 +326,7 @@ class NMNEngine:
                 r["gate"] = gate
             return r
 
-        def jobs(dw, db, yblocks):
+        def jobs(dw, db, yblocks, taps=9):
             # items per job: a launch of ceil(B / chunk) * yblocks workgroups costs ceil(. / 256) rounds of
             # `chunk` items each (+ ~half an item for the atomic add of the job's slab into the shared
             # weight gradient, which is also why a job never has fewer than 4 items); 260 workgroups cost
@@ -333,6 +335,8 @@ class NMNEngine:
                 yblocks *= 2
                 sizes = range(1, 9)
             else:
+                if taps == 9:
+                    yblocks *= 2  # (the streamed 3x3 kernel's slab is 64 x 64 channels: csrc/conv_wgrad_stream.h)
                 sizes = range(4, 33)
             cus = self.conv_cus or 256  # (a trunk that shares the chip: rounds of the CUs it can count on)
             chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // cus)) * (c + 0.5))
@@ -355,7 +359,7 @@ class NMNEngine:
             "stem2_dgrad": conv(gs2 + e * m128, self.wt.data_ptr() + self.wt_stem2 * 4, None, gs1 + e * m128,
                                 gate=s2 + e * m128),
             "cls_wg": wg(fin + e * m128, gcls + e * mcls),
-            "cls_wg_jobs": jobs(go("classifier.0.weight"), go("classifier.0.bias"), 2 * self.cproj // C),
+            "cls_wg_jobs": jobs(go("classifier.0.weight"), go("classifier.0.bias"), 2 * self.cproj // C, taps=1),
             "stem2_wg": wg(s1 + e * m128, gs2 + e * m128, gate=s2 + e * m128),
             "stem2_wg_jobs": jobs(go("stem.2.weight"), go("stem.2.bias"), 2),
             "stem1_wg": wg(xin + e * mcin, gs1 + e * m128, gate=s1 + e * m128),
@@ -512,7 +516,9 @@ class NMNEngine:
             l.add(_hip.OP_WGRAD, len(fixed["stem1_wg_jobs"]), pack.ptr("stem1_wg"), pack.ptr("stem1_wg_jobs"),
                   p=(H, W, 9, self.cin // C, 1, self.cin, C, self.wgrad_cus))
 
-        hit = {"pack": pack, "fwd_tail": rows(fwd_tail), "bwd_head": rows(bwd_head), "bwd_tail": rows(bwd_tail), "dpooled_row": 3}
+        # rows patched per step, by name: d(pooled) of the backward head's max-pool, the stem conv1 weight gradient's items
+        hit = {"pack": pack, "fwd_tail": rows(fwd_tail), "bwd_head": rows(bwd_head), "bwd_tail": rows(bwd_tail), "dpooled_row": 3,
+               "stem1_wg_row": 2}
         self._native_fixed[key] = hit
         return hit
 
@@ -538,7 +544,7 @@ class NMNEngine:
             step_pack = _Pack()
             step_pack.add("stem1_wg", fixed["stem1_wg"])
             step_pack.upload(dev)
-            rows["bwd_tail"][2, 0] = step_pack.ptr("stem1_wg")
+            rows["bwd_tail"][rows["stem1_wg_row"], 0] = step_pack.ptr("stem1_wg")
         H, W, HW = self.H, self.W, self.HW
         pooled = torch.empty(B, self.cproj * (H // 2) * (W // 2), dtype=torch.float32, device=dev)
         rows["fwd_tail"][1, 1] = pooled.data_ptr()

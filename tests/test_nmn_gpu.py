@@ -108,7 +108,7 @@ def test_gradients_per_program_tight():
     dev = torch.device("cuda:0")
     net.to(dev).train()
     g = torch.Generator().manual_seed(1)
-    first, best = [], []
+    first, best, all_tries = [], [], []
     for case in VALIDITY_CASES:
         programs = encode_programs([case, case], stoi)
         tries = []
@@ -128,13 +128,21 @@ def test_gradients_per_program_tight():
         if tries:
             first.append(tries[0])
             best.append(min(tries))
+            all_tries.extend(tries)
     w = np.sort(np.asarray(first))
     print("per-program worst gradient errors (first input):", np.array2string(w, precision=1))
     print("                                  (best of <= 8):", np.array2string(np.sort(np.asarray(best)), precision=1))
     assert len(w) >= 20
     assert np.median(w) < 5e-5
-    assert np.mean(w < 2e-4) >= 0.5
     assert max(best) < 2e-4
+    # The flip RATE is bounded too ("best of eight" alone would pass a kernel that rounded differently on every input):
+    # measured one input in three above the tight bar (rounds 3-5, two different convolution kernels); the bar is that
+    # rate with a margin, over the first inputs and over every input tried.
+    flip_first = float(np.mean(w >= 2e-4))
+    flip_all = float(np.mean(np.asarray(all_tries) >= 2e-4))
+    print("flip rate: %.2f of first inputs, %.2f of all %d inputs" % (flip_first, flip_all, len(all_tries)))
+    assert flip_first <= 0.45, flip_first
+    assert flip_all <= 0.5, flip_all
 
 
 # BASELINE config 5: 28x28 feature maps, programs of up to 40 tokens.  A slice of the golden cases that
