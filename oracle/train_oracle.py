@@ -3,7 +3,13 @@
 (zero_grad -> batch -> _do_iteration -> optimizer.step) and
 module_training_trainer.py:88-98 (NMN forward on the programs, mean loss, backward, element-wise
 clamp of every gradient to [-5, 5]); the optimizer is the reference's own ``torch.optim.Adam``
-(_trainer.py:103-108)."""
+(_trainer.py:103-108).
+
+``zero_grad`` is restated as torch 1.4.0 runs it (the reference pins torch==1.4.0, requirements.txt:6): gradients that
+exist are ZEROED IN PLACE, not dropped -- so a parameter that has received a gradient once keeps being updated by Adam
+(momentum, per-parameter step count) in iterations whose batch does not use its module.  torch >= 2.0 defaults to
+``set_to_none=True``, under which Adam skips such a parameter: a different trajectory as soon as a batch leaves a
+module out (tests/test_trajectory_gpu.py)."""
 from typing import Dict
 
 import torch
@@ -19,7 +25,7 @@ class OracleModuleTrainer:
         self.optimizer = torch.optim.Adam(list(self.params.values()), lr=lr, weight_decay=weight_decay)
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)  # (torch 1.4.0 semantics, see the module docstring)
         out = nmn_oracle.nmn_forward(self.params, self.index_to_token, batch["image"], batch["program"],
                                      batch["answer"])
         loss = out["loss"].mean()
@@ -56,7 +62,7 @@ class OracleJointTrainer:
     def step(self, batch, forced_programs=None):
         from oracle import elbo_oracle, seq2seq_oracle as so
 
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)  # (torch 1.4.0 semantics, see the module docstring)
         sup = batch["supervision"].nonzero().flatten()
         nosup = (1 - batch["supervision"]).nonzero().flatten()
         q, img, ans = batch["question"][nosup], batch["image"][nosup], batch["answer"][nosup]
@@ -108,7 +114,7 @@ class OracleQuestionCodingTrainer:
     def step(self, batch, forced_programs=None):
         from oracle import elbo_oracle, seq2seq_oracle as so
 
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)  # (torch 1.4.0 semantics, see the module docstring)
         sup = batch["supervision"].nonzero().flatten()
         nosup = (1 - batch["supervision"]).nonzero().flatten()
         prog, ques = batch["program"][sup], batch["question"][sup]

@@ -23,7 +23,7 @@ inline int& forced_split() {
     static int forced = [] {
         const char* e = getenv("PNMN_CONV_KSPLIT");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 6 || v == 8) ? v : 0;
     }();
     return forced;
 }
@@ -42,13 +42,16 @@ inline int default_conv_cus() {
 // split 2 halves a wave's channels, split 4 / 8 also share an item's 13 m-tiles among 2 / 4 waves per channel tile
 // (7 / 4 tiles on the longest wave).
 inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0) {
-    if (forced_split()) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
+    if (forced_split() && !(forced_split() == 6 && ntaps != 9)) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
     constexpr int max_seg = 3;
     constexpr double seg_cost = 0.3;    // a further segment: its workgroups start behind a partly drained round
     constexpr double overhead = 0.25;   // start-up, epilogue
-    auto round_cost = [&](int s) { return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : 2.0 / 13.0) + overhead; };
-    constexpr int s_max = 8;
+    // (a wave's (channel tile, m-tile) pairs: 26 / 13 / 7 / 5 / 4 at split 1 / 2 / 4 / 6 / 8)
+    auto round_cost = [&](int s) { return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : s == 6 ? 2.5 / 13.0 : 2.0 / 13.0) + overhead; };
+    // the splits a segment may take, ascending; split 6 (three waves per channel tile) exists for the 3x3 bodies only
+    const int splits[5] = {1, 2, 4, ntaps == 9 ? 6 : 8, 8};
+    const int n_splits = ntaps == 9 ? 5 : 4;
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the
@@ -69,7 +72,8 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
             best = p;
         }
     };
-    for (int s0 = 1; s0 <= s_max; s0 *= 2) {
+    for (int i0 = 0; i0 < n_splits; ++i0) {
+        const int s0 = splits[i0];
         // one launch
         consider(LaunchPlan{1, {s0, 0, 0}, {n_items, 0, 0}}, (double)rounds_of(n_items, s0) * round_cost(s0));
         if (max_seg < 2) continue;
@@ -77,15 +81,17 @@ inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int 
         if (m0 <= 0 || m0 >= n_items) continue;
         const double t0 = (double)rounds_of(m0, s0) * round_cost(s0);
         const long r0 = n_items - m0;
-        for (int s1 = s0; s1 <= s_max; s1 *= 2) {
+        for (int i1 = i0; i1 < n_splits; ++i1) {
+            const int s1 = splits[i1];
             consider(LaunchPlan{2, {s0, s1, 0}, {(int)m0, (int)r0, 0}}, t0 + (double)rounds_of(r0, s1) * round_cost(s1) + seg_cost);
             if (max_seg < 3 || s1 == s0) continue;
             const long m1 = full_of(r0, s1);
             if (m1 <= 0 || m1 >= r0) continue;
             const double t1 = t0 + (double)rounds_of(m1, s1) * round_cost(s1) + seg_cost;
             const long r1 = r0 - m1;
-            for (int s2 = s1 * 2; s2 <= s_max; s2 *= 2)
-                consider(LaunchPlan{3, {s0, s1, s2}, {(int)m0, (int)m1, (int)r1}}, t1 + (double)rounds_of(r1, s2) * round_cost(s2) + seg_cost);
+            for (int i2 = i1 + 1; i2 < n_splits; ++i2)
+                consider(LaunchPlan{3, {s0, s1, splits[i2]}, {(int)m0, (int)m1, (int)r1}},
+                         t1 + (double)rounds_of(r1, splits[i2]) * round_cost(splits[i2]) + seg_cost);
         }
     }
     return best;

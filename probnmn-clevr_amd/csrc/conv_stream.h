@@ -623,18 +623,24 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     using G = Geom<H, W, TH>;
     using std::integral_constant;
     const unsigned long long c_unit = PNMN_CYC();
-    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 8, "workgroups per 128-channel block");
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 6 || SPLIT == 8, "workgroups per 128-channel block");
     constexpr int NW = SPLIT == 1 ? 2 : 1;                        // 16-channel output tiles of a wave
     constexpr int MW = SPLIT <= 2 ? 1 : SPLIT / 2;                // waves that share a channel tile's m-tiles
-    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 13 / 7 / 4
+    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 13 / 7 / 5 / 4
     constexpr int MH = (MTW + 1) / 2;
     constexpr int WSETS = NW == 2 ? 2 : 3;                        // weight sets in flight (taps ahead + 1)
     constexpr uint32_t FULL = (1u << MTW) - 1u;
     const int li = lane & 15, g = lane >> 4;
-    const int nt = wave % (4 / MW);                               // which of the workgroup's wave-sized channel groups
-    const int mbase = (wave / (4 / MW)) * MTW;                    // first m-tile of this wave
+    // SPLIT 6 (round 5): the block's 8 channel tiles x 3 m-parts of 5 / 5 / 3 tiles are dealt to the 24 waves of the
+    // unit's six workgroups in order, so a workgroup's waves straddle channel tiles -- a launch of 39 items fills the chip
+    // with 234 workgroups of 5 tile-times where split 4 leaves 100 CUs idle for 7 and split 8 needs two rounds of 4.
+    constexpr bool DEALT = (MW & (MW - 1)) != 0;
+    const int gw = Wk.sub * 4 + wave;                             // (DEALT) this wave among the unit's waves
+    const int nt = DEALT ? 0 : wave % (4 / (DEALT ? 1 : MW));     // which of the workgroup's wave-sized channel groups
+    const int mbase = DEALT ? (gw % MW) * MTW : (wave / (4 / (DEALT ? 1 : MW))) * MTW;  // first m-tile of this wave
     const pnmn_conv_item it = Wk.items[Wk.item];
-    const int n0 = Wk.cb * CB + Wk.sub * (CB / SPLIT) + nt * 16 * NW;  // this wave's first output channel
+    // this wave's first output channel
+    const int n0 = DEALT ? Wk.cb * CB + (gw / MW) * 16 : Wk.cb * CB + Wk.sub * (CB / SPLIT) + nt * 16 * NW;
     const int band = Wk.band;
     const int cin_total = L.cin_chunks * CB;
     const int slots = Wk.slots;
@@ -911,6 +917,7 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
                 case 1: run_unit<H, W, TH, 1, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 6: run_unit<H, W, TH, 6, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
             }
         }

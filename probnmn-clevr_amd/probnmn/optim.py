@@ -15,10 +15,16 @@ changes and what the next fused step uses; ``state_dict()`` / ``load_state_dict(
 parameter shapes), so optimizer state moves between this class and the reference's Adam in either
 direction.  The moments of arena parameters are views into two arena-shaped buffers.
 
-Deviation (documented, not hidden): ``step`` is one counter for all parameters.  ``torch.optim.Adam``
-starts a parameter's counter at its first non-None gradient; the engine hands every trunk parameter a
-(possibly all-zero) gradient from the first step on.  The two agree as soon as every module has been
-used once -- in the first iteration at the reference's batch sizes.
+Per-parameter step counts, as ``torch.optim.Adam`` keeps them under the reference's torch 1.4.0 (requirements.txt:6):
+a parameter's state starts at its FIRST gradient (a module no program has used yet is skipped), and from then on it is
+updated in EVERY step -- torch 1.4.0's ``zero_grad`` zeroes gradients in place and never drops them, so Adam keeps
+applying the momentum of a module the current batch does not use.  The engine reports which trunk parameters a
+backward pass reached (``ParamArena.touched``); parameters that share a step count go out as contiguous arena ranges of
+one launch (one range per arena once every module has been used: the first iteration at the reference's batch sizes).
+Rounds 1-4 kept ONE counter for all parameters: a module first used at iteration k then took a first step of
+0.74 lr .. 0.32 lr instead of lr (tests/test_trajectory_gpu.py found it).  Data parallel: every trunk parameter counts
+as touched on every rank (the union over the ranks' batches is what a single process would see; at >= 2 ranks x 128
+questions it is all modules), so the replicas stay identical without a collective.
 """
 from typing import Iterable, List, Optional, Sequence
 
@@ -72,23 +78,34 @@ class ClampAdam(torch.optim.Optimizer):
             if missing:
                 raise ValueError("arena parameters missing from the parameter list: %s ..." % missing[:3])
         self.loose: List[nn.Parameter] = [p for p in params if id(p) not in in_arena and p.requires_grad]
-        self.step_count = 0
+        self.step_count = 0  # calls of step()
         self._check_full = True  # first step (and the first after load_state_dict): every parameter checked
         self._arena_state = [(torch.zeros_like(a.flat), torch.zeros_like(a.flat)) for a in self.arenas]
         self._loose_state = [(torch.zeros_like(p, memory_format=torch.contiguous_format),
                               torch.zeros_like(p, memory_format=torch.contiguous_format)) for p in self.loose]
+        # Adam's per-parameter step counts (0: no gradient so far -- no state, as torch.optim.Adam)
+        self._arena_steps = [np.zeros(len(a.names), np.int64) for a in self.arenas]
+        self._loose_steps = np.zeros(len(self.loose), np.int64)
+        self._loose_zero = {}  # zero gradients of started loose parameters a step gave none (rare)
         self._bind_state()
 
     # ---- torch.optim surface -------------------------------------------------------------------
     def _bind_state(self) -> None:
         """self.state in torch.optim.Adam's layout, aliasing the buffers the kernel updates."""
-        for a, (m, v) in zip(self.arenas, self._arena_state):
-            for n in a.names:
+        for a, (m, v), steps in zip(self.arenas, self._arena_state, self._arena_steps):
+            for i, n in enumerate(a.names):
                 p = a.param(n)
-                self.state[p] = {"step": torch.tensor(float(self.step_count)), "exp_avg": a.view_of(m, n),
+                self.state[p] = {"step": torch.tensor(float(steps[i])), "exp_avg": a.view_of(m, n),
                                  "exp_avg_sq": a.view_of(v, n)}
-        for p, (m, v) in zip(self.loose, self._loose_state):
-            self.state[p] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v}
+        for i, (p, (m, v)) in enumerate(zip(self.loose, self._loose_state)):
+            self.state[p] = {"step": torch.tensor(float(self._loose_steps[i])), "exp_avg": m, "exp_avg_sq": v}
+
+    def _sync_steps(self) -> None:
+        for a, steps in zip(self.arenas, self._arena_steps):
+            for i, n in enumerate(a.names):
+                self.state[a.param(n)]["step"].fill_(float(steps[i]))
+        for i, p in enumerate(self.loose):
+            self.state[p]["step"].fill_(float(self._loose_steps[i]))
 
     def add_param_group(self, param_group) -> None:
         if getattr(self, "param_groups", None):
@@ -96,9 +113,11 @@ class ClampAdam(torch.optim.Optimizer):
         super().add_param_group(param_group)
 
     def state_dict(self):
-        for st in self.state.values():
-            st["step"].fill_(float(self.step_count))
-        return super().state_dict()
+        self._sync_steps()
+        sd = super().state_dict()
+        # (torch.optim.Adam holds no state for a parameter that never had a gradient)
+        sd["state"] = {k: v for k, v in sd["state"].items() if float(v["step"]) > 0}
+        return sd
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)  # casts to each parameter's device / dtype, replaces self.state
@@ -114,22 +133,25 @@ class ClampAdam(torch.optim.Optimizer):
         self._check_full = True  # (the next step re-verifies that every parameter still aliases its arena)
         loaded = dict(self.state)
         steps = [float(st["step"]) for st in loaded.values() if "step" in st]
-        if steps and max(steps) != min(steps):
-            raise ValueError("per-parameter step counts differ (%g..%g): ClampAdam keeps one counter"
-                             % (min(steps), max(steps)))
-        self.step_count = int(steps[0]) if steps else 0
+        self.step_count = int(max(steps)) if steps else 0
         with torch.no_grad():
-            for a, (m, v) in zip(self.arenas, self._arena_state):
-                for n in a.names:
+            for a, (m, v), asteps in zip(self.arenas, self._arena_state, self._arena_steps):
+                m.zero_(), v.zero_()
+                asteps[:] = 0
+                for i, n in enumerate(a.names):
                     st = loaded.get(a.param(n))
-                    if st:
+                    if st and "step" in st:  # (no entry: the parameter had no gradient before the checkpoint)
                         a.view_of(m, n).copy_(st["exp_avg"])
                         a.view_of(v, n).copy_(st["exp_avg_sq"])
-            for p, (m, v) in zip(self.loose, self._loose_state):
+                        asteps[i] = int(float(st["step"]))
+            self._loose_steps[:] = 0
+            for i, (p, (m, v)) in enumerate(zip(self.loose, self._loose_state)):
                 st = loaded.get(p)
-                if st:
+                m.zero_(), v.zero_()
+                if st and "step" in st:
                     m.copy_(st["exp_avg"])
                     v.copy_(st["exp_avg_sq"])
+                    self._loose_steps[i] = int(float(st["step"]))
         self.state.clear()
         self._bind_state()
 
@@ -147,32 +169,64 @@ class ClampAdam(torch.optim.Optimizer):
         if closure is not None:
             raise ValueError("ClampAdam.step takes no closure")
         parameters_changed()
+        from probnmn import parallel
+
         group = self.param_groups[0]
         self.step_count += 1
-        items = []
-        for a, (m, v) in zip(self.arenas, self._arena_state):
+        everyone = parallel.world() > 1  # (data parallel: see the module docstring)
+        launches = {}  # Adam step count -> [(param ptr, grad ptr, exp_avg ptr, exp_avg_sq ptr, floats)]
+        for a, (m, v), steps in zip(self.arenas, self._arena_state, self._arena_steps):
             # every parameter on the first step, after load_state_dict and every 64th step; a rotating sample
             # otherwise (a re-pointed parameter would train on while the fused update writes the arena slice)
             if not a.intact(full=self._check_full or self.step_count % 64 == 0):
                 raise _hip.HipLibraryError(
                     "a parameter no longer aliases the arena this optimizer was built on (model.to() / .data = "
                     "after the optimizer was constructed): build the optimizer after placing the model")
-            items.append((a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr(), a.total))
-        for p, (m, v) in zip(self.loose, self._loose_state):
-            if p.grad is None:
+            if a.touched is None or everyone:
+                steps += 1
+            else:
+                steps[(steps > 0) | a.touched] += 1
+            if a.touched is not None:
+                a.touched[:] = False
+            base = (a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr())
+            if steps[0] > 0 and (steps == steps[0]).all():  # (the steady state: one range)
+                launches.setdefault(int(steps[0]), []).append(base + (a.total,))
                 continue
-            if not p.is_contiguous() or not p.grad.is_contiguous():
+            # contiguous runs of parameters with one step count (alignment padding between two parameters rides along:
+            # zero gradient, zero moments, stays zero)
+            names, i, n = a.names, 0, len(a.names)
+            while i < n:
+                j = i
+                while j + 1 < n and steps[j + 1] == steps[i]:
+                    j += 1
+                if steps[i] > 0:
+                    lo = a.offsets[names[i]]
+                    hi = a.offsets[names[j + 1]] if j + 1 < n else a.total
+                    launches.setdefault(int(steps[i]), []).append(tuple(b + 4 * lo for b in base) + (hi - lo,))
+                i = j + 1
+        for i, (p, (m, v)) in enumerate(zip(self.loose, self._loose_state)):
+            g = p.grad
+            if g is None:
+                if self._loose_steps[i] == 0:
+                    continue  # (no gradient so far: no state, as torch.optim.Adam)
+                # torch 1.4.0's zero_grad would have left a zero gradient behind: the momentum goes on
+                g = self._loose_zero.get(i)
+                if g is None:
+                    g = self._loose_zero[i] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if not p.is_contiguous() or not g.is_contiguous():
                 raise _hip.HipLibraryError("ClampAdam needs contiguous loose parameters and gradients")
-            items.append((p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+            self._loose_steps[i] += 1
+            launches.setdefault(int(self._loose_steps[i]), []).append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
         self._check_full = False
-        if not items:
+        if not launches:
             return
-        rec = np.array(items, dtype=np.uint64).view(_hip.ADAM_ITEM).reshape(-1)  # (five 8-byte fields per item)
         device = (self.arenas[0].flat if self.arenas else self.loose[0]).device
-        buf = _hip.to_device(rec, device)
         clamp = float(group["clamp"]) if group["clamp"] is not None else 0.0
-        _hip.check(
-            _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(items), float(group["lr"]), group["betas"][0],
-                                       group["betas"][1], group["eps"], group["weight_decay"], clamp,
-                                       self.step_count, _hip.stream_ptr(device)),
-            "clamp_adam")
+        for step, items in sorted(launches.items()):
+            rec = np.array(items, dtype=np.uint64).view(_hip.ADAM_ITEM).reshape(-1)  # (five 8-byte fields per item)
+            buf = _hip.to_device(rec, device)
+            _hip.check(
+                _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(items), float(group["lr"]), group["betas"][0],
+                                           group["betas"][1], group["eps"], group["weight_decay"], clamp,
+                                           step, _hip.stream_ptr(device)),
+                "clamp_adam")

@@ -35,6 +35,12 @@ class ParamArena:
             self._params[name] = p
             total += _align(p.numel())
         self.total = total
+        # Which parameters received a gradient since the optimizer last looked (bool per name, in ``names`` order), or
+        # None: not tracked -- every parameter counts as touched.  The engine ORs in the modules of a backward pass's
+        # valid programs; ClampAdam reads and clears it: torch.optim.Adam starts a parameter's state at its FIRST
+        # gradient and, under the reference's torch 1.4.0 zero_grad (gradients zeroed in place, never dropped), updates
+        # it in every later step.
+        self.touched = None
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=device)
         self._views: Dict[str, torch.Tensor] = {}

@@ -79,7 +79,7 @@ class _NativePlan:
 
 
 class _State:
-    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows", "step_pack")
+    __slots__ = ("plan", "pack", "fixed", "B", "generation", "valid_examples", "features", "backward_rows", "step_pack", "touched")
 
 
 class NMNEngine:
@@ -265,6 +265,13 @@ class NMNEngine:
             if head:
                 dotw[idx] = a.offsets["%s.%s.weight" % (tok, head)]
                 dotb[idx] = a.offsets["%s.%s.bias" % (tok, head)]
+        # parameters (arena name indices) a program token's module owns, and those every valid program uses: what a
+        # backward pass hands a gradient to (ParamArena.touched)
+        index = {n: i for i, n in enumerate(a.names)}
+        self._token_params = {idx: np.array([i for n, i in index.items() if n.startswith(tok + ".")], np.int64)
+                              for idx, tok in vocab.items()}
+        self._always_params = np.array([i for n, i in index.items() if n.startswith(("stem.", "classifier."))], np.int64)
+        a.touched = np.zeros(len(a.names), bool)
         self.wt_stem2 = add_wt("stem.2.weight")
         self.wt_cls0 = add_wt("classifier.0.weight")
         self.tables = WeightTables(w3, b3, wt3, dotw, dotb)
@@ -580,9 +587,24 @@ class NMNEngine:
             state.features = started["features"]  # (the stem's weight gradient reads the input again)
             state.step_pack = step_pack
             state.generation = self.generation
+            state.touched = self._touched_by(programs, valid)
             n = int(out["n_bwd"])
             state.backward_rows = (self._planner_bwd[:n].copy(), int(out["bwd_piece_cut"]), rows["dpooled_row"])
         return pooled, state, valid
+
+    def _touched_by(self, programs: np.ndarray, valid: np.ndarray) -> np.ndarray:
+        """Arena parameters that get a gradient from a backward pass over these programs: the stem and the classifier
+        conv, and the modules named by the VALID programs' tokens (the reference's interpreter drops an invalid program's
+        partial graph: nmn.py:235-241)."""
+        mask = np.zeros(len(self.arena.names), bool)
+        rows = programs[valid.astype(bool)]
+        if rows.size:
+            mask[self._always_params] = True
+            for tok in np.unique(rows):
+                owned = self._token_params.get(int(tok))
+                if owned is not None and owned.size:
+                    mask[owned] = True
+        return mask
 
     # ---- backward -------------------------------------------------------------------------------
     def run_backward(self, state: _State, dpooled: torch.Tensor):
@@ -591,6 +613,8 @@ class NMNEngine:
                 "NeuralModuleNetwork.forward was called again before backward of the previous call: "
                 "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
         a = self.arena
+        if a.touched is not None and state.touched is not None:
+            a.touched |= state.touched
         chk = _hip.check
         dev = a.device
         st = _hip.stream_ptr(dev)

@@ -25,9 +25,10 @@ def test_is_an_optimizer_with_one_group_and_adam_state_layout():
     sd = opt.state_dict()
     ref = torch.optim.Adam(_model().parameters(), lr=3e-4, weight_decay=0.01)
     assert sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
-    assert set(sd["state"]) == set(range(4))
-    for st, p in zip(sd["state"].values(), m.parameters()):
-        assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and st["exp_avg"].shape == p.shape
+    assert sd["state"] == ref.state_dict()["state"] == {}  # (no gradient so far: no state, as torch.optim.Adam)
+    for p in m.parameters():  # the buffers a step will update exist and alias the state
+        st = opt.state[p]
+        assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and st["exp_avg"].shape == p.shape and float(st["step"]) == 0.0
     with pytest.raises(ValueError):
         opt.add_param_group({"params": [nn.Parameter(torch.zeros(2))]})
 
@@ -93,19 +94,30 @@ def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
     sched_ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref, mode="max", factor=0.5, patience=0, threshold=1e-3)
     g = torch.Generator().manual_seed(2)
 
-    def one_step(optimizers):
+    arena_index = {n: i for i, n in enumerate(arena.names)}
+
+    def one_step(optimizers, unused=()):
+        """``unused``: parameter names this step's "batch" does not reach -- no gradient from backward.  The reference side
+        is torch 1.4.0's bookkeeping (zero_grad zeroes in place): None before a parameter's first gradient, zeros after."""
         grads = [torch.randn(p.shape, generator=g) * 4 for p in ref_params]  # |g| > 5 occurs: the clamp matters
         arena.grad.zero_()
         for p, gr in zip(net.parameters(), grads):
             p.grad = None
         arena.attach_grads()
-        for p, gr in zip(net.parameters(), grads):
-            if p.grad is not None:
+        arena.touched[:] = False
+        for n, p, gr in zip(names, net.parameters(), grads):
+            if n in unused:
+                continue
+            if n in arena_index:
+                arena.touched[arena_index[n]] = True  # (what NMNEngine.run_backward records)
                 p.grad.copy_(gr.to(dev))
             else:
                 p.grad = gr.to(dev)
-        for p, gr in zip(ref_params, grads):
-            p.grad = gr.clamp(-5, 5)
+        for n, p, gr in zip(names, ref_params, grads):
+            if n in unused:
+                p.grad = None if p.grad is None else torch.zeros_like(p)
+            else:
+                p.grad = gr.clamp(-5, 5)
         for o in optimizers:
             o.step()
 
@@ -113,9 +125,19 @@ def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
         for n, p, r in zip(names, net.parameters(), ref_params):
             torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=1e-5, atol=tol, msg=lambda m: "%s %s: %s" % (tag, n, m))
 
+    # per-parameter step counts: two modules and a fully connected layer join at the second step (their first Adam step is a
+    # full lr there), one module sits the third step out (its momentum goes on)
+    late = {n for n in names if n.startswith(("filter_color[red].", "relate[left].", "classifier.6."))}
+    idle = {n for n in names if n.startswith("filter_size[small].")}
+    assert len(late) >= 10 and len(idle) >= 4
+    one_step([opt, ref], unused=late)
     one_step([opt, ref])
-    one_step([opt, ref])
-    check("two steps")
+    check("two steps, some parameters from the second on")
+    assert {float(ref.state[p]["step"]) for n, p in zip(names, ref_params) if n in late} == {1.0}
+    sd = opt.state_dict()["state"]
+    assert [float(sd[i]["step"]) for i in range(len(names))] == [float(ref.state[p]["step"]) for p in ref_params]
+    one_step([opt, ref], unused=idle)
+    check("a module without gradient keeps its momentum")
     sched.step(0.5), sched_ref.step(0.5)
     sched.step(0.5), sched_ref.step(0.5)  # no improvement, patience 0 -> lr halves
     assert opt.lr == pytest.approx(5e-3) == ref.param_groups[0]["lr"]
@@ -124,13 +146,14 @@ def test_fused_step_follows_the_scheduler_and_resumes_from_a_checkpoint():
 
     # checkpoint mid-run: ClampAdam -> fresh ClampAdam, and -> torch.optim.Adam
     sd = copy.deepcopy(opt.state_dict())
-    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    assert [float(sd["state"][i]["step"]) for i in range(len(names))] == [float(ref.state[p]["step"]) for p in ref_params]
+    assert sorted({float(st["step"]) for st in sd["state"].values()}) == [3.0, 4.0]
     opt2 = ClampAdam(net.parameters(), arenas=[arena], lr=123.0)
     opt2.load_state_dict(sd)
     ref2 = torch.optim.Adam(ref_params, lr=123.0)
     ref2.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
                           "param_groups": sd["param_groups"]})
-    assert opt2.lr == pytest.approx(5e-3) and opt2.step_count == 3
+    assert opt2.lr == pytest.approx(5e-3) and opt2.step_count == 4
     one_step([opt2, ref2])
     check("resumed")
 
