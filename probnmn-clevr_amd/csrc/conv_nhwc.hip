@@ -85,7 +85,7 @@ inline int bands_of(int H, int W) { return (H == 14 && W == 14) ? 1 : (H == 28 &
 }  // namespace
 
 extern "C" int pnmn_conv_force_split(int split) {
-    if (split != 0 && split != 1 && split != 2 && split != 4 && split != 6 && split != 8) return PNMN_EINVAL;
+    if (split != 0 && split != 1 && split != 2 && split != 4 && split != 6 && split != 8 && split != 14 && split != 26) return PNMN_EINVAL;
     pnmn::forced_split() = split;
     return 0;
 }

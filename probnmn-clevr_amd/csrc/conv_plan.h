@@ -23,7 +23,7 @@ inline int& forced_split() {
     static int forced = [] {
         const char* e = getenv("PNMN_CONV_KSPLIT");
         const int v = e ? atoi(e) : 0;
-        return (v == 1 || v == 2 || v == 4 || v == 6 || v == 8) ? v : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 6 || v == 8 || v == 14 || v == 26) ? v : 0;
     }();
     return forced;
 }
@@ -42,16 +42,19 @@ inline int default_conv_cus() {
 // split 2 halves a wave's channels, split 4 / 8 also share an item's 13 m-tiles among 2 / 4 waves per channel tile
 // (7 / 4 tiles on the longest wave).
 inline LaunchPlan plan_launch(int n_items, int cout_blocks, int cin_chunks, int ntaps, int cu_budget = 0) {
-    if (forced_split() && !(forced_split() == 6 && ntaps != 9)) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
+    if (forced_split() && !((forced_split() == 6 || forced_split() > 8) && ntaps != 9)) return LaunchPlan{1, {forced_split(), 0, 0}, {n_items, 0, 0}};
     const double work = (double)ntaps * cin_chunks;
     constexpr int max_seg = 3;
     constexpr double seg_cost = 0.3;    // a further segment: its workgroups start behind a partly drained round
     constexpr double overhead = 0.25;   // start-up, epilogue
-    // (a wave's (channel tile, m-tile) pairs: 26 / 13 / 7 / 5 / 4 at split 1 / 2 / 4 / 6 / 8)
-    auto round_cost = [&](int s) { return work * (s == 1 ? 1.0 : s == 2 ? 0.5 : s == 4 ? 3.5 / 13.0 : s == 6 ? 2.5 / 13.0 : 2.0 / 13.0) + overhead; };
-    // the splits a segment may take, ascending; split 6 (three waves per channel tile) exists for the 3x3 bodies only
-    const int splits[5] = {1, 2, 4, ntaps == 9 ? 6 : 8, 8};
-    const int n_splits = ntaps == 9 ? 5 : 4;
+    // (a wave's (channel tile, m-tile) pairs: 26 / 13 / 7 / 5 / 4 / 2 / 1 at split 1 / 2 / 4 / 6 / 8 / 14 / 26)
+    auto round_cost = [&](int s) {
+        const double pairs = s == 1 ? 26.0 : s == 2 ? 13.0 : s == 4 ? 7.0 : s == 6 ? 5.0 : s == 8 ? 4.0 : s == 14 ? 2.0 : 1.0;
+        return work * pairs / 26.0 + overhead;
+    };
+    // the splits a segment may take, ascending; 6 / 14 / 26 (3 / 7 / 13 waves per channel tile) exist for the 3x3 bodies only
+    const int splits[7] = {1, 2, 4, ntaps == 9 ? 6 : 8, 8, 14, 26};
+    const int n_splits = ntaps == 9 ? 7 : 4;
     LaunchPlan best{1, {1, 0, 0}, {n_items, 0, 0}};
     double best_t = 1e30;
     // CUs a round is planned for: all 256, unless the caller says the launch shares the chip (pnmn_conv_nhwc_cus: the

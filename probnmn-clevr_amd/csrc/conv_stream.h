@@ -389,6 +389,8 @@ __device__ __forceinline__ void loader(const Launch& L, const pnmn_conv_item* it
         lap(2);
     };
     // the first stage is requested BEFORE the start-up work: zero rows and table are written while it travels
+    // (measured, round 5: requesting the SECOND stage up front too changes nothing, not even for the split-14 / 26
+    // units that contract a stage in 1-2 us -- 18-19 us for a 7-item launch either way)
     top_up(P.valid() ? P.slots : 0);
     int tab_band = C.valid() ? C.band : -1, tab_dil = C.valid() ? C.dil : -1;
     start_up<H, W, TH>(lds, C, L.ntaps, LOADER_WAVE + LW, lane);
@@ -623,17 +625,20 @@ __device__ __forceinline__ void run_unit(Walker<H, W, TH>& Wk, const Launch& L, 
     using G = Geom<H, W, TH>;
     using std::integral_constant;
     const unsigned long long c_unit = PNMN_CYC();
-    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 6 || SPLIT == 8, "workgroups per 128-channel block");
+    static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4 || SPLIT == 6 || SPLIT == 8 || SPLIT == 14 || SPLIT == 26,
+                  "workgroups per 128-channel block");
     constexpr int NW = SPLIT == 1 ? 2 : 1;                        // 16-channel output tiles of a wave
     constexpr int MW = SPLIT <= 2 ? 1 : SPLIT / 2;                // waves that share a channel tile's m-tiles
-    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 13 / 7 / 5 / 4
+    constexpr int MTW = (MTILES + MW - 1) / MW;                   // m-tiles per wave: 13 / 13 / 7 / 5 / 4 / 2 / 1
     constexpr int MH = (MTW + 1) / 2;
     constexpr int WSETS = NW == 2 ? 2 : 3;                        // weight sets in flight (taps ahead + 1)
     constexpr uint32_t FULL = (1u << MTW) - 1u;
     const int li = lane & 15, g = lane >> 4;
-    // SPLIT 6 (round 5): the block's 8 channel tiles x 3 m-parts of 5 / 5 / 3 tiles are dealt to the 24 waves of the
-    // unit's six workgroups in order, so a workgroup's waves straddle channel tiles -- a launch of 39 items fills the chip
-    // with 234 workgroups of 5 tile-times where split 4 leaves 100 CUs idle for 7 and split 8 needs two rounds of 4.
+    // SPLIT 6 / 14 / 26 (round 5): the block's 8 channel tiles x 3 / 7 / 13 m-parts of 5 / 2 / 1 tiles are dealt to the
+    // waves of the unit's workgroups in order, so a workgroup's waves straddle channel tiles -- a launch of 39 items fills
+    // the chip with 234 workgroups of 5 tile-times where split 4 leaves 100 CUs idle for 7 and split 8 needs two rounds
+    // of 4; the 7- and 14-item launches of the deep program levels (36 of a 1024-question step's 89 conv launches, 27 us
+    // each at split 8: 17 us of MFMAs behind ~8 us of start-up, first-stage latency and epilogue) take 1 and 2.
     constexpr bool DEALT = (MW & (MW - 1)) != 0;
     const int gw = Wk.sub * 4 + wave;                             // (DEALT) this wave among the unit's waves
     const int nt = DEALT ? 0 : wave % (4 / (DEALT ? 1 : MW));     // which of the workgroup's wave-sized channel groups
@@ -918,6 +923,8 @@ __device__ __forceinline__ void conv_stream(const Launch& L, const pnmn_conv_ite
                 case 2: run_unit<H, W, TH, 2, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 4: run_unit<H, W, TH, 4, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 case 6: run_unit<H, W, TH, 6, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 14: run_unit<H, W, TH, 14, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
+                case 26: run_unit<H, W, TH, 26, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
                 default: run_unit<H, W, TH, 8, 0>(Wk, L, lds, cstart, wave, lane, cyc); break;
             }
         }

@@ -335,18 +335,21 @@ class NMNEngine:
 
         def jobs(dw, db, yblocks, taps=9):
             # items per job: a launch of ceil(B / chunk) * yblocks workgroups costs ceil(. / 256) rounds of
-            # `chunk` items each (+ ~half an item for the atomic add of the job's slab into the shared
-            # weight gradient, which is also why a job never has fewer than 4 items); 260 workgroups cost
-            # two rounds, 208 one -- take the chunk with the shortest makespan
+            # `chunk` items each (+ a fraction of an item for the atomic add of the job's slab into the shared
+            # weight gradient); 260 workgroups cost two rounds, 208 one -- take the chunk with the shortest makespan
+            flush = 0.5
             if self.banded:  # four bands per item, twice the slabs per weight
                 yblocks *= 2
                 sizes = range(1, 9)
+            elif taps == 9:
+                # the streamed 3x3 kernel (csrc/conv_wgrad_stream.h): slabs of 64 x 64 channels, the flush a tenth of an
+                # item's 35 us -- a 64-row shard goes out as 64 one-item jobs on 256 workgroups (stem conv2: 126 -> ~45 us)
+                yblocks *= 2
+                sizes, flush = range(1, 33), 0.3
             else:
-                if taps == 9:
-                    yblocks *= 2  # (the streamed 3x3 kernel's slab is 64 x 64 channels: csrc/conv_wgrad_stream.h)
                 sizes = range(4, 33)
             cus = self.conv_cus or 256  # (a trunk that shares the chip: rounds of the CUs it can count on)
-            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // cus)) * (c + 0.5))
+            chunk = min(sizes, key=lambda c: (-(-(-(-B // c) * yblocks) // cus)) * (c + flush))
             starts = np.arange(0, B, chunk)
             j = np.zeros(starts.size, _hip.WGRAD_JOB)
             j["dw"], j["dbias"] = dw, db

@@ -325,7 +325,7 @@ def test_conv_splits_give_bit_identical_activations(n, deep, cus):
     """The streamed convolution (csrc/conv_stream.h) splits OUTPUT work only -- a workgroup computes 128 / 64 / 32 / 16 of
     a unit's channels, a wave one or two 16-channel tiles x 13 / 7 / 4 m-tiles -- and every wave contracts all input
     channels of its outputs in the same order, so the split the launch planner picks (by launch size and CU budget) must
-    not change a single bit of the forward pass: the losses of the whole network are EQUAL under split 1, 2, 4, 6, 8 and
+    not change a single bit of the forward pass: the losses of the whole network are EQUAL under split 1, 2, 4, 6, 8, 14, 26 and
     under the planner's own choice, and the gradients differ by the order of the weight gradients' fp32 atomic adds
     alone (<= 1e-4 of a tensor's largest entry)."""
     from probnmn import _hip
@@ -339,7 +339,7 @@ def test_conv_splits_give_bit_identical_activations(n, deep, cus):
     images, answers = batch["image"].to(dev), batch["answer"].to(dev)
     results = {}
     try:
-        for split in (1, 2, 4, 6, 8, 0):
+        for split in (1, 2, 4, 6, 8, 14, 26, 0):
             _hip.check(_hip.lib().pnmn_conv_force_split(split), "force split")
             torch.manual_seed(7)
             net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
