@@ -555,21 +555,6 @@ def config5_side(vocab, prior, dev, rank, world, args):
     return out
 
 
-def config5_subprocess(args):
-    """``config5_side`` in a fresh process on the same device (see the call site)."""
-    import subprocess
-
-    cmd = [sys.executable, os.path.abspath(__file__), "--config5-only", "--batch28", str(args.batch28),
-           "--fit-iters", str(args.fit_iters), "--fit-target", str(args.fit_target)]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    if res.returncode != 0 or not lines:
-        raise RuntimeError("28x28 side process failed (%d): %s" % (res.returncode, res.stderr[-400:]))
-    out = json.loads(lines[-1])
-    out["process"] = "own"
-    return out
-
-
 def dropin_side(vocab, dev, n, joint_ms, steps=10, warmup=4):
     """What a maintainer of the reference gets from ``probnmn_graft.install()`` with NOTHING else changed: the
     reference's own ``_Trainer.step`` + ``JointTrainingTrainer._do_iteration``
@@ -852,8 +837,6 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     ap.add_argument("--no-extras-but-ingest", action="store_true", help="of the side measurements only joint_training_ingest")
-    ap.add_argument("--config5-only", action="store_true",
-                    help="(internal) measure the 28x28 side object alone and print it: bench.py runs it in a process of its own")
     ap.add_argument("--sides", default=None, help="comma-separated side measurements to run (default: all); A/B aid")
     ap.add_argument("--extras", action="store_true", help="N > 1: run the single-GPU side measurements too (default: N = 1 only)")
     args = ap.parse_args()
@@ -894,15 +877,6 @@ def main():
     from probnmn.trainers.joint_training import JointTrainingStep, QuestionCodingStep
     from probnmn.trainers.module_training import ModuleTrainingStep
     from probnmn.vocabulary import Vocabulary
-
-    if args.config5_only:
-        vocab = Vocabulary.clevr()
-        torch.manual_seed(0)
-        prior = ProgramPrior(vocab, hidden_size=256).to(dev)
-        for p in prior.parameters():
-            p.requires_grad_(False)
-        print(json.dumps(config5_side(vocab, prior, dev, 0, 1, args)), flush=True)
-        return
 
     log("building models")
     vocab = Vocabulary.clevr()
@@ -1005,14 +979,12 @@ def main():
         if "value" in extras.get("weak_scaling", {}):
             extras["weak_scaling"]["scaling"] = "weak"
     if want_extras:
-        # In a process of its own at N = 1: its models and arenas are the largest any side object allocates, and in a
-        # process whose allocator has held and returned other multi-GB blocks (the 6.6 GB feature stores of the ingest side,
-        # before or after it) whichever of the two comes second runs 5-13 ms per step slower -- blocked on the GPU, the host
-        # unchanged (scripts/r04_bisect28.sh; physical placement of the re-mapped memory is the suspect, not established).
+        # (Rounds 3-4 ran this side in a process of its own: whichever of it and the ingest side came second in one process
+        # ran 5-13 ms per step slower on the GPU.  Not the allocator: each built a side / loader stream of its own, and HIP
+        # multiplexes a process's streams onto four hardware queues -- the trainers and loaders now share one stream per
+        # role, probnmn.trainers.joint_training.shared_stream.)
         try:
-            if on("joint_training_28x28") and world == 1:
-                extras["joint_training_28x28"] = config5_subprocess(args)
-            elif on("joint_training_28x28"):
+            if on("joint_training_28x28"):
                 extras["joint_training_28x28"] = config5_side(vocab, prior, dev, rank, world, args)
             if rank == 0 and on("joint_training_28x28"):
                 log("joint_training_28x28: %.1f questions/s" % extras["joint_training_28x28"]["value"])
@@ -1031,6 +1003,23 @@ def main():
                 log("evaluate_answer_accuracy: %.1f questions/s" % extras["evaluate_answer_accuracy"]["value"])
         except Exception as exc:
             extras["evaluate_answer_accuracy"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        try:
+            # train -> validate -> train, as the reference's loop does every CHECKPOINT_EVERY iterations
+            # (/root/reference/scripts/train.py:135-140): the headline step timed again right behind the validation pass
+            # above (eval mode, other batch sizes, other workspaces) -- a process that has been through an evaluation
+            # must train at the speed it trained at before
+            if on("train_validate_train") and "value" in extras.get("evaluate_answer_accuracy", {}):
+                e2, h2, bl2 = timed(lambda: trainer.step(batch), args.steps, 2, dev, world, trainer)
+                extras["train_validate_train"] = {
+                    "metric": "CLEVR questions/sec (joint_training step, timed again behind a validation pass)",
+                    "value": round(total * args.steps / e2, 1), "unit": "questions/s",
+                    "ms_per_step": round(e2 / args.steps * 1e3, 3), "ms_per_step_before": round(elapsed / args.steps * 1e3, 3),
+                    "slowdown_vs_before": round(e2 / elapsed, 4), "steps": args.steps, "warmup": 2,
+                    "workload": "the headline step, %d steps, right behind evaluate_answer_accuracy (%d batches of 256 "
+                                "questions) in the same process" % (args.steps, extras["evaluate_answer_accuracy"]["batches"])}
+                log("train_validate_train: %.3f ms per step (%.3f before)" % (e2 / args.steps * 1e3, elapsed / args.steps * 1e3))
+        except Exception as exc:
+            extras["train_validate_train"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         side("joint_training_b128", "CLEVR questions/sec (joint_training step)",
              "joint_training_ours.yml, 128 questions per GPU (configs[3] read as 1024 over 8 GPUs)", 128,
              lambda: trainer, k=40)  # (8 ms steps whose sampled programs differ: 10 of them scatter by +-4 %)

@@ -228,7 +228,10 @@ class PrefetchingLoader:
         self.keep_on_host = set(keep_on_host)
         # (high priority: the ingest is a trickle of long-latency PCIe reads -- or copy-engine transfers -- that must
         # not queue behind the step's thousands of workgroups)
-        self.stream = torch.cuda.Stream(device=device, priority=-1)
+        # (one loader stream per device and process: see trainers.joint_training.shared_stream)
+        from probnmn.trainers.joint_training import shared_stream
+
+        self.stream = shared_stream(device, "feature ingest", priority=-1)
         self._buffers = [None, None]  # two image buffers: the one in use and the one being filled
 
     def _stage(self, host_batch, slot: int):

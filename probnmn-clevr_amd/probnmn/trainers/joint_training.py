@@ -51,6 +51,27 @@ def _cat_padded(a: torch.Tensor, b: torch.Tensor, pad: int = 0) -> torch.Tensor:
     return torch.cat((a, b), 0)
 
 
+_SHARED_STREAMS: Dict[Any, "torch.cuda.Stream"] = {}
+
+
+def shared_stream(dev: torch.device, role: str, priority: int = 0) -> "torch.cuda.Stream":
+    """ONE stream per (device, role) for the whole process, however many trainers or loaders are built.  HIP multiplexes
+    a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams that land on one
+    queue run their kernels in order: every further ``torch.cuda.Stream()`` -- a second trainer's side stream, a second
+    loader's -- shifted which streams share a queue, and whichever multi-stream workload was built LATER in a process ran
+    5-13 ms per step slower on the GPU with the host unchanged (rounds 3-4: "allocator history"; round 5: the 1024-question
+    step fed from a resident store 28.6 ms alone, 32.4 ms behind a 28x28 side object with its own side stream, 28.6 ms
+    again with GPU_MAX_HW_QUEUES=2 -- profiles/ab/round5_stream_queues.txt).  (A high-priority trunk stream was measured:
+    no effect, profiles/ab/r04m_ab.txt.)"""
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, role)
+    if key not in _SHARED_STREAMS:
+        _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return _SHARED_STREAMS[key]
+
+
 def shared_conv_cus(questions: int, banded: bool) -> int:
     """CUs the trunk's conv launches are cut for while it runs beside the seq2seq passes (0 = all of them).  Up to 128
     questions of 14x14 maps: what the passes' multi-CU kernels leave free -- eight workgroups per 16-row tile, one per CU
@@ -350,8 +371,7 @@ class JointTrainingStep(_TrainerBase):
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":
         if self._side is None or self._side.device != dev:
-            # (a high-priority stream was measured: no effect, profiles/ab/r04m_ab.txt)
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = shared_stream(dev, "nmn trunk")
         return self._side
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
