@@ -26,7 +26,7 @@ import torch
 from probnmn import _hip
 from probnmn.runtime import program_compiler as pc
 from probnmn.runtime.arena import ParamArena
-from probnmn.runtime.schedule import BatchScheduler, WeightTables
+from probnmn.runtime.planner_config import PlannerConfig, WeightTables
 
 C = _hip.CHANNELS
 
@@ -284,8 +284,7 @@ class NMNEngine:
         self._wt_records = _hip.to_device(rec, a.device)
         self._wt_count = len(wt_items)
         self.ones = torch.ones(self.HW, dtype=torch.float32, device=a.device)
-        self.scheduler = BatchScheduler(self.HW, C, self.tables, _DT,
-                                        wgrad_chunk=2 if self.banded else 8, wgrad_groups=1)
+        self.planner_config = PlannerConfig(wgrad_chunk=2 if self.banded else 8, wgrad_groups=1)
 
     # ---- workspaces ---------------------------------------------------------------------------
     def _buf(self, name: str, numel: int) -> torch.Tensor:
@@ -464,9 +463,9 @@ class NMNEngine:
             arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (t.w3, t.b3, t.wt3, t.dotw, t.dotb)]
             cfg = np.zeros(1, _hip.TRUNK_CONFIG)
             cfg[0] = (kinds.ctypes.data,) + tuple(a.ctypes.data for a in arrs) + (
-                kinds.size, C, self.H, self.W, self.scheduler.wgrad_chunk, self.scheduler.wgrad_groups,
-                int(self.scheduler.fuse_mask_bwd), int(self.scheduler.sole_writer_rmw),
-                int(self.scheduler.sort_by_weight), 0)
+                kinds.size, C, self.H, self.W, self.planner_config.wgrad_chunk, self.planner_config.wgrad_groups,
+                int(self.planner_config.fuse_mask_bwd), int(self.planner_config.sole_writer_rmw),
+                int(self.planner_config.sort_by_weight), 0)
             out = np.zeros(1, np.uint64)
             _hip.check(_hip.lib().pnmn_trunk_planner_create(cfg.ctypes.data, out.ctypes.data), "trunk_planner_create")
             self._planner = int(out[0])

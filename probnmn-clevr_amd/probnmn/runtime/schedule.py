@@ -26,6 +26,8 @@ from typing import Dict, List, NamedTuple, Sequence, Tuple
 
 import numpy as np
 
+from probnmn.runtime.planner_config import PlannerConfig, WeightTables  # noqa: F401
+
 from . import program_compiler as pc
 
 HW_ALIGN = 64  # floats; keeps every slot 256-byte aligned
@@ -158,18 +160,6 @@ def build_template(prog: pc.CompiledProgram, hw: int, channels: int) -> Template
 
 
 # ------------------------------------------------------------------------------------------------
-@dataclass
-class WeightTables:
-    """Float offsets (into the parameter / gradient arenas, which mirror each other) per program
-    token; -1 where the token has no such weight.  ``wt3`` indexes the transposed-weight arena."""
-
-    w3: np.ndarray  # [V, 6]  projection, conv1..conv5 weights
-    b3: np.ndarray  # [V, 6]  ... biases
-    wt3: np.ndarray  # [V, 6]  transposed copies (dgrad operand)
-    dotw: np.ndarray  # [V]  conv3 (attention) / conv6 (relate) / conv (same) weight
-    dotb: np.ndarray  # [V]
-
-
 @dataclass
 class Buffers:
     """Device base addresses (bytes) for one step."""

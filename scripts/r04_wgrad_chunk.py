@@ -17,7 +17,7 @@ for chunk in (4, 8, 16, 32, 64):
     torch.manual_seed(0)
     nmn = NeuralModuleNetwork(vocab).to(dev)
     nmn.engine.ensure_arena()
-    nmn.engine.scheduler.wgrad_chunk = chunk
+    nmn.engine.planner_config.wgrad_chunk = chunk
     step = ModuleTrainingStep(nmn, lr=1e-4, report_metrics=False)
     for _ in range(3):
         step.step(batch)

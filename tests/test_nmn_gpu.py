@@ -305,7 +305,7 @@ def test_mask_backward_modes_agree():
         torch.manual_seed(7)
         net = NeuralModuleNetwork(vocab, class_projection_channels=128, classifier_linear_size=64).to(dev)
         net.engine.ensure_arena()
-        net.engine.scheduler.fuse_mask_bwd = mode
+        net.engine.planner_config.fuse_mask_bwd = mode
         net.train()
         out = net(images, batch["program"], answers)
         out["loss"].mean().backward()

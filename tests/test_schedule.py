@@ -1,6 +1,7 @@
 """Host-side scheduler invariants (no GPU): every primitive's inputs are produced at a lower level,
 every buffer a launch writes is written by exactly one item of that launch, arena blocks do not
 overlap, and records are bit-compatible with the C structs."""
+import os
 import numpy as np
 
 from probnmn import _hip
@@ -150,3 +151,13 @@ def test_library_planner_equals_the_numpy_planner(monkeypatch):
     _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
     s.sort_by_weight = False
     _same_plan(s.plan(mixed, BUF), s.plan_numpy(mixed, BUF))
+
+
+def test_the_numpy_planner_is_not_part_of_the_product():
+    """runtime/schedule.py is the specification the library's planner is compared with; the engine configures the
+    library's planner through PlannerConfig alone (one home for the configuration)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import probnmn.runtime.engine, probnmn.models.nmn; "
+            "assert 'probnmn.runtime.schedule' not in sys.modules" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "probnmn-clevr_amd"))
+    subprocess.check_call([sys.executable, "-c", code])
