@@ -369,8 +369,8 @@ int pnmn_joint_objective(const float* pg, const float* qr, const float* prior, c
 /* ---------------------------------------------------------------------------------------------
  * Fused gradient clamp + Adam (trainers: clamp_(-5,5) then optimizer.step()).
  * module_training_trainer.py:94-96, joint_training_trainer.py:182-188, _trainer.py:103-108,193
- * torch.optim.Adam semantics (no amsgrad): g = clamp(g) + wd*p; m,v EMA; bias correction with
- * `step`; p -= lr * mhat / (sqrt(vhat) + eps).
+ * torch.optim.Adam semantics (no amsgrad): g = clamp(g) + wd*p; m,v EMA; bias correction per
+ * item; p -= lr * mhat / (sqrt(vhat) + eps).
  * ------------------------------------------------------------------------------------------- */
 typedef struct pnmn_adam_item {
     float*       param;
@@ -378,9 +378,14 @@ typedef struct pnmn_adam_item {
     float*       exp_avg;
     float*       exp_avg_sq;
     int64_t      n;
-} pnmn_adam_item;         /* 40 bytes */
+    /* bias corrections of THIS parameter's Adam step count s >= 1 (torch.optim.Adam keeps one count per parameter: a
+     * module first used at iteration k starts its state there), computed by the caller in double as torch does on the
+     * host: bc1 = 1 - beta1^s, bc2_sqrt = sqrt(1 - beta2^s).  One launch serves items of different counts. */
+    float        bc1;
+    float        bc2_sqrt;
+} pnmn_adam_item;         /* 48 bytes */
 int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2,
-                    double eps, double weight_decay, double clamp, int step, void* stream);
+                    double eps, double weight_decay, double clamp, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM cell gate math (torch nn.LSTM / nn.LSTMCell, gate order i,f,g,o), the point-wise half of

@@ -396,8 +396,9 @@ __global__ void answer_loss_kernel(const float* __restrict__ logits, const int64
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void clamp_adam_kernel(const pnmn_adam_item* __restrict__ items, float lr,
                                                          float beta1, float beta2, float eps, float wd,
-                                                         float clampv, float bc1, float bc2_sqrt) {
+                                                         float clampv) {
     const pnmn_adam_item it = items[blockIdx.y];
+    const float bc1 = it.bc1, bc2_sqrt = it.bc2_sqrt;
     const int64_t n4 = it.n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float step_size = lr / bc1;
@@ -546,7 +547,7 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
 
 extern "C" {
 
-int pnmn_abi_version(void) { return 8; }
+int pnmn_abi_version(void) { return 9; }
 
 int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
     if (n_items <= 0) return 0;
@@ -665,15 +666,12 @@ int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t*
 }
 
 int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2, double eps,
-                    double weight_decay, double clamp, int step, void* stream) {
+                    double weight_decay, double clamp, void* stream) {
     if (n_items <= 0) return 0;
-    if (!items || step < 1) return PNMN_EINVAL;
-    // bias corrections in double, as torch.optim.Adam computes them on the host
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
+    if (!items) return PNMN_EINVAL;
+    // (the bias corrections travel in the items: computed in double by the caller, as torch.optim.Adam does on the host)
     hipLaunchKernelGGL(clamp_adam_kernel, dim3(2048, n_items), dim3(256), 0, STREAM(stream), items, (float)lr,
-                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)clamp, (float)bc1,
-                       (float)sqrt(bc2));
+                       (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)clamp);
     return last_error();
 }
 

@@ -71,7 +71,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_joint_objective": (_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P),
-    "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
+    "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_seq_fwd": (_P, _P, ctypes.c_int64, _P, _P, _P, _P, _I, _I, _I, _P, _P),
@@ -109,7 +109,7 @@ SIGNATURES: Dict[str, tuple] = {
 }
 
 
-ABI_VERSION = 8  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 9  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:
@@ -242,7 +242,8 @@ DECODER_BWD_JOB = np.dtype([(n, _u64) for n in ("dhs", "act", "cs", "hs", "probs
                                                   "dctx", "dscore", "weights", "dh0")]
                            + [(n, _i32) for n in ("B", "T", "S", "reserved")])
 EINVAL, ESHAPE, EAGAIN = -1, -2, -3  # PNMN_EINVAL / PNMN_ESHAPE / PNMN_EAGAIN
-ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64)])
+ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64),
+                      ("bc1", np.float32), ("bc2_sqrt", np.float32)])
 
 LAUNCH = np.dtype([("a", _u64), ("b", _u64), ("c", _u64), ("op", _i32), ("n", _i32), ("p", _i32, (8,))])
 CONV2D_DESC = np.dtype([("x", _u64), ("w", _u64), ("scale", _u64), ("shift", _u64), ("residual", _u64), ("y", _u64),
@@ -290,7 +291,7 @@ ITEM_SIZES = {
     "pnmn_minmax_item": (MINMAX_ITEM, 64),
     "pnmn_maskbwd_item": (MASKBWD_ITEM, 40),
     "pnmn_axpy_item": (AXPY_ITEM, 24),
-    "pnmn_adam_item": (ADAM_ITEM, 40),
+    "pnmn_adam_item": (ADAM_ITEM, 48),
     "pnmn_derive_job": (DERIVE_JOB, 40),
     "pnmn_plan_in": (PLAN_IN, 216),
     "pnmn_decoder_fwd_job": (DECODER_FWD_JOB, 184),

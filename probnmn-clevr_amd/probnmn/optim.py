@@ -87,6 +87,9 @@ class ClampAdam(torch.optim.Optimizer):
         self._arena_steps = [np.zeros(len(a.names), np.int64) for a in self.arenas]
         self._loose_steps = np.zeros(len(self.loose), np.int64)
         self._loose_zero = {}  # zero gradients of started loose parameters a step gave none (rare)
+        self._arena_bounds = [np.array([a.offsets[n] for n in a.names] + [a.total], np.int64) for a in self.arenas]
+        self._loose_ptrs = [(m.data_ptr(), v.data_ptr()) for m, v in self._loose_state]
+        self._loose_numel = [p.numel() for p in self.loose]
         self._bind_state()
 
     # ---- torch.optim surface -------------------------------------------------------------------
@@ -174,8 +177,11 @@ class ClampAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         self.step_count += 1
         everyone = parallel.world() > 1  # (data parallel: see the module docstring)
-        launches = {}  # Adam step count -> [(param ptr, grad ptr, exp_avg ptr, exp_avg_sq ptr, floats)]
-        for a, (m, v), steps in zip(self.arenas, self._arena_state, self._arena_steps):
+        # ONE launch: an item per contiguous run of arena parameters that share an Adam step count (one run per arena
+        # once every module has been used -- at 128 questions per GPU a rarely sampled module can stay behind for good)
+        # and an item per loose tensor; each item carries the bias corrections of its own count.
+        ptrs, counts, steps_of = [], [], []
+        for k, (a, (m, v), steps) in enumerate(zip(self.arenas, self._arena_state, self._arena_steps)):
             # every parameter on the first step, after load_state_dict and every 64th step; a rotating sample
             # otherwise (a re-pointed parameter would train on while the fused update writes the arena slice)
             if not a.intact(full=self._check_full or self.step_count % 64 == 0):
@@ -188,22 +194,20 @@ class ClampAdam(torch.optim.Optimizer):
                 steps[(steps > 0) | a.touched] += 1
             if a.touched is not None:
                 a.touched[:] = False
-            base = (a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr())
-            if steps[0] > 0 and (steps == steps[0]).all():  # (the steady state: one range)
-                launches.setdefault(int(steps[0]), []).append(base + (a.total,))
-                continue
+            base = np.array((a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr()), np.uint64)
             # contiguous runs of parameters with one step count (alignment padding between two parameters rides along:
             # zero gradient, zero moments, stays zero)
-            names, i, n = a.names, 0, len(a.names)
-            while i < n:
-                j = i
-                while j + 1 < n and steps[j + 1] == steps[i]:
-                    j += 1
-                if steps[i] > 0:
-                    lo = a.offsets[names[i]]
-                    hi = a.offsets[names[j + 1]] if j + 1 < n else a.total
-                    launches.setdefault(int(steps[i]), []).append(tuple(b + 4 * lo for b in base) + (hi - lo,))
-                i = j + 1
+            cuts = np.flatnonzero(steps[1:] != steps[:-1]) + 1
+            first = np.concatenate(([0], cuts))
+            bounds = self._arena_bounds[k]  # float offset of every parameter, then the arena's length
+            lo, hi = bounds[first], bounds[np.concatenate((cuts, [len(steps)]))]
+            live = steps[first] > 0
+            if live.any():
+                lo, hi = lo[live], hi[live]
+                ptrs.append(base[None, :] + (4 * lo).astype(np.uint64)[:, None])
+                counts.append(hi - lo)
+                steps_of.append(steps[first][live])
+        loose_rows = []
         for i, (p, (m, v)) in enumerate(zip(self.loose, self._loose_state)):
             g = p.grad
             if g is None:
@@ -216,17 +220,29 @@ class ClampAdam(torch.optim.Optimizer):
             if not p.is_contiguous() or not g.is_contiguous():
                 raise _hip.HipLibraryError("ClampAdam needs contiguous loose parameters and gradients")
             self._loose_steps[i] += 1
-            launches.setdefault(int(self._loose_steps[i]), []).append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()))
+            loose_rows.append((p.data_ptr(), g.data_ptr(), self._loose_ptrs[i][0], self._loose_ptrs[i][1], self._loose_numel[i],
+                               self._loose_steps[i]))
+        if loose_rows:
+            lr_ = np.array(loose_rows, dtype=np.int64)
+            ptrs.append(lr_[:, :4].astype(np.uint64))
+            counts.append(lr_[:, 4])
+            steps_of.append(lr_[:, 5])
         self._check_full = False
-        if not launches:
+        if not ptrs:
             return
+        ptrs, counts, steps_of = np.concatenate(ptrs), np.concatenate(counts), np.concatenate(steps_of).astype(np.float64)
+        rec = np.zeros(len(counts), _hip.ADAM_ITEM)
+        for c, name in enumerate(("param", "grad", "exp_avg", "exp_avg_sq")):
+            rec[name] = ptrs[:, c]
+        rec["n"] = counts
+        # bias corrections in double, as torch.optim.Adam computes them on the host
+        beta1, beta2 = group["betas"]
+        rec["bc1"] = 1.0 - np.power(float(beta1), steps_of)
+        rec["bc2_sqrt"] = np.sqrt(1.0 - np.power(float(beta2), steps_of))
         device = (self.arenas[0].flat if self.arenas else self.loose[0]).device
         clamp = float(group["clamp"]) if group["clamp"] is not None else 0.0
-        for step, items in sorted(launches.items()):
-            rec = np.array(items, dtype=np.uint64).view(_hip.ADAM_ITEM).reshape(-1)  # (five 8-byte fields per item)
-            buf = _hip.to_device(rec, device)
-            _hip.check(
-                _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(items), float(group["lr"]), group["betas"][0],
-                                           group["betas"][1], group["eps"], group["weight_decay"], clamp,
-                                           step, _hip.stream_ptr(device)),
-                "clamp_adam")
+        buf = _hip.to_device(rec, device)
+        _hip.check(
+            _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(rec), float(group["lr"]), beta1, beta2, group["eps"],
+                                       group["weight_decay"], clamp, _hip.stream_ptr(device)),
+            "clamp_adam")

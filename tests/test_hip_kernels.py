@@ -668,5 +668,6 @@ def test_clamp_adam_matches_torch(hip, map_size):
         gd = grad.to(dev())
         recs = np.zeros(1, hip.ADAM_ITEM)
         recs[0]["param"], recs[0]["grad"], recs[0]["exp_avg"], recs[0]["exp_avg_sq"], recs[0]["n"] = ptr(pd), ptr(gd), ptr(m), ptr(v), p.numel()
-        run(hip, "pnmn_clamp_adam", recs, 1e-3, 0.9, 0.999, 1e-8, 0.01, 5.0, step)
+        recs[0]["bc1"], recs[0]["bc2_sqrt"] = 1.0 - 0.9 ** step, (1.0 - 0.999 ** step) ** 0.5  # (per item: ABI 9)
+        run(hip, "pnmn_clamp_adam", recs, 1e-3, 0.9, 0.999, 1e-8, 0.01, 5.0)
     torch.testing.assert_close(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
