@@ -80,7 +80,16 @@ def wgrad_gemm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     gradient has few output tiles (1024 x 256 -> 32 workgroups on 256 CUs) and a very long reduction;
     splitting K into chunks run as one batched GEMM fills the chip, the partial sums add up after."""
     K = a.size(0)
-    chunks = min(16, K // 2048)
+    if a.size(1) <= 128:
+        # few output rows (an output projection's V = 44-100): more, shorter chunks -- the largest count up to 64 that divides
+        # K and leaves >= 256 rows per chunk (no remainder GEMM: at 128 questions a call costs ~20 us of host time)
+        chunks = max((c for c in range(1, 65) if K % c == 0 and K // c >= 256), default=1)
+        if chunks < 4:
+            chunks = min(64, K // 512)
+    else:
+        chunks = min(16, K // 2048)
+        if chunks > 1 and K % chunks:  # (a count near it that divides K: no remainder GEMM + addition)
+            chunks = max((c for c in range(chunks - 3, 17) if c > 1 and K % c == 0 and K // c >= 1024), default=chunks)
     if chunks <= 1 or not (a.is_contiguous() and b.is_contiguous()):
         return a.t() @ b
     kc = K // chunks
@@ -1071,7 +1080,9 @@ class Seq2SeqBase(nn.Module):
                 etable = F.linear(self._target_embedder.weight, w_e, bias)
                 hs, raw = _AttnLSTMDecoder.apply(None, etable, enc, fmask, h, w_c, self._decoder_cell.weight_hh, w_p,
                                                  b_p, 2 if greedy else 1, steps, seed, self.sample_row_offset, *args)
-            logits_all = self._output_projection_layer(hs)  # one GEMM for all steps
+            # one GEMM for all steps; its weight gradient [V, B*T] x [B*T, H] -- 44-100 output rows over a 13 000-47 000 long
+            # reduction -- through the K-split of wgrad_gemm (as a plain mm: 80-144 us at 3-17 TFLOP/s, scripts/r05_gemm_sites.py)
+            logits_all = linear_rows(hs, w_p, b_p)
             if tgt is not None:
                 output_dict = {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], pad, 1e-13)}
                 if need_predictions or not self.training:
@@ -1148,7 +1159,8 @@ class Seq2SeqBase(nn.Module):
         """Second half: the output projection over all steps and the per-row loss -- the cross entropy of the targets
         (reference :235-254) or, free running, the length-normalised negative log-probability of the trimmed samples
         (reference :222-233)."""
-        logits_all = self._output_projection_layer(hs)
+        proj = self._output_projection_layer
+        logits_all = linear_rows(hs, proj.weight, proj.bias)  # (weight gradient through wgrad_gemm's K-split, see decode)
         tgt = prep["tgt"]
         if tgt is not None:
             return {"loss": sequence_nll(logits_all, tgt[:, 1:], tgt[:, 1:], self._pad_index, 1e-13)}
