@@ -76,10 +76,19 @@ struct MFwdArgs {
 };
 
 constexpr size_t FWD_FIXED_LDS = sizeof(float) * (4 * ROWS * GLD + RW * 4 * H + ROWS * MAXV + RW * MAXS) + sizeof(int) * ROWS;
+constexpr size_t FWD_OVERLAP_LDS = sizeof(float) * (ROWS * H + 64);  // (OVERLAP) the staged h_{t-1} tile + a sink for predicated stores
 
-// ALLPARTS: 16 KB more LDS behind `logl` (the launch adds them when S leaves room: S <= 59), so that the gates
-// phase can hold all four parts of its A operands at once.
-template <bool ALLPARTS>
+// OVERLAP (the launch picks it when S leaves 16.6 KB of LDS free: S <= 59): the step's matrix work is two products,
+// W_hh h_{t-1} and W_c ctx_t, and only the second needs the attention's result.  So h_{t-1} is staged into LDS at the TOP
+// of the step and the 64 MFMAs of its product are issued in four groups of 16 inside the attention phase -- beside the
+// scores' LDS reads and DPP reductions, the softmax and the context sums, which are latency, not issue slots -- and the
+// gates phase behind the context hand-off stages and contracts the context alone: half the matrix time of a step leaves
+// its critical path (cycle stamps before: gate MFMAs 42 % of a step, attention 23 %).  Each partial sum keeps its order
+// (k-blocks ascending, x y z w), so the result is bit-identical to the other path's.  Without OVERLAP (S > 59): both
+// products behind the hand-off, their A operands double buffered in the 16 KB that `cpart` and `logl` leave idle there.
+// SAMPLE: the free-running modes (the kernel picks each step's token); a teacher-forced pass compiles without the token
+// phase -- its logits tile, Philox draw and the pointers they keep live are what the register allocator spills.
+template <bool OVERLAP, bool SAMPLE>
 __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, const int tile, const int part) {
     extern __shared__ __attribute__((aligned(16))) char raw[];
     const int T = a.T, S = a.S;
@@ -88,7 +97,9 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
     float (*scl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&gl[4][0][0]);              // [RW][64]
     int* tokl = reinterpret_cast<int*>(&scl[RW][0]);                                   // [16]
     float (*cpart)[4][H] = reinterpret_cast<float (*)[4][H]>(tokl + ROWS);             // [RW][4][H]
-    float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]  (+ 16 KB: ALLPARTS)
+    float (*logl)[MAXV] = reinterpret_cast<float (*)[MAXV]>(&cpart[RW][0][0]);         // [16][128]
+    float* hst = &logl[ROWS][0];                                                       // (OVERLAP) [4 parts][16 rows][64]
+    float* sink = hst + ROWS * H;                                                      // (OVERLAP) [64]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
@@ -122,20 +133,110 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
     // fetches row r's next one a step ahead
     const int64_t* tf_row = (a.in_tokens && tid < ROWS) ? a.in_tokens + (size_t)min(row0 + tid, a.B - 1) * a.in_stride : nullptr;
     if (tf_row) tokl[tid] = (int)tf_row[0];
+
+    // A-operand tiles (16 rows x 256 columns of h_{t-1} or ctx_t) in LDS: four parts of 64 columns, slot s (16 bytes) of
+    // row r at slot s ^ r -- the 16 lanes of an MFMA operand read hit 16 bank groups.  A thread stages two pieces of a
+    // row, 128 columns apart.
+    constexpr int PARTF = ROWS * 64;  // floats of a part
+    const int s_row = tid >> 5, s_q = tid & 31;
+    const int s_rowc = min(row0 + s_row, a.B - 1);
+    const int s_off = (s_q >> 4) * PARTF + s_row * 64 + 4 * ((s_q & 15) ^ s_row);
+    // the four k-blocks of part p of a staged tile as this lane's MFMA fragments
+    auto frags = [&](const float* tile_lds, const int p, f32x4 (&f)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const f32x4*>(tile_lds + p * PARTF + li * 64 + 4 * ((4 * j + g) ^ li));
+    };
+    // 16 MFMAs: part p of a 256-long product into two partial sums (even / odd k-block), k-blocks ascending, x y z w
+    auto mfma16 = [&](const f32x4 (&f)[4], const f32x4 (&w)[H / 16], const int p, f32x4& even, f32x4& odd) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const int kb = p * 4 + j;
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j].x, w[kb].x, even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j + 1].x, w[kb + 1].x, odd, 0, 0, 0);
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j].y, w[kb].y, even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j + 1].y, w[kb + 1].y, odd, 0, 0, 0);
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j].z, w[kb].z, even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j + 1].z, w[kb + 1].z, odd, 0, 0, 0);
+            even = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j].w, w[kb].w, even, 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(f[j + 1].w, w[kb + 1].w, odd, 0, 0, 0);
+        }
+    };
+
+    // (OVERLAP) the tile's recurrent vector into LDS: h_0 here, h_t right behind the hand-off that completes it
+    auto stage_h = [&](const float* rows, const size_t row_stride) {
+        const float* hsrc = rows + (size_t)s_rowc * row_stride + 4 * s_q;
+        const f32x4 h_lo = *reinterpret_cast<const f32x4*>(hsrc), h_hi = *reinterpret_cast<const f32x4*>(hsrc + 128);
+        *reinterpret_cast<f32x4*>(hst + s_off) = h_lo;
+        *reinterpret_cast<f32x4*>(hst + s_off + 2 * PARTF) = h_hi;
+    };
+    if constexpr (OVERLAP) stage_h(a.h0, H);
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
+        // An opaque zero, added to the row indices below: the per-lane 64-bit addresses of a dozen tensors are then formed
+        // where they are used (a few VALU each) instead of being hoisted out of the step loop, where they cost 2 VGPRs
+        // each for the whole sequence -- beside the 128 weight registers that is what the allocator spilled.
+        int zt = 0;
+        asm volatile("" : "+v"(zt));
+        f32x4 acc;                                             // the step's input projection rows of this wave's gate tile
+        f32x4 ph0 = f32x4{0.f, 0.f, 0.f, 0.f}, ph1 = ph0;      // W_hh h_{t-1}, even / odd k-blocks
+        auto load_inputs = [&] {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = 4 * g + r, row = row0 + rl + zt;
+                const int n = gate * H + u0 + 16 * ub + li;
+                float v = 0.f;
+                if (row < a.B) v = a.xe ? a.xe[((size_t)row * T + t) * G4 + n] : a.etable[(size_t)tokl[rl] * G4 + n];
+                acc[r] = v;
+            }
+        };
         // ---------------- attention for my rows: four waves per row split the source positions ----------------
         {
             const int rl = wave >> 2, q = wave & 3;
-            const int row = myrow0 + rl, rowc = min(row, a.B - 1);
-            const float* hp = t > 0 ? a.hs + ((size_t)rowc * T + (t - 1)) * H : a.h0 + (size_t)rowc * H;
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 4 * lane);
+            const int row = myrow0 + rl + zt, rowc = min(row, a.B - 1);
+            f32x4 hv;
+            if constexpr (OVERLAP) {
+                const int r = RW * part + rl;  // my row within the tile; columns 4 lane .. + 3
+                hv = *reinterpret_cast<const f32x4*>(hst + (lane >> 4) * PARTF + r * 64 + 4 * ((lane & 15) ^ r));
+            } else {
+                const float* hp = t > 0 ? a.hs + ((size_t)rowc * T + (t - 1)) * H : a.h0 + (size_t)rowc * H;
+                hv = *reinterpret_cast<const f32x4*>(hp + 4 * lane);
+            }
             const float* er = encl + (size_t)rl * S * H + 4 * lane;
-            {   // this wave's positions q, q+4, ...: all partial dot products first, then the six-step wave
+            constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
+            int k_first = 0;
+            if constexpr (OVERLAP) {
+                // the first eight positions of this wave as straight-line code (positions past S re-read the last one;
+                // their sums go to the sink), 16 MFMAs of W_hh h_{t-1} inside each batch of four
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 ev[NP], hf[4];
+                    float pk[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int s = q + 4 * (NP * b + k);
+                        ev[k] = *reinterpret_cast<const f32x4*>(er + (size_t)(s < S ? s : S - 1) * H);
+                    }
+                    frags(hst, b, hf);
+                    mfma16(hf, wh, b, ph0, ph1);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) pk[k] = dot4(ev[k], hv);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) pk[k] = wsum(pk[k]);
+                    // (branch-free: lane 0 stores a sum that exists into its place, every other lane into the sink --
+                    // a conditional store would cut the block the MFMAs are scheduled in)
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const int s = q + 4 * (NP * b + k);
+                        float* dst = (lane == 0 && s < S) ? &scl[rl][s] : sink + lane;
+                        *dst = pk[k];
+                    }
+                }
+                k_first = 2 * NP;
+            }
+            {   // this wave's (remaining) positions q + 4 k: all partial dot products first, then the six-step wave
                 // reductions of all of them interleaved (one at a time they are 6 dependent shuffles each)
-                constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
-                for (int k0 = 0; q + 4 * k0 < S; k0 += NP) {
+                for (int k0 = k_first; q + 4 * k0 < S; k0 += NP) {
                     float part[NP];
 #pragma unroll
                     for (int k = 0; k < NP; ++k) {
@@ -150,7 +251,7 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
                 }
             }
             __syncthreads();
-            if (q == 0) {
+            auto softmax = [&] {
                 const float m = row_mask;
                 const float v = (lane < S ? scl[rl][lane] : 0.f) * m;  // allennlp masked_softmax: softmax(vector * mask) ...
                 const float mx = wmax(lane < S ? v : -INFINITY);
@@ -162,68 +263,93 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
                     scl[rl][lane] = wgt;
                     if (row < a.B) a.probs[((size_t)row * T + t) * S + lane] = p;
                 }
+            };
+            if constexpr (OVERLAP) {
+                f32x4 hf[4];
+                frags(hst, 2, hf);
+                if (q == 0) {  // (the MFMAs in both branches: beside the softmax's chain of reductions where there is one)
+                    mfma16(hf, wh, 2, ph0, ph1);
+                    softmax();
+                } else {
+                    mfma16(hf, wh, 2, ph0, ph1);
+                }
+            } else {
+                if (q == 0) softmax();
             }
             __syncthreads();
             f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = q; s < S; s += 4) c4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * scl[rl][s];
+            int s_first = q;
+            if constexpr (OVERLAP) {
+                // the first four positions straight-line (weight 0 past S), the last 16 MFMAs among them
+                constexpr int NC = 4;
+                f32x4 ev[NC], hf[4];
+                float wv[NC];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int s = q + 4 * k, sc = s < S ? s : S - 1;
+                    ev[k] = *reinterpret_cast<const f32x4*>(er + (size_t)sc * H);
+                    const float w = scl[rl][sc];
+                    wv[k] = s < S ? w : 0.f;
+                }
+                frags(hst, 3, hf);
+                mfma16(hf, wh, 3, ph0, ph1);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) c4 += ev[k] * wv[k];
+                s_first = q + 4 * NC;
+            }
+            for (int s = s_first; s < S; s += 4) c4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * scl[rl][s];
             *reinterpret_cast<f32x4*>(&cpart[rl][q][4 * lane]) = c4;
             __syncthreads();
             const int rl2 = tid >> 8, k = tid & 255;
             const float cv = (cpart[rl2][0][k] + cpart[rl2][1][k]) + (cpart[rl2][2][k] + cpart[rl2][3][k]);
-            if (myrow0 + rl2 < a.B) a.ctx[((size_t)(myrow0 + rl2) * T + t) * H + k] = cv;
+            if (myrow0 + rl2 < a.B) a.ctx[((size_t)(myrow0 + rl2 + zt) * T + t) * H + k] = cv;
         }
         cl.signal();
         cl.wait();
 
         // ---------------- gates of my units on the matrix cores ----------------
-        f32x4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rl = 4 * g + r, row = row0 + rl;
-            const int n = gate * H + u0 + 16 * ub + li;
-            float v = 0.f;
-            if (row < a.B) v = a.xe ? a.xe[((size_t)row * T + t) * G4 + n] : a.etable[(size_t)tokl[rl] * G4 + n];
-            acc[r] = v;
-        }
         const int tf_next = tf_row ? (int)tf_row[min(t + 1, T - 1)] : 0;  // (stored into tokl behind the cell phase)
-        {
-            // A operands (the tile's 16 x 256 context and hidden vectors) go through LDS in four parts of 64
-            // columns: one coalesced 16-byte load per thread and part instead of 32 scattered loads per lane in
-            // four batches that each waited out a full L2 round trip in front of their MFMAs (5 400 of the phase's
-            // 13 600 cycles).  ALLPARTS: all four parts are requested at once and stored side by side -- one L2
-            // round trip and one barrier for the lot.  Otherwise (S > 59) they are double buffered in the 16 KB
-            // that the attention phase's partial contexts and the token phase's logits leave idle here, part
-            // p + 1 requested while part p's MFMAs run (32 MFMAs are shorter than that round trip; and holding
-            // all four in registers instead spills -- kernels with scratch memory were seen to cost the HOST
-            // milliseconds per step once a second stream runs beside them).  Slot s of row r sits at slot s ^ r:
-            // the 16 lanes of an MFMA operand read hit 16 bank groups.  This wave owns ONE output tile, so a
-            // single accumulator would make its 128 MFMAs one dependent chain (each waits out the previous one's
-            // full latency, ~3x the issue time): four partial sums -- context / hidden state, even / odd k-block
-            // -- keep four chains in flight.
-            constexpr int NB = 4, NPARTS = (H / 16) / NB, PART = 2 * ROWS * 64;
-            float* stage = &cpart[0][0][0];  // [2 buffers | 4 parts][2 tensors][16 rows][64]
-            const int s_tensor = tid >> 8, s_row = (tid >> 4) & 15, s_slot = tid & 15;
-            const int s_rowc = min(row0 + s_row, a.B - 1);
-            const float* s_src = (s_tensor == 0 ? a.ctx + ((size_t)s_rowc * T + t) * H
-                                                : (t > 0 ? a.hs + ((size_t)s_rowc * T + (t - 1)) * H : a.h0 + (size_t)s_rowc * H)) + 4 * s_slot;
-            float* s_dst = stage + (s_tensor * ROWS + s_row) * 64 + 4 * (s_slot ^ s_row);
-            f32x4 sv;
-            if constexpr (ALLPARTS) {
-                f32x4 all[NPARTS];
-#pragma unroll
-                for (int part = 0; part < NPARTS; ++part) all[part] = *reinterpret_cast<const f32x4*>(s_src + part * 64);
-#pragma unroll
-                for (int part = 0; part < NPARTS; ++part) *reinterpret_cast<f32x4*>(s_dst + part * PART) = all[part];
-            } else {
-                sv = *reinterpret_cast<const f32x4*>(s_src);
-                *reinterpret_cast<f32x4*>(s_dst) = sv;
-            }
+        if constexpr (OVERLAP) {
+            // the context tile through LDS (into the 16 KB of `cpart` + `logl`, idle here), then its 64 MFMAs
+            float* cst = &cpart[0][0][0];
+            const float* csrc = a.ctx + ((size_t)(s_rowc + zt) * T + t) * H + 4 * s_q;
+            const f32x4 c_lo = *reinterpret_cast<const f32x4*>(csrc), c_hi = *reinterpret_cast<const f32x4*>(csrc + 128);
+            load_inputs();  // (requested with the context: kept live across the attention they cost spills)
+            *reinterpret_cast<f32x4*>(cst + s_off) = c_lo;
+            *reinterpret_cast<f32x4*>(cst + s_off + 2 * PARTF) = c_hi;
             __syncthreads();
-            f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0, ph0 = pc0, ph1 = pc0;
+            f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0;
 #pragma unroll
-            for (int part = 0; part < NPARTS; ++part) {
-                if (!ALLPARTS && part + 1 < NPARTS) sv = *reinterpret_cast<const f32x4*>(s_src + (part + 1) * 64);
-                const float* buf = stage + (ALLPARTS ? part : (part & 1)) * PART;
+            for (int p = 0; p < 4; ++p) {
+                f32x4 cf[4];
+                frags(cst, p, cf);
+                mfma16(cf, wc, p, pc0, pc1);
+            }
+            acc += (pc0 + pc1) + (ph0 + ph1);
+        } else {
+            load_inputs();
+            // A operands (the tile's 16 x 256 context and hidden vectors) go through LDS in four parts of 64
+            // columns, double buffered in the 16 KB that the attention phase's partial contexts and the token phase's
+            // logits leave idle here: part p + 1 requested while part p's MFMAs run (holding all four in registers
+            // instead spills -- kernels with scratch memory were seen to cost the HOST milliseconds per step once a
+            // second stream runs beside them).  This wave owns ONE output tile, so a single accumulator would make its
+            // 128 MFMAs one dependent chain: four partial sums -- context / hidden state, even / odd k-block -- keep
+            // four chains in flight.
+            constexpr int NB = 4, NPARTS = (H / 16) / NB, PART = 2 * ROWS * 64;
+            float* stage = &cpart[0][0][0];  // [2 buffers][2 tensors][16 rows][64]
+            const int s_tensor = tid >> 8, o_row = (tid >> 4) & 15, o_slot = tid & 15;
+            const int o_rowc = min(row0 + o_row, a.B - 1);
+            const float* s_src = (s_tensor == 0 ? a.ctx + ((size_t)o_rowc * T + t) * H
+                                                : (t > 0 ? a.hs + ((size_t)o_rowc * T + (t - 1)) * H : a.h0 + (size_t)o_rowc * H)) + 4 * o_slot;
+            float* s_dst = stage + (s_tensor * ROWS + o_row) * 64 + 4 * (o_slot ^ o_row);
+            f32x4 sv = *reinterpret_cast<const f32x4*>(s_src);
+            *reinterpret_cast<f32x4*>(s_dst) = sv;
+            __syncthreads();
+            f32x4 pc0 = f32x4{0.f, 0.f, 0.f, 0.f}, pc1 = pc0;
+#pragma unroll
+            for (int p = 0; p < NPARTS; ++p) {
+                if (p + 1 < NPARTS) sv = *reinterpret_cast<const f32x4*>(s_src + (p + 1) * 64);
+                const float* buf = stage + (p & 1) * PART;
                 f32x4 ac[NB], ah[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -231,28 +357,10 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
                     ac[j] = *reinterpret_cast<const f32x4*>(buf + li * 64 + 4 * slot);
                     ah[j] = *reinterpret_cast<const f32x4*>(buf + (ROWS + li) * 64 + 4 * slot);
                 }
-#pragma unroll
-                for (int j = 0; j < NB; j += 2) {
-                    const int kb = part * NB + j;
-                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].x, wc[kb].x, pc0, 0, 0, 0);
-                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].x, wh[kb].x, ph0, 0, 0, 0);
-                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].x, wc[kb + 1].x, pc1, 0, 0, 0);
-                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].x, wh[kb + 1].x, ph1, 0, 0, 0);
-                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].y, wc[kb].y, pc0, 0, 0, 0);
-                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].y, wh[kb].y, ph0, 0, 0, 0);
-                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].y, wc[kb + 1].y, pc1, 0, 0, 0);
-                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].y, wh[kb + 1].y, ph1, 0, 0, 0);
-                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].z, wc[kb].z, pc0, 0, 0, 0);
-                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].z, wh[kb].z, ph0, 0, 0, 0);
-                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].z, wc[kb + 1].z, pc1, 0, 0, 0);
-                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].z, wh[kb + 1].z, ph1, 0, 0, 0);
-                    pc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j].w, wc[kb].w, pc0, 0, 0, 0);
-                    ph0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j].w, wh[kb].w, ph0, 0, 0, 0);
-                    pc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[j + 1].w, wc[kb + 1].w, pc1, 0, 0, 0);
-                    ph1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j + 1].w, wh[kb + 1].w, ph1, 0, 0, 0);
-                }
-                if (!ALLPARTS && part + 1 < NPARTS) {
-                    *reinterpret_cast<f32x4*>(s_dst + ((part + 1) & 1) * PART) = sv;
+                mfma16(ac, wc, p, pc0, pc1);
+                mfma16(ah, wh, p, ph0, ph1);
+                if (p + 1 < NPARTS) {
+                    *reinterpret_cast<f32x4*>(s_dst + ((p + 1) & 1) * PART) = sv;
                     __syncthreads();
                 }
             }
@@ -264,7 +372,7 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
         // ---------------- cell: thread -> (row, unit) ----------------
         {
             const int rl = tid >> 5, ul = tid & 31;
-            const int row = row0 + rl, u = u0 + ul;
+            const int row = row0 + rl + zt, u = u0 + ul;
             const float ig = sigm(gl[0][rl][ul]), fg = sigm(gl[1][rl][ul]);
             const float gg = tanhf(gl[2][rl][ul]), og = sigm(gl[3][rl][ul]);
             const float c = fg * creg + ig * gg;
@@ -282,12 +390,16 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
             }
         }
         if (tf_row) tokl[tid] = tf_next;       // (read again behind the hand-off's barriers)
-        if (t + 1 == T && !a.sample) break;  // nobody needs h_T
+        if (t + 1 == T && !SAMPLE) break;  // nobody needs h_T
         cl.signal();
         cl.wait();
+        if constexpr (OVERLAP) {  // h_t of the whole tile: the next step's attention and W_hh product, the logits below
+            stage_h(a.hs + ((size_t)zt * T + t) * H, (size_t)T * H);
+            __syncthreads();
+        }
 
         // ---------------- token choice for the next step (every member, all 16 rows) ----------------
-        if (a.sample) {
+        if constexpr (SAMPLE) {
             const int V = a.V;
             if (16 * wave < V) {
                 f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f}, lodd = lacc;
@@ -298,10 +410,11 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
 #pragma unroll
                 for (int part = 0; part < (H / 16) / NB; ++part) {
                     f32x4 ah[NB], bp[NB];
+                    if constexpr (OVERLAP) frags(hst, part, ah);
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const int kb = part * NB + j;
-                        ah[j] = *reinterpret_cast<const f32x4*>(hp + kb * 16);
+                        if constexpr (!OVERLAP) ah[j] = *reinterpret_cast<const f32x4*>(hp + kb * 16);
                         bp[j] = vok ? *reinterpret_cast<const f32x4*>(a.w_p + (size_t)vn * H + kb * 16 + 4 * g)
                                     : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -341,12 +454,12 @@ __device__ __forceinline__ void attn_lstm_fwd_multi_body(const MFwdArgs& a, cons
     cl.finish();
 }
 
-template <bool ALLPARTS>
+template <bool OVERLAP, bool SAMPLE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_multi_kernel(const MFwdArgs a) {
     int tile, part;
     pnmn::cluster_coords<MEMBERS>(tile, part);
     if (tile >= a.tiles) return;
-    attn_lstm_fwd_multi_body<ALLPARTS>(a, tile, part);
+    attn_lstm_fwd_multi_body<OVERLAP, SAMPLE>(a, tile, part);
 }
 
 // TWO independent decoder passes in one launch (the reconstructor's teacher-forced decode and the generator's
@@ -356,7 +469,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // their step counts on the iteration's critical chain; side by side the launch takes as long as the longer one.
 // (Two launches on two streams would do the same but put two kernels that wait for their own workgroups on the chip
 // next to a third -- DESIGN 6; one grid is resident as a whole or not at all.)
-template <bool ALLPARTS>
+template <bool OVERLAP, bool SAMPLE0, bool SAMPLE1>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_fwd_pair_kernel(const MFwdArgs a0,
                                                                                                            const MFwdArgs a1,
                                                                                                            const int tiles0) {
@@ -364,11 +477,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     pnmn::cluster_coords<MEMBERS>(tile, part);
     if (tile < tiles0) {
         if (tile >= a0.tiles) return;
-        attn_lstm_fwd_multi_body<ALLPARTS>(a0, tile, part);
+        attn_lstm_fwd_multi_body<OVERLAP, SAMPLE0>(a0, tile, part);
     } else {
         tile -= tiles0;
         if (tile >= a1.tiles) return;
-        attn_lstm_fwd_multi_body<ALLPARTS>(a1, tile, part);
+        attn_lstm_fwd_multi_body<OVERLAP, SAMPLE1>(a1, tile, part);
     }
 }
 
@@ -632,6 +745,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// the compiled variants of the forward kernels
+const void* fwd_multi_variant(bool overlap, bool sample) {
+    if (overlap) return sample ? reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<true, true>)
+                               : reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<true, false>);
+    return sample ? reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<false, true>)
+                  : reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<false, false>);
+}
+template <bool OVERLAP>
+const void* fwd_pair_variant_of(bool s0, bool s1) {
+    if (s0) return s1 ? reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<OVERLAP, true, true>)
+                      : reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<OVERLAP, true, false>);
+    return s1 ? reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<OVERLAP, false, true>)
+              : reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<OVERLAP, false, false>);
+}
+const void* fwd_pair_variant(bool overlap, bool s0, bool s1) {
+    return overlap ? fwd_pair_variant_of<true>(s0, s1) : fwd_pair_variant_of<false>(s0, s1);
+}
+
 // rows one launch can take: all tiles x 8 members resident, one workgroup per CU
 int rows_per_launch() {
     const int cus = pnmn::device_cus();
@@ -663,16 +794,14 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
     const int chunk = rows_per_launch();
     if (chunk <= 0) return PNMN_ESHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    constexpr size_t ALL_PARTS_LDS = sizeof(float) * 2 * 2 * ROWS * 64;  // parts 2 and 3 of the gates phase's operands
     constexpr size_t LDS_LIMIT = 160 * 1024;
-    const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * S * H + ALL_PARTS_LDS <= LDS_LIMIT;
-    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H + (all_parts ? ALL_PARTS_LDS : 0);
+    const bool overlap = FWD_FIXED_LDS + sizeof(float) * RW * S * H + FWD_OVERLAP_LDS <= LDS_LIMIT;
+    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * S * H + (overlap ? FWD_OVERLAP_LDS : 0);
     {   // (the opt-in is per device and per kernel: lds_optin.h; the limit itself, whatever this launch uses)
-        static std::atomic<uint64_t> cfg[2] = {{0}, {0}};
-        const int e = all_parts ? pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<true>), LDS_LIMIT, cfg[1])
-                                : pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<false>), LDS_LIMIT, cfg[0]);
-        if (e) return e;
+        static std::atomic<uint64_t> cfg[4] = {{0}, {0}, {0}, {0}};
+        if (const int e = pnmn::opt_in_lds(fwd_multi_variant(overlap, sample != 0), LDS_LIMIT, cfg[2 * overlap + (sample != 0)])) return e;
     }
+    const auto kernel = reinterpret_cast<void (*)(const MFwdArgs)>(const_cast<void*>(fwd_multi_variant(overlap, sample != 0)));
     for (int r0 = 0; r0 < B; r0 += chunk) {
         const int rows = B - r0 < chunk ? B - r0 : chunk;
         const int tiles = (rows + ROWS - 1) / ROWS;
@@ -685,8 +814,7 @@ int pnmn_attn_lstm_fwd_multi(const float* xe, const float* etable, const float* 
                    tokens ? tokens + r * T : nullptr, (!sample && !xe) ? in_tokens + r * in_token_stride : nullptr,
                    (long)in_token_stride, sync, rows, T, S, V, tiles, sample,
                    pad_index, unk_index, start_index, seed, row_offset + r};
-        hipLaunchKernelGGL(all_parts ? attn_lstm_fwd_multi_kernel<true> : attn_lstm_fwd_multi_kernel<false>,
-                           dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
+        hipLaunchKernelGGL(kernel, dim3(8 * MEMBERS * ((tiles + 7) / 8)), dim3(512), lds, st, a);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
@@ -774,17 +902,17 @@ int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* ja, const pnmn_dec
         if (hidden != H || j->S < 1 || j->S > MAXS || (j->sample && (j->V < 1 || j->V > MAXV))) return PNMN_ESHAPE;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    constexpr size_t ALL_PARTS_LDS = sizeof(float) * 2 * 2 * ROWS * 64;
     constexpr size_t LDS_LIMIT = 160 * 1024;
     const int smax = ja->S > jb->S ? ja->S : jb->S;
-    const bool all_parts = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + ALL_PARTS_LDS <= LDS_LIMIT;
-    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + (all_parts ? ALL_PARTS_LDS : 0);
+    const bool overlap = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + FWD_OVERLAP_LDS <= LDS_LIMIT;
+    const size_t lds = FWD_FIXED_LDS + sizeof(float) * RW * smax * H + (overlap ? FWD_OVERLAP_LDS : 0);
     {   // (the opt-in is per device and per kernel: lds_optin.h; the limit itself, whatever this launch uses)
-        static std::atomic<uint64_t> cfg[2] = {{0}, {0}};
-        const int e = all_parts ? pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<true>), LDS_LIMIT, cfg[1])
-                                : pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_fwd_pair_kernel<false>), LDS_LIMIT, cfg[0]);
-        if (e) return e;
+        static std::atomic<uint64_t> cfg[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+        const int v = 4 * overlap + 2 * (ja->sample != 0) + (jb->sample != 0);
+        if (const int e = pnmn::opt_in_lds(fwd_pair_variant(overlap, ja->sample != 0, jb->sample != 0), LDS_LIMIT, cfg[v])) return e;
     }
+    const auto kernel = reinterpret_cast<void (*)(const MFwdArgs, const MFwdArgs, const int)>(
+        const_cast<void*>(fwd_pair_variant(overlap, ja->sample != 0, jb->sample != 0)));
     int* sync = nullptr;
     hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
     if (e != hipSuccess) return (int)e;
@@ -797,8 +925,7 @@ int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* ja, const pnmn_dec
     };
     const MFwdArgs a0 = args(ja, sync), a1 = args(jb, sync + tiles0 * pnmn::CLUSTER_COUNTER_STRIDE);
     const int groups = (tiles0 + padded_tiles(jb->B)) / 8;
-    hipLaunchKernelGGL(all_parts ? attn_lstm_fwd_pair_kernel<true> : attn_lstm_fwd_pair_kernel<false>, dim3(8 * MEMBERS * groups),
-                       dim3(512), lds, st, a0, a1, tiles0);
+    hipLaunchKernelGGL(kernel, dim3(8 * MEMBERS * groups), dim3(512), lds, st, a0, a1, tiles0);
     return (int)hipGetLastError();
 }
 
