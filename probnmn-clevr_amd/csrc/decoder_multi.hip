@@ -508,7 +508,7 @@ struct MBwdArgs {
 };
 
 constexpr int DLD = 4 * UW + 4;
-constexpr size_t BWD_FIXED_LDS = sizeof(float) * (ROWS * DLD + 2 * RW * H + 2 * RW * MAXS + RW * 4 * H);
+constexpr size_t BWD_FIXED_LDS = sizeof(float) * (ROWS * DLD + 2 * RW * H + 2 * RW * MAXS + RW * 4 * H + 64);  // (+ a sink for predicated stores)
 
 __device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, const int tile, const int part) {
     extern __shared__ __attribute__((aligned(16))) char raw[];
@@ -516,9 +516,10 @@ __device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, cons
     float* encl = reinterpret_cast<float*>(raw);                                        // [RW][S][H]
     float (*dgl)[DLD] = reinterpret_cast<float (*)[DLD]>(encl + RW * S * H);             // [16][132]
     float (*dctxl)[H] = reinterpret_cast<float (*)[H]>(&dgl[ROWS][0]);                   // [RW][H]
-    float (*dhl)[H] = dctxl + RW;                                                        // [RW][H]
+    float (*dhl)[H] = dctxl + RW;                                                        // [RW][H] (unused since round 5)
     float (*dwl)[MAXS] = reinterpret_cast<float (*)[MAXS]>(&dhl[RW][0]);                 // [RW][64] d weights -> d scores
     float (*dhpart)[4][H] = reinterpret_cast<float (*)[4][H]>(&dwl[2 * RW][0]);          // [RW][4][H]
+    float* sink = &dhpart[RW][0][0];                                                     // [64]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int row0 = tile * ROWS, myrow0 = row0 + RW * part, u0 = UW * part;
@@ -575,19 +576,58 @@ __device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, cons
     };
     Saved sv = load_saved(T - 1);
 
+    // this wave's A fragments of the step's gate gradients (16 rows x my 128 gate columns, K block kl)
+    auto dg_frag = [&](const int kl) { return *reinterpret_cast<const f32x4*>(&dgl[li][kl * 16 + 4 * g]); };
+    // 16 MFMAs of one product (weights as the A operand: the product comes out transposed, each lane holding FOUR
+    // CONSECUTIVE UNITS of one row -- one 16-byte store per tile instead of four 4-byte ones): K blocks kl0, kl0 + 1 of both
+    // output tiles; every accumulator sees its K blocks ascending, x y z w
+    auto mfma16 = [&](const f32x4 (&w)[2][KB], const int kl0, f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int kl = kl0; kl < kl0 + 2; ++kl) {
+            const f32x4 av = dg_frag(kl);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][kl].x, av.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][kl].y, av.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][kl].z, av.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[nt][kl].w, av.w, acc[nt], 0, 0, 0);
+            }
+        }
+    };
+
+    // The two products of a step's gate gradients are not equally urgent: the partial dctx = dgates W_c is what the
+    // attention backward waits for (hand-off A), the partial dh = dgates W_hh only enters dh_{t-1}, which nobody reads
+    // before the NEXT step's cell backward.  So only the dctx product runs in front of hand-off A; the 64 MFMAs of the dh
+    // product are issued inside the attention backward (its scores, softmax backward and d h sums are latency, not issue
+    // slots -- as in the forward kernel), every member publishes its partial with hand-off B, and the next step's cell
+    // backward adds the eight partials (same order as the row owners added them before) to the row owner's attention part.
     for (int t = T - 1; t >= 0; --t) {
         const Saved cur = sv;
+        int zt = 0;  // (an opaque zero in the row indices: addresses formed where they are used, see the forward kernel)
+        asm volatile("" : "+v"(zt));
         // ---------------- cell backward of my units: thread -> (row, unit) ----------------
         {
             const int rl = c_rl, ul = c_ul;
-            const int row = c_row, u = c_u;
+            const int row = c_row + zt, u = c_u;
             float di = 0.f, df = 0.f, dg = 0.f, dout = 0.f, dcp = 0.f;
             if (row < a.B) {
                 const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og;
                 const float c = cur.c;
                 const float cp = cur.cp;
                 const float tc = tanhf(c);
-                const float dhp = t < T - 1 ? x2t[((size_t)((t + 1) & 1) * ROWS + rl) * H + u] : 0.f;
+                float dhp = 0.f;
+                if (t < T - 1) {
+                    // d h_t from step t + 1: the members' partial products, then the row owner's attention part
+                    const float* ph = x1t + (((size_t)((t + 1) & 1) * MEMBERS) * 2 + 1) * ROWS * H + (size_t)(rl + zt) * H + u;
+                    float pv[MEMBERS];
+#pragma unroll
+                    for (int m = 0; m < MEMBERS; ++m) pv[m] = ph[(size_t)(2 * m) * ROWS * H];
+                    const float att = x2t[((size_t)((t + 1) & 1) * ROWS + rl) * H + u];
+                    float sh = 0.f;
+#pragma unroll
+                    for (int m = 0; m < MEMBERS; ++m) sh += pv[m];
+                    dhp = sh + att;
+                }
                 const float dh = cur.dhs + dhp;
                 const float dc = dc_rec + dh * og * (1.f - tc * tc);
                 di = dc * gg * ig * (1.f - ig);
@@ -608,79 +648,81 @@ __device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, cons
             dgl[rl][3 * UW + ul] = dout;
         }
         __syncthreads();
-        // ---------------- partial dctx / dh from my gate columns ----------------
+        // ---------------- partial dctx from my gate columns ----------------
+        float* const pc = x1t + (((size_t)(t & 1) * MEMBERS + part) * 2 + 0) * ROWS * H;
+        float* const ph = pc + ROWS * H;
         {
-            f32x4 accc[2], acch[2];
+            f32x4 accc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) accc[nt] = acch[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kl = 0; kl < KB; kl += 2) mfma16(wc, kl, accc);
 #pragma unroll
-            for (int kl = 0; kl < KB; ++kl) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(&dgl[li][kl * 16 + 4 * g]);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    // (weights as the A operand: the product comes out transposed, each lane holding FOUR
-                    // CONSECUTIVE UNITS of one row -- one 16-byte store per tile below instead of four 4-byte ones)
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].x, av.x, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].y, av.y, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].z, av.z, accc[nt], 0, 0, 0);
-                    accc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][kl].w, av.w, accc[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].x, av.x, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].y, av.y, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].z, av.z, acch[nt], 0, 0, 0);
-                    acch[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[nt][kl].w, av.w, acch[nt], 0, 0, 0);
-                }
-            }
-            float* pc = x1t + (((size_t)(t & 1) * MEMBERS + part) * 2 + 0) * ROWS * H;
-            float* ph = pc + ROWS * H;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-            {
-                const size_t o = (size_t)li * H + 16 * (2 * wave + nt) + 4 * g;  // row li, units 16 (2 wave + nt) + 4 g ..
+            for (int nt = 0; nt < 2; ++nt) {
+                const size_t o = (size_t)(li + zt) * H + 16 * (2 * wave + nt) + 4 * g;  // row li, units 16 (2 wave + nt) + 4 g ..
                 *reinterpret_cast<f32x4*>(pc + o) = accc[nt];
-                *reinterpret_cast<f32x4*>(ph + o) = acch[nt];
             }
         }
         cl.signal();
         cl.wait();
 
-        // ---------------- my rows: gather the partials, attention backward ----------------
+        // ---------------- my rows: gather the dctx partials, attention backward (+ the dh product) ----------------
+        f32x4 acch[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         {
             const int rl2 = tid >> 8, k = tid & 255;
-            const float* src = x1t + (size_t)(t & 1) * MEMBERS * 2 * ROWS * H + (size_t)(RW * part + rl2) * H + k;
-            float sc = 0.f, sh = 0.f;
+            const float* src = x1t + (size_t)(t & 1) * MEMBERS * 2 * ROWS * H + (size_t)(RW * part + rl2 + zt) * H + k;
+            float pv[MEMBERS];
 #pragma unroll
-            for (int s = 0; s < MEMBERS; ++s) {
-                sc += src[(size_t)(2 * s) * ROWS * H];
-                sh += src[(size_t)(2 * s + 1) * ROWS * H];
-            }
+            for (int s = 0; s < MEMBERS; ++s) pv[s] = src[(size_t)(2 * s) * ROWS * H];
+            float sc = 0.f;
+#pragma unroll
+            for (int s = 0; s < MEMBERS; ++s) sc += pv[s];
             dctxl[rl2][k] = sc;
-            dhl[rl2][k] = sh;
-            if (myrow0 + rl2 < a.B) a.dctx[((size_t)(myrow0 + rl2) * T + t) * H + k] = sc;
+            if (myrow0 + rl2 < a.B) a.dctx[((size_t)(myrow0 + rl2 + zt) * T + t) * H + k] = sc;
         }
         __syncthreads();
         {
             const int rl = wave >> 2, q = wave & 3;
-            const int row = myrow0 + rl;
+            const int row = myrow0 + rl + zt;
             const float* er = encl + (size_t)rl * S * H + 4 * lane;
             const f32x4 dc4 = *reinterpret_cast<const f32x4*>(&dctxl[rl][4 * lane]);
-            {   // (all partial products first, then the wave reductions interleaved -- as in the forward)
-                constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
-                for (int k0 = 0; q + 4 * k0 < S; k0 += NP) {
-                    float part[NP];
+            constexpr int NP = 4;  // (more in flight would spill beside the weight registers)
+            // the first eight positions of this wave as straight-line code (positions past S re-read the last one; their
+            // sums go to the sink), 16 MFMAs of the dh product inside each batch of four
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        const int s = q + 4 * (k0 + k);
-                        part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4) : 0.f;
-                    }
+            for (int b = 0; b < 2; ++b) {
+                f32x4 ev[NP];
+                float pk[NP];
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) part[k] = wsum(part[k]);  // (DPP chains: independent, the scheduler interleaves them)
+                for (int k = 0; k < NP; ++k) {
+                    const int s = q + 4 * (NP * b + k);
+                    ev[k] = *reinterpret_cast<const f32x4*>(er + (size_t)(s < S ? s : S - 1) * H);
+                }
+                mfma16(wh, 2 * b, acch);
 #pragma unroll
-                    for (int k = 0; k < NP; ++k)
-                        if (lane == 0 && q + 4 * (k0 + k) < S) dwl[rl][q + 4 * (k0 + k)] = part[k];
+                for (int k = 0; k < NP; ++k) pk[k] = dot4(ev[k], dc4);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) pk[k] = wsum(pk[k]);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {  // (branch-free: lane 0 stores a sum that exists, every other lane into the sink)
+                    const int s = q + 4 * (NP * b + k);
+                    float* dst = (lane == 0 && s < S) ? &dwl[rl][s] : sink + lane;
+                    *dst = pk[k];
                 }
             }
+            for (int k0 = 2 * NP; q + 4 * k0 < S; k0 += NP) {  // (the remaining positions, S > 32)
+                float part[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int s = q + 4 * (k0 + k);
+                    part[k] = s < S ? dot4(*reinterpret_cast<const f32x4*>(er + (size_t)s * H), dc4) : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) part[k] = wsum(part[k]);  // (DPP chains: independent, the scheduler interleaves them)
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (lane == 0 && q + 4 * (k0 + k) < S) dwl[rl][q + 4 * (k0 + k)] = part[k];
+            }
             __syncthreads();
-            if (q == 0) {
+            auto softmax_bwd = [&] {
                 // forward quantities of this (row, step): p (softmax before masking), mask, q, Z
                 const float m = row_mask;
                 const float p = lane < S ? cur.p : 0.f;
@@ -699,25 +741,62 @@ __device__ __forceinline__ void attn_lstm_bwd_multi_body(const MBwdArgs& a, cons
                         a.weights[((size_t)row * T + t) * S + lane] = qv / Z;
                     }
                 }
+            };
+            if (q == 0) {  // (the MFMAs in both branches: beside the chain of reductions where there is one)
+                mfma16(wh, 4, acch);
+                softmax_bwd();
+            } else {
+                mfma16(wh, 4, acch);
             }
             __syncthreads();
             f32x4 dh4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s = q; s < S; s += 4) dh4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * dwl[rl][s];
+            {
+                // the first four positions straight-line (weight 0 past S), the last 16 MFMAs among them
+                constexpr int NC = 4;
+                f32x4 ev[NC];
+                float wv[NC];
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int s = q + 4 * k, sc = s < S ? s : S - 1;
+                    ev[k] = *reinterpret_cast<const f32x4*>(er + (size_t)sc * H);
+                    const float w = dwl[rl][sc];
+                    wv[k] = s < S ? w : 0.f;
+                }
+                mfma16(wh, 6, acch);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) dh4 += ev[k] * wv[k];
+            }
+            for (int s = q + 16; s < S; s += 4) dh4 += *reinterpret_cast<const f32x4*>(er + (size_t)s * H) * dwl[rl][s];
             *reinterpret_cast<f32x4*>(&dhpart[rl][q][4 * lane]) = dh4;
+        }
+        // this member's partial dh: published by hand-off B (the final step's: by the one after the loop)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const size_t o = (size_t)(li + zt) * H + 16 * (2 * wave + nt) + 4 * g;
+            *reinterpret_cast<f32x4*>(ph + o) = acch[nt];
         }
         __syncthreads();
         {
+            // the attention's part of d h_{t-1} for my rows
             const int rl2 = tid >> 8, k = tid & 255;
-            const float v = dhl[rl2][k] + ((dhpart[rl2][0][k] + dhpart[rl2][1][k]) + (dhpart[rl2][2][k] + dhpart[rl2][3][k]));
-            if (t > 0)
-                x2t[((size_t)(t & 1) * ROWS + RW * part + rl2) * H + k] = v;
-            else if (myrow0 + rl2 < a.B)
-                a.dh0[(size_t)(myrow0 + rl2) * H + k] = v;
+            const float v = (dhpart[rl2][0][k] + dhpart[rl2][1][k]) + (dhpart[rl2][2][k] + dhpart[rl2][3][k]);
+            x2t[((size_t)(t & 1) * ROWS + RW * part + rl2 + zt) * H + k] = v;
         }
-        if (t == 0) break;
-        sv = load_saved(t - 1);
+        if (t > 0) sv = load_saved(t - 1);
         cl.signal();
         cl.wait();
+    }
+    {   // d h_0 of my rows: the members' partials of the last step (t = 0), then the attention part (as the cell backward adds them)
+        const int rl2 = tid >> 8, k = tid & 255;
+        const float* ph0 = x1t + (size_t)1 * ROWS * H + (size_t)(RW * part + rl2) * H + k;  // buffer 0 (t = 0), tensor 1
+        float pv[MEMBERS];
+#pragma unroll
+        for (int m = 0; m < MEMBERS; ++m) pv[m] = ph0[(size_t)(2 * m) * ROWS * H];
+        const float att = x2t[((size_t)0 * ROWS + RW * part + rl2) * H + k];
+        float sh = 0.f;
+#pragma unroll
+        for (int m = 0; m < MEMBERS; ++m) sh += pv[m];
+        if (myrow0 + rl2 < a.B) a.dh0[(size_t)(myrow0 + rl2) * H + k] = sh + att;
     }
     cl.finish();
 }
