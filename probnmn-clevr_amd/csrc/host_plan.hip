@@ -353,11 +353,17 @@ extern "C" int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int6
             const std::vector<int> idx = order_by(lv, in->sort_by_weight ? &fw : nullptr, 4);
             out.put(R_PROJ, fw, &idx);
             out.cut(CUT_PROJ, permuted(lv, idx));
-            // two data gradients per projection (one per operand); the halves never share a launch
+            // two data gradients per projection (one per operand), both in ONE launch per level: they add into the
+            // gradients of two different values (a program is a tree), and a launch of 2-7 items is all latency (15-20 us
+            // each, 14 of them per 1024-question step).  Only a comparison of a value with ITSELF -- both halves adding
+            // into one map without atomics -- keeps the halves of the whole batch in launches of their own.
+            bool same_operand = false;
+            for (size_t i = 0; i < pda.rows(); ++i) same_operand = same_operand || pda.row(i)[6] == pdb.row(i)[6];
+            const int64_t odd = same_operand ? 1 : 0;
             KEEP(Mat, pd, 12);
             KEEP(std::vector<int64_t>, lv2);
             for (size_t i = 0; i < pda.rows(); ++i) memcpy(pd.add(), pda.row(i), 12 * sizeof(uint64_t)), lv2.push_back(lv[i] * 2);
-            for (size_t i = 0; i < pdb.rows(); ++i) memcpy(pd.add(), pdb.row(i), 12 * sizeof(uint64_t)), lv2.push_back(lv[i] * 2 + 1);
+            for (size_t i = 0; i < pdb.rows(); ++i) memcpy(pd.add(), pdb.row(i), 12 * sizeof(uint64_t)), lv2.push_back(lv[i] * 2 + odd);
             const std::vector<int> pidx = order_by(lv2, in->sort_by_weight ? &pd : nullptr, 4);
             out.put(R_PDGRAD, pd, &pidx);
             out.cut(CUT_PDGRAD, permuted(lv2, pidx));

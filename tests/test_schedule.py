@@ -98,6 +98,10 @@ def test_synthetic_batch_plan_and_counts():
     n3 = len(plan.records["conv"])
     assert len(plan.records["dgrad"]) == n3 == len(plan.records["wg3"])
     assert len(plan.records["pdgrad"]) == 2 * len(plan.records["proj"])
+    # the two data gradients of a level's projections share ONE launch (they add into different values' gradients:
+    # _check_plan holds that no launch writes a buffer twice)
+    for phase in plan.backward:
+        assert sum(1 for l in phase if l.kind == "pdgrad") <= 1
     # 3x3 conv count per template: T1 6, T2 13, T3 18, T4 25, T5 12, T6 20, T7 6, T8 17
     assert 256 * 6 <= n3 <= 256 * 25
     depth = max(l.level for l in plan.forward)
