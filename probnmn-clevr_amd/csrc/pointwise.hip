@@ -52,9 +52,10 @@ __global__ __launch_bounds__(NT) void same_bwd_kernel(const pnmn_same_item* __re
 }
 
 // And / Or
-__global__ __launch_bounds__(NT) void minmax_fwd_kernel(const pnmn_minmax_item* __restrict__ items, int HW, int Cn) {
+constexpr int MM_NT = 448;  // (seven waves: a 128-channel map of 14x14 / 28x28 is a whole number of rounds, pointwise_body.h)
+__global__ __launch_bounds__(MM_NT) void minmax_fwd_kernel(const pnmn_minmax_item* __restrict__ items, int HW, int Cn) {
     const pnmn_minmax_item it = items[blockIdx.x];
-    pnmn::pointwise::minmax_fwd<NT>(it, HW);
+    pnmn::pointwise::minmax_fwd<MM_NT>(it, HW);
 }
 
 __global__ __launch_bounds__(NT) void minmax_bwd_kernel(const pnmn_minmax_item* __restrict__ items, int HW, int Cn) {
@@ -245,8 +246,21 @@ __global__ __launch_bounds__(256) void layout_kernel(const float* __restrict__ s
     const int cw = (Cn - c0) < 64 ? (Cn - c0) : 64;
     if (TO_NHWC) {
         const float* s0 = src + ((size_t)n * Cn + c0) * HW + p0;
-        copy_batched(cw * np, [&](int i) { const int c = i / np; return s0[(size_t)c * HW + (i - c * np)]; },
-                     [&](int i, float v) { const int c = i / np; tile[c * ld + (i - c * np)] = v; });
+        if (((HW | p0 | np) & 3) == 0) {
+            // 16-byte loads on the pixel-contiguous side too (a channel's row is HW * 4 bytes: 16-byte aligned when HW is a
+            // multiple of 4): with 4-byte loads the three workgroups a CU holds (50 KB of LDS each) keep 24 KB in flight,
+            // a third of what the memory system needs per CU to stream at its rate
+            const int q = np >> 2;
+            copy_batched4(cw * q, [&](int i) { const int c = i / q; return *reinterpret_cast<const float4*>(s0 + (size_t)c * HW + 4 * (i - c * q)); },
+                          [&](int i, float4 v) {
+                              const int c = i / q;
+                              float* t = tile + c * ld + 4 * (i - c * q);
+                              t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+                          });
+        } else {
+            copy_batched(cw * np, [&](int i) { const int c = i / np; return s0[(size_t)c * HW + (i - c * np)]; },
+                         [&](int i, float v) { const int c = i / np; tile[c * ld + (i - c * np)] = v; });
+        }
         __syncthreads();
         if (cw == 64 && (Cn & 3) == 0) {
 #pragma unroll 8
@@ -580,7 +594,7 @@ int pnmn_same_bwd(const pnmn_same_item* items, int n_items, int HW, void* stream
 int pnmn_minmax_fwd(const pnmn_minmax_item* items, int n_items, int HW, int Cn, void* stream) {
     if (n_items <= 0) return 0;
     if (!items || HW <= 0 || Cn != C) return PNMN_EINVAL;
-    hipLaunchKernelGGL(minmax_fwd_kernel, dim3(n_items), dim3(256), 0, STREAM(stream), items, HW, Cn);
+    hipLaunchKernelGGL(minmax_fwd_kernel, dim3(n_items), dim3(MM_NT), 0, STREAM(stream), items, HW, Cn);
     return last_error();
 }
 

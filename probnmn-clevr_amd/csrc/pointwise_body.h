@@ -214,7 +214,8 @@ __device__ __forceinline__ void minmax_fwd(const pnmn_minmax_item& it, int HW) {
     if (oc == C) {
         // a 128-channel result: 16 bytes per thread, eight of them requested before the first is used (the first version
         // -- one float and one integer division per element -- ran at half the HBM rate)
-        constexpr int NB = 7;  // (196 pixels x 32 pieces = 24.5 per thread of 256: 3.5 rounds of 7)
+        constexpr int NB = 7;  // (NT = 448: 196 pixels x 32 pieces = 6 272 = 448 x 7 x 2 -- two full rounds per workgroup, and
+                               // 28x28: eight; with 256 threads it was 3.5 rounds, the last one half empty)
         const int n4 = HW * (C / 4);
         const gfloat* ga = as_global(it.a);
         const gfloat* gb = as_global(it.b);
