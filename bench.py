@@ -960,10 +960,6 @@ def main():
         try:
             b = device_batch(vocab, n, 3000 + rank, dev)
             step = make()
-            if os.environ.get("PNMN_BENCH_GC") == "freeze":  # (A/B aid: does the collector's work on the earlier sides' objects show?)
-                import gc
-                gc.collect()
-                gc.freeze()
             if name == "module_training":
                 b["program"] = b["program"].cpu()
             e, h, bl = timed(lambda: step.step(b), k, 6, dev, world, step)
