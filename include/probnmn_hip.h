@@ -517,6 +517,14 @@ int pnmn_attn_lstm_fwd_multi_pair(const pnmn_decoder_fwd_job* a, const pnmn_deco
                                   void* stream);
 int pnmn_attn_lstm_bwd_multi_pair(const pnmn_decoder_bwd_job* a, const pnmn_decoder_bwd_job* b, int hidden, void* workspace,
                                   void* stream);
+/* ... of THREE passes: in the backward pass of a training iteration the ProgramGenerator's two decodes and the
+ * QuestionReconstructor's are independent (question_coding_trainer.py:128-160, joint_training_trainer.py:150-190: the sampled
+ * programs are discrete, no gradient flows from the reconstruction back into the generator) -- side by side the launch takes as
+ * long as the longest.  Falls back to pair + single when the three do not fit the chip together (identical results).
+ * Workspace: pnmn_attn_lstm_group3_workspace_bytes(Ba, Bb, Bc, backward). */
+int64_t pnmn_attn_lstm_group3_workspace_bytes(int Ba, int Bb, int Bc, int backward);
+int pnmn_attn_lstm_bwd_multi_group3(const pnmn_decoder_bwd_job* a, const pnmn_decoder_bwd_job* b, const pnmn_decoder_bwd_job* c,
+                                    int hidden, void* workspace, void* stream);
 /* The encoder-output gradient from what pnmn_attn_lstm_bwd_multi emits, in one bandwidth-bound launch instead of two
  * strided-batched library GEMMs of B tiny [S x T].[T x 256] products (allennlp SimpleSeq2Seq._prepare_attended_input /
  * DotProductAttention under autograd; seq2seq_base.py:201):

@@ -824,6 +824,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ... of THREE (round 5): the generator's two decodes and the reconstructor's.  In the backward pass of a training iteration
+// the three are independent (the samples are discrete: nothing flows from the reconstructor into the generator), and on one
+// stream they would add their step counts on the iteration's critical chain -- at 128 questions per GPU the seq2seq backward
+// is that chain (scripts/step_timeline.py).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_lstm_bwd_group3_kernel(const MBwdArgs a0,
+                                                                                                             const MBwdArgs a1,
+                                                                                                             const MBwdArgs a2,
+                                                                                                             const int tiles0,
+                                                                                                             const int tiles01) {
+    int tile, part;
+    pnmn::cluster_coords<MEMBERS>(tile, part);
+    if (tile < tiles0) {
+        if (tile >= a0.tiles) return;
+        attn_lstm_bwd_multi_body(a0, tile, part);
+    } else if (tile < tiles01) {
+        tile -= tiles0;
+        if (tile >= a1.tiles) return;
+        attn_lstm_bwd_multi_body(a1, tile, part);
+    } else {
+        tile -= tiles01;
+        if (tile >= a2.tiles) return;
+        attn_lstm_bwd_multi_body(a2, tile, part);
+    }
+}
+
 // the compiled variants of the forward kernels
 const void* fwd_multi_variant(bool overlap, bool sample) {
     if (overlap) return sample ? reinterpret_cast<const void*>(attn_lstm_fwd_multi_kernel<true, true>)
@@ -1048,6 +1073,66 @@ int pnmn_attn_lstm_bwd_multi_pair(const pnmn_decoder_bwd_job* ja, const pnmn_dec
     };
     const MBwdArgs a0 = args(ja, 0), a1 = args(jb, tiles0);
     hipLaunchKernelGGL(attn_lstm_bwd_pair_kernel, dim3(8 * MEMBERS * (total / 8)), dim3(512), lds, st, a0, a1, tiles0);
+    return (int)hipGetLastError();
+}
+
+// ---- three backward passes side by side ----------------------------------------------------------------------
+static bool group3_fits(int Ba, int Bb, int Bc) {
+    const int chunk = rows_per_launch();
+    const int tiles = padded_tiles(Ba) + padded_tiles(Bb) + padded_tiles(Bc);
+    return chunk > 0 && Ba > 0 && Bb > 0 && Bc > 0 && tiles * ROWS <= chunk && tiles <= 128;
+}
+
+int64_t pnmn_attn_lstm_group3_workspace_bytes(int Ba, int Bb, int Bc, int backward) {
+    if (!group3_fits(Ba, Bb, Bc)) {
+        const int64_t ab = pnmn_attn_lstm_pair_workspace_bytes(Ba, Bb, backward), c = pnmn_attn_lstm_multi_workspace_bytes(Bc, backward);
+        return ab > c ? ab : c;
+    }
+    int64_t n = (int64_t)pnmn::CLUSTER_SYNC_BYTES;
+    if (backward) n += (int64_t)(padded_tiles(Ba) + padded_tiles(Bb) + padded_tiles(Bc)) * (2 * MEMBERS * 2 + 2) * ROWS * H * sizeof(float);
+    return n;
+}
+
+int pnmn_attn_lstm_bwd_multi_group3(const pnmn_decoder_bwd_job* ja, const pnmn_decoder_bwd_job* jb, const pnmn_decoder_bwd_job* jc,
+                                    int hidden, void* workspace, void* stream) {
+    if (!ja || !jb || !jc || !workspace) return PNMN_EINVAL;
+    if (!group3_fits(ja->B, jb->B, jc->B) || ja->T <= 0 || jb->T <= 0 || jc->T <= 0) {  // (pair + single: same results)
+        const int rc = pnmn_attn_lstm_bwd_multi_pair(ja, jb, hidden, workspace, stream);
+        return rc != 0 ? rc
+                       : pnmn_attn_lstm_bwd_multi(jc->dhs, jc->act, jc->cs, jc->hs, jc->probs, jc->enc, jc->mask, jc->h0, jc->w_c_t,
+                                                  jc->w_hh_t, jc->dgates, jc->dctx, jc->dscore, jc->weights, jc->dh0, jc->B, jc->T, jc->S,
+                                                  hidden, workspace, stream);
+    }
+    const pnmn_decoder_bwd_job* jobs[3] = {ja, jb, jc};
+    int smax = 0;
+    for (const pnmn_decoder_bwd_job* j : jobs) {
+        if (!j->dhs || !j->act || !j->cs || !j->hs || !j->probs || !j->enc || !j->mask || !j->h0 || !j->w_c_t || !j->w_hh_t ||
+            !j->dgates || !j->dctx || !j->dscore || !j->weights || !j->dh0)
+            return PNMN_EINVAL;
+        if (hidden != H || j->S < 1 || j->S > MAXS) return PNMN_ESHAPE;
+        smax = j->S > smax ? j->S : smax;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = BWD_FIXED_LDS + sizeof(float) * RW * smax * H;
+    {
+        static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
+        if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(attn_lstm_bwd_group3_kernel), 160 * 1024, cfg)) return e;
+    }
+    int* sync = nullptr;
+    hipError_t e = pnmn::cluster_sync_block(workspace, st, &sync);
+    if (e != hipSuccess) return (int)e;
+    const int tiles0 = padded_tiles(ja->B), tiles01 = tiles0 + padded_tiles(jb->B), total = tiles01 + padded_tiles(jc->B);
+    char* ws = static_cast<char*>(workspace);
+    float* x1 = reinterpret_cast<float*>(ws + pnmn::CLUSTER_SYNC_BYTES);
+    float* x2 = x1 + (size_t)total * 2 * MEMBERS * 2 * ROWS * H;
+    auto args = [&](const pnmn_decoder_bwd_job* j, int first_tile) {
+        return MBwdArgs{j->dhs, j->act, j->cs, j->hs, j->probs, j->enc, j->mask, j->h0, j->w_c_t, j->w_hh_t, j->dgates, j->dctx,
+                        j->dscore, j->weights, j->dh0, x1 + (size_t)first_tile * 2 * MEMBERS * 2 * ROWS * H,
+                        x2 + (size_t)first_tile * 2 * ROWS * H, sync + first_tile * pnmn::CLUSTER_COUNTER_STRIDE, j->B, j->T, j->S,
+                        (j->B + ROWS - 1) / ROWS};
+    };
+    const MBwdArgs a0 = args(ja, 0), a1 = args(jb, tiles0), a2 = args(jc, tiles01);
+    hipLaunchKernelGGL(attn_lstm_bwd_group3_kernel, dim3(8 * MEMBERS * (total / 8)), dim3(512), lds, st, a0, a1, a2, tiles0, tiles01);
     return (int)hipGetLastError();
 }
 

@@ -88,6 +88,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_attn_lstm_pair_workspace_bytes": (_I, _I, _I),
     "pnmn_attn_lstm_fwd_multi_pair": (_P, _P, _I, _P, _P),
     "pnmn_attn_lstm_bwd_multi_pair": (_P, _P, _I, _P, _P),
+    "pnmn_attn_lstm_group3_workspace_bytes": (_I, _I, _I, _I),
+    "pnmn_attn_lstm_bwd_multi_group3": (_P, _P, _P, _I, _P, _P),
     "pnmn_attn_denc": (_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P),
     "pnmn_conv_nhwc_launches": (_I, _I, _I, _I, _I, _I),
     "pnmn_conv_force_split": (_I,),
@@ -109,7 +111,7 @@ SIGNATURES: Dict[str, tuple] = {
 }
 
 
-ABI_VERSION = 9  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 10  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:

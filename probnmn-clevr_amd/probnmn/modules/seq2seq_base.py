@@ -667,62 +667,141 @@ class _AttnLSTMDecoderPair(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhs_a, _ta, dhs_b, _tb):
-        saved = ctx.saved_tensors
-        dev = saved[0].device
-        jobs = np.zeros(2, _hip.DECODER_BWD_JOB)
-        sides = []
-        for k, dhs in enumerate((dhs_a, dhs_b)):
-            hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, step_tokens = saved[11 * k: 11 * k + 11]
-            vocab, packs_t, mode, start = ctx.side_meta[k]
-            B, T, Hd = hs.shape
-            S = enc.size(1)
-            dhs_c = torch.zeros_like(hs) if dhs is None else dhs.contiguous()
-            w_c_t, w_hh_t = packs_t if packs_t is not None else (pack_fragments(w_c.t()), pack_fragments(w_hh.t()))
-            dgates, dh0 = torch.empty_like(act), torch.empty_like(h0)
-            dctx, dscore, weights = torch.empty_like(hs), torch.empty_like(probs), torch.empty_like(probs)
-            j = jobs[k]
-            for name, t in (("dhs", dhs_c), ("act", act), ("cs", cs), ("hs", hs), ("probs", probs), ("enc", enc), ("mask", mask),
-                            ("h0", h0), ("w_c_t", w_c_t), ("w_hh_t", w_hh_t), ("dgates", dgates), ("dctx", dctx),
-                            ("dscore", dscore), ("weights", weights), ("dh0", dh0)):
-                j[name] = t.data_ptr()
-            j["B"], j["T"], j["S"] = B, T, S
-            sides.append(dict(hs=hs, cx=cx, enc=enc, h0=h0, step_tokens=step_tokens, vocab=vocab, mode=mode, start=start,
-                              dgates=dgates, dh0=dh0, dctx=dctx, dscore=dscore, weights=weights, keep=(dhs_c, w_c_t, w_hh_t),
-                              B=B, T=T, S=S, Hd=Hd))
-        ws = torch.empty(int(_hip.lib().pnmn_attn_lstm_pair_workspace_bytes(sides[0]["B"], sides[1]["B"], 1)), dtype=torch.uint8, device=dev)
-        _hip.check(_hip.lib().pnmn_attn_lstm_bwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, sides[0]["Hd"], ws.data_ptr(),
-                                                            _hip.stream_ptr(dev)), "attn_lstm_bwd_multi_pair")
-        grads = []
-        for k, sd in enumerate(sides):
-            B, T, S, Hd = sd["B"], sd["T"], sd["S"], sd["Hd"]
-            need = ctx.needs_input_grad[6 * k: 6 * k + 6]
-            denc = None
-            if need[1]:
-                if T <= 64:
-                    denc = torch.empty_like(sd["enc"])
-                    _hip.check(_hip.lib().pnmn_attn_denc(sd["weights"].data_ptr(), sd["dscore"].data_ptr(), sd["dctx"].data_ptr(),
-                                                         sd["hs"].data_ptr(), sd["h0"].data_ptr(), denc.data_ptr(), B, T, S, Hd,
-                                                         _hip.stream_ptr(dev)), "attn_denc")
-                else:
-                    hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
-                    denc = torch.baddbmm(torch.bmm(sd["weights"].transpose(1, 2), sd["dctx"]), sd["dscore"].transpose(1, 2), hprev)
-            flat = sd["dgates"].reshape(B * T, 4 * Hd)
-            dw_c = wgrad_gemm(flat, sd["cx"].reshape(B * T, Hd)) if need[4] else None
-            dw_hh = None
-            if need[5]:
+        return (*_decoder_sides_backward(ctx.saved_tensors, ctx.side_meta, (dhs_a, dhs_b), ctx.needs_input_grad), None)
+
+
+def _decoder_sides_backward(saved, side_meta, dhs_list, needs_input_grad):
+    """Backward of 1-3 decoder passes whose forward saved (hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, step tokens) each:
+    ONE launch for all of them (``pnmn_attn_lstm_bwd_multi`` / ``_pair`` / ``_group3``), then per pass the encoder-output
+    gradient, the two weight-gradient GEMMs and the table gradient.  Returns six gradients per pass, in the order of the
+    forward's tensor inputs (etable, enc, mask, h0, w_c, w_hh)."""
+    dev = saved[0].device
+    n = len(dhs_list)
+    jobs = np.zeros(n, _hip.DECODER_BWD_JOB)
+    sides = []
+    for k, dhs in enumerate(dhs_list):
+        hs, cs, act, cx, probs, enc, mask, h0, w_c, w_hh, step_tokens = saved[11 * k: 11 * k + 11]
+        vocab, packs_t, mode, start = side_meta[k]
+        B, T, Hd = hs.shape
+        S = enc.size(1)
+        dhs_c = torch.zeros_like(hs) if dhs is None else dhs.contiguous()
+        w_c_t, w_hh_t = packs_t if packs_t is not None else (pack_fragments(w_c.t()), pack_fragments(w_hh.t()))
+        dgates, dh0 = torch.empty_like(act), torch.empty_like(h0)
+        dctx, dscore, weights = torch.empty_like(hs), torch.empty_like(probs), torch.empty_like(probs)
+        j = jobs[k]
+        for name, t in (("dhs", dhs_c), ("act", act), ("cs", cs), ("hs", hs), ("probs", probs), ("enc", enc), ("mask", mask),
+                        ("h0", h0), ("w_c_t", w_c_t), ("w_hh_t", w_hh_t), ("dgates", dgates), ("dctx", dctx),
+                        ("dscore", dscore), ("weights", weights), ("dh0", dh0)):
+            j[name] = t.data_ptr()
+        j["B"], j["T"], j["S"] = B, T, S
+        sides.append(dict(hs=hs, cx=cx, enc=enc, h0=h0, step_tokens=step_tokens, vocab=vocab, mode=mode, start=start,
+                          dgates=dgates, dh0=dh0, dctx=dctx, dscore=dscore, weights=weights, keep=(dhs_c, w_c_t, w_hh_t),
+                          B=B, T=T, S=S, Hd=Hd))
+    lib, Hd = _hip.lib(), sides[0]["Hd"]
+    rows = [sd["B"] for sd in sides]
+    if n == 1:
+        ws = torch.empty(int(lib.pnmn_attn_lstm_multi_workspace_bytes(rows[0], 1)), dtype=torch.uint8, device=dev)
+        j = jobs[0]
+        _hip.check(lib.pnmn_attn_lstm_bwd_multi(*(int(j[f]) for f in ("dhs", "act", "cs", "hs", "probs", "enc", "mask", "h0", "w_c_t",
+                                                                      "w_hh_t", "dgates", "dctx", "dscore", "weights", "dh0")),
+                                                rows[0], sides[0]["T"], sides[0]["S"], Hd, ws.data_ptr(), _hip.stream_ptr(dev)),
+                   "attn_lstm_bwd_multi")
+    elif n == 2:
+        ws = torch.empty(int(lib.pnmn_attn_lstm_pair_workspace_bytes(rows[0], rows[1], 1)), dtype=torch.uint8, device=dev)
+        _hip.check(lib.pnmn_attn_lstm_bwd_multi_pair(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, Hd, ws.data_ptr(),
+                                                     _hip.stream_ptr(dev)), "attn_lstm_bwd_multi_pair")
+    else:
+        ws = torch.empty(int(lib.pnmn_attn_lstm_group3_workspace_bytes(rows[0], rows[1], rows[2], 1)), dtype=torch.uint8, device=dev)
+        _hip.check(lib.pnmn_attn_lstm_bwd_multi_group3(jobs[0:1].ctypes.data, jobs[1:2].ctypes.data, jobs[2:3].ctypes.data, Hd,
+                                                       ws.data_ptr(), _hip.stream_ptr(dev)), "attn_lstm_bwd_multi_group3")
+    grads = []
+    for k, sd in enumerate(sides):
+        B, T, S, Hd = sd["B"], sd["T"], sd["S"], sd["Hd"]
+        need = needs_input_grad[6 * k: 6 * k + 6]
+        denc = None
+        if need[1]:
+            if T <= 64:
+                denc = torch.empty_like(sd["enc"])
+                _hip.check(_hip.lib().pnmn_attn_denc(sd["weights"].data_ptr(), sd["dscore"].data_ptr(), sd["dctx"].data_ptr(),
+                                                     sd["hs"].data_ptr(), sd["h0"].data_ptr(), denc.data_ptr(), B, T, S, Hd,
+                                                     _hip.stream_ptr(dev)), "attn_denc")
+            else:
                 hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
-                dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
-            detable = None
-            if need[0]:
-                if sd["mode"] == 0:
-                    detable = _table_grad(sd["dgates"], sd["step_tokens"], sd["vocab"])
-                elif sd["vocab"] <= 128:  # step t's input is the token chosen at step t - 1 (@start@ first)
-                    detable = embedding_grad(sd["dgates"], sd["step_tokens"], sd["vocab"], shift=True, start=sd["start"])
-                else:
-                    tok_in = torch.cat((sd["step_tokens"].new_full((B, 1), sd["start"]), sd["step_tokens"][:, :-1]), 1).reshape(-1)
-                    detable = torch.zeros(sd["vocab"], 4 * Hd, dtype=flat.dtype, device=dev).index_add_(0, tok_in, flat)
-            grads += [detable, denc, None, sd["dh0"], dw_c, dw_hh]
-        return (*grads, None)
+                denc = torch.baddbmm(torch.bmm(sd["weights"].transpose(1, 2), sd["dctx"]), sd["dscore"].transpose(1, 2), hprev)
+        flat = sd["dgates"].reshape(B * T, 4 * Hd)
+        dw_c = wgrad_gemm(flat, sd["cx"].reshape(B * T, Hd)) if need[4] else None
+        dw_hh = None
+        if need[5]:
+            hprev = torch.cat((sd["h0"].unsqueeze(1), sd["hs"][:, :-1]), 1)
+            dw_hh = wgrad_gemm(flat, hprev.reshape(B * T, Hd))
+        detable = None
+        if need[0]:
+            if sd["mode"] == 0:
+                detable = _table_grad(sd["dgates"], sd["step_tokens"], sd["vocab"])
+            elif sd["vocab"] <= 128:  # step t's input is the token chosen at step t - 1 (@start@ first)
+                detable = embedding_grad(sd["dgates"], sd["step_tokens"], sd["vocab"], shift=True, start=sd["start"])
+            else:
+                tok_in = torch.cat((sd["step_tokens"].new_full((B, 1), sd["start"]), sd["step_tokens"][:, :-1]), 1).reshape(-1)
+                detable = torch.zeros(sd["vocab"], 4 * Hd, dtype=flat.dtype, device=dev).index_add_(0, tok_in, flat)
+        grads += [detable, denc, None, sd["dh0"], dw_c, dw_hh]
+    return grads
+
+
+class _Capture:
+    """Stands in for an autograd context where a Function's ``forward`` is run for its launches only (the graph node that
+    owns what it saved is created later: ``_AttnLSTMDecoderGroup``)."""
+
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+class _AttnLSTMDecoderGroup(torch.autograd.Function):
+    """ONE graph node for up to three decoder passes whose forward launches happened at different times, so that their
+    BACKWARD is one launch (``pnmn_attn_lstm_bwd_multi_group3``).  In a training iteration the generator's two decodes
+    run first (their samples are the reconstructor's input), the reconstructor's decode later -- but backward the three are
+    independent, and on one stream they add their step counts on the iteration's critical chain (at 128 questions per GPU
+    the seq2seq backward IS that chain: 275 + 470 us of decoder kernels become 470).  Inputs: per pass etable, enc, mask,
+    h0, W_c, W_hh (as ``_AttnLSTMDecoderPair``), then ``meta`` (one dict per pass; ``meta[k]["pre"]`` = index of the pass in
+    ``pre``, the ``_Capture`` of an earlier ``decode_pair_launch``, or None: launched here) and ``pre``."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        meta, pre = args[-2], args[-1]
+        tens = args[:-2]
+        saved, side_meta, outs = [], [], []
+        for k, m in enumerate(meta):
+            etable, enc, mask, h0, w_c, w_hh = tens[6 * k: 6 * k + 6]
+            if m.get("pre") is not None:
+                j = m["pre"]
+                saved += list(pre.saved[11 * j: 11 * j + 11])
+                side_meta.append(pre.side_meta[j])
+                outs += [pre.outs[2 * j], pre.outs[2 * j + 1]]
+                continue
+            cap = _Capture()
+            if m["mode"] == 0:
+                hs, tok = _AttnLSTMDecoder.forward(cap, None, etable, enc, mask, h0, w_c, w_hh, None, None, 0, m["T"], 0, 0, 0, 0,
+                                                   m["start"], m["packs"], m["in_tokens"])
+                step_tokens = cap.in_tokens
+            else:
+                hs, tok = _AttnLSTMDecoder.forward(cap, None, etable, enc, mask, h0, w_c, w_hh, m["w_p"], m["b_p"], m["mode"], m["T"],
+                                                   m["seed"], m["row_offset"], m["pad"], m["unk"], m["start"], m["packs"])
+                step_tokens = cap.saved[10]
+            saved += list(cap.saved[:10]) + [step_tokens]
+            side_meta.append((cap.vocab, cap.packs_t, cap.mode, cap.start))
+            outs += [hs, tok]
+        ctx.save_for_backward(*saved)
+        ctx.side_meta = side_meta
+        ctx.mark_non_differentiable(*outs[1::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (*_decoder_sides_backward(ctx.saved_tensors, ctx.side_meta, grads[0::2], ctx.needs_input_grad), None, None)
 
 
 def choose_tokens(logits: torch.Tensor, greedy: bool, seed: int, row_offset: int, step: int,
@@ -1243,3 +1322,29 @@ def decode_pair(prep_a, prep_b):
         prep_b["etable"], prep_b["enc"], prep_b["fmask"], prep_b["h"], prep_b["w_c"], prep_b["w_hh"],
         (prep_a["meta"], prep_b["meta"]))
     return prep_a["model"].decode_finish(prep_a, hs_a, tok_a), prep_b["model"].decode_finish(prep_b, hs_b, tok_b)
+
+
+def decode_pair_launch(prep_a, prep_b):
+    """The forward launch of two prepared decodes NOW, without a graph node: returns what ``decode_group`` needs to create
+    the node later (``.outs`` = (hidden states a, tokens a, hidden states b, tokens b))."""
+    cap = _Capture()
+    with torch.no_grad():
+        cap.outs = _AttnLSTMDecoderPair.forward(
+            cap, prep_a["etable"], prep_a["enc"], prep_a["fmask"], prep_a["h"], prep_a["w_c"], prep_a["w_hh"],
+            prep_b["etable"], prep_b["enc"], prep_b["fmask"], prep_b["h"], prep_b["w_c"], prep_b["w_hh"],
+            (prep_a["meta"], prep_b["meta"]))
+    return cap
+
+
+def decode_group(preps, pre, pre_index):
+    """One graph node for the prepared decodes ``preps`` (``_AttnLSTMDecoderGroup``): ``pre_index[k]`` = position of pass k in
+    the earlier ``decode_pair_launch`` ``pre``, or None (launched now); then each model's second half.  Returns the
+    passes' output dicts."""
+    flat, metas = [], []
+    for p, j in zip(preps, pre_index):
+        flat += [p["etable"], p["enc"], p["fmask"], p["h"], p["w_c"], p["w_hh"]]
+        m = dict(p["meta"])
+        m["pre"] = j
+        metas.append(m)
+    outs = _AttnLSTMDecoderGroup.apply(*flat, metas, pre)
+    return [p["model"].decode_finish(p, outs[2 * k], outs[2 * k + 1]) for k, p in enumerate(preps)]

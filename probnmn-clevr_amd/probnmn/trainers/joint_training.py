@@ -103,6 +103,10 @@ def _image_rows(images, rows_host, rows_dev):
 
 
 class _TrainerBase(StepBase):
+    # the backward passes of the generator's two decodes and the reconstructor's in ONE launch (False: pair + single -- A/B
+    # aid and the reference point of tests/test_joint_gpu.py)
+    group_decoder_backward = True
+
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
         params = []
@@ -200,6 +204,7 @@ class _TrainerBase(StepBase):
         if after_encode is not None:
             out["after_encode"] = after_encode()
         paired = False
+        group = None  # (the generator's prepared decodes and their launch: their graph node is created with the reconstructor's)
         if n_nosup:
             prep_s = None
             if n_sup and dev.type == "cuda":
@@ -207,18 +212,27 @@ class _TrainerBase(StepBase):
                 # pass and are independent: one launch each way for both -- the persistent decoder kernels are latency
                 # bound, so the supervised pass rides along for free while the sampling pass, which the step's critical
                 # chain waits for, takes as long as it did alone (Seq2SeqBase.decode_prepare / decode_pair)
-                from probnmn.modules.seq2seq_base import decode_pair
+                from probnmn.modules.seq2seq_base import decode_pair, decode_pair_launch
 
                 prep_s = self.pg.decode_prepare(state_nosup, None, "sampling")
                 prep_t = self.pg.decode_prepare(state_sup, prog_sup) if prep_s is not None else None
-                if prep_t is not None:
+                if prep_t is not None and self.group_decoder_backward:
+                    # ... and BACKWARD the reconstructor's decode joins them (nothing flows from the reconstruction into the
+                    # generator: the samples are discrete): the pair is launched now, without a graph node; the node that
+                    # owns all three passes is created where the reconstructor decodes (decode_group below)
+                    pre = decode_pair_launch(prep_s, prep_t)
+                    group = (prep_s, prep_t, pre)
+                    z = self.pg._trim_predictions(pre.outs[1])
+                    paired = True
+                elif prep_t is not None:
                     out["pg"], o_sup = decode_pair(prep_s, prep_t)
                     out["pg_sup_rows"] = o_sup["loss"]
                     paired = True
             if not paired:
                 drawn = prep_s["meta"]["seed"] if prep_s is not None else None  # (a prepared pass has drawn its seed)
                 out["pg"] = self.pg.decode(state_nosup, None, "sampling", seed=drawn)
-            z = out["pg"]["predictions"]
+            if group is None:
+                z = out["pg"]["predictions"]
             out["programs"] = z
             if host_programs:
                 out["programs_host"] = self._host_copy(z)
@@ -227,7 +241,19 @@ class _TrainerBase(StepBase):
         # per-row losses; "qr_rows" = the sampled rows' reconstruction losses followed by the supervised rows'
         if n_sup and not paired:
             out["pg_sup_rows"] = self.pg.decode(state_sup, prog_sup, "sampling", need_predictions=False)["loss"]
-        if n_sup and n_nosup:
+        if group is not None:
+            from probnmn.modules.seq2seq_base import decode_group
+
+            prep_s, prep_t, pre = group
+            source = _cat_padded(z, prog_sup)
+            prep_q = self.qr.decode_prepare(self.qr.encode(source), ques_both)
+            if prep_q is not None:
+                out["pg"], o_sup, o_qr = decode_group([prep_s, prep_t, prep_q], pre, [0, 1, None])
+            else:  # (shapes outside the fused decoder: the reconstructor goes its own way)
+                out["pg"], o_sup = decode_group([prep_s, prep_t], pre, [0, 1])
+                o_qr = self.qr.decode(self.qr.encode(source), ques_both, "sampling", False)
+            out["pg_sup_rows"], out["qr_rows"] = o_sup["loss"], o_qr["loss"]
+        elif n_sup and n_nosup:
             out["qr_rows"] = self.qr(_cat_padded(z, prog_sup), ques_both, "sampling", False)["loss"]
         elif n_sup:
             out["qr_rows"] = self.qr(prog_sup, ques_sup, "sampling", False)["loss"]

@@ -50,7 +50,6 @@ wrap(qr, "forward", "qr")
 wrap(prior, "forward", "prior")
 wrap(nmn, "begin", "nmn.begin(stem)")
 wrap(nmn, "forward", "nmn.forward (plan + trunk + head)")
-wrap(nmn.engine, "run_forward", "trunk fwd")
 wrap(nmn.engine, "run_forward_tokens", "trunk fwd")
 wrap(nmn, "forward_trunk", "nmn.forward_trunk")
 wrap(nmn, "forward_head", "nmn.forward_head")

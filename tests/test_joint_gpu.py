@@ -246,3 +246,48 @@ def test_joint_training_step_at_config5_shapes_with_the_full_classifier():
                 assert float((got - g_ref).norm()) <= 5e-2 * float(g_ref.norm()) + 1e-9, (key, name)
             else:
                 assert float((got - g_ref).abs().max()) / (float(g_ref.abs().max()) + 1e-12) < 5e-3, (key, name)
+
+
+def test_grouped_decoder_backward_is_the_pair_and_single_backward():
+    """The backward passes of the generator's two decodes and the reconstructor's in ONE launch (round 5,
+    ``_AttnLSTMDecoderGroup`` / ``pnmn_attn_lstm_bwd_multi_group3``) against pair + single launches: same kernels' bodies,
+    same operands -- the decoders' own gradients are bit-identical and everything else agrees to the order of the embedding gradient's
+    atomic adds, for a question-coding iteration (no NMN: nothing
+    atomic in the step) at two batch sizes, one of them with a shard the three passes do not fit the chip for together."""
+    from probnmn.data.synthetic import synthetic_batch
+    from probnmn.models import ProgramGenerator, ProgramPrior, QuestionReconstructor
+    from probnmn.trainers.joint_training import QuestionCodingStep
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    for n in (40, 600):
+        grads, losses = {}, {}
+        for grouped in (True, False):
+            torch.manual_seed(11)
+            pg, qr, prior = ProgramGenerator(vocab).to(dev), QuestionReconstructor(vocab).to(dev), ProgramPrior(vocab, hidden_size=256).to(dev)
+            batch = synthetic_batch(vocab, n, seed=5, with_image=False)
+            dbatch = {k: v.to(dev) for k, v in batch.items()}
+            dbatch["supervision"] = batch["supervision"]
+            step = QuestionCodingStep(pg, qr, prior, objective="ours", lr=0.0)  # (lr 0: the gradients stay to be read)
+            step.group_decoder_backward = grouped
+            torch.manual_seed(12)
+            out = step.step(dbatch)
+            torch.cuda.synchronize()
+            losses[grouped] = float(out["objective"])
+            grads[grouped] = {"%s.%s" % (k, name): p.grad.detach().clone() for k, m in (("pg", pg), ("qr", qr))
+                              for name, p in m.named_parameters() if p.grad is not None}
+        assert losses[True] == losses[False]
+        assert set(grads[True]) == set(grads[False]) and len(grads[True]) > 20
+        exact = 0
+        for name in grads[True]:
+            # (what passes through pnmn_embedding_grad -- per-token sums by global atomics -- differs in the last digits from
+            # run to run; the decoders' own weights come straight out of the grouped launch and the GEMMs behind it)
+            if "_decoder_cell.weight_hh" in name or "_output_projection_layer" in name:
+                assert torch.equal(grads[True][name], grads[False][name]), (n, name)
+                exact += 1
+            else:
+                scale = float(grads[False][name].abs().max())
+                torch.testing.assert_close(grads[True][name], grads[False][name], rtol=0.0, atol=2e-6 * scale + 1e-12,
+                                           msg=lambda m: "%s %s: %s" % (n, name, m))
+        assert exact >= 6
