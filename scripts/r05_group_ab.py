@@ -1,4 +1,6 @@
-"""A/B of the 128-question joint step: generator-encoder lane on / off, decoder backward grouped / not, same process, alternating."""
+"""A/B of the 128-question joint step: the three decoders' backward passes in one launch / as pair + single, same process,
+alternating.  (profiles/ab/round5_b128_group_lane_ab.txt also holds the cells of a generator-encoder stream that was tried
+with this script and not kept.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "probnmn-clevr_amd")]
@@ -29,7 +31,6 @@ def run(n=60):
 
 
 for rep in range(3):
-    for lane, grouped in ((0, False), (0, True), (128, True), (128, False)):
-        step.pg_encoder_stream_max_rows = lane
+    for grouped in (False, True):
         step.group_decoder_backward = grouped
-        print("rep %d  lane %3d  grouped %-5s  %.3f ms" % (rep, lane, grouped, run()), flush=True)
+        print("rep %d  grouped %-5s  %.3f ms" % (rep, grouped, run()), flush=True)
