@@ -420,6 +420,249 @@ int launch_wgrad_band(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 1x1 weight gradient over ONE 128-channel input block (the classifier conv, nmn.py:67-78: 128 -> 1024 channels): no taps,
+// no halo -- a plain GEMM  dW[cout][cin] += sum over the job's pixels k of dy[k][cout] (gate[k][cout] > 0) x[k][cin] xmask[k]
+// with a 100 000-long reduction (512 items x 196 pixels).  conv_wgrad_kernel<.., 1> staged an item's whole x map and 64
+// output channels of dy, then contracted them with 4 MFMAs per two LDS reads: 65 TFLOP/s.  Here a workgroup (4 waves, one
+// per SIMD) owns 256 output x 128 input channels of a job -- 32 accumulators of 16x16 per wave (64 output x 128 input
+// channels), resident across the job -- and streams BOTH operands in stages of 28 pixels (196 = 7 stages, 784 = 28) through
+// two LDS buffers: the next stage's 11 pieces of 16 bytes per thread are requested before the current stage is contracted
+// (7 k-steps x 32 MFMAs per wave against 12 four-byte operand reads each) and stored behind it.  Rows are padded by 16
+// floats: the four pixel groups of an operand read then fall on two disjoint halves of the banks.
+// ------------------------------------------------------------------------------------------------
+constexpr int G1_CO = 256;            // output channels of a workgroup
+constexpr int G1_PX = 28;             // pixels of a stage
+constexpr int G1_DLD = G1_CO + 16;    // floats per staged dy row
+constexpr int G1_XLD = CB + 16;       // ... per staged x row
+constexpr int G1_STAGE = G1_PX * (G1_DLD + G1_XLD);  // floats per buffer
+constexpr size_t G1_LDS = (size_t)G1_STAGE * sizeof(float);  // ONE buffer: two workgroups share a CU and fill each other's gaps
+
+// Work split: the (job, item, stage) sequence of an output block is ONE reduction -- every job of a classifier launch adds
+// into the same weight -- so it is cut into equal stage ranges, one per workgroup (a quarter of the grid per output block):
+// no round quantisation (65 jobs x 4 blocks on 256 CUs would run 260 units in two rounds) and one atomic flush per
+// workgroup; a range that crosses into a job with another weight flushes there.
+constexpr int G1_MAX_JOBS = 512;      // job records live in LDS (24 B each) ...
+constexpr int G1_MAX_ITEMS = 256;     // ... and the item records of a workgroup's range (48 B each; longer ranges go in pieces)
+constexpr size_t G1_JOBS_OFF = G1_LDS, G1_JOFF_OFF = G1_JOBS_OFF + (size_t)G1_MAX_JOBS * sizeof(pnmn_wgrad_job);
+constexpr size_t G1_ITEMS_OFF = G1_JOFF_OFF + (size_t)G1_MAX_JOBS * sizeof(int);
+constexpr size_t G1_LDS_ALL = G1_ITEMS_OFF + (size_t)G1_MAX_ITEMS * sizeof(pnmn_wgrad_item);
+static_assert(2 * G1_LDS_ALL <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_1x1_gemm_kernel(const pnmn_wgrad_item* __restrict__ items,
+                                                                  const pnmn_wgrad_job* __restrict__ jobs, int x_stride,
+                                                                  int dy_stride, int HW, int n_jobs, int n_cob) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* const lds = reinterpret_cast<float*>(smem_raw);
+    // The job records and the item records of this workgroup's range live in LDS: a stage's loads must not begin with a
+    // chase job -> item -> operands through global memory (two dependent round trips in front of every stage's MFMAs, and
+    // the in-order memory counter then also holds the operand loads back: the first version ran 54 TFLOP/s that way).
+    pnmn_wgrad_job* const jl = reinterpret_cast<pnmn_wgrad_job*>(smem_raw + G1_JOBS_OFF);
+    int* const joff = reinterpret_cast<int*>(smem_raw + G1_JOFF_OFF);   // slot of a job's first item of the range in `il`
+    pnmn_wgrad_item* const il = reinterpret_cast<pnmn_wgrad_item*>(smem_raw + G1_ITEMS_OFF);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    constexpr int ND = G1_PX * G1_CO / 4 / 256;                 // 7 pieces of dy per thread and stage
+    constexpr int NX = (G1_PX * CB / 4 + 255) / 256;            // 4 (the last one for the first 128 threads)
+    const int spi = HW / G1_PX;                                 // stages per item
+    const int cob = blockIdx.x % n_cob, w = blockIdx.x / n_cob, wpc = gridDim.x / n_cob;
+    for (int j = tid; j < n_jobs; j += 256) jl[j] = jobs[j];
+    __syncthreads();
+    if (w >= wpc) return;
+    // this workgroup's stage range [t0, t1) of the block's reduction, and the (job, item, stage) it starts at
+    long total = 0;
+    for (int j = 0; j < n_jobs; ++j) total += (long)(jl[j].item_end - jl[j].item_begin) * spi;
+    const long r0 = total * w / wpc, r1 = total * (w + 1) / wpc;
+    struct Cursor {
+        int job, item, st;  // job, absolute item index, stage within the item
+    };
+    // (a range of more items than the LDS holds records of goes in pieces: one more flush per 511 items)
+    for (long t0 = r0; t0 < r1;) {
+    const long t1 = r1 - t0 > (long)(G1_MAX_ITEMS - 1) * spi ? t0 + (long)(G1_MAX_ITEMS - 1) * spi : r1;
+    __syncthreads();  // (the previous piece's records and stage buffers are no longer read)
+    Cursor cur{0, 0, 0};
+    {
+        long base = 0;
+        for (; cur.job < n_jobs; ++cur.job) {
+            const long n = (long)(jl[cur.job].item_end - jl[cur.job].item_begin) * spi;
+            if (t0 < base + n) break;
+            base += n;
+        }
+        const int local = (int)(t0 - base);
+        cur.item = jl[cur.job].item_begin + local / spi, cur.st = local % spi;
+    }
+    // the items of the range, job by job, into LDS (slot of item i of job j: joff[j] + i)
+    {
+        const long n_items_mine = (cur.st + (t1 - t0) + spi - 1) / spi;
+        long left = n_items_mine;
+        int slot = 0;
+        for (int j = cur.job; j < n_jobs && left > 0; ++j) {
+            const int lo = j == cur.job ? cur.item : jl[j].item_begin, hi = jl[j].item_end;
+            const int n = (int)((long)(hi - lo) < left ? hi - lo : left);
+            if (tid == 0) joff[j] = slot - lo;
+            for (int k = tid; k < n; k += 256) il[slot + k] = items[lo + k];
+            slot += n > 0 ? n : 0;
+            left -= n > 0 ? n : 0;
+        }
+        __syncthreads();
+    }
+    // the item behind item `c.item` of job `c.job`; false: none
+    auto item_after = [&](const Cursor& c, Cursor& n) {
+        n.job = c.job, n.item = c.item + 1, n.st = 0;
+        if (n.item < jl[n.job].item_end) return true;
+        for (++n.job; n.job < n_jobs; ++n.job)
+            if (jl[n.job].item_end > jl[n.job].item_begin) {
+                n.item = jl[n.job].item_begin;
+                return true;
+            }
+        return false;
+    };
+
+    f32x4 acc[4][8];
+    // bias gradient of output channels 4 (tid & 63) .. + 3 over the pixels this thread stages: `bias_staged` = of the stage in
+    // LDS (taken over when that stage is contracted: the stage behind a change of weight is staged before the flush)
+    f32x4 bias_acc = f32x4{0.f, 0.f, 0.f, 0.f}, bias_staged = bias_acc;
+    auto zero = [&] {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[ct][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bias_acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // acc[ct][nt][r] = dW[cout = 256 cob + 64 wave + 16 ct + 4 g + r][cin = 16 nt + li]
+    auto flush = [&](float* dw, float* dbias) {
+        float* const out = dw + (size_t)(cob * G1_CO + wave * 64 + 4 * g) * CB + li;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(out + (size_t)(ct * 16 + r) * CB + nt * 16, acc[ct][nt][r]);
+        if (dbias != nullptr) {
+            float* const b = dbias + cob * G1_CO + 4 * (tid & 63);
+            unsafeAtomicAdd(b + 0, bias_acc.x);
+            unsafeAtomicAdd(b + 1, bias_acc.y);
+            unsafeAtomicAdd(b + 2, bias_acc.z);
+            unsafeAtomicAdd(b + 3, bias_acc.w);
+        }
+    };
+    f32x4 dv[ND], xv[NX];
+    float mk[NX];
+    const pnmn::gfloat* gate_at = nullptr;  // the staged pieces' ReLU gate map (applied where they are stored), or null
+    auto fetch = [&](const pnmn_wgrad_item& it, int st) {
+        const int p0 = st * G1_PX;
+        const pnmn::gfloat* d = pnmn::as_global(it.dy) + (size_t)p0 * dy_stride + cob * G1_CO;
+        const pnmn::gfloat* x = pnmn::as_global(it.x) + (size_t)p0 * x_stride;
+        gate_at = it.gate ? pnmn::as_global(it.gate) + (size_t)p0 * dy_stride + cob * G1_CO : nullptr;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + 256 * i, px = idx >> 6, c4 = idx & 63;
+            dv[i] = pnmn::load4(d + (size_t)px * dy_stride + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + 256 * i, px = idx >> 5, c4 = idx & 31;
+            const int pxc = idx < G1_PX * CB / 4 ? px : 0;  // (the fourth piece exists for half the threads: the others re-read row 0)
+            xv[i] = pnmn::load4(x + (size_t)pxc * x_stride + 4 * c4);
+            mk[i] = 1.f;
+        }
+        if (it.xmask != nullptr) {
+            const pnmn::gfloat* xm = pnmn::as_global(it.xmask) + p0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int idx = tid + 256 * i, px = idx >> 5;
+                mk[i] = xm[idx < G1_PX * CB / 4 ? px : 0];
+            }
+        }
+    };
+    auto stash = [&] {
+        float* dl = lds;
+        float* xl = dl + G1_PX * G1_DLD;
+        if (gate_at != nullptr) {  // (a gated weight gradient is not the classifier's: its map is fetched here, not a stage ahead)
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + 256 * i, px = idx >> 6, c4 = idx & 63;
+                const f32x4 gt = pnmn::load4(gate_at + (size_t)px * dy_stride + 4 * c4);
+                dv[i].x = gt.x > 0.f ? dv[i].x : 0.f;
+                dv[i].y = gt.y > 0.f ? dv[i].y : 0.f;
+                dv[i].z = gt.z > 0.f ? dv[i].z : 0.f;
+                dv[i].w = gt.w > 0.f ? dv[i].w : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + 256 * i, px = idx >> 6, c4 = idx & 63;
+            *reinterpret_cast<f32x4*>(dl + px * G1_DLD + 4 * c4) = dv[i];
+            bias_staged += dv[i];  // (the gated values, as they are contracted)
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + 256 * i, px = idx >> 5, c4 = idx & 31;
+            if (idx < G1_PX * CB / 4) *reinterpret_cast<f32x4*>(xl + px * G1_XLD + 4 * c4) = xv[i] * mk[i];
+        }
+    };
+    fetch(il[joff[cur.job] + cur.item], cur.st);
+    stash();
+    __syncthreads();
+    const int n_mine = (int)(t1 - t0);
+    const float* const dl = lds;
+    const float* const xl = dl + G1_PX * G1_DLD;
+    const float* const ap = dl + g * G1_DLD + wave * 64 + li;   // A[m = li][k = g]: dy[pixel 4 kk + g][output channel]
+    const float* const bp = xl + g * G1_XLD + li;               // B[k = g][n = li]: x[pixel 4 kk + g][input channel]
+    for (int s = 0; s < n_mine;) {
+        // a run of stages that add into one weight: the accumulators stay put until its end (a flush inside the stage
+        // loop made the compiler carry them in other registers round the loop and copy all 128 every stage)
+        const pnmn_wgrad_job job = jl[cur.job];
+        zero();
+        for (;;) {
+            const bool more = s + 1 < n_mine;
+            Cursor nxt{cur.job, cur.item, cur.st + 1};
+            if (nxt.st == spi && !item_after(cur, nxt)) nxt = cur;  // (only behind the last stage of all: never fetched)
+            const bool go_on = more && jl[nxt.job].dw == job.dw && jl[nxt.job].dbias == job.dbias;
+            if (more) fetch(il[joff[nxt.job] + nxt.item], nxt.st);
+            bias_acc += bias_staged;
+            bias_staged = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < G1_PX / 4; ++kk) {
+                float a[4], b[8];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) a[ct] = ap[kk * 4 * G1_DLD + ct * 16];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) b[nt] = bp[kk * 4 * G1_XLD + nt * 16];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) acc[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct], b[nt], acc[ct][nt], 0, 0, 0);
+            }
+            __syncthreads();  // (everyone has read the buffer)
+            if (more) stash();
+            __syncthreads();
+            cur = nxt, ++s;
+            if (!go_on) break;
+        }
+        flush(job.dw, job.dbias);
+    }
+    t0 = t1;
+    }
+}
+
+int launch_wgrad_1x1_gemm(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jobs, int n_jobs, int HW, int cout_blocks,
+                          int x_stride, int dy_stride, int cus, hipStream_t stream) {
+    static std::atomic<uint64_t> configured{0};  // (per device: lds_optin.h)
+    if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(conv_wgrad_1x1_gemm_kernel), G1_LDS_ALL, configured)) return e;
+    const int n_cob = cout_blocks / 2;
+    // workgroups per output block: two per CU the launch may use, shared out among the blocks -- but a range of at least
+    // ~4 stages each (n_jobs x HW / 28 stages is a lower bound that needs no look at the device records: every job holds
+    // at least one item)
+    const int budget = (cus >= 1 && cus <= 256) ? cus : pnmn::default_conv_cus();
+    int wpc = 2 * budget / n_cob;
+    const long least = (long)n_jobs * (HW / G1_PX);
+    if (wpc > least / 4) wpc = (int)(least / 4);
+    if (wpc < 1) wpc = 1;
+    hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel, dim3((unsigned)(wpc * n_cob)), dim3(256), G1_LDS_ALL, stream, items, jobs, x_stride,
+                       dy_stride, HW, n_jobs, n_cob);
+    return (int)hipGetLastError();
+}
+
 // 3x3 on 14x14 maps: the streamed kernel (conv_wgrad_stream.h)
 __global__ __launch_bounds__(pnmn::stream::NTHREADS, 1) void conv_wgrad_stream_kernel(const pnmn_wgrad_item* __restrict__ items,
                                                                                      const pnmn_wgrad_job* __restrict__ jobs,
@@ -477,12 +720,12 @@ extern "C" int pnmn_conv_wgrad_cus(const pnmn_wgrad_item* items, const pnmn_wgra
         return PNMN_EINVAL;
     if ((x_stride & 3) || (dy_stride & 3)) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // a 1x1 weight gradient over one 128-channel input block and whole 256-channel output blocks (the classifier conv,
+    // either map size): the GEMM kernel
+    if (ntaps == 1 && cin_blocks == 1 && (cout_blocks & 1) == 0 && (H * W) % G1_PX == 0 && x_stride >= CB && n_jobs <= G1_MAX_JOBS)
+        return launch_wgrad_1x1_gemm(items, jobs, n_jobs, H * W, cout_blocks, x_stride, dy_stride, cus, s);
     if (H == 14 && W == 14) {
-        if (ntaps == 9) {
-            static const bool old_kernel = getenv("PNMN_WGRAD_OLD") != nullptr;  // (A/B hook of round 5; goes with the old kernel)
-            if (old_kernel) return launch_wgrad<14, 14, 9>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride, dy_stride, cus, s);
-            return launch_wgrad_stream(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride, dy_stride, cus, s);
-        }
+        if (ntaps == 9) return launch_wgrad_stream(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride, dy_stride, cus, s);
         return launch_wgrad<14, 14, 1>(items, jobs, n_jobs, cin_blocks, cout_blocks, x_stride,
                                        dy_stride, cus, s);
     }

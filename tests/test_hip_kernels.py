@@ -428,6 +428,35 @@ def test_wgrad_1x1_two_sources_and_wide_output(hip):
     torch.testing.assert_close(dw.cpu().reshape(1024, C), wc.grad.reshape(1024, C), rtol=RT, atol=5 * AT)
     torch.testing.assert_close(db.cpu(), bc.grad, rtol=RT, atol=5 * AT)
 
+    # the GEMM kernel's work split (round 5): three jobs of 5 + 1 + 3 items, the last one adding into ANOTHER weight, with a
+    # ReLU gate and an attention mask -- two workgroups per output block whose stage ranges begin and end inside items and
+    # cross the job with the other weight (a flush in the middle of a range)
+    n = 9
+    a = torch.relu(torch.randn(n, C, H, W, generator=g))
+    m = torch.sigmoid(torch.randn(n, 1, H, W, generator=g))
+    w1 = (torch.randn(512, C, 1, 1, generator=g) * 0.05).requires_grad_(True)
+    w2 = (torch.randn(512, C, 1, 1, generator=g) * 0.05).requires_grad_(True)
+    b1, b2 = torch.zeros(512, requires_grad=True), torch.zeros(512, requires_grad=True)
+    xin = a * m
+    y = torch.cat((F.relu(F.conv2d(xin[:6], w1, b1)), F.relu(F.conv2d(xin[6:], w2, b2))), 0)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ad, md, dyd, yd = nhwc(a), m.reshape(n, HW).to(dev()), nhwc(dy), nhwc(y.detach())
+    items = np.zeros(n, hip.WGRAD_ITEM)
+    for i in range(n):
+        items[i]["x"], items[i]["xmask"], items[i]["dy"], items[i]["gate"] = ptr(ad[i]), ptr(md[i]), ptr(dyd[i]), ptr(yd[i])
+    dws = [torch.zeros(512, 1, C, device=dev()) for _ in range(2)]
+    dbs = [torch.zeros(512, device=dev()) for _ in range(2)]
+    jobs = np.zeros(3, hip.WGRAD_JOB)
+    for j, (lo, hi, k) in enumerate(((0, 5, 0), (5, 6, 0), (6, 9, 1))):
+        jobs[j]["dw"], jobs[j]["dbias"], jobs[j]["item_begin"], jobs[j]["item_end"] = ptr(dws[k]), ptr(dbs[k]), lo, hi
+    ibuf, jbuf = hip.to_device(items, dev()), hip.to_device(jobs, dev())
+    hip.check(hip.lib().pnmn_conv_wgrad(ibuf.data_ptr(), jbuf.data_ptr(), 3, H, W, 1, 1, 4, C, 512, hip.stream_ptr(dev())), "wgrad")
+    torch.cuda.synchronize()
+    for k, (wk, bk) in enumerate(((w1, b1), (w2, b2))):
+        torch.testing.assert_close(dws[k].cpu().reshape(512, C), wk.grad.reshape(512, C), rtol=RT, atol=5 * AT)
+        torch.testing.assert_close(dbs[k].cpu(), bk.grad, rtol=RT, atol=5 * AT)
+
 
 def test_dot1_sigmoid_fwd_bwd(hip):
     g = gen(40)
