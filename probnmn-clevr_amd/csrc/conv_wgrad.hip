@@ -651,12 +651,12 @@ int launch_wgrad_1x1_gemm(const pnmn_wgrad_item* items, const pnmn_wgrad_job* jo
     if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(conv_wgrad_1x1_gemm_kernel), G1_LDS_ALL, configured)) return e;
     const int n_cob = cout_blocks / 2;
     // workgroups per output block: two per CU the launch may use, shared out among the blocks -- but a range of at least
-    // ~4 stages each (n_jobs x HW / 28 stages is a lower bound that needs no look at the device records: every job holds
+    // ~2 stages each (n_jobs x HW / 28 stages is a lower bound that needs no look at the device records: every job holds
     // at least one item)
     const int budget = (cus >= 1 && cus <= 256) ? cus : pnmn::default_conv_cus();
     int wpc = 2 * budget / n_cob;
     const long least = (long)n_jobs * (HW / G1_PX);
-    if (wpc > least / 4) wpc = (int)(least / 4);
+    if (wpc > least / 2) wpc = (int)(least / 2);
     if (wpc < 1) wpc = 1;
     hipLaunchKernelGGL(conv_wgrad_1x1_gemm_kernel, dim3((unsigned)(wpc * n_cob)), dim3(256), G1_LDS_ALL, stream, items, jobs, x_stride,
                        dy_stride, HW, n_jobs, n_cob);
