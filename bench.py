@@ -313,7 +313,7 @@ def recurrent_kernel_report(dev):
     """Launch time, latency per time step and achieved FLOP/s of the persistent recurrent kernels at
     the shapes of the headline step (these kernels are bound by the per-step hand-off
     latency, not by a roofline; both figures are reported)."""
-    from probnmn.modules.seq2seq_base import _AttnLSTMDecoder, _LSTMLayerSeq
+    from probnmn.modules.seq2seq_base import _AttnLSTMDecoder, _LSTMLayerSeq, pack_fragments
 
     g = torch.Generator().manual_seed(0)
     r = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g) * scale).to(dev)  # noqa: E731
@@ -336,8 +336,11 @@ def recurrent_kernel_report(dev):
     B, T = 1024, 46
     xp, w = r(B, T, 4 * Hd, scale=0.5).requires_grad_(True), r(4 * Hd, Hd, scale=0.05)
     dhs = r(B, T, Hd)
-    fwd = clock(lambda: _LSTMLayerSeq.apply(xp.detach(), w))
-    both = clock(lambda: _LSTMLayerSeq.apply(xp, w).backward(dhs))
+    # (the fragment-order copies of the recurrent weights are made once per optimiser step and shared by every pass --
+    # DerivedParams -- so they are operands here, not part of the launch: rounds 1-4 timed two permute kernels with it)
+    wp, w_t = pack_fragments(w), pack_fragments(w.t())
+    fwd = clock(lambda: _LSTMLayerSeq.apply(xp.detach(), w, wp, w_t))
+    both = clock(lambda: _LSTMLayerSeq.apply(xp, w, wp, w_t).backward(dhs))
     flops = 2.0 * B * T * Hd * 4 * Hd
     out["lstm_layer"] = {"rows": B, "steps": T, "fwd_ms": round(fwd, 3), "fwd_us_per_step": round(fwd / T * 1e3, 2),
                          "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3)}
@@ -351,7 +354,8 @@ def recurrent_kernel_report(dev):
         etable = r(V, 4 * Hd, scale=0.5)
         teacher = torch.randint(0, V, (B, T), device=dev) if mode == 0 else None  # (inputs = rows of etable, as the models run it)
         dh = r(B, T, Hd)
-        run = lambda e: _AttnLSTMDecoder.apply(None, etable, e, mask, h0, w_c, w_hh, w_p, b_p, mode, T, 5, 0, 0, 1, 2, None, teacher)[0]  # noqa: E731
+        packs = (pack_fragments(w_c), pack_fragments(w_hh), pack_fragments(w_c.t()), pack_fragments(w_hh.t()))
+        run = lambda e: _AttnLSTMDecoder.apply(None, etable, e, mask, h0, w_c, w_hh, w_p, b_p, mode, T, 5, 0, 0, 1, 2, packs, teacher)[0]  # noqa: E731
         fwd = clock(lambda: run(enc.detach()))
         both = clock(lambda: run(enc).backward(dh))
         flops = B * T * (2.0 * 2 * Hd * 4 * Hd + 4.0 * S * Hd + (2.0 * V * Hd if mode else 0.0))
