@@ -27,7 +27,7 @@ namespace pnmn {
 // the agent-scope pair costs 6-9 us per hand-off with 256 workgroups resident (every release writes
 // back all of the XCD's dirty output lines); the same-XCD pair costs a fraction of that.
 struct Cluster {
-    int* counter;   // [0] arrivals (monotonic), [1] OR of (1 << XCC id) over the members, [2] members that finished
+    int* counter;   // [0] arrivals (monotonic), [1] OR of (1 << XCC id) over the members | members started << 16, [2] members that finished
     int handoffs;
     int members;
     bool fast;
@@ -75,8 +75,12 @@ struct Cluster {
         }
     }
 
-    // First hand-off of a launch (always with full agent-scope ordering): the members publish the XCD
-    // they run on and all take the same decision.
+    // Start of a launch: the members publish the XCD they run on and all take the same decision.  ONE word carries both
+    // the OR of (1 << XCC id) (low half) and the number of members that have published (high half): a member's two
+    // relaxed read-modify-writes of that word are ordered (same address), so whoever reads the full count also reads every
+    // member's bit -- no release / acquire pair, which with 256 workgroups resident costs 6-9 us per launch (an agent-scope
+    // release writes back the XCD's dirty lines; a step has ~20 such launches).  Nothing else is published here: what the
+    // members read of earlier kernels is ordered by the kernel boundary.
     __device__ __forceinline__ void start(int* tile_counter, int n_members) {
         counter = tile_counter;
         handoffs = 0;
@@ -85,11 +89,17 @@ struct Cluster {
         if (threadIdx.x == 0) {
             const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
             __hip_atomic_fetch_or(counter + 1, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(counter + 1, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((__hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) < members) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 26)) __builtin_trap();
+            }
         }
-        signal();
-        wait();
-        const int mask = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fast = __builtin_popcount(mask) == 1;
+        __syncthreads();
+        // (the word only grows until the last member's finish(): whoever reads it now reads every member's bit)
+        const int word = __hip_atomic_load(counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fast = __builtin_popcount(word & 0xFFFF) == 1;
     }
 };
 
