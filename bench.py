@@ -59,6 +59,8 @@ for p in (ROOT, os.environ.get("PNMN_PKG_DIR") or os.path.join(ROOT, "probnmn-cl
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from probnmn import launch_guard  # noqa: E402
+
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
 
@@ -66,6 +68,7 @@ JOINT = dict(objective="ours", alpha=100.0, beta=0.1, gamma=1.0, delta=0.99, lr=
 
 
 def log(*a):
+    launch_guard.beat()
     if os.environ.get("RANK", "0") == "0":
         print("[bench %7.1fs]" % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
@@ -437,6 +440,7 @@ def timed(step_fn, steps, warmup, dev, world, trainer=None):
     # allocator's pools reach their steady size; a synchronise behind every warm-up step left that growth to the first
     # timed steps: 45 instead of 34 ms on the 28x28 side object, whose records are the largest)
     for i in range(warmup):
+        launch_guard.beat()
         step_fn()
         if i == 0:
             torch.cuda.synchronize()
@@ -446,6 +450,7 @@ def timed(step_fn, steps, warmup, dev, world, trainer=None):
     w0 = blocked_now()
     t0 = time.perf_counter()
     for _ in range(steps):
+        launch_guard.beat()  # (one utime() per step under the N > 1 launch guard, nothing otherwise)
         step_fn()
     host = time.perf_counter() - t0
     blocked = blocked_now() - w0
@@ -500,6 +505,7 @@ def fit_program_generator(pg, vocab, batch, dev, max_iters, target, min_iters=0)
     frac, it = valid_fraction(), 0
     while (frac < target or it < min_iters) and it < max_iters:
         for _ in range(50):
+            launch_guard.beat()
             opt.zero_grad()
             pg(batch["question"], batch["program"], decoding_strategy="sampling")["loss"].mean().backward()
             parallel.all_reduce_gradients([], opt.loose)
@@ -689,6 +695,7 @@ def collective_report(trainer, step_fn, dev, world, passes=4):
 
     parallel.TIMING = []
     for _ in range(passes):
+        launch_guard.beat()
         step_fn()
     torch.cuda.synchronize()
     timing, parallel.TIMING = parallel.TIMING, None
@@ -734,6 +741,8 @@ def collective_report(trainer, step_fn, dev, world, passes=4):
         "allreduce_hidden_frac": round(max(0.0, 1.0 - exposed / standalone), 3) if standalone > 0 else None,
         "allreduce_algbw_GBs": round(nbytes / standalone / 1e6, 1) if standalone > 0 else None,
         "cluster_cus": int(__import__("probnmn._hip", fromlist=["lib"]).lib().pnmn_cluster_reserve_cus(-1)),
+        "reserve": int(os.environ.get("PNMN_DP_RESERVE_CUS", "32")),
+        "serial_collectives": parallel.serial_collectives(),
         "note": "allreduce_ms_per_step: the step's collectives alone on an idle chip; exposed: what the step's stream "
                 "waits for them behind backward (median of %d instrumented steps, max over ranks)" % passes,
     }
@@ -769,12 +778,14 @@ def ingest_side(vocab, trainer, dev, rank, world, args, resident_ms):
     def run(the_store, method):
         it = iter(PrefetchingLoader(batches(w + k + 1), the_store, dev, method=method))
         for _ in range(w):
+            launch_guard.beat()
             trainer.step(next(it))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(k):
+            launch_guard.beat()
             trainer.step(next(it))
         torch.cuda.synchronize()
         if world > 1:
@@ -852,6 +863,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if world > 1 and not launch_guard.is_worker() and os.environ.get("PNMN_BENCH_GUARD", "1") != "0":
+        # N > 1: this process only SUPERVISES the rank (probnmn/launch_guard.py, DESIGN 6 "Hang guard"): the rank's work
+        # runs in a worker process whose heartbeat it watches; a hang or a crash on any rank restarts all workers once with
+        # PNMN_DP_SERIAL_COLLECTIVES=1, and if that fails too rank 0 still prints a JSON line ("hung": true) and every
+        # rank exits non-zero instead of waiting forever.
+        raise SystemExit(launch_guard.supervise(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+            watchdog_s=float(os.environ.get("PNMN_BENCH_WATCHDOG_S", "150")),
+            first_beat_s=float(os.environ.get("PNMN_BENCH_FIRST_BEAT_S", "420")),
+            last_resort=lambda info: {
+                "metric": "CLEVR questions/sec (joint_training step)", "value": None, "unit": "questions/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "hung": True,
+                "config": {"workload": "joint_training_ours.yml, global batch %d over %d GPUs -- NOT MEASURED: the ranks hung or "
+                                       "failed twice (overlapped and serial collectives)" % (args.batch, world),
+                           "parallelism": "dp%d" % world},
+                "launch_guard": info}))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the measured path)")
     total = args.batch  # as given on the command line
@@ -904,7 +932,15 @@ def main():
     # set-up, like the generator fit above: a few iterations so that what only happens at the start of a
     # run (allocator pools growing, GEMM heuristics, templates of program structures seen for the first
     # time) is over before the W warm-up + K timed steps, whatever W the caller passes
+    if (os.environ.get("PNMN_BENCH_FORCE_HANG") == "1" and world > 1 and rank == world - 1
+            and launch_guard.is_worker() and launch_guard.attempt() == 0):
+        # test hook (tests/test_bench_launch_gpu.py): the last rank never joins the first step's collectives -- what a
+        # deadlock between a collective and a recurrent kernel looks like from the outside
+        log_all = "[bench rank %d] PNMN_BENCH_FORCE_HANG: sleeping instead of stepping" % rank
+        print(log_all, file=sys.stderr, flush=True)
+        time.sleep(1e6)
     for _ in range(args.settle):
+        launch_guard.beat()
         trainer.step(batch)
     torch.cuda.synchronize()
     log("joint_training: warmup + %d timed steps" % args.steps)
@@ -922,7 +958,7 @@ def main():
     roof = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the step's collectives); rank 0 reports
-        agg = kernel_rooflines(nmn.engine, lambda: trainer.step(batch), passes=args.roofline_passes, trainer=trainer)
+        agg = kernel_rooflines(nmn.engine, lambda: (launch_guard.beat(), trainer.step(batch)), passes=args.roofline_passes, trainer=trainer)
         if rank == 0:
             roof = roofline_object(agg)
         log("roofline pass done")

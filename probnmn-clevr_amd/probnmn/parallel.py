@@ -23,6 +23,17 @@ def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def serial_collectives() -> bool:
+    """``PNMN_DP_SERIAL_COLLECTIVES=1``: no collective is started during backward -- no early reducer, no cut in the
+    trunk's backward launch list; ``all_reduce_gradients`` issues all of them behind the joined streams, in the same
+    fixed order, so a collective never shares the chip with a recurrent kernel.  The fallback ``probnmn.launch_guard``
+    restarts a data-parallel job with after a hang (same gradients bit for bit: the sums do not depend on when they
+    start).  Must be set identically on every rank."""
+    import os
+
+    return os.environ.get("PNMN_DP_SERIAL_COLLECTIVES", "0") == "1"
+
+
 _DP_SAFE_DONE = False
 
 
@@ -182,6 +193,8 @@ def early_reducer_for(big_params, engines) -> "EarlyReducer":
     single process gets the hooks only (they return at once) and no cut in the engine's launch lists."""
     pieces = []
     dp_safe()
+    if world() > 1 and serial_collectives():
+        return None
     if world() > 1:
         for e in engines:
             pieces.extend(e.grad_pieces())
