@@ -277,7 +277,8 @@ int pnmn_answer_loss(const float* logits, const int64_t* answers, const int32_t*
  * pnmn_mask_last_fwd/bwd   PytorchSeq2SeqWrapper's zeroed padded steps + get_final_encoder_states:
  *     enc = hs * fmask[..., None],  hlast[b] = enc[b][last[b]]  (negative index: from the end)
  *     dhs = (denc + [t == last[b]] dhlast[b]) * fmask        (denc, dhlast may be null)
- * pnmn_embedding_grad      dw[v] = sum_{rows with token v} dy[row]   (V <= 128, C % 4 == 0; dw is written whole;
+ * pnmn_embedding_grad      dw[v] = sum_{rows with token v} dy[row]   (V <= 128, C % 4 == 0; dw is written whole, or --
+ *                          accumulate != 0 -- added to;
  *                          rows = (b, t) of tokens [B][T]; shift = 1: row (b, t) takes token (b, t-1) and
  *                          `start` at t = 0; token `skip` contributes nothing; workspace: device memory of
  *                          pnmn_embedding_grad_workspace_bytes(B, T, V) bytes, any contents)
@@ -302,7 +303,7 @@ int pnmn_mask_last_bwd(const float* denc, const float* dhlast, const float* fmas
                        int H, float* dhs, void* stream);
 int64_t pnmn_embedding_grad_workspace_bytes(int B, int T, int V);
 int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
-                        int V, int shift, int start, int skip, float* dw, void* workspace, void* stream);
+                        int V, int shift, int start, int skip, int accumulate, float* dw, void* workspace, void* stream);
 int pnmn_derive_params(const pnmn_derive_job* jobs, int n_jobs, int max_quads, void* stream);
 
 /* Per-token projection table of an embedding layer (V <= 128 rows; K, N multiples of 16 / 64):
@@ -316,7 +317,21 @@ int pnmn_token_table_fwd(const float* emb, const float* weight, int64_t weight_r
                          const float* bias, int V, int K, int N, float* table, void* stream);
 int pnmn_token_table_bwd(const float* dtable, const float* emb, const float* weight,
                          int64_t weight_row_stride, int V, int K, int N, int padding_idx, float* demb,
-                         float* dweight, float* dbias, void* stream);
+                         float* dweight, int64_t dweight_row_stride /* 0: K */, float* dbias,
+                         float* dbias2 /* second copy of dbias (b_ih and b_hh receive the same) or NULL */, void* stream);
+
+/* Rows of token matrices gathered through an index, concatenated and right-padded into one [sum rows][W] matrix:
+ * the index_select / cat / F.pad a training iteration applies to its question / program matrices to form the
+ * supervised and unsupervised row subsets (reference question_coding_trainer.py:128-160, joint_training_trainer.py:150-190). */
+#define PNMN_TOKEN_SEGS 4
+typedef struct pnmn_token_seg {
+    const int64_t* src;        /* [.][row_stride] */
+    const int64_t* index;      /* [rows] row numbers in src, or NULL: rows 0 .. rows-1 */
+    int64_t        row_stride;
+    int32_t        rows;
+    int32_t        width;      /* columns copied; columns width .. W-1 of the output are `pad` */
+} pnmn_token_seg;
+int pnmn_token_rows(const pnmn_token_seg* segs /* HOST array */, int n_segs, int64_t* dst, int W, int64_t pad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-sequence masked-mean negative log-likelihood            seq2seq_base.py:235-254 (sampled programs:
@@ -734,7 +749,50 @@ int pnmn_conv2d_nhwc(const pnmn_conv2d_desc* desc, void* stream);
 int pnmn_conv2d_weight_floats(int Cout, int Cin, int kh, int kw);
 int pnmn_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
-/* Library self-description (no GPU needed).  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* ---------------------------------------------------------------------------------------------
+ * fp32 GEMM, up to PNMN_GEMM_MAX independent problems per launch (csrc/gemm.hip).
+ * Replaces: every product over all time steps that the reference reaches through nn.LSTM / nn.Linear / autograd in
+ *           the seq2seq models (probnmn/modules/seq2seq_base.py:101-155 via allennlp's SimpleSeq2Seq: encoder input
+ *           projections, `_output_projection_layer`, and the weight / data gradients autograd derives for them) and
+ *           ProgramPrior's projection + tied output layer (probnmn/models/program_prior.py:101-104).
+ *   C[M][N] (row stride ldc) = [C +] op(A) op(B) [+ bias[N]]
+ *   A: [M][K] with row stride lda, or -- PNMN_GEMM_A_TRANSPOSED -- stored [K][M] (a weight gradient's dy^T)
+ *   B: [K][N] with row stride ldb, or -- PNMN_GEMM_B_TRANSPOSED -- stored [N][K] (nn.Linear's weight)
+ *   shift_t > 0 (B as [K][N] only): k row r reads storage row r - 1, and where r % shift_t == 0 row r / shift_t of
+ *     shift_h0 (row stride ld_h0; zeros when NULL): "h_{t-1}" of a [B][T][N] tensor of states without a shifted copy
+ *   split_k > 1: the K range is cut into that many chunks (whole 32-wide k tiles) whose partial tiles meet in
+ *     `workspace` (pnmn_gemm_workspace_bytes; zeroed ONCE by the caller, the kernel leaves its counters zeroed) and are
+ *     added in chunk order by whichever chunk arrives last: deterministic.  pnmn_gemm_split_k proposes a count.
+ * ------------------------------------------------------------------------------------------- */
+#define PNMN_GEMM_MAX 8
+#define PNMN_GEMM_A_TRANSPOSED 1
+#define PNMN_GEMM_B_TRANSPOSED 2
+#define PNMN_GEMM_ACCUMULATE   4
+typedef struct pnmn_gemm_desc {
+    const float* a;
+    const float* b;
+    float*       c;
+    const float* bias;      /* [N] or NULL */
+    int64_t      lda, ldb, ldc;
+    int32_t      M, N, K;
+    int32_t      flags;     /* PNMN_GEMM_* */
+    int32_t      split_k;   /* <= 1: none */
+    int32_t      shift_t;
+    const float* shift_h0;
+    int64_t      ld_h0;
+    float*       workspace; /* split_k > 1 */
+} pnmn_gemm_desc;
+int pnmn_gemm(const pnmn_gemm_desc* descs /* HOST array */, int n, void* stream);
+int64_t pnmn_gemm_workspace_bytes(int M, int N, int split_k);
+int pnmn_gemm_split_k(int M, int N, int K, int cus);
+
+/* out[c] = [out[c] +] sum_r x[r*ld + c], c < C; also stored to out2 when not NULL (an LSTM layer's b_ih and b_hh receive
+ * the same gradient: torch autograd's sum over rows of the gate gradients).  workspace: pnmn_colsum_workspace_bytes,
+ * zeroed once by the caller. */
+int pnmn_colsum(const float* x, int64_t ld, int R, int C, float* out, float* out2, int accumulate, void* workspace, void* stream);
+int64_t pnmn_colsum_workspace_bytes(int R, int C);
+
+/* Library self-description (no GPU needed).  11 = round 6: pnmn_gemm / pnmn_colsum / pnmn_token_rows, an accumulate flag on pnmn_embedding_grad, row stride + second bias output on pnmn_token_table_bwd.  10 = round 5.  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

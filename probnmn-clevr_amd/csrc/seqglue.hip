@@ -46,6 +46,26 @@ __global__ __launch_bounds__(256) void token_prep_kernel(const int64_t* __restri
     }
 }
 
+// ---- rows of token matrices gathered / concatenated / padded into one matrix --------------------------------
+// dst [sum of rows][W]: segment s contributes `rows` rows, row i = src[(idx ? idx[i] : i) * stride + 0 .. width) followed
+// by `pad` up to W columns.  What a training iteration does with index_select / cat / F.pad on its question and program
+// matrices (reference question_coding_trainer.py:128-160: the supervised / unsupervised row subsets) in one launch.
+struct TokenSegs {
+    pnmn_token_seg s[PNMN_TOKEN_SEGS];
+    int n;
+};
+__global__ __launch_bounds__(256) void token_rows_kernel(const TokenSegs segs, int64_t* __restrict__ dst, int W, int64_t pad,
+                                                         int total) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= total) return;
+    int k = 0, first = 0;
+    while (k + 1 < segs.n && r >= first + segs.s[k].rows) first += segs.s[k].rows, ++k;
+    const pnmn_token_seg sg = segs.s[k];
+    const int64_t i = sg.index ? sg.index[r - first] : (int64_t)(r - first);
+    const int64_t* row = sg.src + i * sg.row_stride;
+    for (int w = lane; w < W; w += 64) dst[(size_t)r * W + w] = w < sg.width ? row[w] : pad;
+}
+
 // ---- trim predictions at the first @end@ (reference seq2seq_base.py:278-293) -------------------------------
 // keep a row up to and including its first `end`; a row that starts with `end` becomes all zeros; a row
 // without `end` is kept whole.  One wave per row.
@@ -139,7 +159,7 @@ __device__ __forceinline__ int eg_token(const int64_t* __restrict__ tokens, int6
 __global__ __launch_bounds__(1024) void embedding_rows_kernel(const int64_t* __restrict__ tokens, int64_t tok_bstride, int B,
                                                               int T, unsigned magic, int V, int shift, int start, int skip, int C,
                                                               int* __restrict__ order, int* __restrict__ chunks, int max_per,
-                                                              int* __restrict__ count, float* __restrict__ dw) {
+                                                              int* __restrict__ count, float* __restrict__ dw, int keep) {
     // one histogram per wave: 47 k rows through 93 shared counters would queue up behind each other
     __shared__ int whist[16][128], hist[128], rowbase[128], chbase[128];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -160,8 +180,9 @@ __global__ __launch_bounds__(1024) void embedding_rows_kernel(const int64_t* __r
         for (int u = 0; u < UN; ++u)
             if (r0 + 1024 * u < R && v[u] >= 0) atomicAdd(&whist[wave][v[u]], 1);
     }
-    for (size_t i = blockIdx.x * 1024 + tid; i < (size_t)V * C / 4; i += 1024 * gridDim.x)
-        reinterpret_cast<float4*>(dw)[i] = float4{0.f, 0.f, 0.f, 0.f};
+    if (!keep)  // (keep: the sums are added to what dw holds -- a second pass over other rows of the same table)
+        for (size_t i = blockIdx.x * 1024 + tid; i < (size_t)V * C / 4; i += 1024 * gridDim.x)
+            reinterpret_cast<float4*>(dw)[i] = float4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     if (tid < 128) {  // counts -> this wave's first position inside the token's bucket
         int run = 0;
@@ -301,7 +322,8 @@ __global__ __launch_bounds__(256) void token_table_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void token_table_bwd_kernel(const float* __restrict__ dtable, const float* __restrict__ emb,
                                                               const float* __restrict__ w, long ldw, int V, int K, int N,
                                                               int padding_idx, float* __restrict__ demb,
-                                                              float* __restrict__ dw, float* __restrict__ dbias) {
+                                                              float* __restrict__ dw, long lddw, float* __restrict__ dbias,
+                                                              float* __restrict__ dbias2) {
     __shared__ float lds[128 * 17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int V16 = (V + 15) & ~15;
@@ -316,6 +338,7 @@ __global__ __launch_bounds__(256) void token_table_bwd_kernel(const float* __res
             float sum = 0.f;
             for (int v = 0; v < V; ++v) sum += lds[v * 17 + tid];
             dbias[n0 + tid] = sum;
+            if (dbias2) dbias2[n0 + tid] = sum;
         }
         if (!dw) return;
         for (int kt = wave; kt < K / 16; kt += 4) {
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(256) void token_table_bwd_kernel(const float* __res
                 acc = mfma4(a, b, acc);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dw[(size_t)(n0 + 4 * g + r) * K + 16 * kt + li] = acc[r];
+            for (int r = 0; r < 4; ++r) dw[(size_t)(n0 + 4 * g + r) * lddw + 16 * kt + li] = acc[r];
         }
         return;
     }
@@ -366,6 +389,23 @@ extern "C" int pnmn_token_prep(const int64_t* tokens, int64_t token_row_stride, 
     if (!tokens || !out || T < 0) return PNMN_EINVAL;
     hipLaunchKernelGGL(token_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), tokens,
                        token_row_stride, B, T, pad, bos, eos, drop_first, out, fmask, last);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pnmn_token_rows(const pnmn_token_seg* segs, int n_segs, int64_t* dst, int W, int64_t pad, void* stream) {
+    if (n_segs <= 0 || W <= 0) return 0;
+    if (!segs || !dst || n_segs > PNMN_TOKEN_SEGS) return PNMN_EINVAL;
+    TokenSegs t;
+    int total = 0;
+    for (int k = 0; k < n_segs; ++k) {
+        if (segs[k].rows < 0 || (segs[k].rows > 0 && !segs[k].src) || segs[k].width < 0) return PNMN_EINVAL;
+        t.s[k] = segs[k];
+        total += segs[k].rows;
+    }
+    t.n = n_segs;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(token_rows_kernel, dim3((total + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), t, dst, W, pad,
+                       total);
     return (int)hipGetLastError();
 }
 
@@ -409,11 +449,12 @@ extern "C" int64_t pnmn_embedding_grad_workspace_bytes(int B, int T, int V) {
 }
 
 extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64_t token_row_stride, int B, int T, int C,
-                                   int V, int shift, int start, int skip, float* dw, void* workspace, void* stream) {
+                                   int V, int shift, int start, int skip, int accumulate, float* dw, void* workspace,
+                                   void* stream) {
     if (V <= 0 || C <= 0) return 0;
     if (!dw || (C & 3) || V > 128) return PNMN_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (B <= 0 || T <= 0) return (int)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)V * C, s);
+    if (B <= 0 || T <= 0) return accumulate ? 0 : (int)hipMemsetAsync(dw, 0, sizeof(float) * (size_t)V * C, s);
     if (!dy || !tokens || !workspace) return PNMN_EINVAL;
     const long rows = (long)B * T;
     if (rows * T >= (1L << 32)) return PNMN_ESHAPE;
@@ -423,7 +464,7 @@ extern "C" int pnmn_embedding_grad(const float* dy, const int64_t* tokens, int64
     int* chunks = order + rows;
     int* count = chunks + 3 * (size_t)EG_SLICES * max_per;
     hipLaunchKernelGGL(embedding_rows_kernel, dim3(EG_SLICES), dim3(1024), 0, s, tokens, token_row_stride, B, T, magic, V, shift,
-                       start, skip, C, order, chunks, max_per, count, dw);
+                       start, skip, C, order, chunks, max_per, count, dw, accumulate);
     hipLaunchKernelGGL(embedding_sum_kernel, dim3(EG_SLICES * max_per, (C + 1023) / 1024), dim3(256), 0, s, dy, order, chunks,
                        max_per, count, C, dw);
     return (int)hipGetLastError();
@@ -448,13 +489,15 @@ extern "C" int pnmn_token_table_fwd(const float* emb, const float* weight, int64
 }
 
 extern "C" int pnmn_token_table_bwd(const float* dtable, const float* emb, const float* weight, int64_t weight_row_stride, int V,
-                                    int K, int N, int padding_idx, float* demb, float* dweight, float* dbias, void* stream) {
+                                    int K, int N, int padding_idx, float* demb, float* dweight, int64_t dweight_row_stride,
+                                    float* dbias, float* dbias2, void* stream) {
     if (V <= 0) return 0;
     if (!dtable || !emb || !weight) return PNMN_EINVAL;
     if (V > 128 || K < 16 || K % 16 || N < 64 || N % 64) return PNMN_ESHAPE;
     const int blocks = N / 16 + (demb ? ((V + 15) / 16) * (K / 16) : 0);
     hipLaunchKernelGGL(token_table_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dtable, emb, weight,
-                       (long)weight_row_stride, V, K, N, padding_idx, demb, dweight, dbias);
+                       (long)weight_row_stride, V, K, N, padding_idx, demb, dweight,
+                       (long)(dweight_row_stride > 0 ? dweight_row_stride : K), dbias, dbias2);
     return (int)hipGetLastError();
 }
 

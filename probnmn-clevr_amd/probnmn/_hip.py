@@ -66,7 +66,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_trim_predictions": (_P, _I, _I, _I, _P, _P),
     "pnmn_mask_last_fwd": (_P, _P, _P, _I, _I, _I, _P, _P, _P),
     "pnmn_mask_last_bwd": (_P, _P, _P, _P, _I, _I, _I, _P, _P),
-    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P),
+    "pnmn_embedding_grad": (_P, _P, ctypes.c_int64, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P),
     "pnmn_embedding_grad_workspace_bytes": (_I, _I, _I),
     "pnmn_derive_params": (_P, _I, _I, _P),
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
@@ -77,7 +77,8 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_lstm_seq_fwd": (_P, _P, ctypes.c_int64, _P, _P, _P, _P, _I, _I, _I, _P, _P),
     "pnmn_lstm_seq_bwd": (_P, _P, _P, _P, _P, _I, _I, _I, _P, _P),
     "pnmn_token_table_fwd": (_P, _P, ctypes.c_int64, _P, _I, _I, _I, _P, _P),
-    "pnmn_token_table_bwd": (_P, _P, _P, ctypes.c_int64, _I, _I, _I, _I, _P, _P, _P, _P),
+    "pnmn_token_table_bwd": (_P, _P, _P, ctypes.c_int64, _I, _I, _I, _I, _P, _P, ctypes.c_int64, _P, _P, _P),
+    "pnmn_token_rows": (_P, _I, _P, _I, ctypes.c_int64, _P),
     "pnmn_lstm_seq_workspace_bytes": (_I, _I),
     "pnmn_cluster_reserve_cus": (_I,),
     "pnmn_attn_lstm_fwd": (_P,) * 15 + (_I,) * 9 + (ctypes.c_uint64, ctypes.c_uint64, _P, ctypes.c_int64, _P),
@@ -108,10 +109,15 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
+    "pnmn_gemm": (_P, _I, _P),
+    "pnmn_gemm_workspace_bytes": (_I, _I, _I),
+    "pnmn_gemm_split_k": (_I, _I, _I, _I),
+    "pnmn_colsum": (_P, ctypes.c_int64, _I, _I, _P, _P, _I, _P, _P),
+    "pnmn_colsum_workspace_bytes": (_I, _I),
 }
 
 
-ABI_VERSION = 10  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 11  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:
@@ -243,6 +249,11 @@ DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "
 DECODER_BWD_JOB = np.dtype([(n, _u64) for n in ("dhs", "act", "cs", "hs", "probs", "enc", "mask", "h0", "w_c_t", "w_hh_t", "dgates",
                                                   "dctx", "dscore", "weights", "dh0")]
                            + [(n, _i32) for n in ("B", "T", "S", "reserved")])
+GEMM_DESC = np.dtype([(n, _u64) for n in ("a", "b", "c", "bias")] + [(n, np.int64) for n in ("lda", "ldb", "ldc")]
+                     + [(n, _i32) for n in ("M", "N", "K", "flags", "split_k", "shift_t")]
+                     + [("shift_h0", _u64), ("ld_h0", np.int64), ("workspace", _u64)])  # pnmn_gemm_desc
+GEMM_MAX, GEMM_A_T, GEMM_B_T, GEMM_ACC = 8, 1, 2, 4
+TOKEN_SEG = np.dtype([("src", _u64), ("index", _u64), ("row_stride", np.int64), ("rows", _i32), ("width", _i32)])  # pnmn_token_seg
 EINVAL, ESHAPE, EAGAIN = -1, -2, -3  # PNMN_EINVAL / PNMN_ESHAPE / PNMN_EAGAIN
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64),
                       ("bc1", np.float32), ("bc2_sqrt", np.float32)])
@@ -300,6 +311,8 @@ ITEM_SIZES = {
     "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
     "pnmn_trunk_io": (TRUNK_IO, 224),
+    "pnmn_gemm_desc": (GEMM_DESC, 104),
+    "pnmn_token_seg": (TOKEN_SEG, 32),
 }
 
 

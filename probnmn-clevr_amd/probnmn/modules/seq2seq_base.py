@@ -266,7 +266,7 @@ class _TokenTable(torch.autograd.Function):
             ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
             _hip.check(_hip.lib().pnmn_token_table_bwd(dtable.data_ptr(), emb.data_ptr(), weight.data_ptr(), weight.stride(0),
                                                        V, K, N, -1 if ctx.padding_idx is None else ctx.padding_idx,
-                                                       ptr(demb), ptr(dweight), ptr(dbias), _hip.stream_ptr(emb.device)),
+                                                       ptr(demb), ptr(dweight), 0, ptr(dbias), None, _hip.stream_ptr(emb.device)),
                        "token_table_bwd")
             return demb, dweight, dbias, None
         demb = dweight = dbias = None
@@ -346,7 +346,7 @@ def embedding_grad(dy: torch.Tensor, tokens: torch.Tensor, vocab: int, shift: bo
     dw = torch.empty(vocab, C, dtype=dy.dtype, device=dy.device)
     ws = torch.empty(int(_hip.lib().pnmn_embedding_grad_workspace_bytes(B, T, vocab)), dtype=torch.uint8, device=dy.device)
     _hip.check(_hip.lib().pnmn_embedding_grad(dy.data_ptr(), tokens.data_ptr(), tokens.stride(0), B, T, C, vocab, int(shift),
-                                              start, skip, dw.data_ptr(), ws.data_ptr(), _hip.stream_ptr(dy.device)),
+                                              start, skip, 0, dw.data_ptr(), ws.data_ptr(), _hip.stream_ptr(dy.device)),
                "embedding_grad")
     return dw
 

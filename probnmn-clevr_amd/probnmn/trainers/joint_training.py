@@ -106,6 +106,54 @@ class _TrainerBase(StepBase):
     # the backward passes of the generator's two decodes and the reconstructor's in ONE launch (False: pair + single -- A/B
     # aid and the reference point of tests/test_joint_gpu.py)
     group_decoder_backward = True
+    # the seq2seq passes of an iteration as a static launch plan (probnmn.runtime.seq_plan: one autograd node, no torch op in
+    # the passes) where the batch has supervised AND unsupervised rows and the models have the shapes the plan is built for;
+    # False, or anything else: the eager passes below (one autograd node per kernel -- the plan's reference in
+    # tests/test_seq_plan_gpu.py)
+    use_plan = os.environ.get("PNMN_SEQ_PLAN", "1") != "0"
+
+    def _plan(self, dev, n: int, m: int, tq: int, tp: int):
+        """The cached plan for this shape signature (None: not plannable -- remembered, so the check is paid once)."""
+        from probnmn.runtime.seq_plan import PlanUnsupported, Seq2SeqPlan
+
+        plans = self.__dict__.setdefault("_plans", {})
+        key = (dev.index, n, m, tq, tp, self.pg._max_decoding_steps)
+        plan = plans.get(key)
+        if plan is not None and plan is not False and not plan.still_valid():
+            plan = None
+        if plan is None:
+            try:
+                plan = Seq2SeqPlan(self.pg, self.qr, self.prior, dev, n, m, tq, tp)
+            except PlanUnsupported:
+                plan = False
+            if len(plans) > 8:  # (a run with many batch shapes: keep the workspaces of the recent ones only)
+                plans.pop(next(iter(plans)))
+            plans[key] = plan
+        return plan or None
+
+    def _planned_passes(self, plan, batch, sup_d, nosup_d, host_programs, after_sampling, before_prior, after_encode):
+        """``_seq2seq_passes`` of a batch with supervised and unsupervised rows through the launch plan: the same passes in
+        the same order on the same stream, the same callbacks at the same points."""
+        out = {"n_nosup": plan.n, "n_sup": plan.m}
+        plan.run_encoder(batch["question"], batch["program"], nosup_d, sup_d)
+        if after_encode is not None:
+            out["after_encode"] = after_encode()
+        z = plan.run_decoders()
+        # (z is the plan's buffer, rewritten by the next iteration: what the caller gets to keep is a copy)
+        out["programs"] = z.clone()
+        if host_programs:
+            out["programs_host"] = self._host_copy(z)
+        if after_sampling is not None:
+            out["after_sampling"] = after_sampling()
+        plan.run_generator_finish()
+        plan.run_reconstructor()
+        if before_prior is not None:
+            out["before_prior"] = before_prior(out["programs_host"])
+        out["prior"] = plan.run_prior()
+        loss_s, loss_t, loss_q = plan.losses()
+        out["pg"] = {"loss": loss_s, "predictions": out["programs"]}
+        out["pg_sup_rows"], out["qr_rows"] = loss_t, loss_q
+        return out
 
     def _make_optimizer(self, models, lr, weight_decay):
         arenas = []
@@ -183,6 +231,11 @@ class _TrainerBase(StepBase):
             out["n_nosup"], out["n_sup"] = 0, 0
             return out
         question = batch["question"]
+        if (self.use_plan and n_sup and n_nosup and prior and reconstruct and dev.type == "cuda" and torch.is_grad_enabled()
+                and self.pg.training and self.qr.training and batch["program"].device == dev):
+            plan = self._plan(dev, n_nosup, n_sup, int(question.size(1)), int(batch["program"].size(1)))
+            if plan is not None:
+                return self._planned_passes(plan, batch, sup_d, nosup_d, host_programs, after_sampling, before_prior, after_encode)
         ques_both = None
         if n_sup:
             program = batch["program"].to(dev)
