@@ -173,7 +173,6 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
 
 __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][OP_FLOATS] = 72 KB: two workgroups per CU
-    __shared__ int last_flag;
     int pi = 0;
     while (pi + 1 < batch.n && (int)blockIdx.x >= batch.first[pi + 1]) ++pi;
     const pnmn_gemm_desc d = batch.d[pi];  // (into scalar registers: the kernel argument segment is read once)
@@ -223,59 +222,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     ws[(64 * wm + 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3)) * TN + 64 * wn + 32 * nt + i] = acc[mt][nt][r];
-        __threadfence();   // partials visible device-wide before the arrival is counted
-        __syncthreads();
-        int* counter = reinterpret_cast<int*>(d.workspace + (size_t)tiles_m * tiles_n * split * (TM * TN)) + tile;
-        if (tid == 0) {
-            const int old = atomicAdd(counter, 1);
-            last_flag = old == split - 1;
-            if (last_flag) *counter = 0;  // (ready for the next launch on this workspace: launches are stream-ordered)
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        __threadfence();   // acquire: the other chunks' partials
-        // The tile is row-major in the workspace: thread t sums the 16-byte pieces t + 256 j of every chunk (sixteen loads
-        // in flight per chunk, chunk order: the same sum whichever chunk arrived last) and stores them as they lie.
-        const gfloat* wt = as_global(d.workspace) + (size_t)tile * split * (TM * TN);
-        f32x4 sum[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < split; ++c) {
-            const gfloat* wc = wt + (size_t)c * (TM * TN);
-            f32x4 v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const pnmn::gf32x4*>(wc) + tid + 256 * j);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sum[j] += v[j];
-        }
-        gfloat* C = as_global(d.c);
-        const gfloat* bias = as_global(d.bias);
-        const bool accumulate = (d.flags & PNMN_GEMM_ACCUMULATE) != 0;
-        const bool cvec = (d.ldc & 3) == 0 && ((uintptr_t)d.c & 15) == 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = tid + 256 * j, row = m0 + (p >> 5), col = n0 + 4 * (p & 31);
-            if (row >= d.M || col >= d.N) continue;
-            gfloat* dst = C + (int64_t)row * d.ldc + col;
-            f32x4 v = sum[j];
-            if (cvec && col + 3 < d.N) {
-                if (d.bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bias[col + e];
-                }
-                if (accumulate) v += pnmn::load4(dst);
-                pnmn::store4(dst, v);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (col + e < d.N) {
-                        float x = v[e] + (d.bias ? bias[col + e] : 0.f);
-                        if (accumulate) x += dst[e];
-                        dst[e] = x;
-                    }
-            }
-        }
-        return;
+        return;  // (gemm_reduce_kernel, launched behind this one, adds the chunks up in chunk order)
     }
     gfloat* C = as_global(d.c);
     const gfloat* bias = as_global(d.bias);
@@ -300,28 +247,85 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
     }
 }
 
+// Second launch of a split-K batch: every output tile's partial tiles added in chunk order (deterministic; the kernel
+// boundary is what makes the partials visible -- a fence + "last chunk reduces" inside the product kernel cost an L2
+// write-back per workgroup, 150 us for a 3 GFLOP weight gradient).  Block = a quarter tile (32 rows x 128 columns).
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const Batch batch) {
+    int pi = 0;
+    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.first[pi + 1]) ++pi;
+    const pnmn_gemm_desc d = batch.d[pi];
+    const int local = blockIdx.x - batch.first[pi];
+    const int tiles_n = (d.N + TN - 1) / TN;
+    const int quarter = local & 3, tile = local >> 2;
+    const int m0 = (tile / tiles_n) * TM + 32 * quarter, n0 = (tile % tiles_n) * TN;
+    const int split = d.split_k, tid = threadIdx.x;
+    const gfloat* wt = as_global(d.workspace) + (size_t)tile * split * (TM * TN) + quarter * (32 * TN);
+    f32x4 sum[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < split; ++c) {
+        const gfloat* wc = wt + (size_t)c * (TM * TN);
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pnmn::load4(wc + 4 * (tid + 256 * j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += v[j];
+    }
+    gfloat* C = as_global(d.c);
+    const gfloat* bias = as_global(d.bias);
+    const bool accumulate = (d.flags & PNMN_GEMM_ACCUMULATE) != 0;
+    const bool cvec = (d.ldc & 3) == 0 && ((uintptr_t)d.c & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = tid + 256 * j, row = m0 + (p >> 5), col = n0 + 4 * (p & 31);
+        if (row >= d.M || col >= d.N) continue;
+        gfloat* dst = C + (int64_t)row * d.ldc + col;
+        f32x4 v = sum[j];
+        if (cvec && col + 3 < d.N) {
+            if (d.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bias[col + e];
+            }
+            if (accumulate) v += pnmn::load4(dst);
+            pnmn::store4(dst, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < d.N) {
+                    float x = v[e] + (d.bias ? bias[col + e] : 0.f);
+                    if (accumulate) x += dst[e];
+                    dst[e] = x;
+                }
+        }
+    }
+}
+
 // column sums of a row-major [R][C] matrix: out[c] = sum_r x[r][c] (optionally also written to out2; bias gradients of an
-// LSTM layer: b_ih and b_hh receive the same).  grid (C / 256 column blocks, slices of rows) -> partials -> last slice sums.
+// LSTM layer: b_ih and b_hh receive the same).  grid (C / 64 column blocks, slices of rows); a workgroup = 64 columns x 4
+// row phases (256-byte row segments, four rows in flight per wave), partials -> the last slice of a column block sums them
+// in slice order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int R, int C, float* __restrict__ partial,
                                                      int* __restrict__ counter, float* __restrict__ out, float* __restrict__ out2,
                                                      int accumulate) {
     __shared__ int last_flag;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     const int slices = gridDim.y, s = blockIdx.y;
     const int per = (R + slices - 1) / slices;
     const int r0 = s * per, r1 = min(R, r0 + per);
-    float sum = 0.f;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
-        int r = r0;
-        for (; r + 3 < r1; r += 4) {
+        int r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[e] += x[(int64_t)(r + e) * ld + c];
+            for (int e = 0; e < 4; ++e) part[e] += x[(int64_t)(r + 4 * e) * ld + c];
         }
-        for (; r < r1; ++r) part[0] += x[(int64_t)r * ld + c];
-        sum = (part[0] + part[1]) + (part[2] + part[3]);
-        partial[(size_t)s * C + c] = sum;
+        for (; r < r1; r += 4) part[0] += x[(int64_t)r * ld + c];
     }
+    red[ty][tx] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+    if (ty == 0 && c < C) partial[(size_t)s * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         if (last_flag) counter[blockIdx.x] = 0;
     }
     __syncthreads();
-    if (!last_flag || c >= C) return;
+    if (!last_flag || ty != 0 || c >= C) return;
     __threadfence();
     float total = 0.f;
     for (int k = 0; k < slices; ++k) total += __builtin_nontemporal_load(partial + (size_t)k * C + c);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 extern "C" int64_t pnmn_gemm_workspace_bytes(int M, int N, int split_k) {
     if (split_k <= 1) return 0;
     const int64_t tiles = (int64_t)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    return tiles * split_k * (TM * TN) * (int64_t)sizeof(float) + tiles * (int64_t)sizeof(int);
+    return tiles * split_k * (TM * TN) * (int64_t)sizeof(float);
 }
 
 extern "C" int pnmn_gemm_split_k(int M, int N, int K, int cus) {
@@ -384,24 +388,39 @@ extern "C" int pnmn_gemm(const pnmn_gemm_desc* descs, int n, void* stream) {
     static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
     if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(gemm_kernel), lds, cfg)) return e;
     hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), lds, static_cast<hipStream_t>(stream), b);
+    // the split problems' reduction: four blocks per output tile
+    Batch r;
+    int rblocks = 0, rlive = 0;
+    for (int k = 0; k < live; ++k) {
+        if (b.d[k].split_k <= 1) continue;
+        r.d[rlive] = b.d[k];
+        r.first[rlive] = rblocks;
+        rblocks += 4 * ((b.d[k].M + TM - 1) / TM) * ((b.d[k].N + TN - 1) / TN);
+        ++rlive;
+    }
+    if (rlive) {
+        r.first[rlive] = rblocks;
+        r.n = rlive;
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3(rblocks), dim3(256), 0, static_cast<hipStream_t>(stream), r);
+    }
     return (int)hipGetLastError();
 }
 
 extern "C" int64_t pnmn_colsum_workspace_bytes(int R, int C) {
     (void)R;
-    return (int64_t)64 * C * sizeof(float) + (int64_t)((C + 255) / 256) * sizeof(int);
+    return (int64_t)64 * C * sizeof(float) + (int64_t)((C + 63) / 64) * sizeof(int);
 }
 
 extern "C" int pnmn_colsum(const float* x, int64_t ld, int R, int C, float* out, float* out2, int accumulate, void* workspace,
                            void* stream) {
     if (C <= 0) return 0;
     if (!out || !workspace || (R > 0 && !x)) return PNMN_EINVAL;
-    int slices = (R + 127) / 128;
+    int slices = (R + 63) / 64;
     if (slices > 64) slices = 64;
     if (slices < 1) slices = 1;
     float* partial = static_cast<float*>(workspace);
     int* counter = reinterpret_cast<int*>(partial + (size_t)64 * C);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, R, C,
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, R, C,
                        partial, counter, out, out2, accumulate);
     return (int)hipGetLastError();
 }

@@ -32,6 +32,10 @@ import torch
 from probnmn import _hip
 
 
+#: workgroups a launch of split-K products is cut for (256 CUs, the 72 KB tiles of pnmn_gemm sit two to a CU)
+SPLIT_TARGET_WORKGROUPS = 384
+
+
 class PlanUnsupported(Exception):
     """The models / shapes are outside what the plan is built for: the trainer keeps the eager passes."""
 
@@ -136,6 +140,12 @@ class Seq2SeqPlan:
         for lo in range(0, len(descs), _hip.GEMM_MAX):
             part = descs[lo:lo + _hip.GEMM_MAX]
             rec = np.zeros(len(part), _hip.GEMM_DESC)
+            # split-K of the problems that ask for it ("auto"), chosen for the LAUNCH: the problems of one launch share the
+            # chip, so the chunk count that brings the launch's workgroups to one or two per CU -- every chunk writes a
+            # 64 KB partial tile and the last one reads them all back, which at 32 chunks per tile cost more than the products
+            tiles = [((d["M"] + 127) // 128) * ((d["N"] + 127) // 128) for d in part]
+            ktiles = [(d["K"] + 31) // 32 for d in part]
+            total = sum(tiles)
             for i, d in enumerate(part):
                 r = rec[i]
                 r["a"], r["b"], r["c"] = d["a"], d["b"], d["c"]
@@ -145,7 +155,7 @@ class Seq2SeqPlan:
                 r["bias"] = d.get("bias", 0)
                 split = d.get("split", 1)
                 if split == "auto":
-                    split = int(lib.pnmn_gemm_split_k(d["M"], d["N"], d["K"], 256))
+                    split = max(1, min(-(-SPLIT_TARGET_WORKGROUPS // total), ktiles[i] // 8, 64))
                 r["split_k"] = split
                 if split > 1:
                     ws = self.bytes_buf("%s.ws%d" % (name, lo + i), lib.pnmn_gemm_workspace_bytes(d["M"], d["N"], split), zero=True)
@@ -203,7 +213,7 @@ class Seq2SeqPlan:
         calls.add("pnmn_lstm_seq_bwd", dhs2.data_ptr(), e["act2"].data_ptr(), e["cs2"].data_ptr(), derived["l1.hhT"].data_ptr(),
                   dg2.data_ptr(), rows, T, 256, ws.data_ptr(), st)
         self._gemm(calls, tag + ".dx", [dict(a=dg2.data_ptr(), b=lstm.weight_ih_l1.data_ptr(), c=dhs1.data_ptr(), M=rows * T, N=256,
-                                              K=1024, lda=1024, ldb=256, ldc=256)])
+                                              K=1024, lda=1024, ldb=256, ldc=256, split="auto")])
         calls.add("pnmn_lstm_seq_bwd", dhs1.data_ptr(), e["act1"].data_ptr(), e["cs1"].data_ptr(), derived["l0.hhT"].data_ptr(),
                   dg1.data_ptr(), rows, T, 256, ws.data_ptr(), st)
         calls.add("pnmn_embedding_grad", dg1.data_ptr(), e["src"].data_ptr(), e["src"].stride(0), rows, T, 1024, V, 0, 0, -1, 0,

@@ -147,10 +147,14 @@ class _TrainerBase(StepBase):
             out["after_sampling"] = after_sampling()
         plan.run_generator_finish()
         plan.run_reconstructor()
+        # The plan's autograd node is created HERE, before the trunk is launched: autograd runs later-created nodes first, so
+        # backward issues the NMN head, then the trunk's backward (the iteration's longest chain, on its own stream), then this
+        # node's launch list -- created after the trunk's node it held the trunk's backward up by the ~0.5 ms of host time its
+        # own replay takes (profiles/r06d_b128_timeline.txt: trunk backward 1.6 ms behind the objective).
+        loss_s, loss_t, loss_q = plan.losses()
         if before_prior is not None:
             out["before_prior"] = before_prior(out["programs_host"])
         out["prior"] = plan.run_prior()
-        loss_s, loss_t, loss_q = plan.losses()
         out["pg"] = {"loss": loss_s, "predictions": out["programs"]}
         out["pg_sup_rows"], out["qr_rows"] = loss_t, loss_q
         return out

@@ -136,13 +136,12 @@ def test_colsum(R, C):
 def test_rate_report(capsys):
     """Not an assertion on speed (boxes differ): prints TFLOP/s of the shapes the seq2seq plan launches."""
     shapes = [("xp2 b1024", 47104, 1024, 256, 0, 1, 1), ("xp2 b128", 5888, 1024, 256, 0, 1, 1), ("dx b1024", 47104, 256, 1024, 0, 0, 1),
-              ("wgrad b1024", 1024, 256, 47104, 1, 0, 32), ("wgrad b128", 1024, 256, 5888, 1, 0, 32), ("logits b1024", 47104, 93, 256, 0, 1, 1)]
+              ("logits b1024", 47104, 93, 256, 0, 1, 1), ("dx b128", 5888, 256, 1024, 0, 0, 3)] \
+        + [("wgrad b1024", 1024, 256, 47104, 1, 0, s) for s in (4, 16, 32)] + [("wgrad b128", 1024, 256, 5888, 1, 0, s) for s in (1, 2, 4, 8, 16, 32)]
     for name, M, N, K, ta, tb, split in shapes:
         A = torch.randn((K, M) if ta else (M, K), device="cuda:0")
         B = torch.randn((N, K) if tb else (K, N), device="cuda:0")
         C = torch.empty(M, N, device="cuda:0")
-        if split > 1:
-            split = int(_hip.lib().pnmn_gemm_split_k(M, N, K, 256))
         ws = _ws(M, N, split)
         d = _desc(A, B, C, M, N, K, flags=ta * _hip.GEMM_A_T + tb * _hip.GEMM_B_T, split=split, ws=ws)
         st = _hip.stream_ptr(A.device)
