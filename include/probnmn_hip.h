@@ -750,6 +750,38 @@ int pnmn_conv2d_weight_floats(int Cout, int Cin, int kh, int kw);
 int pnmn_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Several LSTM-layer passes in ONE launch; the two layers of an encoder as a wavefront (csrc/lstm_stack.hip).
+ * Replaces: the stacked nn.LSTM of the seq2seq encoders and of ProgramPrior under autograd
+ *           (probnmn/modules/seq2seq_base.py:56-60 via allennlp PytorchSeq2SeqWrapper; probnmn/models/program_prior.py:50-56),
+ *           i.e. pnmn_lstm_seq_fwd + the input-projection GEMM + pnmn_lstm_seq_fwd per encoder (and the same backward).
+ * A job = one layer over [B][T] (hidden 256).  dep < 0: the layer's step inputs / output gradients are given (`xp` + `tokens`
+ * as pnmn_lstm_seq_fwd; `dhs` as pnmn_lstm_seq_bwd).  dep >= 0, forward: the layer ABOVE job `dep` -- its input is that
+ * job's `hs`, projected in the kernel with `w_ih` (fragment order of W_ih [4H][H]) and `bias` (b_ih + b_hh); backward: the
+ * layer BELOW job `dep` -- its output gradient is that job's dgates times `w_ih` (fragment order of W_ih^T, i.e. of the
+ * matrix [H][4H]).  A job has at most one dependant, chains are two long, linked jobs have equal B and T.  `w_hh`:
+ * fragment order of W_hh (forward) / of W_hh^T (backward), as pnmn_lstm_seq_*.  All jobs' workgroups (8 per 16 rows) must
+ * be resident at once: pnmn_lstm_stack_workspace_bytes returns 0 when they are not (use the per-layer entry points).
+ * ------------------------------------------------------------------------------------------- */
+#define PNMN_LSTM_STACK_JOBS 6
+typedef struct pnmn_lstm_stack_job {
+    const float*   xp;            /* forward, dep < 0 */
+    const int64_t* tokens;
+    int64_t        token_stride;
+    const float*   w_hh;
+    const float*   w_ih;          /* dep >= 0 */
+    const float*   bias;          /* forward, dep >= 0 */
+    float*         hs;            /* forward out */
+    float*         cs;            /* forward out, backward in */
+    float*         act;           /* forward out, backward in */
+    const float*   dhs;           /* backward, dep < 0 */
+    float*         dgates;        /* backward out */
+    int32_t        B, T, dep, reserved;
+} pnmn_lstm_stack_job;            /* 104 bytes */
+int64_t pnmn_lstm_stack_workspace_bytes(const pnmn_lstm_stack_job* jobs /* HOST */, int n, int backward);
+int pnmn_lstm_stack_fwd(const pnmn_lstm_stack_job* jobs /* HOST */, int n, void* workspace, void* stream);
+int pnmn_lstm_stack_bwd(const pnmn_lstm_stack_job* jobs /* HOST */, int n, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * fp32 GEMM, up to PNMN_GEMM_MAX independent problems per launch (csrc/gemm.hip).
  * Replaces: every product over all time steps that the reference reaches through nn.LSTM / nn.Linear / autograd in
  *           the seq2seq models (probnmn/modules/seq2seq_base.py:101-155 via allennlp's SimpleSeq2Seq: encoder input

@@ -109,6 +109,9 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_plan_batch": (_P, _P, ctypes.c_int64, _P, _P, _I),
     "pnmn_compile_programs": (_P, _I, _I, _P, _I, _I, _P, _P, _P, _P),
     "pnmn_sample_tokens": (_P, _P, _P, _I, _I, _I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, _I, _I, _I, _P),
+    "pnmn_lstm_stack_workspace_bytes": (_P, _I, _I),
+    "pnmn_lstm_stack_fwd": (_P, _I, _P, _P),
+    "pnmn_lstm_stack_bwd": (_P, _I, _P, _P),
     "pnmn_gemm": (_P, _I, _P),
     "pnmn_gemm_workspace_bytes": (_I, _I, _I),
     "pnmn_gemm_split_k": (_I, _I, _I, _I),
@@ -253,6 +256,9 @@ GEMM_DESC = np.dtype([(n, _u64) for n in ("a", "b", "c", "bias")] + [(n, np.int6
                      + [(n, _i32) for n in ("M", "N", "K", "flags", "split_k", "shift_t")]
                      + [("shift_h0", _u64), ("ld_h0", np.int64), ("workspace", _u64)])  # pnmn_gemm_desc
 GEMM_MAX, GEMM_A_T, GEMM_B_T, GEMM_ACC = 8, 1, 2, 4
+LSTM_STACK_JOB = np.dtype([("xp", _u64), ("tokens", _u64), ("token_stride", np.int64)] + [(n, _u64) for n in ("w_hh", "w_ih", "bias", "hs", "cs", "act", "dhs", "dgates")]
+                          + [(n, _i32) for n in ("B", "T", "dep", "reserved")])  # pnmn_lstm_stack_job
+LSTM_STACK_JOBS = 6
 TOKEN_SEG = np.dtype([("src", _u64), ("index", _u64), ("row_stride", np.int64), ("rows", _i32), ("width", _i32)])  # pnmn_token_seg
 EINVAL, ESHAPE, EAGAIN = -1, -2, -3  # PNMN_EINVAL / PNMN_ESHAPE / PNMN_EAGAIN
 ADAM_ITEM = np.dtype([("param", _u64), ("grad", _u64), ("exp_avg", _u64), ("exp_avg_sq", _u64), ("n", np.int64),
@@ -313,6 +319,7 @@ ITEM_SIZES = {
     "pnmn_trunk_io": (TRUNK_IO, 224),
     "pnmn_gemm_desc": (GEMM_DESC, 104),
     "pnmn_token_seg": (TOKEN_SEG, 32),
+    "pnmn_lstm_stack_job": (LSTM_STACK_JOB, 104),
 }
 
 
