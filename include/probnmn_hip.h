@@ -815,6 +815,9 @@ typedef struct pnmn_gemm_desc {
     float*       workspace; /* split_k > 1 */
 } pnmn_gemm_desc;
 int pnmn_gemm(const pnmn_gemm_desc* descs /* HOST array */, int n, void* stream);
+/* ... with at most `max_workgroups` workgroups (0 = one per tile): a launch that shares the chip with another stream's
+ * dependent chain of kernels (the NMN trunk beside the seq2seq passes) and must not take every CU from it. */
+int pnmn_gemm_cus(const pnmn_gemm_desc* descs /* HOST array */, int n, int max_workgroups, void* stream);
 int64_t pnmn_gemm_workspace_bytes(int M, int N, int split_k);
 int pnmn_gemm_split_k(int M, int N, int K, int cus);
 

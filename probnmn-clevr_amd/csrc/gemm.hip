@@ -173,10 +173,13 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
 
 __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][OP_FLOATS] = 72 KB: two workgroups per CU
+    // (a launch cut for fewer workgroups than it has units -- pnmn_gemm_cus: products that share the chip with another
+    // stream's latency chain -- walks them; the LDS buffers are free again behind the last barrier of contract())
+    for (int unit = blockIdx.x; unit < batch.first[batch.n]; unit += gridDim.x) {
     int pi = 0;
-    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.first[pi + 1]) ++pi;
+    while (pi + 1 < batch.n && unit >= batch.first[pi + 1]) ++pi;
     const pnmn_gemm_desc d = batch.d[pi];  // (into scalar registers: the kernel argument segment is read once)
-    const int local = blockIdx.x - batch.first[pi];
+    const int local = unit - batch.first[pi];
     const int tiles_n = (d.N + TN - 1) / TN, tiles_m = (d.M + TM - 1) / TM;
     const int split = d.split_k > 1 ? d.split_k : 1;
     // chunk fastest: the chunks of one output tile run together and the last one finds the others' partials in L2
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     ws[(64 * wm + 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3)) * TN + 64 * wn + 32 * nt + i] = acc[mt][nt][r];
-        return;  // (gemm_reduce_kernel, launched behind this one, adds the chunks up in chunk order)
+        continue;  // (gemm_reduce_kernel, launched behind this one, adds the chunks up in chunk order)
     }
     gfloat* C = as_global(d.c);
     const gfloat* bias = as_global(d.bias);
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
                     *dst = v;
                 }
             }
+    }
     }
 }
 
@@ -364,7 +368,9 @@ extern "C" int pnmn_gemm_split_k(int M, int N, int K, int cus) {
     return want < 1 ? 1 : (int)want;
 }
 
-extern "C" int pnmn_gemm(const pnmn_gemm_desc* descs, int n, void* stream) {
+extern "C" int pnmn_gemm(const pnmn_gemm_desc* descs, int n, void* stream) { return pnmn_gemm_cus(descs, n, 0, stream); }
+
+extern "C" int pnmn_gemm_cus(const pnmn_gemm_desc* descs, int n, int max_workgroups, void* stream) {
     if (n <= 0) return 0;
     if (!descs || n > PNMN_GEMM_MAX) return PNMN_EINVAL;
     Batch b;
@@ -387,7 +393,8 @@ extern "C" int pnmn_gemm(const pnmn_gemm_desc* descs, int n, void* stream) {
     constexpr size_t lds = (size_t)4 * OP_FLOATS * sizeof(float);
     static std::atomic<uint64_t> cfg{0};  // (per device: lds_optin.h)
     if (const int e = pnmn::opt_in_lds(reinterpret_cast<const void*>(gemm_kernel), lds, cfg)) return e;
-    hipLaunchKernelGGL(gemm_kernel, dim3(blocks), dim3(256), lds, static_cast<hipStream_t>(stream), b);
+    const int grid = (max_workgroups > 0 && max_workgroups < blocks) ? max_workgroups : blocks;
+    hipLaunchKernelGGL(gemm_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), b);
     // the split problems' reduction: four blocks per output tile
     Batch r;
     int rblocks = 0, rlive = 0;

@@ -113,6 +113,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_lstm_stack_fwd": (_P, _I, _P, _P),
     "pnmn_lstm_stack_bwd": (_P, _I, _P, _P),
     "pnmn_gemm": (_P, _I, _P),
+    "pnmn_gemm_cus": (_P, _I, _I, _P),
     "pnmn_gemm_workspace_bytes": (_I, _I, _I),
     "pnmn_gemm_split_k": (_I, _I, _I, _I),
     "pnmn_colsum": (_P, ctypes.c_int64, _I, _I, _P, _P, _I, _P, _P),

@@ -897,13 +897,18 @@ def lstm_derived_specs(lstm: nn.LSTM, prefix: str = "l"):
         specs.append(("%s%d.hh" % (prefix, layer), "pack", w_hh, None))
         specs.append(("%s%d.hhT" % (prefix, layer), "packT", w_hh, None))
         specs.append(("%s%d.b" % (prefix, layer), "sum", getattr(lstm, "bias_ih_l%d" % layer), getattr(lstm, "bias_hh_l%d" % layer)))
+        if layer > 0 and lstm.input_size == lstm.hidden_size == 256:
+            # the wavefront launches (pnmn_lstm_stack_*) keep a slice of the upper layers' input weights in registers too
+            w_ih = getattr(lstm, "weight_ih_l%d" % layer)
+            specs.append(("%s%d.ih" % (prefix, layer), "pack", w_ih, None))
+            specs.append(("%s%d.ihT" % (prefix, layer), "packT", w_ih, None))
     return specs
 
 
 def lstm_derived_params(lstm: nn.LSTM):
     """The parameters ``lstm_derived_specs`` reads (cache key of ``DerivedParams.get``)."""
     return [getattr(lstm, "%s_l%d" % (n, layer)) for layer in range(lstm.num_layers)
-            for n in ("weight_hh", "bias_ih", "bias_hh")]
+            for n in ("weight_hh", "bias_ih", "bias_hh") + (("weight_ih",) if layer > 0 else ())]
 
 
 _SLOW_PATHS_NOTED = set()

@@ -34,6 +34,19 @@ from probnmn import _hip
 
 #: workgroups a launch of split-K products is cut for (256 CUs, the 72 KB tiles of pnmn_gemm sit two to a CU)
 SPLIT_TARGET_WORKGROUPS = 384
+#: an encoder's two LSTM layers as a wavefront, independent encoder passes in one launch (pnmn_lstm_stack_*); False: a launch
+#: per layer with the input projection as a GEMM in between (A/B aid, and what batches too large for the chip fall back to)
+USE_STACK = True
+#: encoder passes per wavefront launch, forward / backward (0: a launch per layer), and decoder passes per backward launch --
+#: A/B aids (env PNMN_PLAN_FWD_ENC / PNMN_PLAN_BWD_ENC / PNMN_PLAN_DEC_GROUP); the defaults are what measured best beside
+#: the NMN trunk at 128 questions (DESIGN 5 "Round 6")
+import os as _os
+STACK_FWD_ENCODERS = int(_os.environ.get("PNMN_PLAN_FWD_ENC", "2"))
+STACK_PG_ENCODER = int(_os.environ.get("PNMN_PLAN_PG_ENC", "1"))
+STACK_BWD_ENCODERS = int(_os.environ.get("PNMN_PLAN_BWD_ENC", "0"))
+DECODER_BWD_GROUP = int(_os.environ.get("PNMN_PLAN_DEC_GROUP", "3"))
+#: workgroups a GEMM launch of the plan may occupy (0: one per tile)
+GEMM_WORKGROUPS = int(_os.environ.get("PNMN_PLAN_GEMM_WGS", "0"))
 
 
 class PlanUnsupported(Exception):
@@ -162,77 +175,144 @@ class Seq2SeqPlan:
                     r["workspace"] = ws.data_ptr()
                 r["shift_t"], r["shift_h0"], r["ld_h0"] = d.get("shift_t", 0), d.get("h0", 0), d.get("ld_h0", 0)
             self._keep.append(rec)
-            calls.add("pnmn_gemm", rec.ctypes.data, len(rec), self.stream)
+            calls.add("pnmn_gemm_cus", rec.ctypes.data, len(rec), GEMM_WORKGROUPS, self.stream)
 
-    def _encoder_fwd(self, calls: _Calls, tag: str, mm: _Model, derived, tokens: torch.Tensor, width: int, rows: int,
-                     drop_first: bool, emb: torch.Tensor, pad_idx: int, lstm, want_last: bool = True) -> Dict[str, torch.Tensor]:
-        """token_prep -> per-token table -> layer 1 -> input projection of layer 2 -> layer 2 [-> mask + last state]."""
-        lib, st = _hip.lib(), self.stream
+    def _encoder_prepare(self, calls: _Calls, tag: str, mm: Optional[_Model], derived, tokens: torch.Tensor, width: int, rows: int,
+                         drop_first: bool, emb: torch.Tensor, pad_idx, lstm, want_last: bool = True) -> Dict:
+        """Buffers of one encoder pass + what precedes its recurrence: token_prep and the per-token table of layer 1."""
+        st = self.stream
         model = mm.model if mm is not None else self.prior
         pad, bos, eos = model._pad_index, model._start_index, model._end_index
         T = width + 2 - int(drop_first)
         V = emb.size(0)
         f = self.buf
-        src, fmask, last = f(tag + ".src", rows, T, dtype=torch.long), f(tag + ".fmask", rows, T), f(tag + ".last", rows, dtype=torch.int32)
-        table = f(tag + ".table", V, 1024)
-        hs1, cs1, act1 = f(tag + ".hs1", rows, T, 256), f(tag + ".cs1", rows, T, 256), f(tag + ".act1", rows, T, 1024)
-        xp2 = f(tag + ".xp2", rows, T, 1024)
-        hs2, cs2, act2 = f(tag + ".hs2", rows, T, 256), f(tag + ".cs2", rows, T, 256), f(tag + ".act2", rows, T, 1024)
-        ws = self.bytes_buf(tag + ".lstm_ws", lib.pnmn_lstm_seq_workspace_bytes(rows, 0))
-        calls.add("pnmn_token_prep", tokens.data_ptr(), tokens.stride(0), rows, width, pad, bos, eos, int(drop_first), src.data_ptr(),
-                  fmask.data_ptr(), last.data_ptr(), st)
+        e = dict(tag=tag, mm=mm, derived=derived, lstm=lstm, T=T, rows=rows, V=V, pad_idx=-1 if pad_idx is None else pad_idx, emb=emb,
+                 want_last=want_last,
+                 src=f(tag + ".src", rows, T, dtype=torch.long), fmask=f(tag + ".fmask", rows, T), last=f(tag + ".last", rows, dtype=torch.int32),
+                 table=f(tag + ".table", V, 1024), hs1=f(tag + ".hs1", rows, T, 256), cs1=f(tag + ".cs1", rows, T, 256),
+                 act1=f(tag + ".act1", rows, T, 1024), hs2=f(tag + ".hs2", rows, T, 256), cs2=f(tag + ".cs2", rows, T, 256),
+                 act2=f(tag + ".act2", rows, T, 1024))
+        calls.add("pnmn_token_prep", tokens.data_ptr(), tokens.stride(0), rows, width, pad, bos, eos, int(drop_first), e["src"].data_ptr(),
+                  e["fmask"].data_ptr(), e["last"].data_ptr(), st)
         calls.add("pnmn_token_table_fwd", emb.data_ptr(), lstm.weight_ih_l0.data_ptr(), lstm.weight_ih_l0.stride(0),
-                  derived["l0.b"].data_ptr(), V, 256, 1024, table.data_ptr(), st)
-        calls.add("pnmn_lstm_seq_fwd", table.data_ptr(), src.data_ptr(), src.stride(0), derived["l0.hh"].data_ptr(), hs1.data_ptr(),
-                  cs1.data_ptr(), act1.data_ptr(), rows, T, 256, ws.data_ptr(), st)
-        self._gemm(calls, tag + ".xp2g", [dict(a=hs1.data_ptr(), b=lstm.weight_ih_l1.data_ptr(), c=xp2.data_ptr(), M=rows * T, N=1024,
-                                                K=256, lda=256, ldb=256, ldc=1024, tb=1, bias=derived["l1.b"].data_ptr())])
-        calls.add("pnmn_lstm_seq_fwd", xp2.data_ptr(), None, 0, derived["l1.hh"].data_ptr(), hs2.data_ptr(), cs2.data_ptr(),
-                  act2.data_ptr(), rows, T, 256, ws.data_ptr(), st)
-        out = dict(src=src, fmask=fmask, last=last, table=table, hs1=hs1, cs1=cs1, act1=act1, hs2=hs2, cs2=cs2, act2=act2, T=T,
-                   rows=rows, V=V, pad_idx=pad_idx, emb=emb)
+                  derived["l0.b"].data_ptr(), V, 256, 1024, e["table"].data_ptr(), st)
         if want_last:
-            enc, h = f(tag + ".enc", rows, T, 256), f(tag + ".h", rows, 256)
-            calls.add("pnmn_mask_last_fwd", hs2.data_ptr(), fmask.data_ptr(), last.data_ptr(), rows, T, 256, enc.data_ptr(), h.data_ptr(), st)
-            out.update(enc=enc, h=h)
-        return out
+            e["enc"], e["h"] = f(tag + ".enc", rows, T, 256), f(tag + ".h", rows, 256)
+        return e
 
-    def _encoder_bwd(self, calls: _Calls, deferred: List, tag: str, mm: _Model, derived, e, denc: torch.Tensor, dh: torch.Tensor) -> None:
+    def _stack_jobs(self, encs: List[Dict], backward: bool) -> np.ndarray:
+        jobs = np.zeros(2 * len(encs), _hip.LSTM_STACK_JOB)
+        for k, e in enumerate(encs):
+            d = e["derived"]
+            if not backward:
+                a, b = jobs[2 * k], jobs[2 * k + 1]
+                a["xp"], a["tokens"], a["token_stride"], a["w_hh"] = e["table"].data_ptr(), e["src"].data_ptr(), e["src"].stride(0), d["l0.hh"].data_ptr()
+                a["hs"], a["cs"], a["act"], a["dep"] = e["hs1"].data_ptr(), e["cs1"].data_ptr(), e["act1"].data_ptr(), -1
+                b["w_hh"], b["w_ih"], b["bias"] = d["l1.hh"].data_ptr(), d["l1.ih"].data_ptr(), d["l1.b"].data_ptr()
+                b["hs"], b["cs"], b["act"], b["dep"] = e["hs2"].data_ptr(), e["cs2"].data_ptr(), e["act2"].data_ptr(), 2 * k
+            else:  # layer 2 first (top), layer 1 below it
+                a, b = jobs[2 * k], jobs[2 * k + 1]
+                a["dhs"], a["act"], a["cs"], a["w_hh"], a["dgates"], a["dep"] = (e["dhs2"].data_ptr(), e["act2"].data_ptr(), e["cs2"].data_ptr(),
+                                                                                 d["l1.hhT"].data_ptr(), e["dg2"].data_ptr(), -1)
+                b["act"], b["cs"], b["w_hh"], b["w_ih"], b["dgates"], b["dep"] = (e["act1"].data_ptr(), e["cs1"].data_ptr(), d["l0.hhT"].data_ptr(),
+                                                                                 d["l1.ihT"].data_ptr(), e["dg1"].data_ptr(), 2 * k)
+            for j in (a, b):
+                j["B"], j["T"] = e["rows"], e["T"]
+        return jobs
+
+    def _stack_launches(self, calls: _Calls, name: str, encs: List[Dict], backward: bool, most: Optional[int] = None) -> List[Dict]:
+        """The recurrences of several encoder passes as wavefront launches: all of them in one launch when their workgroups
+        fit the chip together, else greedily as many as fit per launch; returns the encoders no stack launch takes (their
+        layers go out one by one)."""
+        lib, left, group = _hip.lib(), [], []
+        if most is None:
+            most = STACK_BWD_ENCODERS if backward else STACK_FWD_ENCODERS
+        use = USE_STACK and most > 0 and all("l1.ih" in e["derived"] for e in encs)
+
+        def flush():
+            if not group:
+                return
+            jobs = self._stack_jobs(group, backward)
+            ws = self.bytes_buf("%s.stack_ws%d" % (name, len(self._keep)), lib.pnmn_lstm_stack_workspace_bytes(jobs.ctypes.data, len(jobs), int(backward)))
+            self._keep.append(jobs)
+            calls.add("pnmn_lstm_stack_bwd" if backward else "pnmn_lstm_stack_fwd", jobs.ctypes.data, len(jobs), ws.data_ptr(), self.stream)
+            del group[:]
+
+        for e in encs:
+            if not use:
+                left.append(e)
+                continue
+            trial = self._stack_jobs(group + [e], backward)
+            if len(group) < most and 2 * (len(group) + 1) <= _hip.LSTM_STACK_JOBS and int(lib.pnmn_lstm_stack_workspace_bytes(trial.ctypes.data, len(trial), int(backward))) > 0:
+                group.append(e)
+                continue
+            flush()
+            alone = self._stack_jobs([e], backward)
+            if int(lib.pnmn_lstm_stack_workspace_bytes(alone.ctypes.data, 2, int(backward))) > 0:
+                group.append(e)
+            else:
+                left.append(e)
+        flush()
+        return left
+
+    def _encoders_fwd(self, calls: _Calls, name: str, encs: List[Dict], most: Optional[int] = None) -> None:
         lib, st = _hip.lib(), self.stream
-        lstm = mm.lstm
-        rows, T, V = e["rows"], e["T"], e["V"]
+        for e in self._stack_launches(calls, name, encs, False, most):
+            d, lstm, rows, T = e["derived"], e["lstm"], e["rows"], e["T"]
+            xp2 = self.buf(e["tag"] + ".xp2", rows, T, 1024)
+            ws = self.bytes_buf(e["tag"] + ".lstm_ws", lib.pnmn_lstm_seq_workspace_bytes(rows, 0))
+            calls.add("pnmn_lstm_seq_fwd", e["table"].data_ptr(), e["src"].data_ptr(), e["src"].stride(0), d["l0.hh"].data_ptr(),
+                      e["hs1"].data_ptr(), e["cs1"].data_ptr(), e["act1"].data_ptr(), rows, T, 256, ws.data_ptr(), st)
+            self._gemm(calls, e["tag"] + ".xp2g", [dict(a=e["hs1"].data_ptr(), b=lstm.weight_ih_l1.data_ptr(), c=xp2.data_ptr(), M=rows * T,
+                                                        N=1024, K=256, lda=256, ldb=256, ldc=1024, tb=1, bias=d["l1.b"].data_ptr())])
+            calls.add("pnmn_lstm_seq_fwd", xp2.data_ptr(), None, 0, d["l1.hh"].data_ptr(), e["hs2"].data_ptr(), e["cs2"].data_ptr(),
+                      e["act2"].data_ptr(), rows, T, 256, ws.data_ptr(), st)
+        for e in encs:
+            if e["want_last"]:
+                calls.add("pnmn_mask_last_fwd", e["hs2"].data_ptr(), e["fmask"].data_ptr(), e["last"].data_ptr(), e["rows"], e["T"], 256,
+                          e["enc"].data_ptr(), e["h"].data_ptr(), st)
+
+    def _encoders_bwd(self, calls: _Calls, deferred: List, name: str, encs: List[Dict]) -> None:
+        """encs: encoder dicts with "denc" / "dh" set (gradients of the masked outputs and of the last states)."""
+        lib, st = _hip.lib(), self.stream
         f = self.buf
-        dhs2, dg2 = f(tag + ".dhs2", rows, T, 256), f(tag + ".dg2", rows, T, 1024)
-        dhs1, dg1 = f(tag + ".dhs1", rows, T, 256), f(tag + ".dg1", rows, T, 1024)
-        dtable = f(tag + ".dtable", V, 1024)
-        ws = self.bytes_buf(tag + ".lstm_bws", lib.pnmn_lstm_seq_workspace_bytes(rows, 1))
-        ews = self.bytes_buf(tag + ".emb_ws", lib.pnmn_embedding_grad_workspace_bytes(rows, T, V))
-        cws = self.bytes_buf(tag + ".col_ws", lib.pnmn_colsum_workspace_bytes(rows * T, 1024), zero=True)
-        calls.add("pnmn_mask_last_bwd", denc.data_ptr(), dh.data_ptr(), e["fmask"].data_ptr(), e["last"].data_ptr(), rows, T, 256,
-                  dhs2.data_ptr(), st)
-        calls.add("pnmn_lstm_seq_bwd", dhs2.data_ptr(), e["act2"].data_ptr(), e["cs2"].data_ptr(), derived["l1.hhT"].data_ptr(),
-                  dg2.data_ptr(), rows, T, 256, ws.data_ptr(), st)
-        self._gemm(calls, tag + ".dx", [dict(a=dg2.data_ptr(), b=lstm.weight_ih_l1.data_ptr(), c=dhs1.data_ptr(), M=rows * T, N=256,
-                                              K=1024, lda=1024, ldb=256, ldc=256, split="auto")])
-        calls.add("pnmn_lstm_seq_bwd", dhs1.data_ptr(), e["act1"].data_ptr(), e["cs1"].data_ptr(), derived["l0.hhT"].data_ptr(),
-                  dg1.data_ptr(), rows, T, 256, ws.data_ptr(), st)
-        calls.add("pnmn_embedding_grad", dg1.data_ptr(), e["src"].data_ptr(), e["src"].stride(0), rows, T, 1024, V, 0, 0, -1, 0,
-                  dtable.data_ptr(), ews.data_ptr(), st)
-        g = mm.grad
-        calls.add("pnmn_token_table_bwd", dtable.data_ptr(), e["emb"].data_ptr(), lstm.weight_ih_l0.data_ptr(), lstm.weight_ih_l0.stride(0),
-                  V, 256, 1024, e["pad_idx"], g(e["emb"]).data_ptr(), g(lstm.weight_ih_l0).data_ptr(), 0, g(lstm.bias_ih_l0).data_ptr(),
-                  g(lstm.bias_hh_l0).data_ptr(), st)
-        calls.add("pnmn_colsum", dg2.data_ptr(), 1024, rows * T, 1024, g(lstm.bias_ih_l1).data_ptr(), g(lstm.bias_hh_l1).data_ptr(), 0,
-                  cws.data_ptr(), st)
-        K = rows * T
-        deferred += [
-            dict(a=dg2.data_ptr(), b=e["hs2"].data_ptr(), c=g(lstm.weight_hh_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
-                 ldc=256, ta=1, split="auto", shift_t=T),
-            dict(a=dg2.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_ih_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
-                 ldc=256, ta=1, split="auto"),
-            dict(a=dg1.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_hh_l0).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
-                 ldc=256, ta=1, split="auto", shift_t=T),
-        ]
+        for e in encs:
+            tag, rows, T = e["tag"], e["rows"], e["T"]
+            e["dhs2"], e["dg2"], e["dg1"] = f(tag + ".dhs2", rows, T, 256), f(tag + ".dg2", rows, T, 1024), f(tag + ".dg1", rows, T, 1024)
+            calls.add("pnmn_mask_last_bwd", e["denc"].data_ptr(), e["dh"].data_ptr(), e["fmask"].data_ptr(), e["last"].data_ptr(), rows, T, 256,
+                      e["dhs2"].data_ptr(), st)
+        for e in self._stack_launches(calls, name, encs, True):
+            d, lstm, tag, rows, T = e["derived"], e["lstm"], e["tag"], e["rows"], e["T"]
+            dhs1 = f(tag + ".dhs1", rows, T, 256)
+            ws = self.bytes_buf(tag + ".lstm_bws", lib.pnmn_lstm_seq_workspace_bytes(rows, 1))
+            calls.add("pnmn_lstm_seq_bwd", e["dhs2"].data_ptr(), e["act2"].data_ptr(), e["cs2"].data_ptr(), d["l1.hhT"].data_ptr(),
+                      e["dg2"].data_ptr(), rows, T, 256, ws.data_ptr(), st)
+            self._gemm(calls, tag + ".dx", [dict(a=e["dg2"].data_ptr(), b=lstm.weight_ih_l1.data_ptr(), c=dhs1.data_ptr(), M=rows * T, N=256,
+                                                 K=1024, lda=1024, ldb=256, ldc=256, split="auto")])
+            calls.add("pnmn_lstm_seq_bwd", dhs1.data_ptr(), e["act1"].data_ptr(), e["cs1"].data_ptr(), d["l0.hhT"].data_ptr(),
+                      e["dg1"].data_ptr(), rows, T, 256, ws.data_ptr(), st)
+        for e in encs:  # parameter gradients: the table's rows and the bias sums now, everything GEMM-shaped deferred
+            mm, lstm, tag, rows, T, V = e["mm"], e["lstm"], e["tag"], e["rows"], e["T"], e["V"]
+            dtable = f(tag + ".dtable", V, 1024)
+            ews = self.bytes_buf(tag + ".emb_ws", lib.pnmn_embedding_grad_workspace_bytes(rows, T, V))
+            cws = self.bytes_buf(tag + ".col_ws", lib.pnmn_colsum_workspace_bytes(rows * T, 1024), zero=True)
+            dg1, dg2, g = e["dg1"], e["dg2"], mm.grad
+            calls.add("pnmn_embedding_grad", dg1.data_ptr(), e["src"].data_ptr(), e["src"].stride(0), rows, T, 1024, V, 0, 0, -1, 0,
+                      dtable.data_ptr(), ews.data_ptr(), st)
+            calls.add("pnmn_token_table_bwd", dtable.data_ptr(), e["emb"].data_ptr(), lstm.weight_ih_l0.data_ptr(), lstm.weight_ih_l0.stride(0),
+                      V, 256, 1024, e["pad_idx"], g(e["emb"]).data_ptr(), g(lstm.weight_ih_l0).data_ptr(), 0, g(lstm.bias_ih_l0).data_ptr(),
+                      g(lstm.bias_hh_l0).data_ptr(), st)
+            calls.add("pnmn_colsum", dg2.data_ptr(), 1024, rows * T, 1024, g(lstm.bias_ih_l1).data_ptr(), g(lstm.bias_hh_l1).data_ptr(), 0,
+                      cws.data_ptr(), st)
+            K = rows * T
+            deferred += [
+                dict(a=dg2.data_ptr(), b=e["hs2"].data_ptr(), c=g(lstm.weight_hh_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
+                     ldc=256, ta=1, split="auto", shift_t=T),
+                dict(a=dg2.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_ih_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
+                     ldc=256, ta=1, split="auto"),
+                dict(a=dg1.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_hh_l0).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
+                     ldc=256, ta=1, split="auto", shift_t=T),
+            ]
 
     def _decoder_side(self, tag: str, rows: int, T: int, S: int, base: Dict[str, torch.Tensor], row0: int) -> Dict[str, torch.Tensor]:
         """Views of a model's concatenated decoder buffers for one pass: rows*T sequence rows starting at flat row ``row0``."""
@@ -258,8 +338,12 @@ class Seq2SeqPlan:
         # ---- generator: encoder over [unsupervised ; supervised] questions -------------------------------------------------
         ques = f("ques", B, tq, dtype=torch.long)
         prog_sup = f("prog_sup", m, tp, dtype=torch.long)
-        e_pg = self._encoder_fwd(self.fwd_pg_enc, "pg.e", pg, dpg, ques, tq, B, True, pg.emb_src, pg.model._source_embedder.embedding.padding_idx,
-                                 pg.lstm)
+        e_pg = self._encoder_prepare(self.fwd_pg_enc, "pg.e", pg, dpg, ques, tq, B, True, pg.emb_src,
+                                     pg.model._source_embedder.embedding.padding_idx, pg.lstm)
+        self._encoders_fwd(self.fwd_pg_enc, "pg.e", [e_pg], most=STACK_PG_ENCODER)
+        #: workgroups of the generator's encoder launch (0: a launch per layer): a trainer that runs the NMN's stem beside it
+        #: cuts the stem's launches for the CUs this leaves (JointTrainingStep)
+        self.pg_encoder_workgroups = 16 * (-(-B // 16)) if any(n == "pnmn_lstm_stack_fwd" for _, _, n in self.fwd_pg_enc) else 0
         S = e_pg["T"]
         if S > 64 or D > 64:
             raise PlanUnsupported("more than 64 source positions / decoding steps")
@@ -316,7 +400,19 @@ class Seq2SeqPlan:
         self._keep.append(segs)
         c = self.fwd_qr
         c.add("pnmn_token_rows", segs.ctypes.data, 2, source.data_ptr(), Wq, 0, st)
-        e_qr = self._encoder_fwd(c, "qr.e", qr, dqr, source, Wq, B, True, qr.emb_src, qr.model._source_embedder.embedding.padding_idx, qr.lstm)
+        e_qr = self._encoder_prepare(c, "qr.e", qr, dqr, source, Wq, B, True, qr.emb_src, qr.model._source_embedder.embedding.padding_idx,
+                                     qr.lstm)
+        # the prior reads the same samples: its two LSTM layers ride in the reconstructor encoder's launch (its projections
+        # and loss follow in `fwd_prior`, behind the trunk's launch)
+        e_pr = None
+        if self.with_prior:
+            pr = self.prior
+            dpr = pr._derived()
+            if dpr is None:
+                raise PlanUnsupported("prior derived parameters")
+            e_pr = self._encoder_prepare(c, "pr.e", None, dpr, z, D, n, False, pr._embedder.embedding.weight,
+                                         pr._embedder.embedding.padding_idx, pr._encoder._module, want_last=False)
+        self._encoders_fwd(c, "qr.e", [e_qr] + ([e_pr] if e_pr is not None else []))
         Sq = e_qr["T"]
         Tq = tq + 1
         if Sq > 64 or Tq > 64:
@@ -344,15 +440,9 @@ class Seq2SeqPlan:
               loss_q.data_ptr(), lse_q.data_ptr(), B, Tq, Vq, 1e-13, st)
         # ---- prior: LSTM language model over the samples (no gradient: its loss only enters the detached reward) ---------------
         if self.with_prior:
-            pr = self.prior
-            dpr = pr._derived()
-            if dpr is None:
-                raise PlanUnsupported("prior derived parameters")
             c = self.fwd_prior
             emb = pr._embedder.embedding.weight
             Vz = emb.size(0)
-            e_pr = self._encoder_fwd(c, "pr.e", None, dpr, z, D, n, False, emb, pr._embedder.embedding.padding_idx, pr._encoder._module,
-                                     want_last=False)
             Tz = e_pr["T"]
             proj, plog = f("pr.proj", n * Tz, 256), f("pr.logits", n * Tz, Vz)
             loss_p, lse_p = f("pr.loss", n), f("pr.lse", n, Tz - 1)
@@ -390,8 +480,21 @@ class Seq2SeqPlan:
             j["dh0"] = dh[r0:].data_ptr()
             j["B"], j["T"], j["S"] = sd["rows"], sd["T"], sd["S"]
         self._keep.append(bj)
-        gws = self.bytes_buf("group_ws", lib.pnmn_attn_lstm_group3_workspace_bytes(n, m, B, 1))
-        c.add("pnmn_attn_lstm_bwd_multi_group3", bj[0:1].ctypes.data, bj[1:2].ctypes.data, bj[2:3].ctypes.data, 256, gws.data_ptr(), st)
+        if DECODER_BWD_GROUP >= 3:
+            gws = self.bytes_buf("group_ws", lib.pnmn_attn_lstm_group3_workspace_bytes(n, m, B, 1))
+            c.add("pnmn_attn_lstm_bwd_multi_group3", bj[0:1].ctypes.data, bj[1:2].ctypes.data, bj[2:3].ctypes.data, 256, gws.data_ptr(), st)
+        else:
+            singles = [0, 1, 2]
+            if DECODER_BWD_GROUP == 2:
+                gws = self.bytes_buf("pair_bws", lib.pnmn_attn_lstm_pair_workspace_bytes(n, m, 1))
+                c.add("pnmn_attn_lstm_bwd_multi_pair", bj[0:1].ctypes.data, bj[1:2].ctypes.data, 256, gws.data_ptr(), st)
+                singles = [2]
+            for k in singles:
+                j = bj[k]
+                sws = self.bytes_buf("single_bws%d" % k, lib.pnmn_attn_lstm_multi_workspace_bytes(int(j["B"]), 1))
+                c.add("pnmn_attn_lstm_bwd_multi", *(int(j[fld]) for fld in ("dhs", "act", "cs", "hs", "probs", "enc", "mask", "h0", "w_c_t", "w_hh_t",
+                                                                            "dgates", "dctx", "dscore", "weights", "dh0")),
+                      int(j["B"]), int(j["T"]), int(j["S"]), 256, sws.data_ptr(), st)
         for sd, e, r0, denc in ((side_s, e_pg, 0, denc_pg), (side_t, e_pg, n, denc_pg), (side_q, e_qr, 0, denc_qr)):
             c.add("pnmn_attn_denc", sd["weights"].data_ptr(), sd["dscore"].data_ptr(), sd["dctx"].data_ptr(), sd["hs"].data_ptr(),
                   e["h"][r0:].data_ptr(), denc[r0:].data_ptr(), sd["rows"], sd["T"], sd["S"], 256, st)
@@ -423,8 +526,8 @@ class Seq2SeqPlan:
                 deferred.append(dict(a=sd["dg"].data_ptr(), b=sd["hs"].data_ptr(), c=g(mdl.cell.weight_hh).data_ptr(), M=1024, N=256,
                                      K=sd["R"], lda=1024, ldb=256, ldc=256, ta=1, split="auto", shift_t=sd["T"],
                                      h0=e["h"][r0:].data_ptr(), ld_h0=256, acc=1 if k else 0))
-        self._encoder_bwd(c, deferred, "pg.e", pg, dpg, e_pg, denc_pg, dh_pg)
-        self._encoder_bwd(c, deferred, "qr.e", qr, dqr, e_qr, denc_qr, dh_qr)
+        e_pg["denc"], e_pg["dh"], e_qr["denc"], e_qr["dh"] = denc_pg, dh_pg, denc_qr, dh_qr
+        self._encoders_bwd(c, deferred, "enc", [e_pg, e_qr])
         # (an accumulating product must follow the product it adds to: keep them in different launches)
         first = [d for d in deferred if not d.get("acc")]
         second = [d for d in deferred if d.get("acc")]

@@ -131,6 +131,14 @@ class _TrainerBase(StepBase):
             plans[key] = plan
         return plan or None
 
+    def _planned_encoder_workgroups(self, batch, sup, nosup) -> int:
+        """Workgroups of the generator's encoder launch of this batch's plan (0: no plan, or a launch per layer)."""
+        dev = batch["question"].device
+        if not (self.use_plan and sup.numel() and nosup.numel() and dev.type == "cuda" and batch["program"].device == dev):
+            return 0
+        plan = self._plan(dev, int(nosup.numel()), int(sup.numel()), int(batch["question"].size(1)), int(batch["program"].size(1)))
+        return plan.pg_encoder_workgroups if plan is not None else 0
+
     def _planned_passes(self, plan, batch, sup_d, nosup_d, host_programs, after_sampling, before_prior, after_encode):
         """``_seq2seq_passes`` of a batch with supervised and unsupervised rows through the launch plan: the same passes in
         the same order on the same stream, the same callbacks at the same points."""
@@ -508,10 +516,20 @@ class JointTrainingStep(_TrainerBase):
                 def launch_stem():
                     if stem_mode == 2:  # (the stem also WAITS for the encoder pass on the GPU)
                         side.wait_stream(main)
+                    # Beside the stem runs the generator's encoder, whose workgroups must ALL be resident before its first step:
+                    # as a two-layer wavefront launch (probnmn.runtime.seq_plan) it needs twice the CUs a single layer does, and
+                    # a stem cut for 192 CUs made it wait for the stem's 0.8 ms workgroups to drain (1.05 ms for the 0.2 ms
+                    # launch, profiles/r06i_b128_timeline.txt).  The stem is needed ~1.5 ms later: it takes what is left.
+                    budget = engine.conv_cus if engine is not None else 0
+                    plan_wgs = self._planned_encoder_workgroups(batch, sup, nosup)
+                    if engine is not None and budget and plan_wgs and not stem_mode:
+                        engine.conv_cus = max(64, min(budget, 256 - plan_wgs))
                     with torch.cuda.stream(side):
                         # (the unsupervised examples' features -- 0.8 MB each -- are read through the row index by the
                         # layout kernel: no gathered copy)
                         token["started"] = self.nmn.begin(images, rows=rows_d)
+                    if engine is not None:
+                        engine.conv_cus = budget
 
                 if not stem_mode:
                     launch_stem()

@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: minutes of oracle time (skipped unless PNMN_RUN_SLOW=1)")
 
 
 @pytest.fixture(scope="session")

@@ -136,7 +136,9 @@ def test_colsum(R, C):
 def test_rate_report(capsys):
     """Not an assertion on speed (boxes differ): prints TFLOP/s of the shapes the seq2seq plan launches."""
     shapes = [("xp2 b1024", 47104, 1024, 256, 0, 1, 1), ("xp2 b128", 5888, 1024, 256, 0, 1, 1), ("dx b1024", 47104, 256, 1024, 0, 0, 1),
-              ("logits b1024", 47104, 93, 256, 0, 1, 1), ("dx b128", 5888, 256, 1024, 0, 0, 3)] \
+              ("logits b1024", 47104, 93, 256, 0, 1, 1), ("dx b128", 5888, 256, 1024, 0, 0, 3),
+              ("fc1 fwd 64", 64, 1024, 50176, 0, 1, 48), ("fc1 dx 64", 64, 50176, 1024, 0, 0, 1), ("fc1 dw 64", 1024, 50176, 64, 1, 0, 1),
+              ("fc1 fwd 512", 512, 1024, 50176, 0, 1, 12), ("fc1 dx 512", 512, 50176, 1024, 0, 0, 1), ("fc1 dw 512", 1024, 50176, 512, 1, 0, 1)] \
         + [("wgrad b1024", 1024, 256, 47104, 1, 0, s) for s in (4, 16, 32)] + [("wgrad b128", 1024, 256, 5888, 1, 0, s) for s in (1, 2, 4, 8, 16, 32)]
     for name, M, N, K, ta, tb, split in shapes:
         A = torch.randn((K, M) if ta else (M, K), device="cuda:0")
