@@ -353,12 +353,26 @@ extern "C" int pnmn_plan_batch(const pnmn_plan_in* in, uint64_t* out_words, int6
             const std::vector<int> idx = order_by(lv, in->sort_by_weight ? &fw : nullptr, 4);
             out.put(R_PROJ, fw, &idx);
             out.cut(CUT_PROJ, permuted(lv, idx));
-            // two data gradients per projection (one per operand), both in ONE launch per level: they add into the
-            // gradients of two different values (a program is a tree), and a launch of 2-7 items is all latency (15-20 us
-            // each, 14 of them per 1024-question step).  Only a comparison of a value with ITSELF -- both halves adding
-            // into one map without atomics -- keeps the halves of the whole batch in launches of their own.
+            // two data gradients per projection (one per operand), both in ONE launch per level: they add (non-atomic
+            // read-modify-write) into the gradients of two different values, and a launch of 2-7 items is all latency (15-20 us
+            // each, 14 of them per 1024-question step).  The guard is structural: if ANY map is some item's first operand and
+            // some item's second operand in this batch, the halves go out in launches of their own.  (Inside a half no two
+            // items of one level share a map: the interpreter is a two-register machine, nmn.py:197-238 -- `saved_output` may
+            // feed several binary modules of a program, but each also takes the running `output`, which depends on the
+            // previous one, so the uses lie on different levels; different examples own disjoint arena blocks.)
             bool same_operand = false;
-            for (size_t i = 0; i < pda.rows(); ++i) same_operand = same_operand || pda.row(i)[6] == pdb.row(i)[6];
+            {
+                std::vector<uint64_t> as, bs;
+                for (size_t i = 0; i < pda.rows(); ++i) as.push_back(pda.row(i)[6]), bs.push_back(pdb.row(i)[6]);
+                std::sort(as.begin(), as.end());
+                std::sort(bs.begin(), bs.end());
+                size_t i = 0, j = 0;
+                while (i < as.size() && j < bs.size() && !same_operand) {
+                    if (as[i] == bs[j]) same_operand = true;
+                    else if (as[i] < bs[j]) ++i;
+                    else ++j;
+                }
+            }
             const int64_t odd = same_operand ? 1 : 0;
             KEEP(Mat, pd, 12);
             KEEP(std::vector<int64_t>, lv2);

@@ -22,9 +22,10 @@ applying the momentum of a module the current batch does not use.  The engine re
 backward pass reached (``ParamArena.touched``); parameters that share a step count go out as contiguous arena ranges of
 one launch (one range per arena once every module has been used: the first iteration at the reference's batch sizes).
 Rounds 1-4 kept ONE counter for all parameters: a module first used at iteration k then took a first step of
-0.74 lr .. 0.32 lr instead of lr (tests/test_trajectory_gpu.py found it).  Data parallel: every trunk parameter counts
-as touched on every rank (the union over the ranks' batches is what a single process would see; at >= 2 ranks x 128
-questions it is all modules), so the replicas stay identical without a collective.
+0.74 lr .. 0.32 lr instead of lr (tests/test_trajectory_gpu.py found it).  Data parallel: a trunk parameter counts as
+touched when ANY rank's batch reached it -- the union over the shards is what a single process on the whole batch would
+see -- through one host-side OR per step (``parallel.host_or``, a few hundred bytes over gloo), so the replicas' Adam
+states stay identical and equal the single-process ones (round 5 counted every parameter as touched on every rank).
 """
 from typing import Iterable, List, Optional, Sequence
 
@@ -176,7 +177,7 @@ class ClampAdam(torch.optim.Optimizer):
 
         group = self.param_groups[0]
         self.step_count += 1
-        everyone = parallel.world() > 1  # (data parallel: see the module docstring)
+        dp = parallel.world() > 1
         # ONE launch: an item per contiguous run of arena parameters that share an Adam step count (one run per arena
         # once every module has been used -- at 128 questions per GPU a rarely sampled module can stay behind for good)
         # and an item per loose tensor; each item carries the bias corrections of its own count.
@@ -188,10 +189,13 @@ class ClampAdam(torch.optim.Optimizer):
                 raise _hip.HipLibraryError(
                     "a parameter no longer aliases the arena this optimizer was built on (model.to() / .data = "
                     "after the optimizer was constructed): build the optimizer after placing the model")
-            if a.touched is None or everyone:
+            if a.touched is None:
                 steps += 1
             else:
-                steps[(steps > 0) | a.touched] += 1
+                # data parallel: a parameter counts as touched when ANY rank's batch reached it (what one process on the
+                # whole batch would see) -- one tiny host-side collective per step keeps the replicas' Adam states identical
+                touched = parallel.host_or(a.touched) if dp else a.touched
+                steps[(steps > 0) | touched] += 1
             if a.touched is not None:
                 a.touched[:] = False
             base = np.array((a.flat.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr()), np.uint64)

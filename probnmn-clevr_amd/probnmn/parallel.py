@@ -278,6 +278,27 @@ def all_reduce_gradients(arenas: Sequence, loose_params: Iterable[torch.nn.Param
         torch._foreach_copy_(small, [c.view_as(g) for c, g in zip(bucket.split([g.numel() for g in small]), small)])
 
 
+_HOST_GROUP = None
+
+
+def host_or(mask):
+    """Element-wise OR of a small host-side bool array over the ranks (numpy in, numpy out) -- which parameters received a
+    gradient on ANY rank: ``ClampAdam`` starts a parameter's Adam state at its first gradient, and the replicas must start it
+    in the same iteration (a module one shard samples and the other does not would otherwise drift apart).  Travels over a
+    gloo group of its own (created on first use: every rank must reach that call -- the optimiser step -- together): the
+    result decides host-side step counts, and reading it back from the device would cost a stream synchronisation per step."""
+    import numpy as np
+
+    if world() == 1:
+        return mask
+    global _HOST_GROUP
+    if _HOST_GROUP is None:
+        _HOST_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    t = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_HOST_GROUP)
+    return t.numpy().astype(bool)
+
+
 def all_reduce_scalars(values: torch.Tensor) -> torch.Tensor:
     """Sum a small tensor of per-rank partial sums / counts (REINFORCE baseline, metrics)."""
     if world() > 1:

@@ -271,6 +271,9 @@ class NMNEngine:
         self._token_params = {idx: np.array([i for n, i in index.items() if n.startswith(tok + ".")], np.int64)
                               for idx, tok in vocab.items()}
         self._always_params = np.array([i for n, i in index.items() if n.startswith(("stem.", "classifier."))], np.int64)
+        self._stem_params = np.array([i for n, i in index.items() if n.startswith("stem.")], np.int64)
+        self._classifier_params = np.array([i for n, i in index.items() if n.startswith("classifier.")], np.int64)
+        self._reach_cache = {}
         a.touched = np.zeros(len(a.names), bool)
         self.wt_stem2 = add_wt("stem.2.weight")
         self.wt_cls0 = add_wt("classifier.0.weight")
@@ -595,18 +598,47 @@ class NMNEngine:
         return pooled, state, valid
 
     def _touched_by(self, programs: np.ndarray, valid: np.ndarray) -> np.ndarray:
-        """Arena parameters that get a gradient from a backward pass over these programs: the stem and the classifier
-        conv, and the modules named by the VALID programs' tokens (the reference's interpreter drops an invalid program's
-        partial graph: nmn.py:235-241)."""
+        """Arena parameters that get a gradient from a backward pass over these programs, as the reference's autograd would
+        hand them out (nmn.py:197-241): the classifier conv always (every example's zero / final map goes through it: its
+        gradient is a tensor even when every program is invalid -- all zeros then); the stem and the modules of the calls the
+        VALID programs' RESULTS depend on.  The interpreter is a two-register machine: a chain whose value is overwritten by a
+        later ``scene`` before a binary module reads it is executed but not part of the loss graph -- its modules keep
+        ``grad = None`` and torch.optim.Adam starts no state for them; an invalid program's partial graph is dropped whole
+        (nmn.py:235-241).  One mask per distinct program, cached by the token row's bytes."""
         mask = np.zeros(len(self.arena.names), bool)
+        mask[self._classifier_params] = True
         rows = programs[valid.astype(bool)]
         if rows.size:
-            mask[self._always_params] = True
-            for tok in np.unique(rows):
-                owned = self._token_params.get(int(tok))
-                if owned is not None and owned.size:
-                    mask[owned] = True
+            mask[self._stem_params] = True
+            cache = self._reach_cache
+            if len(cache) > 200000:
+                cache.clear()
+            for row in rows:
+                key = row.tobytes()
+                hit = cache.get(key)
+                if hit is None:
+                    hit = cache[key] = self._reachable_params(row)
+                mask[hit] = True
         return mask
+
+    def _reachable_params(self, tokens: np.ndarray) -> np.ndarray:
+        """Indices (into the arena's names) of the parameters of the modules one valid program's result depends on."""
+        prog = self.compiler.compile(tokens.tolist())
+        owned = []
+        if prog.valid:
+            calls = prog.calls
+            seen, todo = set(), [prog.result]
+            while todo:
+                v = todo.pop()
+                if v < 2 or v in seen:  # FEAT / ONES, or a call already walked
+                    continue
+                seen.add(v)
+                c = calls[v - 2]
+                p = self._token_params.get(int(c.token))
+                if p is not None and p.size:
+                    owned.append(p)
+                todo += [c.a, c.b]
+        return np.unique(np.concatenate(owned)) if owned else np.zeros(0, np.int64)
 
     # ---- backward -------------------------------------------------------------------------------
     def run_backward(self, state: _State, dpooled: torch.Tensor):
@@ -615,6 +647,7 @@ class NMNEngine:
                 "NeuralModuleNetwork.forward was called again before backward of the previous call: "
                 "the engine keeps one step's activations (run evaluation passes under torch.no_grad())")
         a = self.arena
+        self.last_touched = state.touched  # (diagnostics / smoke(): which parameters this backward pass reaches)
         if a.touched is not None and state.touched is not None:
             a.touched |= state.touched
         chk = _hip.check

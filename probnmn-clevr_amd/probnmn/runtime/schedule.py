@@ -460,14 +460,18 @@ class BatchScheduler:
             fw[:, 4], fw[:, 5], fw[:, 6] = buf.params + w_off * 4, buf.params + b_off * 4, o_f[m]
             fw[:, 7] = 1
             finish("proj", fw, lv, "conv", wcol=4)
-            # two dgrads (one per operand), accumulate flag set, ONE launch per level -- unless a comparison of a value
-            # with itself is in the batch (both halves would add into one map): then the halves stay apart (host_plan.hip)
+            # two dgrads (one per operand), accumulate flag set (non-atomic read-modify-write), ONE launch per level -- unless
+            # ANY map is both some item's first and some item's second operand in the batch: then the halves stay apart
+            # (host_plan.hip).  Why the halves themselves never alias: the interpreter is a two-register machine (nmn.py:197-238);
+            # `saved_output` may feed several binary modules of one program, but each of them also takes the running `output`,
+            # which depends on the previous one -- so two uses of one map inside a program lie on different levels, and
+            # different examples own disjoint arena blocks (tests/test_trunk_planner.py checks the invariant on sampled programs).
             pd = np.zeros((2 * n, 12), u64)
             pd[:, 0], pd[:, 3] = np.tile(o_g[m], 2), np.tile(o_f[m], 2)
             pd[:n, 4], pd[n:, 4] = buf.wt + wt_off * 4, buf.wt + (wt_off + C * C) * 4
             pd[:n, 6], pd[n:, 6] = a_g[m], b_g[m]
             pd[:, 7] = 1 | (1 << 32)
-            odd = 1 if bool((a_g[m] == b_g[m]).any()) else 0
+            odd = 1 if np.intersect1d(a_g[m], b_g[m]).size else 0
             finish("pdgrad", pd, np.concatenate((lv * 2, lv * 2 + odd)), "conv", wcol=4)
             wg = np.zeros((n, 6), u64)
             wg[:, 0], wg[:, 1], wg[:, 3], wg[:, 4] = a_f[m], b_f[m], o_g[m], o_f[m]

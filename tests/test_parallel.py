@@ -125,3 +125,34 @@ def test_single_process_is_a_noop():
     a.grad.fill_(2.0)
     parallel.all_reduce_gradients([a])
     assert parallel.world() == 1 and a.grad.tolist() == [2.0] * 4
+
+
+def _or_worker(rank, world, port, out_path):
+    import sys
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "probnmn-clevr_amd"))
+    from probnmn import parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mask = np.zeros(7, bool)
+    mask[[0, 2] if rank == 0 else [2, 5]] = True
+    got = parallel.host_or(mask)
+    again = parallel.host_or(np.zeros(7, bool))
+    torch.save((got.tolist(), again.tolist(), mask.tolist()), out_path + str(rank))
+    dist.destroy_process_group()
+
+
+def test_host_or_over_ranks(tmp_path):
+    """``parallel.host_or``: which trunk parameters received a gradient on ANY rank (ClampAdam's per-parameter step counts)."""
+    out = str(tmp_path / "o")
+    mp.spawn(_or_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        got, again, mine = torch.load(out + str(r))
+        assert got == [True, False, True, False, False, True, False]
+        assert again == [False] * 7
+        assert mine == ([True, False, True, False, False, False, False] if r == 0 else [False, False, True, False, False, True, False])

@@ -191,3 +191,52 @@ def test_long_module_training_trajectory():
     spread = max(abs(acc[1] - acc[2]), abs(acc[1] - acc[3]), abs(acc[2] - acc[3]))
     assert abs(acc[0] - acc[1]) <= spread + 10
     assert agree >= ctl_agree - 0.10 and agree >= 0.88
+
+
+def test_touched_parameters_are_the_ones_the_reference_gives_a_gradient():
+    """the parameters counted as "received a gradient" (torch.optim.Adam starts a parameter's state at its first
+    gradient) must be the ones autograd reaches in the reference's interpreter -- not every token of a valid program: a chain
+    saved by ``scene`` and never read by a binary module is executed but not part of the loss graph (its modules keep
+    ``grad = None``), an invalid program's modules get none, the classifier conv always gets one."""
+    from oracle import nmn_oracle
+    from probnmn.models.nmn import NeuralModuleNetwork
+    from probnmn.vocabulary import Vocabulary
+
+    dev = torch.device("cuda:0")
+    vocab = Vocabulary.clevr()
+    itos = vocab.get_index_to_token_vocabulary("programs")
+    stoi = vocab.get_token_to_index_vocabulary("programs")
+    torch.manual_seed(0)
+    net = NeuralModuleNetwork(vocab)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net.to(dev)
+    engine = net.engine
+    arena = engine.ensure_arena()
+
+    def row(*tokens):
+        r = [stoi[t] for t in tokens]
+        return r + [0] * (12 - len(r))
+
+    programs = torch.tensor([
+        row("query_color", "filter_shape[cube]", "scene", "filter_color[red]", "scene"),     # filter_color[red]: dead chain
+        row("count", "filter_size[large]", "scene"),                                           # plain chain
+        row("filter_material[metal]", "scene"),                                                # invalid: ends on an attention
+        row("equal_color", "query_color", "filter_shape[sphere]", "scene", "query_color", "filter_color[blue]", "scene"),
+    ])
+    g = torch.Generator().manual_seed(1)
+    image = torch.randn(4, 1024, 14, 14, generator=g).relu_()
+    answers = torch.tensor([1, 2, 3, 4])
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    out = nmn_oracle.nmn_forward(params, itos, image, programs, answers)
+    out["loss"].mean().backward()
+    want = {k for k, p in params.items() if p.grad is not None and k in arena.offsets}
+    compiled = engine.compiler.compile_batch(programs.numpy())
+    valid = np.array([c.valid for c in compiled])
+    assert valid.tolist() == [True, True, False, True]
+    mask = engine._touched_by(programs.numpy(), valid)
+    got = {n for n, m in zip(arena.names, mask) if m}
+    assert got == want, (sorted(got - want), sorted(want - got))
+    assert not any(n.startswith("filter_color[red].") for n in got) and not any(n.startswith("filter_material[metal].") for n in got)
+    # every program invalid: the classifier conv's gradient is still a tensor (zeros), nothing else is reached
+    none_valid = engine._touched_by(programs.numpy()[2:3], np.array([False]))
+    assert {n for n, m in zip(arena.names, none_valid) if m} == {n for n in arena.names if n.startswith("classifier.")}

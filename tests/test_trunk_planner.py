@@ -175,3 +175,40 @@ def test_native_planner_reports_a_too_small_arena_and_an_empty_batch():
     assert rc == 0 and valid.tolist() == [1, 1, 1] and out["n_feat_result"] == 3 and out["n_prims"] == 0
     assert [int(l["op"]) for l in fwd] == [_hip.OP_SET_ROWS, _hip.OP_MAXPOOL_FWD]
     _hip.lib().pnmn_trunk_planner_destroy(planner)
+
+
+def test_no_accumulating_launch_writes_one_map_twice():
+    """the projections' two data gradients of a level share ONE launch whose items add into their target maps
+    with a non-atomic read-modify-write.  Invariant of every plan: inside one such launch all target maps are distinct --
+    checked on synthetic batches (shallow and deep) and on hand-built programs in which ``saved_output`` feeds two
+    comparisons (the second use lies a level deeper) and in which a comparison takes one value for both operands."""
+    v, comp, s = _scheduler()
+    stoi = v.get_token_to_index_vocabulary("programs")
+
+    def row(*tokens, width=24):
+        r = [stoi[t] for t in tokens]
+        return r + [0] * (width - len(r))
+
+    hand = np.array([
+        # executed right to left: scene saves FEAT ... equal_size(q, saved) -> equal_color(that, saved): `saved` is read twice
+        row("equal_color", "equal_size", "query_size", "filter_shape[cube]", "scene", "query_color", "filter_color[red]", "scene"),
+        # a comparison of the saved value with itself is not expressible (output always moves on), but equal operands of two
+        # DIFFERENT items are: two copies of one program
+        row("equal_shape", "query_shape", "filter_size[large]", "scene", "query_shape", "filter_size[small]", "scene"),
+        row("equal_shape", "query_shape", "filter_size[large]", "scene", "query_shape", "filter_size[small]", "scene"),
+    ], dtype=np.int64)
+    batches = [hand] + [np.asarray(synthetic_batch(v, n, seed=seed, with_image=False, deep=deep)["program"].numpy())
+                        for seed, n, deep in ((5, 200, False), (6, 120, True), (7, 64, True))]
+    checked = 0
+    for programs in batches:
+        compiled = comp.compile_batch(programs)
+        plan = s.plan(compiled, BUF)
+        for phase in plan.backward:
+            for l in phase:
+                if l.kind != "pdgrad":
+                    continue
+                rec = plan.records["pdgrad"][l.begin:l.end]
+                targets = rec["out"]
+                assert len(np.unique(targets)) == len(targets), (l.level, targets)
+                checked += 1
+    assert checked >= 4, checked
