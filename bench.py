@@ -250,6 +250,7 @@ def pmc_traffic(kernel):
         return None
     want = source_sha()
     tag, total, calls = tags[-1], 0.0, 0
+    win_total, win_alg, win_seen = 0.0, [], 0
     for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.txt" % (tag, counter))
         if not os.path.exists(path):
@@ -259,6 +260,12 @@ def pmc_traffic(kernel):
             m = re.match(r"#\s*source_sha:\s*(\w+)", line)
             if m:
                 sha = m.group(1)
+            # the counters of the PMC run's own instrumented passes, beside that run's algorithmic bytes (one population)
+            m = re.match(r"# window %s: last (\d+) launches .*: %s ([0-9.]+) per launch; algorithmic bytes per launch (\d+)" % (kernel, counter), line)
+            if m:
+                win_total += factor * 1024.0 * float(m.group(2))
+                win_alg.append(float(m.group(3)))
+                win_seen += 1
             m = re.match(r"(\S+)\s+%s\s+(\d+)\s+([0-9.]+)" % counter, line)
             # (the conv_nhwc family -- pnmn_conv_nhwc calls -- is conv_stream_kernel since round 4; a call is one launch)
             if m and any(name in m.group(1) for name in KERNEL_FAMILY.get(kernel, (kernel,))):
@@ -267,7 +274,43 @@ def pmc_traffic(kernel):
         if sha != want:
             return None
         calls = max(calls, n)
-    return {"bytes_per_launch": round(total / calls), "source": "profiles/%s_pmc_*_SIZE.txt (source_sha %s)" % (tag, want)} if calls else None
+    if not calls:
+        return None
+    out = {"bytes_per_launch": round(total / calls), "source": "profiles/%s_pmc_*_SIZE.txt (source_sha %s)" % (tag, want)}
+    if win_seen == 2 and min(win_alg) > 0:
+        # traffic / algorithmic on ONE population: the PMC runs' instrumented passes (each run's own algorithmic bytes)
+        out.update(window_bytes_per_launch=round(win_total), window_algorithmic_bytes_per_launch=round(sum(win_alg) / 2),
+                   ratio=round(win_total / (sum(win_alg) / 2), 3))
+    return out
+
+
+def pmc_table(suffix):
+    """{kernel name: HBM bytes per launch} from the newest committed pair profiles/*_pmc_<suffix>{FETCH,WRITE}_SIZE.txt whose
+    `# source_sha` equals these sources' (None otherwise): 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950 correction as in
+    pmc_traffic)."""
+    import glob
+    import re
+
+    tags = sorted({os.path.basename(f).split("_pmc_")[0] for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%sFETCH_SIZE.txt" % suffix))})
+    if not tags:
+        return None
+    want, table = source_sha(), {}
+    for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s%s.txt" % (tags[-1], suffix, counter))
+        if not os.path.exists(path):
+            return None
+        sha = None
+        for line in open(path):
+            m = re.match(r"#\s*source_sha:\s*(\w+)", line)
+            if m:
+                sha = m.group(1)
+            m = re.match(r"(\S+)\s+%s\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)" % counter, line)
+            if m:
+                table[m.group(1)] = table.get(m.group(1), 0.0) + factor * 1024.0 * float(m.group(4))
+        if sha != want:
+            return None
+    table["_source"] = "profiles/%s_pmc_%s*_SIZE.txt" % (tags[-1], suffix)
+    return table
 
 
 def roofline_object(agg, kernel=None):
@@ -284,8 +327,12 @@ def roofline_object(agg, kernel=None):
         "peak": PEAK_FP32_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-        "traffic": pmc["bytes_per_launch"] if pmc else None,
+        # PMC figures: per launch of the PMC runs' instrumented passes where the summaries carry them (`# window` lines:
+        # traffic and algorithmic bytes of ONE population of launches -> traffic_ratio), else of the whole PMC process
+        "traffic": (pmc.get("window_bytes_per_launch") or pmc["bytes_per_launch"]) if pmc else None,
         "traffic_unit": "HBM bytes per launch (PMC, %s)" % pmc["source"] if pmc else None,
+        "traffic_ratio": pmc.get("ratio") if pmc else None,
+        "traffic_algorithmic_bytes_per_launch": pmc.get("window_algorithmic_bytes_per_launch") if pmc else None,
         "algorithmic_bytes_per_launch": round(a["bytes_per_launch_all"]),
         "launches_per_pass": a["launches_per_pass"],
         "avg_launch_ms": round(a["ms"] / a["launches"], 4),
@@ -345,8 +392,19 @@ def recurrent_kernel_report(dev):
     fwd = clock(lambda: _LSTMLayerSeq.apply(xp.detach(), w, wp, w_t))
     both = clock(lambda: _LSTMLayerSeq.apply(xp, w, wp, w_t).backward(dhs))
     flops = 2.0 * B * T * Hd * 4 * Hd
+    # PMC traffic of exactly these launches: scripts/profile_round.sh runs THIS report alone under rocprofv3 --pmc
+    # (scripts/r06_recurrent_pmc.py) -> profiles/*_pmc_recurrent_*; quoted only on matching sources
+    pmc = pmc_table("recurrent_") or {}
+
+    def traffic(*names):
+        hit = [v for k, v in pmc.items() if any(n in k for n in names) and not k.startswith("_")]
+        return round(sum(hit)) if hit else None
+
     out["lstm_layer"] = {"rows": B, "steps": T, "fwd_ms": round(fwd, 3), "fwd_us_per_step": round(fwd / T * 1e3, 2),
-                         "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3)}
+                         "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3),
+                         # step inputs + hidden / cell states + activated gates once; backward: dh, saved gates and cells, dgates
+                         "fwd_algorithmic_bytes": B * T * (4 * Hd + 2 * Hd + 4 * Hd) * 4, "fwd_traffic": traffic("lstm_seq_fwd_cluster_kernel"),
+                         "bwd_algorithmic_bytes": B * T * (Hd + 4 * Hd + Hd + 4 * Hd) * 4, "bwd_traffic": traffic("lstm_seq_bwd_cluster_kernel")}
     # decoders: the reconstructor's teacher-forced decode and the generator's sampling decode
     for name, B, T, S, mode in (("decoder_teacher_forced", 1024, 46, 27, 0), ("decoder_sampling", 512, 26, 46, 1)):
         V = 96 if mode == 0 else 44
@@ -362,10 +420,21 @@ def recurrent_kernel_report(dev):
         fwd = clock(lambda: run(enc.detach()))
         both = clock(lambda: run(enc).backward(dh))
         flops = B * T * (2.0 * 2 * Hd * 4 * Hd + 4.0 * S * Hd + (2.0 * V * Hd if mode else 0.0))
+        launches = max(1, -(-B // 512))
+        fwd_kernel = "attn_lstm_fwd_multi_kernelILb1ELb0" if mode == 0 else "attn_lstm_fwd_multi_kernelILb1ELb1"
+        t_f, t_b = traffic(fwd_kernel), (traffic("attn_lstm_bwd_multi_kernel") if mode == 0 else None)
         out[name] = {"rows": B, "steps": T, "source_positions": S, "fwd_ms": round(fwd, 3),
-                     "fwd_us_per_step": round(fwd / T * 1e3 / max(1, -(-B // 512)), 2),
-                     "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3)}
-    out["note"] = "fwd_us_per_step = launch time / steps (per 512-row launch for the decoders); peak fp32 %.1f TFLOP/s" % PEAK_FP32_TFLOPS
+                     "fwd_us_per_step": round(fwd / T * 1e3 / launches, 2),
+                     "fwd_tflops": round(flops / fwd / 1e9, 2), "fwd_bwd_ms": round(both, 3),
+                     # forward: encoder outputs and the token table once, h / c / context / gates / attention written;
+                     # backward: those read again + dh, dgates / dctx / dscore / weights written
+                     "fwd_algorithmic_bytes": (B * T * (7 * Hd + S) + B * S * Hd + V * 4 * Hd) * 4,
+                     "fwd_traffic": t_f * launches if t_f else None,
+                     "bwd_algorithmic_bytes": (B * T * (12 * Hd + 3 * S) + B * S * Hd) * 4,
+                     "bwd_traffic": t_b * launches if t_b else None}
+    out["note"] = ("fwd_us_per_step = launch time / steps (per 512-row launch for the decoders); peak fp32 %.1f TFLOP/s; *_traffic = HBM bytes "
+                   "(PMC, 2 x FETCH_SIZE + WRITE_SIZE) of the same launches (%s; null: no summary on these sources; the teacher-forced "
+                   "backward kernel's figure also averages the sampling decoder's backward launches)" % (PEAK_FP32_TFLOPS, pmc.get("_source")))
     return out
 
 

@@ -59,8 +59,11 @@ def main(path):
             name[:72], r[1], r[2] / 1e6, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
 
 
-def pmc(path):
-    """Per-kernel sums of the PMC counters of a `rocprofv3 --kernel-trace --pmc X` run."""
+def pmc(path, window_json=None):
+    """Per-kernel sums of the PMC counters of a `rocprofv3 --kernel-trace --pmc X` run.  ``window_json``: the bench line this
+    very run printed (its `roofline` object counts the conv launches of the instrumented passes, the LAST conv launches of
+    the process, and their algorithmic bytes): the counters of exactly those launches are summed too, so that traffic and
+    algorithmic bytes are quoted on ONE population of launches (`# window` header lines, read by bench.py)."""
     db = sqlite3.connect(path)
     cur = db.cursor()
     tab = [r[0] for r in cur.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")][0]
@@ -75,6 +78,25 @@ def pmc(path):
     print("# PMC summary of %s (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide" % path)
     print("# coalesced reads at half their bytes -- MI355X_MICROARCH.md, HBM section)")
     print("%-72s %-12s %8s %14s %12s" % ("kernel", "counter", "calls", "sum", "avg/launch"))
+    if window_json:
+        import json
+
+        line = [l for l in open(window_json) if l.startswith("{")][-1]
+        roof = json.loads(line).get("roofline") or {}
+        n_win = int(sum(roof.get("launches_per_pass") or []))
+        fam = {"conv_nhwc": "conv_stream_kernel"}.get(roof.get("kernel"), roof.get("kernel") or "")
+        if n_win and fam:
+            rows = list(cur.execute(f"""select i.name, d.start, sum(e.value)
+                    from rocpd_pmc_event{suffix} e
+                    join rocpd_kernel_dispatch{suffix} d on d.event_id = e.event_id
+                    join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id
+                    join rocpd_info_pmc{suffix} i on i.id = e.pmc_id
+                    where s.kernel_name like '%{fam}%' group by i.name, d.id order by d.start"""))
+            for ctr in sorted({r[0] for r in rows}):
+                vals = [r[2] for r in rows if r[0] == ctr][-n_win:]
+                print("# window %s: last %d launches of %s (the instrumented passes of this run): %s %.2f per launch; "
+                      "algorithmic bytes per launch %d" % (roof.get("kernel"), len(vals), fam, ctr, sum(vals) / max(len(vals), 1),
+                                                           int(roof.get("algorithmic_bytes_per_launch") or 0)))
     for name, ctr, n, tot, avg in cur.execute(q):
         print("%-72s %-12s %8d %14.1f %12.2f" % (name.replace(".kd", "")[:72], ctr, n, tot, avg))
 
@@ -172,7 +194,7 @@ if __name__ == "__main__":
     elif sys.argv[1] == "--timeline":
         timeline(sys.argv[2])
     elif sys.argv[1] == "--pmc":
-        pmc(sys.argv[2])
+        pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     elif sys.argv[1] == "--steady":
         steady(sys.argv[3], int(sys.argv[2]))
     else:
