@@ -401,6 +401,11 @@ typedef struct pnmn_adam_item {
 } pnmn_adam_item;         /* 48 bytes */
 int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2,
                     double eps, double weight_decay, double clamp, void* stream);
+/* ... with `blocks_per_item` workgroups walking each item (pnmn_clamp_adam: 2048).  A launch of a few hundred (two per CU)
+ * still streams at the HBM rate and leaves wave slots on every CU: the multi-CU recurrent kernels of ANOTHER stream, which
+ * need all their workgroups resident before their first step, then start beside it instead of behind it. */
+int pnmn_clamp_adam_blocks(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, double clamp, int blocks_per_item, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM cell gate math (torch nn.LSTM / nn.LSTMCell, gate order i,f,g,o), the point-wise half of
@@ -662,7 +667,10 @@ typedef struct pnmn_trunk_io {
     int32_t            wgrad_cus;     /* in: CU budget of their weight-gradient launches (0 = none) */
     int32_t            n_conv, n_proj;           /* out: 3x3 / projection records of the batch (FLOP accounting)       */
     int32_t            reserved;
-} pnmn_trunk_io;           /* 224 bytes */
+    uint64_t           touched_tokens[4];        /* out: bit t set = some VALID program's result depends on a call of program
+                                                    token t (t < 256) -- the modules the reference's autograd reaches: a chain
+                                                    a later `scene` drops is executed there but gets no gradient (nmn.py:197-241) */
+} pnmn_trunk_io;           /* 256 bytes */
 int pnmn_trunk_planner_create(const pnmn_trunk_config* config, void** planner);
 int pnmn_trunk_planner_destroy(void* planner);
 int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream);

@@ -56,6 +56,7 @@ struct Program {
     bool valid = false;
     int tid = -1;
     std::vector<int64_t> tokens;  // token of every call
+    uint64_t reach[4] = {0, 0, 0, 0};  // tokens of the calls the result depends on (the template's primitives)
 };
 
 struct Call {
@@ -253,6 +254,14 @@ int compile_new(Planner& P, const int64_t* rows, int length, const std::vector<i
                 P.bank_dirty = true;
             }
             prog.tid = th->second;
+            const Template& tpl = P.templates[prog.tid];
+            for (int q = 0; q < tpl.n_prims; ++q) {
+                const int64_t call = tpl.table[(size_t)q * NCOLS + 2];
+                if (call >= 0 && call < (int64_t)prog.tokens.size()) {
+                    const int64_t tok = prog.tokens[call];
+                    if (tok >= 0 && tok < 256) prog.reach[tok >> 6] |= 1ull << (tok & 63);
+                }
+            }
         }
         if (P.program_ids.size() > 500000) {  // bounded: sampled programs keep arriving for a whole training run
             P.program_ids.clear();
@@ -405,6 +414,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
     int cmax = 1;
     int64_t arena = 0, n_total = 0;
     io->n_invalid = 0, io->n_feat_result = 0;
+    io->touched_tokens[0] = io->touched_tokens[1] = io->touched_tokens[2] = io->touched_tokens[3] = 0;
     for (int i = 0; i < B; ++i) {
         const Program& pr = P.programs[ids[i]];
         io->valid[i] = pr.valid ? 1 : 0;
@@ -413,6 +423,7 @@ int pnmn_trunk_plan_and_launch(void* planner, pnmn_trunk_io* io, void* stream_) 
             continue;
         }
         const Template& t = P.templates[pr.tid];
+        for (int w = 0; w < 4; ++w) io->touched_tokens[w] |= pr.reach[w];
         P.tids.push_back(pr.tid);
         P.examples.push_back(i);
         P.base.push_back(arena);

@@ -684,7 +684,14 @@ int pnmn_clamp_adam(const pnmn_adam_item* items, int n_items, double lr, double 
     if (n_items <= 0) return 0;
     if (!items) return PNMN_EINVAL;
     // (the bias corrections travel in the items: computed in double by the caller, as torch.optim.Adam does on the host)
-    hipLaunchKernelGGL(clamp_adam_kernel, dim3(2048, n_items), dim3(256), 0, STREAM(stream), items, (float)lr,
+    return pnmn_clamp_adam_blocks(items, n_items, lr, beta1, beta2, eps, weight_decay, clamp, 2048, stream);
+}
+
+int pnmn_clamp_adam_blocks(const pnmn_adam_item* items, int n_items, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, double clamp, int blocks_per_item, void* stream) {
+    if (n_items <= 0) return 0;
+    if (!items || blocks_per_item <= 0) return PNMN_EINVAL;
+    hipLaunchKernelGGL(clamp_adam_kernel, dim3(blocks_per_item, n_items), dim3(256), 0, STREAM(stream), items, (float)lr,
                        (float)beta1, (float)beta2, (float)eps, (float)weight_decay, (float)clamp);
     return last_error();
 }

@@ -72,6 +72,7 @@ SIGNATURES: Dict[str, tuple] = {
     "pnmn_elbo_rows": (_P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P),
     "pnmn_joint_objective": (_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P),
     "pnmn_clamp_adam": (_P, _I, _D, _D, _D, _D, _D, _D, _P),
+    "pnmn_clamp_adam_blocks": (_P, _I, _D, _D, _D, _D, _D, _D, _I, _P),
     "pnmn_lstm_cell_fwd": (_P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_cell_bwd": (_P, _P, _P, _P, _P, _P, _P, _I, _I, _P),
     "pnmn_lstm_seq_fwd": (_P, _P, ctypes.c_int64, _P, _P, _P, _P, _I, _I, _I, _P, _P),
@@ -245,7 +246,8 @@ TRUNK_IO = np.dtype([(n, _u64) for n in ("programs", "params", "grads", "wt", "a
                     + [("arena_floats", np.int64)]
                     + [(n, _i32) for n in ("n_programs", "length", "n_fwd_tail", "n_bwd_head", "n_bwd_tail", "bwd_capacity",
                                            "need_backward", "launch", "n_bwd", "bwd_piece_cut", "n_prims", "n_fwd", "depth",
-                                           "n_invalid", "n_feat_result", "conv_cus", "wgrad_cus", "n_conv", "n_proj", "reserved")])
+                                           "n_invalid", "n_feat_result", "conv_cus", "wgrad_cus", "n_conv", "n_proj", "reserved")]
+                    + [("touched_tokens", _u64, (4,))])
 DECODER_FWD_JOB = np.dtype([(n, _u64) for n in ("xe", "etable", "enc", "mask", "h0", "w_c", "w_hh", "w_p", "b_p", "hs", "cs", "act",
                                                   "ctx", "probs", "tokens", "in_tokens")]
                            + [("in_token_stride", np.int64), ("seed", _u64), ("row_offset", _u64)]
@@ -317,7 +319,7 @@ ITEM_SIZES = {
     "pnmn_decoder_fwd_job": (DECODER_FWD_JOB, 184),
     "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
-    "pnmn_trunk_io": (TRUNK_IO, 224),
+    "pnmn_trunk_io": (TRUNK_IO, 256),
     "pnmn_gemm_desc": (GEMM_DESC, 104),
     "pnmn_token_seg": (TOKEN_SEG, 32),
     "pnmn_lstm_stack_job": (LSTM_STACK_JOB, 104),

@@ -274,6 +274,7 @@ class NeuralModuleNetwork(nn.Module):
         # launch is on the critical path of a small-batch step)
         valid_host = compiled.valid.tolist()
         valid = _hip.small_to_device(valid_host, torch.int32, pooled.device)
+        self._engine.wait_params(pooled.device)  # (an optimiser step of the FC layers still running on the trunk's stream)
         if trunk_stream is not None:
             current = torch.cuda.current_stream(pooled.device)
             current.wait_stream(trunk_stream)

@@ -37,6 +37,8 @@ from probnmn import _hip
 
 
 _PARAMETER_EPOCH = 0
+import os as _os
+SIDE_BLOCKS_PER_ITEM = int(_os.environ.get("PNMN_ADAM_SIDE_BLOCKS", "512"))
 
 
 def parameter_epoch() -> int:
@@ -169,7 +171,12 @@ class ClampAdam(torch.optim.Optimizer):
         return self.param_groups[0]["lr"]
 
     @torch.no_grad()
-    def step(self, closure=None) -> None:
+    def step(self, closure=None, side_stream=None, side_params=()) -> None:
+        """``side_stream`` (with ``side_params``: ids of loose parameters): the update of every ARENA and of those loose
+        parameters is launched on that stream instead of the current one -- a trainer whose NMN runs on its own stream lets
+        the NMN's share of the update (the 51 M-parameter fully connected layer: three quarters of the traffic) run there,
+        beside the next iteration's first kernels on the current stream, instead of at the end of this one.  The caller
+        orders the stream behind the gradients and everything that reads those parameters behind the stream."""
         if closure is not None:
             raise ValueError("ClampAdam.step takes no closure")
         parameters_changed()
@@ -182,6 +189,7 @@ class ClampAdam(torch.optim.Optimizer):
         # once every module has been used -- at 128 questions per GPU a rarely sampled module can stay behind for good)
         # and an item per loose tensor; each item carries the bias corrections of its own count.
         ptrs, counts, steps_of = [], [], []
+        side_ids = set(side_params) if side_stream is not None else set()
         for k, (a, (m, v), steps) in enumerate(zip(self.arenas, self._arena_state, self._arena_steps)):
             # every parameter on the first step, after load_state_dict and every 64th step; a rotating sample
             # otherwise (a re-pointed parameter would train on while the fused update writes the arena slice)
@@ -211,7 +219,8 @@ class ClampAdam(torch.optim.Optimizer):
                 ptrs.append(base[None, :] + (4 * lo).astype(np.uint64)[:, None])
                 counts.append(hi - lo)
                 steps_of.append(steps[first][live])
-        loose_rows = []
+        n_arena_items = sum(len(c) for c in counts)
+        loose_rows, loose_side = [], []
         for i, (p, (m, v)) in enumerate(zip(self.loose, self._loose_state)):
             g = p.grad
             if g is None:
@@ -226,6 +235,10 @@ class ClampAdam(torch.optim.Optimizer):
             self._loose_steps[i] += 1
             loose_rows.append((p.data_ptr(), g.data_ptr(), self._loose_ptrs[i][0], self._loose_ptrs[i][1], self._loose_numel[i],
                                self._loose_steps[i]))
+            on_side = id(p) in side_ids
+            loose_side.append(on_side)
+            if on_side:
+                g.record_stream(side_stream)  # (read there after the caller has dropped the tensor)
         if loose_rows:
             lr_ = np.array(loose_rows, dtype=np.int64)
             ptrs.append(lr_[:, :4].astype(np.uint64))
@@ -245,8 +258,24 @@ class ClampAdam(torch.optim.Optimizer):
         rec["bc2_sqrt"] = np.sqrt(1.0 - np.power(float(beta2), steps_of))
         device = (self.arenas[0].flat if self.arenas else self.loose[0]).device
         clamp = float(group["clamp"]) if group["clamp"] is not None else 0.0
-        buf = _hip.to_device(rec, device)
-        _hip.check(
-            _hip.lib().pnmn_clamp_adam(buf.data_ptr(), len(rec), float(group["lr"]), beta1, beta2, group["eps"],
-                                       group["weight_decay"], clamp, _hip.stream_ptr(device)),
-            "clamp_adam")
+
+        def launch(items, blocks=2048):
+            # (one launch, grid = (blocks, items).  Measured and not kept: the ~45 small tensors of the seq2seq models in a
+            # launch of their own with 64 workgroups each -- their 90 000 mostly idle workgroups are cheaper than a second
+            # launch: 0.357 -> 0.39 ms)
+            if len(items):
+                buf = _hip.to_device(items, device)
+                _hip.check(
+                    _hip.lib().pnmn_clamp_adam_blocks(buf.data_ptr(), len(items), float(group["lr"]), beta1, beta2, group["eps"],
+                                                      group["weight_decay"], clamp, blocks, _hip.stream_ptr(device)),
+                    "clamp_adam")
+
+        if side_stream is None:
+            launch(rec)
+            return
+        on_side = np.ones(len(rec), bool)
+        on_side[n_arena_items:] = loose_side
+        launch(rec[~on_side])
+        with torch.cuda.stream(side_stream):  # (record upload and launch both on that stream)
+            # two workgroups per CU: the next iteration's recurrent kernels (other stream) find wave slots on every CU
+            launch(rec[on_side], SIDE_BLOCKS_PER_ITEM)

@@ -112,6 +112,9 @@ class NMNEngine:
         # data parallel: called with k when every kernel that writes gradient piece k of the arena has been
         # queued (see grad_pieces); a trainer points it at its EarlyReducer.piece_ready
         self.on_grad_piece = None
+        # event behind an optimiser step of these parameters that runs on another stream than its caller's
+        # (trainers/joint_training.py: overlap_optimizer); every entry point that reads parameters waits for it
+        self.params_ready = None
         # CUs the trunk's conv launches are planned for: 0 = all of them; a trainer that runs the trunk on its own stream
         # beside other work sets the number it may count on (JointTrainingStep: 192 -- the seq2seq passes' multi-CU
         # kernels hold 64-96 CUs, and a launch cut for 256 workgroups then takes two rounds)
@@ -392,6 +395,10 @@ class NMNEngine:
         return out
 
     # ---- forward --------------------------------------------------------------------------------
+    def wait_params(self, device) -> None:
+        if self.params_ready is not None:
+            torch.cuda.current_stream(device).wait_event(self.params_ready)
+
     def begin_forward(self, features: torch.Tensor, need_backward: bool, rows: Optional[torch.Tensor] = None):
         """The part of the forward pass that does not depend on the programs: layout change of the
         input features and the two stem convolutions.  A trainer whose programs are still being
@@ -402,6 +409,7 @@ class NMNEngine:
         through the index."""
         a = self.ensure_arena()
         dev = a.device
+        self.wait_params(dev)
         if features.device != dev:
             raise _hip.HipLibraryError("features on %s but the network is on %s" % (features.device, dev))
         from probnmn.data.feature_store import ResidentRows
@@ -543,6 +551,7 @@ class NMNEngine:
               or (not started["subset"] and started["B"] != features.size(0))):
             raise ValueError("begin_forward token does not belong to this forward pass")
         a = self.ensure_arena()
+        self.wait_params(a.device)
         dev = a.device
         B, ws, fixed = started["B"], started["ws"], started["fixed"]
         programs = np.ascontiguousarray(programs, dtype=np.int64)
@@ -575,7 +584,7 @@ class NMNEngine:
                      self._planner_bwd.ctypes.data, self._planner_valid.ctypes.data, 0,
                      B, programs.shape[1], rows["fwd_tail"].shape[0], rows["bwd_head"].shape[0], rows["bwd_tail"].shape[0],
                      self._planner_bwd.shape[0], int(need_backward), 1, 0, 0, 0, 0, 0, 0, 0, self.conv_cus, self.wgrad_cus,
-                     0, 0, 0)
+                     0, 0, 0, (0, 0, 0, 0))
             rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, st)
             if rc != _hip.EAGAIN:
                 break
@@ -592,10 +601,28 @@ class NMNEngine:
             state.features = started["features"]  # (the stem's weight gradient reads the input again)
             state.step_pack = step_pack
             state.generation = self.generation
-            state.touched = self._touched_by(programs, valid)
+            state.touched = self._touched_from_tokens(out["touched_tokens"], bool(valid.any()))
             n = int(out["n_bwd"])
             state.backward_rows = (self._planner_bwd[:n].copy(), int(out["bwd_piece_cut"]), rows["dpooled_row"])
         return pooled, state, valid
+
+    def _touched_from_tokens(self, words, any_valid: bool) -> np.ndarray:
+        """``_touched_by`` from what the library's planner reports of the batch it just compiled (pnmn_trunk_io.touched_tokens:
+        the program tokens some valid program's result depends on) -- no per-program work on the host: the Python walk below
+        cost 25 us per NEW program, 8 ms per 1024-question iteration, between the samples' arrival and the trunk's launch."""
+        mask = np.zeros(len(self.arena.names), bool)
+        mask[self._classifier_params] = True
+        if any_valid:
+            mask[self._stem_params] = True
+            for w in range(4):
+                bits = int(words[w])
+                while bits:
+                    low = bits & -bits
+                    owned = self._token_params.get(64 * w + low.bit_length() - 1)
+                    if owned is not None and owned.size:
+                        mask[owned] = True
+                    bits ^= low
+        return mask
 
     def _touched_by(self, programs: np.ndarray, valid: np.ndarray) -> np.ndarray:
         """Arena parameters that get a gradient from a backward pass over these programs, as the reference's autograd would

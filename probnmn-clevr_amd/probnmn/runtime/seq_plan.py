@@ -47,6 +47,18 @@ STACK_BWD_ENCODERS = int(_os.environ.get("PNMN_PLAN_BWD_ENC", "0"))
 DECODER_BWD_GROUP = int(_os.environ.get("PNMN_PLAN_DEC_GROUP", "3"))
 #: workgroups a GEMM launch of the plan may occupy (0: one per tile)
 GEMM_WORKGROUPS = int(_os.environ.get("PNMN_PLAN_GEMM_WGS", "0"))
+#: parameter gradients of the passes on an auxiliary stream beside the backward chains (0: on the one stream, at the end)
+USE_AUX_STREAM = _os.environ.get("PNMN_PLAN_AUX", "0") != "0"
+_AUX_STREAMS: Dict = {}
+
+
+def _aux_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """ONE auxiliary stream per device for every plan of the process (HIP multiplexes a process's streams onto four hardware
+    queues: every further stream shifts which of them share one -- see trainers.joint_training.shared_stream)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _AUX_STREAMS[key]
 
 
 class PlanUnsupported(Exception):
@@ -272,8 +284,9 @@ class Seq2SeqPlan:
                 calls.add("pnmn_mask_last_fwd", e["hs2"].data_ptr(), e["fmask"].data_ptr(), e["last"].data_ptr(), e["rows"], e["T"], 256,
                           e["enc"].data_ptr(), e["h"].data_ptr(), st)
 
-    def _encoders_bwd(self, calls: _Calls, deferred: List, name: str, encs: List[Dict]) -> None:
-        """encs: encoder dicts with "denc" / "dh" set (gradients of the masked outputs and of the last states)."""
+    def _encoders_bwd(self, calls: _Calls, name: str, encs: List[Dict]) -> None:
+        """The encoders' backward CHAIN.  encs: encoder dicts with "denc" / "dh" set (gradients of the masked outputs and of
+        the last states)."""
         lib, st = _hip.lib(), self.stream
         f = self.buf
         for e in encs:
@@ -291,7 +304,13 @@ class Seq2SeqPlan:
                                                  K=1024, lda=1024, ldb=256, ldc=256, split="auto")])
             calls.add("pnmn_lstm_seq_bwd", dhs1.data_ptr(), e["act1"].data_ptr(), e["cs1"].data_ptr(), d["l0.hhT"].data_ptr(),
                       e["dg1"].data_ptr(), rows, T, 256, ws.data_ptr(), st)
-        for e in encs:  # parameter gradients: the table's rows and the bias sums now, everything GEMM-shaped deferred
+
+    def _encoders_param_grads(self, calls: _Calls, deferred: List, encs: List[Dict]) -> None:
+        """The encoders' parameter gradients from what the chain left behind (dgates of both layers): the table's rows and the
+        bias sums as launches, everything GEMM-shaped appended to ``deferred``."""
+        lib, st = _hip.lib(), self.stream
+        f = self.buf
+        for e in encs:
             mm, lstm, tag, rows, T, V = e["mm"], e["lstm"], e["tag"], e["rows"], e["T"], e["V"]
             dtable = f(tag + ".dtable", V, 1024)
             ews = self.bytes_buf(tag + ".emb_ws", lib.pnmn_embedding_grad_workspace_bytes(rows, T, V))
@@ -498,7 +517,16 @@ class Seq2SeqPlan:
         for sd, e, r0, denc in ((side_s, e_pg, 0, denc_pg), (side_t, e_pg, n, denc_pg), (side_q, e_qr, 0, denc_qr)):
             c.add("pnmn_attn_denc", sd["weights"].data_ptr(), sd["dscore"].data_ptr(), sd["dctx"].data_ptr(), sd["hs"].data_ptr(),
                   e["h"][r0:].data_ptr(), denc[r0:].data_ptr(), sd["rows"], sd["T"], sd["S"], 256, st)
-        # decoders' parameter gradients: the table's rows, then everything GEMM-shaped deferred
+        # Parameter gradients leave the chain: nothing in backward waits for them, so they go to an auxiliary stream behind
+        # events -- the decoders' right behind the decoder launch, the encoders' behind their layers -- and fill the CUs the
+        # latency-bound chains (this one and the NMN trunk's on its stream) leave idle; every kernel there is one of this
+        # library's that never waits for another workgroup.  PNMN_PLAN_AUX=0: all on the one stream, at the end.
+        main_stream = self.stream
+        self.bwd_a, self.bwd_b, self.aux_a, self.aux_b = c, _Calls(), _Calls(), _Calls()
+        self.aux_stream = _aux_stream(self.dev) if USE_AUX_STREAM else None
+        if self.aux_stream is not None:
+            self.stream = self.aux_stream.cuda_stream
+        ca = self.aux_a if self.aux_stream is not None else _Calls()
         deferred: List[dict] = []
         for mdl, der, tab, tag, sides in ((pg, dpg, table_d, "pg", ((side_s, raw, D, 1, 0), (side_t, tgt, tp + 2, 0, 0))),
                                           (qr, dqr, table_q, "qr", ((side_q, qtgt, tq + 2, 0, 0),))):
@@ -507,16 +535,17 @@ class Seq2SeqPlan:
             g = mdl.grad
             for k, (sd, toks, tstride, shift, _) in enumerate(sides):
                 ews = self.bytes_buf("%s.d.emb_ws%d" % (tag, k), lib.pnmn_embedding_grad_workspace_bytes(sd["rows"], sd["T"], V))
-                c.add("pnmn_embedding_grad", sd["dg"].data_ptr(), toks.data_ptr(), tstride, sd["rows"], sd["T"], 1024, V, shift, bos, -1,
-                      1 if k else 0, dtab.data_ptr(), ews.data_ptr(), st)
+                ca.add("pnmn_embedding_grad", sd["dg"].data_ptr(), toks.data_ptr(), tstride, sd["rows"], sd["T"], 1024, V, shift, bos, -1,
+                       1 if k else 0, dtab.data_ptr(), ews.data_ptr(), self.stream)
             w_ih = mdl.cell.weight_ih
-            c.add("pnmn_token_table_bwd", dtab.data_ptr(), mdl.emb_tgt.data_ptr(), w_ih.data_ptr() + 4 * 256, 512, V, 256, 1024, -1,
-                  g(mdl.emb_tgt).data_ptr(), g(w_ih).data_ptr() + 4 * 256, 512, g(mdl.cell.bias_ih).data_ptr(), g(mdl.cell.bias_hh).data_ptr(), st)
+            ca.add("pnmn_token_table_bwd", dtab.data_ptr(), mdl.emb_tgt.data_ptr(), w_ih.data_ptr() + 4 * 256, 512, V, 256, 1024, -1,
+                   g(mdl.emb_tgt).data_ptr(), g(w_ih).data_ptr() + 4 * 256, 512, g(mdl.cell.bias_ih).data_ptr(), g(mdl.cell.bias_hh).data_ptr(),
+                   self.stream)
             bs = base if mdl is pg else qbase
             R = bs["hs"].size(0)
             lg, dlg = (logits, dlogits) if mdl is pg else (qlogits, qdlogits)
             cws = self.bytes_buf(tag + ".d.col_ws", lib.pnmn_colsum_workspace_bytes(R, V), zero=True)
-            c.add("pnmn_colsum", dlg.data_ptr(), V, R, V, g(mdl.proj.bias).data_ptr(), None, 0, cws.data_ptr(), st)
+            ca.add("pnmn_colsum", dlg.data_ptr(), V, R, V, g(mdl.proj.bias).data_ptr(), None, 0, cws.data_ptr(), self.stream)
             deferred.append(dict(a=dlg.data_ptr(), b=bs["hs"].data_ptr(), c=g(mdl.proj.weight).data_ptr(), M=V, N=256, K=R, lda=V, ldb=256,
                                  ldc=256, ta=1, split="auto"))
             deferred.append(dict(a=bs["dg"].data_ptr(), b=bs["cx"].data_ptr(), c=g(w_ih).data_ptr(), M=1024, N=256, K=R, lda=1024, ldb=256,
@@ -526,14 +555,34 @@ class Seq2SeqPlan:
                 deferred.append(dict(a=sd["dg"].data_ptr(), b=sd["hs"].data_ptr(), c=g(mdl.cell.weight_hh).data_ptr(), M=1024, N=256,
                                      K=sd["R"], lda=1024, ldb=256, ldc=256, ta=1, split="auto", shift_t=sd["T"],
                                      h0=e["h"][r0:].data_ptr(), ld_h0=256, acc=1 if k else 0))
+
+        def flush(calls, name):
+            # (an accumulating product must follow the product it adds to: keep them in different launches)
+            first = [d for d in deferred if not d.get("acc")]
+            second = [d for d in deferred if d.get("acc")]
+            if first:
+                self._gemm(calls, name, first)
+            if second:
+                self._gemm(calls, name + "2", second)
+            del deferred[:]
+
+        if self.aux_stream is not None:
+            flush(ca, "wgrad_dec")
+        # the encoders' chain on the main stream ...
+        self.stream = main_stream
         e_pg["denc"], e_pg["dh"], e_qr["denc"], e_qr["dh"] = denc_pg, dh_pg, denc_qr, dh_qr
-        self._encoders_bwd(c, deferred, "enc", [e_pg, e_qr])
-        # (an accumulating product must follow the product it adds to: keep them in different launches)
-        first = [d for d in deferred if not d.get("acc")]
-        second = [d for d in deferred if d.get("acc")]
-        self._gemm(c, "wgrad", first)
-        if second:
-            self._gemm(c, "wgrad2", second)
+        self._encoders_bwd(self.bwd_b, "enc", [e_pg, e_qr])
+        # ... their parameter gradients behind it
+        if self.aux_stream is not None:
+            self.stream = self.aux_stream.cuda_stream
+            self._encoders_param_grads(self.aux_b, deferred, [e_pg, e_qr])
+            flush(self.aux_b, "wgrad_enc")
+            self.stream = main_stream
+            self.events = [torch.cuda.Event() for _ in range(3)]
+        else:
+            self.bwd_b.extend(ca)
+            self._encoders_param_grads(self.bwd_b, deferred, [e_pg, e_qr])
+            flush(self.bwd_b, "wgrad")
         self.out = dict(z=z, raw=raw, loss_s=loss_s, loss_t=loss_t, loss_q=loss_q, loss_p=self._bufs.get("pr.loss"), ques=ques,
                         prog_sup=prog_sup)
         self._derived_sig = self._sig()
@@ -606,7 +655,21 @@ class Seq2SeqPlan:
                 self.d_rows[key].zero_()
             else:
                 self.d_rows[key].copy_(d)
-        self.bwd.run()
+        self.bwd_a.run()
+        if self.aux_stream is not None:
+            main = torch.cuda.current_stream(self.dev)
+            e1, e2, e3 = self.events
+            e1.record(main)
+            self.aux_stream.wait_event(e1)
+            self.aux_a.run()
+            self.bwd_b.run()
+            e2.record(main)
+            self.aux_stream.wait_event(e2)
+            self.aux_b.run()
+            e3.record(self.aux_stream)
+            main.wait_event(e3)  # (the optimiser and the gradient all-reduce read the gradients on this stream)
+        else:
+            self.bwd_b.run()
         self.pg.attach()
         self.qr.attach()
 

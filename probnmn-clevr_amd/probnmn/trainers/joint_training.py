@@ -193,16 +193,52 @@ class _TrainerBase(StepBase):
             loss.backward()
             _hip.mark("backward issued")
         side = getattr(self, "_side", None)
-        if side is not None:  # the NMN's backward ran on its own stream: gradients are used below on this one
+        engine = getattr(getattr(self, "nmn", None), "engine", None)
+        # The NMN's share of the optimiser step on the NMN's stream (single process; JointTrainingStep.overlap_optimizer): 28
+        # bytes per parameter over the 63 M of the trunk arena and the fully connected layers are 0.33 ms with nothing beside
+        # them at the end of the iteration -- 5 % of the 128-question step.  Launched on the side stream behind both backward
+        # passes, they run beside the next iteration's generator passes; whatever reads NMN parameters next waits for
+        # engine.params_ready (the stem and the trunk are on that stream anyway, the head waits for it).
+        overlap = (getattr(self, "overlap_optimizer", False) and side is not None and engine is not None and parallel.world() == 1
+                   and loss.requires_grad)
+        if side is not None and not overlap:  # the NMN's backward ran on its own stream: gradients are used below on this one
             torch.cuda.current_stream(side.device).wait_stream(side)
         parallel.all_reduce_gradients(self.optimizer.arenas, self.optimizer.loose, early=getattr(self, "_early", None))
-        self.optimizer.step()
+        if overlap:
+            side.wait_stream(torch.cuda.current_stream(side.device))  # (the FC layers' gradients come from this stream)
+            self.optimizer.step(side_stream=side, side_params=self._nmn_loose_ids())
+            ready = torch.cuda.Event()
+            ready.record(side)
+            engine.params_ready = ready
+        else:
+            self.optimizer.step()
         self.iteration += 1
-        engine = getattr(getattr(self, "nmn", None), "engine", None)
         if engine is not None:
             # the step's CU budgets end with it (everything is queued): a validation pass or another trainer that runs
             # this network next has the chip to itself
             engine.conv_cus = engine.wgrad_cus = 0
+
+    def _nmn_loose_ids(self):
+        ids = self.__dict__.get("_nmn_loose")
+        if ids is None:
+            ids = self.__dict__["_nmn_loose"] = {id(p) for p in self.nmn.parameters()}
+        return ids
+
+    def settle(self) -> None:
+        """Make the current stream wait for an optimiser step still running on the NMN's stream (``overlap_optimizer``):
+        call before reading NMN parameters outside the models' own methods (checkpoints do, through ``state_dict``)."""
+        engine = getattr(getattr(self, "nmn", None), "engine", None)
+        ready = getattr(engine, "params_ready", None)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+
+    def state_dict(self):
+        self.settle()
+        return super().state_dict()
+
+    def close(self) -> None:
+        self.settle()
+        super().close()
 
     def _host_copy(self, tokens: torch.Tensor):
         """Start the device -> host copy of the sampled programs into a (cached) pinned buffer and
@@ -446,7 +482,7 @@ class JointTrainingStep(_TrainerBase):
         # it whenever they run, and the convs run between them: 256 questions 10.28-10.38 ms at 256 against 10.53-10.56 at
         # 192, 512: 17.8-18.9 / 18.5, 1024: 31.0-31.1 against 31.4-31.5 at 224 and 31.8 at 208 (profiles/ab/r04j_ab.txt).
         # (0: by batch size; a number fixes it.)
-        self.shared_conv_cus = 0
+        self.shared_conv_cus = int(os.environ.get("PNMN_SHARED_CONV_CUS", "0"))  # (env: A/B aid)
         # (the same for the weight-gradient launches -- at most that many persistent workgroups -- measured at 128
         # questions: 192 -> 7.22 ms, 160 -> 7.8, unbounded 7.1-7.27: off by default, profiles/ab/r04a_ab.txt)
         self.shared_wgrad_cus = 0
@@ -458,6 +494,8 @@ class JointTrainingStep(_TrainerBase):
         # (profiles/ab/r04t_ab.txt, r04u_ab.txt; 128 questions: no difference).  1: issued behind the encoder pass without the wait (measured at 128 questions, r03f_ab.txt:
         # 7.85-7.89 against 7.83-7.92 ms, and at 1024: 30.78-30.96 -- no difference).  (None: by batch size.)
         self.stem_after_encode = None
+        # the NMN's share of clamp + Adam on the NMN's stream, beside the next iteration's first passes (see _finish)
+        self.overlap_optimizer = os.environ.get("PNMN_OVERLAP_OPTIMIZER", "0") != "0"
         self._side = None
 
     def _nmn_stream(self, dev) -> "torch.cuda.Stream":

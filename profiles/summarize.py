@@ -134,6 +134,20 @@ def mfma(path):
         print("%-88s %8d %16.0f %14.0f %7.1f%%" % (name[:88], a["calls"], busy, act, 100.0 * busy / (act * 1024) if act else 0.0))
 
 
+def _step_marks(rows):
+    """End times of the training iterations: an iteration ends with its clamp_adam_kernel dispatch -- the LARGE one where a
+    trainer splits the update over two streams (round 6: the NMN's share on the trunk's stream, a small launch for the
+    seq2seq models on the other)."""
+    ends = sorted(r[2] for r in rows if "clamp_adam_kernel" in r[0])
+    marks = []
+    for e in ends:  # launches that end within a millisecond of each other belong to one iteration: its last one marks it
+        if marks and e - marks[-1] < 1e6:
+            marks[-1] = e
+        else:
+            marks.append(e)
+    return marks
+
+
 def steady(path, nsteps):
     """Per-STEP kernel table of the last `nsteps` training iterations of the trace (an iteration ends with its
     clamp_adam_kernel dispatch): what the timed region of bench.py looks like without the set-up work."""
@@ -143,7 +157,7 @@ def steady(path, nsteps):
     suffix = tab.replace("rocpd_kernel_dispatch", "")
     rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch{suffix} d
                                 join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id order by d.start"""))
-    marks = [r[2] for r in rows if "clamp_adam_kernel" in r[0]]
+    marks = _step_marks(rows)
     t0, t1 = marks[-nsteps - 1], marks[-1]
     win = [r for r in rows if r[1] >= t0 and r[2] <= t1]
     agg = {}
@@ -174,7 +188,7 @@ def timeline(path):
     qcol = "d.stream_id" if "stream_id" in cols else ("d.queue_id" if "queue_id" in cols else "0")
     rows = list(cur.execute(f"""select s.kernel_name, d.start, d.end, {qcol} from rocpd_kernel_dispatch{suffix} d
                                 join rocpd_info_kernel_symbol{suffix} s on d.kernel_id = s.id order by d.start"""))
-    marks = [r[2] for r in rows if "clamp_adam_kernel" in r[0]]
+    marks = _step_marks(rows)
     t0, t1 = marks[-2], marks[-1]
     print("# columns of %s: %s" % (tab, ", ".join(cols)))
     print("# last iteration: %.3f ms" % ((t1 - t0) / 1e6))

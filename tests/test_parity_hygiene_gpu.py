@@ -236,6 +236,12 @@ def test_touched_parameters_are_the_ones_the_reference_gives_a_gradient():
     mask = engine._touched_by(programs.numpy(), valid)
     got = {n for n, m in zip(arena.names, mask) if m}
     assert got == want, (sorted(got - want), sorted(want - got))
+    # the shipped path: the library's planner reports the reachable tokens of the batch it compiled
+    net.train()
+    out = net(image.to(dev), programs.to(dev), answers.to(dev))
+    out["loss"].mean().backward()
+    shipped = {n for n, m in zip(arena.names, engine.last_touched) if m}
+    assert shipped == want, (sorted(shipped - want), sorted(want - shipped))
     assert not any(n.startswith("filter_color[red].") for n in got) and not any(n.startswith("filter_material[metal].") for n in got)
     # every program invalid: the classifier conv's gradient is still a tensor (zeros), nothing else is reached
     none_valid = engine._touched_by(programs.numpy()[2:3], np.array([False]))

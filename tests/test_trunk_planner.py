@@ -44,7 +44,7 @@ def _run(planner, programs, capacity=1 << 40, conv_cus=0):
     io = np.zeros(1, _hip.TRUNK_IO)
     io[0] = (programs.ctypes.data, BUF.params, BUF.grads, BUF.wt, BUF.act, BUF.gact, BUF.feat, BUF.gfeat, BUF.final, BUF.gfinal,
              BUF.ones, capacity, fwd_tail.ctypes.data, bwd_head.ctypes.data, bwd_tail.ctypes.data, bwd.ctypes.data,
-             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, conv_cus, 0, 0, 0, 0)
+             valid.ctypes.data, 0, B, programs.shape[1], 1, 2, 1, bwd.shape[0], 1, 0, 0, 0, 0, 0, 0, 0, 0, conv_cus, 0, 0, 0, 0, (0, 0, 0, 0))
     rc = _hip.lib().pnmn_trunk_plan_and_launch(planner, io.ctypes.data, None)
     out = io[0]
     if rc != 0:
