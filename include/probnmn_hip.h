@@ -800,9 +800,9 @@ int pnmn_lstm_stack_bwd(const pnmn_lstm_stack_job* jobs /* HOST */, int n, void*
  *   B: [K][N] with row stride ldb, or -- PNMN_GEMM_B_TRANSPOSED -- stored [N][K] (nn.Linear's weight)
  *   shift_t > 0 (B as [K][N] only): k row r reads storage row r - 1, and where r % shift_t == 0 row r / shift_t of
  *     shift_h0 (row stride ld_h0; zeros when NULL): "h_{t-1}" of a [B][T][N] tensor of states without a shifted copy
- *   split_k > 1: the K range is cut into that many chunks (whole 32-wide k tiles) whose partial tiles meet in
- *     `workspace` (pnmn_gemm_workspace_bytes; zeroed ONCE by the caller, the kernel leaves its counters zeroed) and are
- *     added in chunk order by whichever chunk arrives last: deterministic.  pnmn_gemm_split_k proposes a count.
+ *   split_k > 1: the K range is cut into that many chunks (whole 32-wide k tiles) whose partial tiles go to
+ *     `workspace` (pnmn_gemm_workspace_bytes) and are added in chunk order (+ bias, + C when accumulating) by a second
+ *     small launch behind the product on the same stream: deterministic, no atomics.  pnmn_gemm_split_k proposes a count.
  * ------------------------------------------------------------------------------------------- */
 #define PNMN_GEMM_MAX 8
 #define PNMN_GEMM_A_TRANSPOSED 1

@@ -15,9 +15,9 @@
 // OTHER index contiguous ("MC": A given as [K][M] -- a weight gradient's dy^T -- or B [K][N]) is staged as it lies,
 // [32][128 + 4], with 16-byte stores, and read with ds_read_b32 at the same k.  Global loads of tile t + 1 are in flight
 // while tile t is contracted (registers -> the other LDS buffer, one barrier per tile).
-// Split-K: blockIdx walks (problem, tile, chunk); chunks write partial tiles to the problem's workspace and the LAST
-// chunk to arrive (one counter per tile, agent-scope fences around it) adds them in chunk order -- deterministic, one
-// launch, no atomics on the output.
+// Split-K: blockIdx walks (problem, tile, chunk); chunks write partial tiles to the problem's workspace and a second
+// small launch (gemm_reduce_kernel) adds them in chunk order -- deterministic, no atomics on the output; the kernel
+// boundary makes the partials visible (a fence + "last chunk reduces" in-kernel cost an L2 write-back per workgroup).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -98,6 +98,27 @@ __device__ __forceinline__ void load_tile(const gfloat* base, int64_t ld, int ro
     }
 }
 
+// The same for a tile that lies wholly inside the operand (all 128 rows, all 32 k, 16-byte aligned rows): four
+// unconditional 16-byte loads from per-thread pointers that advance by one k-tile per call -- the bounds-checked loader
+// above compiles to a branch per piece (exec-masked scalar fall-backs), which serialises the eight loads of a k-tile.
+template <bool KC>
+__device__ __forceinline__ void load_tile_fast(const gfloat* (&ptr)[4], int64_t step, f32x4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[j] = pnmn::load4(ptr[j]);
+        ptr[j] += step;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_pointers(const gfloat* base, int64_t ld, int row0, int k0, int tid, const gfloat* (&ptr)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = tid + 256 * j;
+        ptr[j] = KC ? base + (int64_t)(row0 + (p >> 3)) * ld + k0 + 4 * (p & 7) : base + (int64_t)(k0 + (p >> 5)) * ld + row0 + 4 * (p & 31);
+    }
+}
+
 template <bool KC>
 __device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&r)[4]) {
 #pragma unroll
@@ -132,18 +153,32 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
     float* la = lds;                    // [2][OP_FLOATS]
     float* lb = lds + 2 * OP_FLOATS;    // [2][OP_FLOATS]
     f32x4 ra[4], rb[4];
-    load_tile<AKC>(A, d.lda, m0, kbeg, d.M, kend, avec, tid, ra, 0, nullptr, 0);
-    load_tile<BKC>(Bm, d.ldb, n0, kbeg, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
+    // interior tiles (the common case) take the straight-line loader; `kfull` = k-tiles that lie wholly below kend
+    const bool afast = avec && m0 + TM <= d.M, bfast = bvec && n0 + TN <= d.N && (BKC || d.shift_t == 0);
+    const int kfull = kbeg + (kend - kbeg) / TK * TK;
+    const gfloat* pa[4];
+    const gfloat* pb[4];
+    tile_pointers<AKC>(A, d.lda, m0, kbeg, tid, pa);
+    tile_pointers<BKC>(Bm, d.ldb, n0, kbeg, tid, pb);
+    const int64_t sa = AKC ? TK : (int64_t)TK * d.lda, sb = BKC ? TK : (int64_t)TK * d.ldb;
+    auto fetch = [&](int k0) {
+        if (afast && k0 < kfull)
+            load_tile_fast<AKC>(pa, sa, ra);
+        else
+            load_tile<AKC>(A, d.lda, m0, k0, d.M, kend, avec, tid, ra, 0, nullptr, 0);
+        if (bfast && k0 < kfull)
+            load_tile_fast<BKC>(pb, sb, rb);
+        else
+            load_tile<BKC>(Bm, d.ldb, n0, k0, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
+    };
+    fetch(kbeg);
     store_tile<AKC>(la, tid, ra);
     store_tile<BKC>(lb, tid, rb);
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
         const bool more = k0 + TK < kend;
-        if (more) {
-            load_tile<AKC>(A, d.lda, m0, k0 + TK, d.M, kend, avec, tid, ra, 0, nullptr, 0);
-            load_tile<BKC>(Bm, d.ldb, n0, k0 + TK, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
-        }
+        if (more) fetch(k0 + TK);
         const float* ca = la + cur * OP_FLOATS;
         const float* cb = lb + cur * OP_FLOATS;
 #pragma unroll
@@ -305,31 +340,41 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const Batch batch) {
 }
 
 // column sums of a row-major [R][C] matrix: out[c] = sum_r x[r][c] (optionally also written to out2; bias gradients of an
-// LSTM layer: b_ih and b_hh receive the same).  grid (C / 64 column blocks, slices of rows); a workgroup = 64 columns x 4
-// row phases (256-byte row segments, four rows in flight per wave), partials -> the last slice of a column block sums them
-// in slice order (deterministic).
+// LSTM layer: b_ih and b_hh receive the same).  grid (column blocks of 256, slices of rows); a workgroup = 64 lanes x 16 bytes
+// across (a 1 KiB row segment per wave and load) x 4 row phases, four loads in flight per thread; partials -> the last slice
+// of a column block adds them in slice order (deterministic).  Scalar path for C % 4 != 0 (the vocabulary-wide dlogits).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int R, int C, float* __restrict__ partial,
                                                      int* __restrict__ counter, float* __restrict__ out, float* __restrict__ out2,
-                                                     int accumulate) {
+                                                     int accumulate, int vec) {
     __shared__ int last_flag;
-    __shared__ float red[4][64];
+    __shared__ float red[4][256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int c0 = blockIdx.x * 256 + 4 * tx;
     const int slices = gridDim.y, s = blockIdx.y;
     const int per = (R + slices - 1) / slices;
     const int r0 = s * per, r1 = min(R, r0 + per);
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < C) {
-        int r = r0 + ty;
-        for (; r + 12 < r1; r += 16) {
+    f32x4 acc[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (c0 < C) {
+        if (vec && c0 + 3 < C) {
+            int r = r0 + ty;
+            for (; r + 12 < r1; r += 16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[e] += x[(int64_t)(r + 4 * e) * ld + c];
+                for (int e = 0; e < 4; ++e) acc[e] += *reinterpret_cast<const f32x4*>(x + (int64_t)(r + 4 * e) * ld + c0);
+            }
+            for (; r < r1; r += 4) acc[0] += *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c0);
+        } else {
+            for (int r = r0 + ty; r < r1; r += 4)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + k < C) acc[0][k] += x[(int64_t)r * ld + c0 + k];
         }
-        for (; r < r1; r += 4) part[0] += x[(int64_t)r * ld + c];
     }
-    red[ty][tx] = (part[0] + part[1]) + (part[2] + part[3]);
+    const f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[ty][4 * tx + k] = t[k];
     __syncthreads();
-    if (ty == 0 && c < C) partial[(size_t)s * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) partial[(size_t)s * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -338,7 +383,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         if (last_flag) counter[blockIdx.x] = 0;
     }
     __syncthreads();
-    if (!last_flag || ty != 0 || c >= C) return;
+    if (!last_flag || c >= C) return;
     __threadfence();
     float total = 0.f;
     for (int k = 0; k < slices; ++k) total += __builtin_nontemporal_load(partial + (size_t)k * C + c);
@@ -415,7 +460,7 @@ extern "C" int pnmn_gemm_cus(const pnmn_gemm_desc* descs, int n, int max_workgro
 
 extern "C" int64_t pnmn_colsum_workspace_bytes(int R, int C) {
     (void)R;
-    return (int64_t)64 * C * sizeof(float) + (int64_t)((C + 63) / 64) * sizeof(int);
+    return (int64_t)128 * C * sizeof(float) + (int64_t)((C + 255) / 256) * sizeof(int);
 }
 
 extern "C" int pnmn_colsum(const float* x, int64_t ld, int R, int C, float* out, float* out2, int accumulate, void* workspace,
@@ -423,11 +468,12 @@ extern "C" int pnmn_colsum(const float* x, int64_t ld, int R, int C, float* out,
     if (C <= 0) return 0;
     if (!out || !workspace || (R > 0 && !x)) return PNMN_EINVAL;
     int slices = (R + 63) / 64;
-    if (slices > 64) slices = 64;
+    if (slices > 128) slices = 128;
     if (slices < 1) slices = 1;
     float* partial = static_cast<float*>(workspace);
-    int* counter = reinterpret_cast<int*>(partial + (size_t)64 * C);
-    hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64, slices), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, R, C,
-                       partial, counter, out, out2, accumulate);
+    int* counter = reinterpret_cast<int*>(partial + (size_t)128 * C);
+    const int vec = (ld & 3) == 0 && ((uintptr_t)x & 15) == 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, slices), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, R, C,
+                       partial, counter, out, out2, accumulate, vec);
     return (int)hipGetLastError();
 }

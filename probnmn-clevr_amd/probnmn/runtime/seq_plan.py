@@ -33,7 +33,8 @@ from probnmn import _hip
 
 
 #: workgroups a launch of split-K products is cut for (256 CUs, the 72 KB tiles of pnmn_gemm sit two to a CU)
-SPLIT_TARGET_WORKGROUPS = 384
+SPLIT_TARGET_WORKGROUPS = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_WGS", "2048"))
+SPLIT_MIN_KTILES = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_MIN", "16"))
 #: an encoder's two LSTM layers as a wavefront, independent encoder passes in one launch (pnmn_lstm_stack_*); False: a launch
 #: per layer with the input projection as a GEMM in between (A/B aid, and what batches too large for the chip fall back to)
 USE_STACK = True
@@ -165,12 +166,16 @@ class Seq2SeqPlan:
         for lo in range(0, len(descs), _hip.GEMM_MAX):
             part = descs[lo:lo + _hip.GEMM_MAX]
             rec = np.zeros(len(part), _hip.GEMM_DESC)
-            # split-K of the problems that ask for it ("auto"), chosen for the LAUNCH: the problems of one launch share the
-            # chip, so the chunk count that brings the launch's workgroups to one or two per CU -- every chunk writes a
-            # 64 KB partial tile and the last one reads them all back, which at 32 chunks per tile cost more than the products
+            # split-K of the problems that ask for it ("auto"), chosen for the LAUNCH: chunks of one common length (in 32-wide
+            # k tiles) for every problem of the launch, such that the launch has ~SPLIT_TARGET_WORKGROUPS workgroups of equal
+            # work -- several rounds of them balance problems of different K dynamically, where a chunk count per problem that
+            # merely filled the chip once left the CUs holding two long chunks running after the others had finished (eight
+            # weight gradients of 512-question passes: 78 TFLOP/s).  Floor of 16 k tiles per chunk: every chunk writes a 64 KB
+            # partial tile that the reduction launch reads back.
             tiles = [((d["M"] + 127) // 128) * ((d["N"] + 127) // 128) for d in part]
             ktiles = [(d["K"] + 31) // 32 for d in part]
-            total = sum(tiles)
+            work = sum(t * k for t, k, d in zip(tiles, ktiles, part) if d.get("split") == "auto")
+            chunk_len = min(max(work // SPLIT_TARGET_WORKGROUPS, SPLIT_MIN_KTILES), 128)
             for i, d in enumerate(part):
                 r = rec[i]
                 r["a"], r["b"], r["c"] = d["a"], d["b"], d["c"]
@@ -180,7 +185,7 @@ class Seq2SeqPlan:
                 r["bias"] = d.get("bias", 0)
                 split = d.get("split", 1)
                 if split == "auto":
-                    split = max(1, min(-(-SPLIT_TARGET_WORKGROUPS // total), ktiles[i] // 8, 64))
+                    split = max(1, min(-(-ktiles[i] // chunk_len), 64))
                 r["split_k"] = split
                 if split > 1:
                     ws = self.bytes_buf("%s.ws%d" % (name, lo + i), lib.pnmn_gemm_workspace_bytes(d["M"], d["N"], split), zero=True)
