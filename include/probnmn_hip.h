@@ -803,6 +803,9 @@ int pnmn_lstm_stack_bwd(const pnmn_lstm_stack_job* jobs /* HOST */, int n, void*
  *   split_k > 1: the K range is cut into that many chunks (whole 32-wide k tiles) whose partial tiles go to
  *     `workspace` (pnmn_gemm_workspace_bytes) and are added in chunk order (+ bias, + C when accumulating) by a second
  *     small launch behind the product on the same stream: deterministic, no atomics.  pnmn_gemm_split_k proposes a count.
+ *   colsum != NULL (PNMN_GEMM_A_TRANSPOSED only, else PNMN_ESHAPE): colsum[m] = sum_k A[k][m], m < M, also stored to
+ *     colsum2 when given -- the bias gradient torch's autograd forms as dy.sum(0) beside the weight gradient dy^T x; the
+ *     rows of dy pass through the workgroups of the first tile column anyway (fixed summation order, split or not).
  * ------------------------------------------------------------------------------------------- */
 #define PNMN_GEMM_MAX 8
 #define PNMN_GEMM_A_TRANSPOSED 1
@@ -821,6 +824,8 @@ typedef struct pnmn_gemm_desc {
     const float* shift_h0;
     int64_t      ld_h0;
     float*       workspace; /* split_k > 1 */
+    float*       colsum;    /* A stored [K][M] only: colsum[m] = sum_k A[k][m] (the bias gradient beside a weight gradient */
+    float*       colsum2;   /*   dy^T x: the rows of dy pass through the kernel anyway), also stored here; or NULL          */
 } pnmn_gemm_desc;
 int pnmn_gemm(const pnmn_gemm_desc* descs /* HOST array */, int n, void* stream);
 /* ... with at most `max_workgroups` workgroups (0 = one per tile): a launch that shares the chip with another stream's
@@ -835,7 +840,7 @@ int pnmn_gemm_split_k(int M, int N, int K, int cus);
 int pnmn_colsum(const float* x, int64_t ld, int R, int C, float* out, float* out2, int accumulate, void* workspace, void* stream);
 int64_t pnmn_colsum_workspace_bytes(int R, int C);
 
-/* Library self-description (no GPU needed).  11 = round 6: pnmn_gemm / pnmn_colsum / pnmn_token_rows, an accumulate flag on pnmn_embedding_grad, row stride + second bias output on pnmn_token_table_bwd.  10 = round 5.  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
+/* Library self-description (no GPU needed).  12: pnmn_gemm_desc gains colsum / colsum2 (120 bytes), pnmn_gemm_workspace_bytes includes the column-sum partials.  11 = round 6: pnmn_gemm / pnmn_colsum / pnmn_token_rows, an accumulate flag on pnmn_embedding_grad, row stride + second bias output on pnmn_token_table_bwd.  10 = round 5.  8 = round 4: the trunk executor of version 7 removed again (pnmn_trunk_exec, pnmn_plan_batch_owners, the EXEC launch op; pnmn_trunk_io shrinks to 224 bytes), streamed convolution kernel behind the same pnmn_conv_nhwc entry points (split 16 gone).  7: the trunk executor (pnmn_trunk_exec, EXEC launch op, pnmn_trunk_io grows to 232 bytes), conv segments in one launch; 6 = round 3: pnmn_conv_nhwc_cus, paired decoder launches, pnmn_attn_denc, pnmn_joint_objective, ingest by copy engine; 5: the trunk planner (pnmn_trunk_*), pnmn_set_rows, SET_ROWS / ACCUMULATE / ZERO launch ops; 4: pnmn_cluster_reserve_cus.  3 = round 2: 28x28 maps in the conv / weight-gradient / layout /
  * pool entry points, pnmn_conv_nhwc_launches takes H and W, sequence-loss / ELBO / feature-ingest entry points
  * added, the persistent dataflow executor (pnmn_dataflow) removed. */
 int pnmn_abi_version(void);

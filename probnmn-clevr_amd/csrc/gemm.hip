@@ -102,21 +102,17 @@ __device__ __forceinline__ void load_tile(const gfloat* base, int64_t ld, int ro
 // unconditional 16-byte loads from per-thread pointers that advance by one k-tile per call -- the bounds-checked loader
 // above compiles to a branch per piece (exec-masked scalar fall-backs), which serialises the eight loads of a k-tile.
 template <bool KC>
-__device__ __forceinline__ void load_tile_fast(const gfloat* (&ptr)[4], int64_t step, f32x4 (&r)[4]) {
+__device__ __forceinline__ void load_tile_fast(const gfloat*& ptr, int64_t piece_stride, int64_t step, f32x4 (&r)[4]) {
+    // (ONE per-thread pointer per operand: the pieces of a thread lie a uniform stride apart -- 32 rows (KC) / 8 k rows (MC)
+    // -- which stays in scalar registers; four pointers per operand cost 16 VGPRs and the second workgroup of a CU)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r[j] = pnmn::load4(ptr[j]);
-        ptr[j] += step;
-    }
+    for (int j = 0; j < 4; ++j) r[j] = pnmn::load4(ptr + j * piece_stride);
+    ptr += step;
 }
 
 template <bool KC>
-__device__ __forceinline__ void tile_pointers(const gfloat* base, int64_t ld, int row0, int k0, int tid, const gfloat* (&ptr)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = tid + 256 * j;
-        ptr[j] = KC ? base + (int64_t)(row0 + (p >> 3)) * ld + k0 + 4 * (p & 7) : base + (int64_t)(k0 + (p >> 5)) * ld + row0 + 4 * (p & 31);
-    }
+__device__ __forceinline__ const gfloat* tile_pointer(const gfloat* base, int64_t ld, int row0, int k0, int tid) {
+    return KC ? base + (int64_t)(row0 + (tid >> 3)) * ld + k0 + 4 * (tid & 7) : base + (int64_t)(k0 + (tid >> 5)) * ld + row0 + 4 * (tid & 31);
 }
 
 template <bool KC>
@@ -139,8 +135,12 @@ __device__ __forceinline__ f32x4 frag(const float* lds, int row, int q, int h) {
     return f32x4{p[0], p[MC_LD], p[2 * MC_LD], p[3 * MC_LD]};
 }
 
+// `cs` (A stored [K][M] only): the thread's share of the COLUMN SUMS of A over this chunk's k range -- piece j of a tile is
+// k row tid / 32 + 8 j, m quad tid % 32, so a thread meets the same four columns in every piece and adds them up as the
+// registers arrive for the LDS store (sum_k A[k][m] = the bias gradient that goes with a weight gradient dy^T x).
 template <bool AKC, bool BKC>
-__device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0, int kbeg, int kend, float* lds, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0, int kbeg, int kend, float* lds, f32x16 (&acc)[2][2],
+                                         bool want_cs, f32x4& cs) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const gfloat* A = as_global(d.a);
@@ -156,24 +156,24 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
     // interior tiles (the common case) take the straight-line loader; `kfull` = k-tiles that lie wholly below kend
     const bool afast = avec && m0 + TM <= d.M, bfast = bvec && n0 + TN <= d.N && (BKC || d.shift_t == 0);
     const int kfull = kbeg + (kend - kbeg) / TK * TK;
-    const gfloat* pa[4];
-    const gfloat* pb[4];
-    tile_pointers<AKC>(A, d.lda, m0, kbeg, tid, pa);
-    tile_pointers<BKC>(Bm, d.ldb, n0, kbeg, tid, pb);
+    const gfloat* pa = tile_pointer<AKC>(A, d.lda, m0, kbeg, tid);
+    const gfloat* pb = tile_pointer<BKC>(Bm, d.ldb, n0, kbeg, tid);
     const int64_t sa = AKC ? TK : (int64_t)TK * d.lda, sb = BKC ? TK : (int64_t)TK * d.ldb;
+    const int64_t ja = (AKC ? 32 : 8) * d.lda, jb = (BKC ? 32 : 8) * d.ldb;  // piece j = tid + 256 j: 32 rows / 8 k rows on
     auto fetch = [&](int k0) {
         if (afast && k0 < kfull)
-            load_tile_fast<AKC>(pa, sa, ra);
+            load_tile_fast<AKC>(pa, ja, sa, ra);
         else
             load_tile<AKC>(A, d.lda, m0, k0, d.M, kend, avec, tid, ra, 0, nullptr, 0);
         if (bfast && k0 < kfull)
-            load_tile_fast<BKC>(pb, sb, rb);
+            load_tile_fast<BKC>(pb, jb, sb, rb);
         else
             load_tile<BKC>(Bm, d.ldb, n0, k0, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
     };
     fetch(kbeg);
     store_tile<AKC>(la, tid, ra);
     store_tile<BKC>(lb, tid, rb);
+    if (!AKC && want_cs) cs += (ra[0] + ra[1]) + (ra[2] + ra[3]);
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
@@ -200,13 +200,16 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
         if (more) {
             store_tile<AKC>(la + (cur ^ 1) * OP_FLOATS, tid, ra);
             store_tile<BKC>(lb + (cur ^ 1) * OP_FLOATS, tid, rb);
+            if (!AKC && want_cs) cs += (ra[0] + ra[1]) + (ra[2] + ra[3]);
         }
         __syncthreads();
         cur ^= 1;
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
+// (waves_per_eu 2: the register allocator must stay within 256 registers per wave, accumulators included -- at 260 the second
+// workgroup of a CU is gone and every product of the plan ran 20 % slower)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel(const Batch batch) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][OP_FLOATS] = 72 KB: two workgroups per CU
     // (a launch cut for fewer workgroups than it has units -- pnmn_gemm_cus: products that share the chip with another
     // stream's latency chain -- walks them; the LDS buffers are free again behind the last barrier of contract())
@@ -220,7 +223,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
     // chunk fastest: the chunks of one output tile run together and the last one finds the others' partials in L2
     const int chunk = local % split, tile = local / split;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
-    (void)tiles_m;
     const int m0 = tm * TM, n0 = tn * TN;
     // k range of this chunk: whole k-tiles, the first chunks one longer
     const int ktiles = (d.K + TK - 1) / TK;
@@ -236,20 +238,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Batch batch) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    const bool akc = !(d.flags & PNMN_GEMM_A_TRANSPOSED), bkc = (d.flags & PNMN_GEMM_B_TRANSPOSED) != 0;
+    const bool want_cs = d.colsum != nullptr && !akc && tn == 0;  // (the first tile column of a row of tiles carries them)
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
     if (kbeg < kend) {
-        const bool akc = !(d.flags & PNMN_GEMM_A_TRANSPOSED), bkc = (d.flags & PNMN_GEMM_B_TRANSPOSED) != 0;
         if (akc && bkc)
-            contract<true, true>(d, m0, n0, kbeg, kend, lds, acc);
+            contract<true, true>(d, m0, n0, kbeg, kend, lds, acc, false, cs);
         else if (akc)
-            contract<true, false>(d, m0, n0, kbeg, kend, lds, acc);
+            contract<true, false>(d, m0, n0, kbeg, kend, lds, acc, false, cs);
         else if (bkc)
-            contract<false, true>(d, m0, n0, kbeg, kend, lds, acc);
+            contract<false, true>(d, m0, n0, kbeg, kend, lds, acc, want_cs, cs);
         else
-            contract<false, false>(d, m0, n0, kbeg, kend, lds, acc);
+            contract<false, false>(d, m0, n0, kbeg, kend, lds, acc, want_cs, cs);
     }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    if (want_cs) {
+        // eight threads (k rows u, u + 8, ...: u = tid / 32) hold partial sums of the same four columns: added in u order
+        // through LDS (free behind contract()'s last barrier); a chunk's 128 sums go behind the partial tiles in the
+        // workspace, an unsplit product's straight to the output
+        *reinterpret_cast<f32x4*>(lds + (tid >> 5) * TM + 4 * (tid & 31)) = cs;
+        __syncthreads();
+        if (tid < TM) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += lds[u * TM + tid];
+            if (split > 1) {
+                as_global(d.workspace)[(size_t)tiles_m * tiles_n * split * (TM * TN) + ((size_t)tm * split + chunk) * TM + tid] = t;
+            } else if (m0 + tid < d.M) {
+                d.colsum[m0 + tid] = t;
+                if (d.colsum2) d.colsum2[m0 + tid] = t;
+            }
+        }
+        __syncthreads();  // (the next unit of a persistent workgroup stages into the same LDS)
+    }
     // accumulator (mt, nt), register r: row 64 wm + 32 mt + 8 (r / 4) + 4 h + r % 4, column 64 wn + 32 nt + i
     if (split > 1) {
         gfloat* ws = as_global(d.workspace) + ((size_t)tile * split + chunk) * (TM * TN);
@@ -309,6 +332,17 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const Batch batch) {
         for (int j = 0; j < 4; ++j) v[j] = pnmn::load4(wc + 4 * (tid + 256 * j));
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum[j] += v[j];
+    }
+    if (d.colsum && (d.flags & PNMN_GEMM_A_TRANSPOSED) && quarter == 0 && tile % tiles_n == 0 && tid < TM) {
+        // the chunks' column sums of A (gemm_kernel), in chunk order
+        const int tiles_m = (d.M + TM - 1) / TM, tm = tile / tiles_n;
+        const gfloat* wc = as_global(d.workspace) + (size_t)tiles_m * tiles_n * split * (TM * TN) + (size_t)tm * split * TM + tid;
+        float t = 0.f;
+        for (int c = 0; c < split; ++c) t += wc[(size_t)c * TM];
+        if (tm * TM + tid < d.M) {
+            d.colsum[tm * TM + tid] = t;
+            if (d.colsum2) d.colsum2[tm * TM + tid] = t;
+        }
     }
     gfloat* C = as_global(d.c);
     const gfloat* bias = as_global(d.bias);
@@ -396,8 +430,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 extern "C" int64_t pnmn_gemm_workspace_bytes(int M, int N, int split_k) {
     if (split_k <= 1) return 0;
-    const int64_t tiles = (int64_t)((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    return tiles * split_k * (TM * TN) * (int64_t)sizeof(float);
+    const int64_t tiles_m = (M + TM - 1) / TM, tiles = tiles_m * ((N + TN - 1) / TN);
+    // partial tiles [tile][chunk][128 x 128], then the chunks' column sums of A [tile row][chunk][128]
+    return (tiles * split_k * (TM * TN) + tiles_m * split_k * TM) * (int64_t)sizeof(float);
 }
 
 extern "C" int pnmn_gemm_split_k(int M, int N, int K, int cus) {
@@ -426,6 +461,7 @@ extern "C" int pnmn_gemm_cus(const pnmn_gemm_desc* descs, int n, int max_workgro
         if (!d.a || !d.b || !d.c || d.K < 0) return PNMN_EINVAL;
         if (d.split_k > 1 && !d.workspace) return PNMN_EINVAL;
         if (d.shift_t > 0 && (d.flags & PNMN_GEMM_B_TRANSPOSED)) return PNMN_ESHAPE;  // (the shifted operand is B as [K][N])
+        if (d.colsum && !(d.flags & PNMN_GEMM_A_TRANSPOSED)) return PNMN_ESHAPE;      // (column sums: of A stored [K][M])
         b.d[live] = d;
         b.first[live] = blocks;
         const int tiles = ((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN);

@@ -561,7 +561,7 @@ static int launch_pool(const float* in, const float* dout, float* out, int n, in
 
 extern "C" {
 
-int pnmn_abi_version(void) { return 11; }
+int pnmn_abi_version(void) { return 12; }
 
 int pnmn_dot1_sigmoid_fwd(const pnmn_dot1_item* items, int n_items, int HW, void* stream) {
     if (n_items <= 0) return 0;

@@ -122,7 +122,7 @@ SIGNATURES: Dict[str, tuple] = {
 }
 
 
-ABI_VERSION = 11  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
+ABI_VERSION = 12  # pnmn_abi_version() of the library these signatures describe (include/probnmn_hip.h)
 
 
 def lib() -> ctypes.CDLL:
@@ -257,7 +257,7 @@ DECODER_BWD_JOB = np.dtype([(n, _u64) for n in ("dhs", "act", "cs", "hs", "probs
                            + [(n, _i32) for n in ("B", "T", "S", "reserved")])
 GEMM_DESC = np.dtype([(n, _u64) for n in ("a", "b", "c", "bias")] + [(n, np.int64) for n in ("lda", "ldb", "ldc")]
                      + [(n, _i32) for n in ("M", "N", "K", "flags", "split_k", "shift_t")]
-                     + [("shift_h0", _u64), ("ld_h0", np.int64), ("workspace", _u64)])  # pnmn_gemm_desc
+                     + [("shift_h0", _u64), ("ld_h0", np.int64), ("workspace", _u64), ("colsum", _u64), ("colsum2", _u64)])  # pnmn_gemm_desc
 GEMM_MAX, GEMM_A_T, GEMM_B_T, GEMM_ACC = 8, 1, 2, 4
 LSTM_STACK_JOB = np.dtype([("xp", _u64), ("tokens", _u64), ("token_stride", np.int64)] + [(n, _u64) for n in ("w_hh", "w_ih", "bias", "hs", "cs", "act", "dhs", "dgates")]
                           + [(n, _i32) for n in ("B", "T", "dep", "reserved")])  # pnmn_lstm_stack_job
@@ -320,7 +320,7 @@ ITEM_SIZES = {
     "pnmn_decoder_bwd_job": (DECODER_BWD_JOB, 136),
     "pnmn_trunk_config": (TRUNK_CONFIG, 88),
     "pnmn_trunk_io": (TRUNK_IO, 256),
-    "pnmn_gemm_desc": (GEMM_DESC, 104),
+    "pnmn_gemm_desc": (GEMM_DESC, 120),
     "pnmn_token_seg": (TOKEN_SEG, 32),
     "pnmn_lstm_stack_job": (LSTM_STACK_JOB, 104),
 }

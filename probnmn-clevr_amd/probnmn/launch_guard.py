@@ -132,6 +132,17 @@ def _wait_count(store: _Store, key: str, world: int, seconds: float, abort_key: 
     return "timeout"
 
 
+def _leave(store: _Store, rank: int, world: int, tag: str) -> None:
+    """Last store access of a supervisor: rank 0 may be HOSTING the store (no launcher), so it stays until every rank has
+    signed off -- a supervisor still polling a counter when the host exits would die on the closed connection."""
+    try:
+        store.add(tag, 1)
+        if rank == 0:
+            _wait_count(store, tag, world, 30.0)
+    except Exception as exc:  # (nothing left to coordinate: the outcome is decided)
+        _log(rank, "sign-off: %r" % (exc,))
+
+
 def supervise(worker_argv: List[str], watchdog_s: float = 150.0, first_beat_s: float = 420.0,
               fallback_env: Optional[Dict[str, str]] = None,
               last_resort: Optional[Callable[[Dict], Dict]] = None) -> int:
@@ -194,6 +205,7 @@ def supervise(worker_argv: List[str], watchdog_s: float = 150.0, first_beat_s: f
                 _kill(child)
             reader.join(timeout=5)
             if status == "ok":
+                _leave(store, rank, world, "a%d/left" % a)
                 _release(rank, captured, info)
                 return 0
             reason = store.get(abort_key) if store.has(abort_key) else status
@@ -204,6 +216,7 @@ def supervise(worker_argv: List[str], watchdog_s: float = 150.0, first_beat_s: f
             _wait_count(store, "a%d/cleared" % a, world, 90.0)
             if rank == 0:
                 _log(rank, "attempt %d aborted (%s)%s" % (a, reason, "; restarting the workers with %s" % fallback_env if a == 0 else ""))
+        _leave(store, rank, world, "left")
         if rank == 0 and last_resort is not None:
             print(json.dumps(last_resort(info)), flush=True)
         return 3

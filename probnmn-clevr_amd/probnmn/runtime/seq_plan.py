@@ -161,7 +161,7 @@ class Seq2SeqPlan:
 
     # ---- pieces ------------------------------------------------------------------------------------------------------------
     def _gemm(self, calls: _Calls, name: str, descs) -> None:
-        """descs: list of dicts(a, b, c, M, N, K, lda, ldb, ldc, ta, tb, acc, bias, split, shift_t, h0, ld_h0)."""
+        """descs: list of dicts(a, b, c, M, N, K, lda, ldb, ldc, ta, tb, acc, bias, split, shift_t, h0, ld_h0, colsum, colsum2)."""
         lib = _hip.lib()
         for lo in range(0, len(descs), _hip.GEMM_MAX):
             part = descs[lo:lo + _hip.GEMM_MAX]
@@ -191,6 +191,7 @@ class Seq2SeqPlan:
                     ws = self.bytes_buf("%s.ws%d" % (name, lo + i), lib.pnmn_gemm_workspace_bytes(d["M"], d["N"], split), zero=True)
                     r["workspace"] = ws.data_ptr()
                 r["shift_t"], r["shift_h0"], r["ld_h0"] = d.get("shift_t", 0), d.get("h0", 0), d.get("ld_h0", 0)
+                r["colsum"], r["colsum2"] = d.get("colsum", 0), d.get("colsum2", 0)
             self._keep.append(rec)
             calls.add("pnmn_gemm_cus", rec.ctypes.data, len(rec), GEMM_WORKGROUPS, self.stream)
 
@@ -319,19 +320,18 @@ class Seq2SeqPlan:
             mm, lstm, tag, rows, T, V = e["mm"], e["lstm"], e["tag"], e["rows"], e["T"], e["V"]
             dtable = f(tag + ".dtable", V, 1024)
             ews = self.bytes_buf(tag + ".emb_ws", lib.pnmn_embedding_grad_workspace_bytes(rows, T, V))
-            cws = self.bytes_buf(tag + ".col_ws", lib.pnmn_colsum_workspace_bytes(rows * T, 1024), zero=True)
             dg1, dg2, g = e["dg1"], e["dg2"], mm.grad
             calls.add("pnmn_embedding_grad", dg1.data_ptr(), e["src"].data_ptr(), e["src"].stride(0), rows, T, 1024, V, 0, 0, -1, 0,
                       dtable.data_ptr(), ews.data_ptr(), st)
             calls.add("pnmn_token_table_bwd", dtable.data_ptr(), e["emb"].data_ptr(), lstm.weight_ih_l0.data_ptr(), lstm.weight_ih_l0.stride(0),
                       V, 256, 1024, e["pad_idx"], g(e["emb"]).data_ptr(), g(lstm.weight_ih_l0).data_ptr(), 0, g(lstm.bias_ih_l0).data_ptr(),
                       g(lstm.bias_hh_l0).data_ptr(), st)
-            calls.add("pnmn_colsum", dg2.data_ptr(), 1024, rows * T, 1024, g(lstm.bias_ih_l1).data_ptr(), g(lstm.bias_hh_l1).data_ptr(), 0,
-                      cws.data_ptr(), st)
             K = rows * T
+            # (layer 2's bias gradients = the column sums of dgates2: the weight-gradient product that reads dgates2 as its
+            # transposed operand adds them up on the way -- pnmn_gemm_desc.colsum)
             deferred += [
                 dict(a=dg2.data_ptr(), b=e["hs2"].data_ptr(), c=g(lstm.weight_hh_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
-                     ldc=256, ta=1, split="auto", shift_t=T),
+                     ldc=256, ta=1, split="auto", shift_t=T, colsum=g(lstm.bias_ih_l1).data_ptr(), colsum2=g(lstm.bias_hh_l1).data_ptr()),
                 dict(a=dg2.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_ih_l1).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
                      ldc=256, ta=1, split="auto"),
                 dict(a=dg1.data_ptr(), b=e["hs1"].data_ptr(), c=g(lstm.weight_hh_l0).data_ptr(), M=1024, N=256, K=K, lda=1024, ldb=256,
@@ -549,10 +549,8 @@ class Seq2SeqPlan:
             bs = base if mdl is pg else qbase
             R = bs["hs"].size(0)
             lg, dlg = (logits, dlogits) if mdl is pg else (qlogits, qdlogits)
-            cws = self.bytes_buf(tag + ".d.col_ws", lib.pnmn_colsum_workspace_bytes(R, V), zero=True)
-            ca.add("pnmn_colsum", dlg.data_ptr(), V, R, V, g(mdl.proj.bias).data_ptr(), None, 0, cws.data_ptr(), self.stream)
             deferred.append(dict(a=dlg.data_ptr(), b=bs["hs"].data_ptr(), c=g(mdl.proj.weight).data_ptr(), M=V, N=256, K=R, lda=V, ldb=256,
-                                 ldc=256, ta=1, split="auto"))
+                                 ldc=256, ta=1, split="auto", colsum=g(mdl.proj.bias).data_ptr()))
             deferred.append(dict(a=bs["dg"].data_ptr(), b=bs["cx"].data_ptr(), c=g(w_ih).data_ptr(), M=1024, N=256, K=R, lda=1024, ldb=256,
                                  ldc=512, ta=1, split="auto"))
             for k, (sd, _, _, _, _) in enumerate(sides):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     handle = _hip.lib()
     for n in names:
         assert hasattr(handle, n), n
-    assert handle.pnmn_abi_version() == _hip.ABI_VERSION == 11
+    assert handle.pnmn_abi_version() == _hip.ABI_VERSION == 12
 
 
 def test_launch_trace_without_launches_is_empty():

@@ -166,3 +166,37 @@ def test_rate_report(capsys):
         with capsys.disabled():
             print("gemm %-14s M %6d N %5d K %6d split %2d: %7.1f us = %6.1f TFLOP/s (torch %7.1f us)"
                   % (name, M, N, K, split, ms * 1e3, 2.0 * M * N * K / ms / 1e9, ms_t * 1e3))
+
+
+@pytest.mark.parametrize("M,N,K,split,tb", [(1024, 256, 128 * 37 + 5, 9, 0), (44, 256, 3000, 1, 0), (100, 256, 6000, 5, 0), (300, 130, 257, 1, 1),
+                                            (1024, 512, 4096, 4, 0)])
+def test_column_sums_of_the_transposed_operand(M, N, K, split, tb):
+    """pnmn_gemm_desc.colsum: the bias gradient beside a weight gradient dy^T x (sum over the rows of dy), split or not,
+    ragged widths (lda = vocabulary size: the scalar loader), two outputs; twice the same bits."""
+    g = torch.Generator(device="cuda:0").manual_seed(M + N + K)
+    dy = torch.randn(K, M, device="cuda:0", generator=g)
+    x = torch.randn((N, K) if tb else (K, N), device="cuda:0", generator=g)
+    ws = _ws(M, N, split)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(M, N, device="cuda:0")
+        s1 = torch.full((M + 3,), float("nan"), device="cuda:0")
+        s2 = torch.full((M + 3,), float("nan"), device="cuda:0")
+        d = _desc(dy, x, C, M, N, K, flags=_hip.GEMM_A_T + tb * _hip.GEMM_B_T, split=split, ws=ws)
+        d["colsum"], d["colsum2"] = s1.data_ptr(), s2.data_ptr()
+        _run([d])
+        outs.append((C, s1, s2))
+    C, s1, s2 = outs[0]
+    _close(C, dy.double().t() @ (x.double().t() if tb else x.double()), K)
+    _close(s1[:M], dy.double().sum(0), K)
+    assert torch.equal(s1[:M], s2[:M]) and bool(torch.isnan(s1[M:]).all()) and bool(torch.isnan(s2[M:]).all())
+    assert torch.equal(outs[1][1][:M], s1[:M]) and torch.equal(outs[1][0], C)
+
+
+def test_column_sums_need_the_transposed_layout():
+    a = torch.zeros(128, 64, device="cuda:0")
+    b = torch.zeros(64, 128, device="cuda:0")
+    c = torch.zeros(128, 128, device="cuda:0")
+    d = _desc(a, b, c, 128, 128, 64)
+    d["colsum"] = c.data_ptr()
+    assert _hip.lib().pnmn_gemm(d.ctypes.data, 1, _hip.stream_ptr(torch.device("cuda:0"))) == _hip.ESHAPE
