@@ -9,4 +9,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python
 DB=$(find /tmp/prof_$TAG -name '*_results.db' | head -1)
 python profiles/summarize.py $DB > gpurun_out/${TAG}_b${B}_kernel_stats.txt 2>&1
 python profiles/gaps.py $DB 0.5 > gpurun_out/${TAG}_b${B}_gaps.txt 2>&1
+python profiles/summarize.py --steady 20 $DB > gpurun_out/${TAG}_b${B}_steady.txt 2>&1
+python profiles/summarize.py --timeline $DB > gpurun_out/${TAG}_b${B}_timeline.txt 2>&1
 timeout 300 python scripts/joint_host_profile.py $B > gpurun_out/${TAG}_b${B}_host.txt 2>&1
