@@ -8,18 +8,23 @@
 // 128-question step no longer pays ~20 library calls of 15-30 us host time and a dependent dispatch each.
 //
 // Kernel shape: 256 threads = 2 x 2 waves, workgroup tile 128 x 128, k-tiles of 32, v_mfma_f32_32x32x2_f32 (a wave owns
-// 64 x 64 = four accumulators of 16 registers).  An operand whose storage is contiguous along k ("KC": A [M][K], B given
-// as [N][K]) is staged row-major [128][32 + 4] and read back with one ds_read_b128 per (32-row tile, 8 k): lane (i, h)
-// takes k = 8 q + 4 h .. + 3, and the four MFMAs of that group contract k = 8 q + 4 h + s from both operands alike (a
-// permutation of the k order inside a tile: the sum is the same, the rounding order fixed).  An operand stored with the
-// OTHER index contiguous ("MC": A given as [K][M] -- a weight gradient's dy^T -- or B [K][N]) is staged as it lies,
-// [32][128 + 4], with 16-byte stores, and read with ds_read_b32 at the same k.  Global loads of tile t + 1 are in flight
-// while tile t is contracted (registers -> the other LDS buffer, one barrier per tile).
+// 64 x 64 = four accumulators of 16 registers), two stages of 2 x 16 KB in LDS -> two workgroups per CU.  An operand whose
+// storage is contiguous along k ("KC": A [M][K], B given as [N][K]) lies in LDS as [128 rows][32 k] with the 16-byte pieces of
+// a row permuted by the row index (store_tile: conflict-free ds_read_b128 without padding) and is read back with one
+// ds_read_b128 per (32-row tile, 8 k): lane (i, h) takes k = 8 q + 4 h .. + 3, and the four MFMAs of that group contract
+// k = 8 q + 4 h + s from both operands alike (a permutation of the k order inside a tile: the sum is the same, the rounding
+// order fixed).  An operand stored with the OTHER index contiguous ("MC": A given as [K][M] -- a weight gradient's dy^T -- or
+// B [K][N]) lies as it is stored, [32][128], and is read with ds_read_b32 at the same k.  Interior tiles travel from global
+// memory straight into that image (global_load_lds_dwordx4, struct Direct: no staging registers, no ds_write pass) while
+// the tile before them is contracted; ragged tiles, unaligned operands and the shifted "previous state" operand go through
+// registers (load_tile / load_tile_shift).  One barrier per k tile.
 // Split-K: blockIdx walks (problem, tile, chunk); chunks write partial tiles to the problem's workspace and a second
 // small launch (gemm_reduce_kernel) adds them in chunk order -- deterministic, no atomics on the output; the kernel
 // boundary makes the partials visible (a fence + "last chunk reduces" in-kernel cost an L2 write-back per workgroup).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/probnmn_hip.h"
 #include "global_ptr.h"
@@ -32,9 +37,9 @@ using pnmn::as_global;
 using pnmn::gfloat;
 
 constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int KC_LD = TK + 4;   // row-major [128][36]: 144-byte rows, 16-byte aligned, conflict-free ds_read_b128
-constexpr int MC_LD = TM + 4;   // k-major  [32][132]
-constexpr int OP_FLOATS = TM * KC_LD > TK * MC_LD ? TM * KC_LD : TK * MC_LD;  // 4608 floats = 18 KB per operand buffer
+constexpr int OP_FLOATS = TM * TK;  // 4096 floats = 16 KB per operand tile and stage, no padding (see store_tile)
+using lchar = __attribute__((address_space(3))) char;
+using gchar = __attribute__((address_space(1))) char;
 
 struct Batch {
     pnmn_gemm_desc d[PNMN_GEMM_MAX];
@@ -98,49 +103,106 @@ __device__ __forceinline__ void load_tile(const gfloat* base, int64_t ld, int ro
     }
 }
 
-// The same for a tile that lies wholly inside the operand (all 128 rows, all 32 k, 16-byte aligned rows): four
-// unconditional 16-byte loads from per-thread pointers that advance by one k-tile per call -- the bounds-checked loader
-// above compiles to a branch per piece (exec-masked scalar fall-backs), which serialises the eight loads of a k-tile.
-template <bool KC>
-__device__ __forceinline__ void load_tile_fast(const gfloat*& ptr, int64_t piece_stride, int64_t step, f32x4 (&r)[4]) {
-    // (ONE per-thread pointer per operand: the pieces of a thread lie a uniform stride apart -- 32 rows (KC) / 8 k rows (MC)
-    // -- which stays in scalar registers; four pointers per operand cost 16 VGPRs and the second workgroup of a CU)
+// The shifted operand's INTERIOR tiles (stored [K][N], all 32 k rows and 128 columns inside, 16-byte aligned rows): k row r
+// reads storage row r - 1, or h0[r / shift_t] where r % shift_t == 0 (zeros when h0 is null) -- straight-line: the source
+// pointer is selected, not branched on (the bounds-checked loader above is a branch per piece with an integer division).
+__device__ __forceinline__ void load_tile_shift(const gfloat* base, int64_t ld, int col0, int k0, int tid, f32x4 (&r)[4], int shift_t,
+                                                float rcp_t, const gfloat* h0, int64_t ld_h0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = pnmn::load4(ptr + j * piece_stride);
-    ptr += step;
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + (tid >> 5) + 8 * j, col = col0 + 4 * (tid & 31);
+        const int b = (int)(((float)k + 0.5f) * rcp_t);  // k / shift_t (the true quotient of the half-integer is >= 1 / (2 shift_t) away from an integer, the float product within k * 1.2e-7 of it: exact below 2^22 rows; the caller stops at 2^21)
+        const bool first = k == b * shift_t;
+        const gfloat* prev = base + (int64_t)(k - 1) * ld + col;  // (k = 0 is always `first`: never dereferenced)
+        const gfloat* init = h0 ? h0 + (int64_t)b * ld_h0 + col : base + col;
+        f32x4 v = pnmn::load4(first ? init : prev);
+        if (first && !h0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        r[j] = v;
+    }
 }
 
-template <bool KC>
-__device__ __forceinline__ const gfloat* tile_pointer(const gfloat* base, int64_t ld, int row0, int k0, int tid) {
-    return KC ? base + (int64_t)(row0 + (tid >> 3)) * ld + k0 + 4 * (tid & 7) : base + (int64_t)(k0 + (tid >> 5)) * ld + row0 + 4 * (tid & 31);
-}
-
+// LDS image of an operand tile (16 KB, the same for the register loader and the direct-to-LDS loader):
+//   KC  row r = 128 bytes = eight 16-byte pieces; piece g (k = 4 g .. 4 g + 3) sits at position g ^ ((r >> 1) & 7).
+//       ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32);
+//       rows of equal parity share banks, and within a group the eight values of (r >> 1) & 7 occur once per parity: the
+//       sixteen lanes of a group read sixteen different (parity, position) slots -- no conflicts, no padding;
+//   MC  k row = 512 bytes as it lies; ds_read_b32 of consecutive lanes reads consecutive words.
 template <bool KC>
 __device__ __forceinline__ void store_tile(float* lds, int tid, const f32x4 (&r)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = tid + 256 * j;
-        if (KC)
-            *reinterpret_cast<f32x4*>(lds + (p >> 3) * KC_LD + 4 * (p & 7)) = r[j];
-        else
-            *reinterpret_cast<f32x4*>(lds + (p >> 5) * MC_LD + 4 * (p & 31)) = r[j];
+        if (KC) {
+            const int row = p >> 3;
+            *reinterpret_cast<f32x4*>(lds + row * TK + 4 * ((p & 7) ^ ((row >> 1) & 7))) = r[j];
+        } else {
+            *reinterpret_cast<f32x4*>(lds + (p >> 5) * TM + 4 * (p & 31)) = r[j];
+        }
     }
 }
 
 // the four operand values of k group q (k = 8 q + 4 h + s, s = 0..3) for the 32-row tile at `row`
 template <bool KC>
 __device__ __forceinline__ f32x4 frag(const float* lds, int row, int q, int h) {
-    if (KC) return *reinterpret_cast<const f32x4*>(lds + row * KC_LD + 8 * q + 4 * h);
-    const float* p = lds + (8 * q + 4 * h) * MC_LD + row;
-    return f32x4{p[0], p[MC_LD], p[2 * MC_LD], p[3 * MC_LD]};
+    if (KC) return *reinterpret_cast<const f32x4*>(lds + row * TK + 4 * ((2 * q + h) ^ ((row >> 1) & 7)));
+    const float* p = lds + (8 * q + 4 * h) * TM + row;
+    return f32x4{p[0], p[TM], p[2 * TM], p[3 * TM]};
 }
 
-// `cs` (A stored [K][M] only): the thread's share of the COLUMN SUMS of A over this chunk's k range -- piece j of a tile is
-// k row tid / 32 + 8 j, m quad tid % 32, so a thread meets the same four columns in every piece and adds them up as the
-// registers arrive for the LDS store (sum_k A[k][m] = the bias gradient that goes with a weight gradient dy^T x).
+// Interior tiles go from global memory STRAIGHT into that image (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass).  A wave-load writes 1 KiB lane-linear (base + 16 lane), so the piece permutation is applied to the SOURCE
+// address: wave w fills rows 32 w .. + 31 (KC: four loads of eight rows; lane l -> row 8 j + l / 8, position l % 8, i.e.
+// piece (l % 8) ^ (4 (j & 1) + l / 16)) or k rows 8 w .. + 7 (MC: four loads of two k rows).
+template <bool KC>
+struct Direct {
+    // source of load j = base (wave-uniform: scalar registers, advanced on the scalar unit) + j * piece + this lane's offset
+    const gchar* base;
+    uint32_t v0, v1;      // the lane's byte offset for the even / the odd loads (KC: their piece index differs by 4)
+    int64_t piece, step;  // bytes from load j to j + 1, bytes per k tile (uniform)
+    uint32_t off;         // byte offset of the wave's first load inside the operand tile (uniform)
+
+    __device__ __forceinline__ void start(const gfloat* origin, int64_t ld, int row0, int k0, int tid) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        // (the pointer comes out of a descriptor in the kernel arguments: uniform, but only readfirstlane says so)
+        const uint64_t o64 = (uint64_t)(uintptr_t)origin;
+        const gchar* o = (const gchar*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(o64 >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)o64));
+        if (KC) {
+            const int c = (lane & 7) ^ (lane >> 4);
+            base = o + ((int64_t)(row0 + 32 * wave) * ld + k0) * 4;
+            v0 = (uint32_t)((lane >> 3) * ld) * 4u + 16u * c, v1 = (uint32_t)((lane >> 3) * ld) * 4u + 16u * (c ^ 4);
+            piece = 32 * ld, step = 4 * TK, off = (uint32_t)wave * 32u * 128u;
+        } else {
+            base = o + ((int64_t)(k0 + 8 * wave) * ld + row0) * 4;
+            v0 = v1 = (uint32_t)((lane >> 5) * ld) * 4u + 16u * (lane & 31);
+            piece = 8 * ld, step = 4 * (int64_t)TK * ld, off = (uint32_t)wave * 8u * 512u;
+        }
+    }
+    // Issued as inline assembly: the compiler orders a __builtin_amdgcn_global_load_lds against EVERY later LDS read with
+    // s_waitcnt vmcnt(0) (it cannot tell the stage being filled from the stage being read), which puts the whole global
+    // latency of the prefetch in front of the first fragment read of every k tile.  contract() waits itself (vmcnt(0) +
+    // barrier at the end of a k tile).  M0 = LDS byte address of the load's 1 KiB; nothing else in this kernel uses M0.
+    __device__ __forceinline__ void issue(float* tile) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((lchar*)tile)) + off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t src = (uint64_t)(uintptr_t)(base + j * piece);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :
+                         : "v"(KC && (j & 1) ? v1 : v0), "s"(src), "s"(dst + 1024u * j)
+                         : "memory");
+        }
+        base += step;
+    }
+};
+
+// `cs` (A stored [K][M] only; waves of the first wave column): this lane's share of the COLUMN SUMS of A over the chunk's k
+// range -- the A fragments a wave feeds its MFMAs with hold A[k][row] for all 32 k of a tile and the wave's 64 rows, lane
+// (i, h) those of k = 8 q + 4 h + s: adding them up as they pass costs eight additions per k group and no memory access
+// (sum_k A[k][m] = the bias gradient that goes with a weight gradient dy^T x).
 template <bool AKC, bool BKC>
 __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0, int kbeg, int kend, float* lds, f32x16 (&acc)[2][2],
-                                         bool want_cs, f32x4& cs) {
+                                         bool want_cs, float (&cs)[2]) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const gfloat* A = as_global(d.a);
@@ -152,65 +214,95 @@ __device__ __forceinline__ void contract(const pnmn_gemm_desc& d, int m0, int n0
                                                                        ((d.ld_h0 & 3) == 0 && ((uintptr_t)d.shift_h0 & 15) == 0));
     float* la = lds;                    // [2][OP_FLOATS]
     float* lb = lds + 2 * OP_FLOATS;    // [2][OP_FLOATS]
-    f32x4 ra[4], rb[4];
-    // interior tiles (the common case) take the straight-line loader; `kfull` = k-tiles that lie wholly below kend
-    const bool afast = avec && m0 + TM <= d.M, bfast = bvec && n0 + TN <= d.N && (BKC || d.shift_t == 0);
+    // interior tiles (the common case) go straight to LDS; `kfull` = k-tiles that lie wholly below kend; ragged tiles,
+    // unaligned operands and the shifted operand take the bounds-checked loader through registers
+    const bool adir = avec && m0 + TM <= d.M, bdir = bvec && n0 + TN <= d.N && (BKC || d.shift_t == 0);
     const int kfull = kbeg + (kend - kbeg) / TK * TK;
-    const gfloat* pa = tile_pointer<AKC>(A, d.lda, m0, kbeg, tid);
-    const gfloat* pb = tile_pointer<BKC>(Bm, d.ldb, n0, kbeg, tid);
-    const int64_t sa = AKC ? TK : (int64_t)TK * d.lda, sb = BKC ? TK : (int64_t)TK * d.ldb;
-    const int64_t ja = (AKC ? 32 : 8) * d.lda, jb = (BKC ? 32 : 8) * d.ldb;  // piece j = tid + 256 j: 32 rows / 8 k rows on
-    auto fetch = [&](int k0) {
-        if (afast && k0 < kfull)
-            load_tile_fast<AKC>(pa, ja, sa, ra);
-        else
-            load_tile<AKC>(A, d.lda, m0, k0, d.M, kend, avec, tid, ra, 0, nullptr, 0);
-        if (bfast && k0 < kfull)
-            load_tile_fast<BKC>(pb, jb, sb, rb);
-        else
-            load_tile<BKC>(Bm, d.ldb, n0, k0, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
-    };
-    fetch(kbeg);
-    store_tile<AKC>(la, tid, ra);
-    store_tile<BKC>(lb, tid, rb);
-    if (!AKC && want_cs) cs += (ra[0] + ra[1]) + (ra[2] + ra[3]);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        const bool more = k0 + TK < kend;
-        if (more) fetch(k0 + TK);
-        const float* ca = la + cur * OP_FLOATS;
-        const float* cb = lb + cur * OP_FLOATS;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = frag<AKC>(ca, 64 * wm + 32 * t + i, q, h);
-                b[t] = frag<BKC>(cb, 64 * wn + 32 * t + i, q, h);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<AKC>(la + (cur ^ 1) * OP_FLOATS, tid, ra);
-            store_tile<BKC>(lb + (cur ^ 1) * OP_FLOATS, tid, rb);
-            if (!AKC && want_cs) cs += (ra[0] + ra[1]) + (ra[2] + ra[3]);
-        }
+    const float rcp_t = d.shift_t > 0 ? 1.f / (float)d.shift_t : 0.f;
+    Direct<AKC> da;
+    Direct<BKC> db;
+    da.start(A, d.lda, m0, kbeg, tid);
+    db.start(Bm, d.ldb, n0, kbeg, tid);
+    // One loop per loader combination (compile time: a loop that may take either path carries the staging registers through
+    // every iteration, and the copies at the joins wait for ALL outstanding loads, the direct ones included).
+    //   AD / BD: the operand goes straight to LDS.  k tiles [lo, hi); stage 0 first; every loop starts and ends with all of
+    //   LDS free (behind a barrier).
+    auto loop = [&](auto ad_tag, auto bd_tag, int lo, int hi) {
+        constexpr bool AD = decltype(ad_tag)::value, BD = decltype(bd_tag)::value;
+        f32x4 ra[4], rb[4];
+        auto fetch = [&](int k0, int st) {
+            if constexpr (AD)
+                da.issue(la + st * OP_FLOATS);
+            else
+                load_tile<AKC>(A, d.lda, m0, k0, d.M, kend, avec, tid, ra, 0, nullptr, 0);
+            if constexpr (BD)
+                db.issue(lb + st * OP_FLOATS);
+            else if constexpr (AD && !BKC)  // (direct A beside B through the registers: the shifted operand's interior tiles)
+                load_tile_shift(Bm, d.ldb, n0, k0, tid, rb, d.shift_t, rcp_t, h0, d.ld_h0);
+            else
+                load_tile<BKC>(Bm, d.ldb, n0, k0, d.N, kend, bvec, tid, rb, BKC ? 0 : d.shift_t, h0, d.ld_h0);
+        };
+        auto commit = [&](int st) {
+            if constexpr (!AD) store_tile<AKC>(la + st * OP_FLOATS, tid, ra);
+            if constexpr (!BD) store_tile<BKC>(lb + st * OP_FLOATS, tid, rb);
+        };
+        if (lo >= hi) return;
+        fetch(lo, 0);
+        commit(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the direct loads' data is in LDS once the counter says so)
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int k0 = lo; k0 < hi; k0 += TK) {
+            const bool more = k0 + TK < hi;
+            if (more) fetch(k0 + TK, cur ^ 1);  // (stage cur ^ 1 was read last in the previous iteration: free behind its barrier)
+            const float* ca = la + cur * OP_FLOATS;
+            const float* cb = lb + cur * OP_FLOATS;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = frag<AKC>(ca, 64 * wm + 32 * t + i, q, h);
+                    b[t] = frag<BKC>(cb, 64 * wn + 32 * t + i, q, h);
+                }
+                if (!AKC && want_cs) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) cs[t] += (a[t][0] + a[t][1]) + (a[t][2] + a[t][3]);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+            }
+            if (more) commit(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    if (adir && bdir) {
+        loop(yes{}, yes{}, kbeg, kfull);
+        loop(no{}, no{}, kfull, kend);  // (a last partial k tile)
+    } else if (!BKC && adir && bvec && d.shift_t > 0 && n0 + TN <= d.N && kend <= (1 << 21)) {
+        // a weight gradient against the "previous state": the shifted operand through the registers, dy^T direct
+        if constexpr (!BKC) {
+            loop(yes{}, no{}, kbeg, kfull);
+            loop(no{}, no{}, kfull, kend);
+        }
+    } else {
+        loop(no{}, no{}, kbeg, kend);
     }
 }
 
 // (waves_per_eu 2: the register allocator must stay within 256 registers per wave, accumulators included -- at 260 the second
 // workgroup of a CU is gone and every product of the plan ran 20 % slower)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel(const Batch batch) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][OP_FLOATS] = 72 KB: two workgroups per CU
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2 stages][A, B][OP_FLOATS] = 64 KB: two workgroups per CU
     // (a launch cut for fewer workgroups than it has units -- pnmn_gemm_cus: products that share the chip with another
     // stream's latency chain -- walks them; the LDS buffers are free again behind the last barrier of contract())
     for (int unit = blockIdx.x; unit < batch.first[batch.n]; unit += gridDim.x) {
@@ -239,8 +331,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
     const bool akc = !(d.flags & PNMN_GEMM_A_TRANSPOSED), bkc = (d.flags & PNMN_GEMM_B_TRANSPOSED) != 0;
-    const bool want_cs = d.colsum != nullptr && !akc && tn == 0;  // (the first tile column of a row of tiles carries them)
-    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the first tile column of a row of tiles carries them, and of its waves the first wave column)
+    const bool want_cs = d.colsum != nullptr && !akc && tn == 0 && ((threadIdx.x >> 6) & 1) == 0;
+    const bool tile_cs = d.colsum != nullptr && !akc && tn == 0;
+    float cs[2] = {0.f, 0.f};
     if (kbeg < kend) {
         if (akc && bkc)
             contract<true, true>(d, m0, n0, kbeg, kend, lds, acc, false, cs);
@@ -252,23 +346,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             contract<false, false>(d, m0, n0, kbeg, kend, lds, acc, want_cs, cs);
     }
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    // (everything the epilogue addresses with is derived from values the compiler cannot see through: it otherwise forms the
+    // 32 row pointers of the output tile in front of the k loop and carries them -- or their spill slots -- through it)
+    int tid = threadIdx.x, m0e = m0, n0e = n0;
+    asm volatile("" : "+v"(tid), "+s"(m0e), "+s"(n0e));
+    const int wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    if (want_cs) {
-        // eight threads (k rows u, u + 8, ...: u = tid / 32) hold partial sums of the same four columns: added in u order
-        // through LDS (free behind contract()'s last barrier); a chunk's 128 sums go behind the partial tiles in the
-        // workspace, an unsplit product's straight to the output
-        *reinterpret_cast<f32x4*>(lds + (tid >> 5) * TM + 4 * (tid & 31)) = cs;
+    if (tile_cs) {
+        // lane (i, h) of wave (wm, 0) holds the sums of rows 64 wm + 32 t + i over the k of its half h: the halves meet in
+        // LDS (free behind contract()'s last barrier) and are added in h order; a chunk's 128 sums go behind the partial
+        // tiles in the workspace, an unsplit product's straight to the output
+        if (want_cs) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) lds[h * TM + 64 * wm + 32 * t + i] = cs[t];
+        }
         __syncthreads();
         if (tid < TM) {
-            float t = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t += lds[u * TM + tid];
+            const float t = lds[tid] + lds[TM + tid];
             if (split > 1) {
                 as_global(d.workspace)[(size_t)tiles_m * tiles_n * split * (TM * TN) + ((size_t)tm * split + chunk) * TM + tid] = t;
-            } else if (m0 + tid < d.M) {
-                d.colsum[m0 + tid] = t;
-                if (d.colsum2) d.colsum2[m0 + tid] = t;
+            } else if (m0e + tid < d.M) {
+                d.colsum[m0e + tid] = t;
+                if (d.colsum2) d.colsum2[m0e + tid] = t;
             }
         }
         __syncthreads();  // (the next unit of a persistent workgroup stages into the same LDS)
@@ -290,14 +389,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool accumulate = (d.flags & PNMN_GEMM_ACCUMULATE) != 0;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + 64 * wn + 32 * nt + i;
+        const int col = n0e + 64 * wn + 32 * nt + i;
         if (col >= d.N) continue;
         const float bv = d.bias ? bias[col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 64 * wm + 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3);
+                const int row = m0e + 64 * wm + 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3);
                 if (row < d.M) {
                     gfloat* dst = C + (int64_t)row * d.ldc + col;
                     float v = acc[mt][nt][r] + bv;

@@ -32,9 +32,10 @@ import torch
 from probnmn import _hip
 
 
-#: workgroups a launch of split-K products is cut for (256 CUs, the 72 KB tiles of pnmn_gemm sit two to a CU)
-SPLIT_TARGET_WORKGROUPS = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_WGS", "2048"))
-SPLIT_MIN_KTILES = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_MIN", "16"))
+#: workgroup slots of the chip for a launch of split-K products (256 CUs, the 64 KB workgroups of pnmn_gemm sit two to a CU)
+#: and the shortest chunk (k tiles) a product is cut into
+SPLIT_SLOTS = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_SLOTS", "512"))
+SPLIT_MIN_KTILES = int(__import__("os").environ.get("PNMN_PLAN_SPLIT_MIN", "8"))
 #: an encoder's two LSTM layers as a wavefront, independent encoder passes in one launch (pnmn_lstm_stack_*); False: a launch
 #: per layer with the input projection as a GEMM in between (A/B aid, and what batches too large for the chip fall back to)
 USE_STACK = True
@@ -167,15 +168,26 @@ class Seq2SeqPlan:
             part = descs[lo:lo + _hip.GEMM_MAX]
             rec = np.zeros(len(part), _hip.GEMM_DESC)
             # split-K of the problems that ask for it ("auto"), chosen for the LAUNCH: chunks of one common length (in 32-wide
-            # k tiles) for every problem of the launch, such that the launch has ~SPLIT_TARGET_WORKGROUPS workgroups of equal
-            # work -- several rounds of them balance problems of different K dynamically, where a chunk count per problem that
-            # merely filled the chip once left the CUs holding two long chunks running after the others had finished (eight
-            # weight gradients of 512-question passes: 78 TFLOP/s).  Floor of 16 k tiles per chunk: every chunk writes a 64 KB
-            # partial tile that the reduction launch reads back.
+            # k tiles) for every problem of the launch, so that the launch is a few ROUNDS of equal workgroups over the chip's
+            # 512 slots (two 64 KB workgroups per CU) -- a chunk count per problem that merely filled the chip once left the CUs
+            # holding two long chunks running after the others had finished (eight weight gradients of 512-question passes:
+            # 78 TFLOP/s).  The length is the one with the least modelled time among 8 .. 128 k tiles: rounds x chunk length,
+            # a started last round counting 0.6 (its workgroups have their CU to themselves), plus the partial tiles' trip
+            # through memory (64 KB written and read back per chunk: ~4 k tiles' worth of a workgroup's time).  2114 equal
+            # chunks are 4.13 rounds -- five in practice; 2040 are four.
             tiles = [((d["M"] + 127) // 128) * ((d["N"] + 127) // 128) for d in part]
             ktiles = [(d["K"] + 31) // 32 for d in part]
-            work = sum(t * k for t, k, d in zip(tiles, ktiles, part) if d.get("split") == "auto")
-            chunk_len = min(max(work // SPLIT_TARGET_WORKGROUPS, SPLIT_MIN_KTILES), 128)
+            auto = [i for i, d in enumerate(part) if d.get("split") == "auto"]
+            fixed_units = sum(t for i, t in enumerate(tiles) if i not in auto)
+            chunk_len, best = SPLIT_MIN_KTILES, None
+            for cand in range(SPLIT_MIN_KTILES, 129):
+                splits = [max(1, min(-(-ktiles[i] // cand), 64)) for i in auto]
+                units = fixed_units + sum(tiles[i] * sp for i, sp in zip(auto, splits))
+                longest = max([-(-ktiles[i] // sp) for i, sp in zip(auto, splits)] + [ktiles[i] for i in range(len(part)) if i not in auto] + [1])
+                rounds = units // SPLIT_SLOTS + (0.6 if units % SPLIT_SLOTS else 0.0)
+                cost = rounds * longest + 4.0 * sum(tiles[i] * sp for i, sp in zip(auto, splits) if sp > 1) / SPLIT_SLOTS
+                if best is None or cost < best:
+                    chunk_len, best = cand, cost
             for i, d in enumerate(part):
                 r = rec[i]
                 r["a"], r["b"], r["c"] = d["a"], d["b"], d["c"]
