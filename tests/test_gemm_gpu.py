@@ -200,3 +200,46 @@ def test_column_sums_need_the_transposed_layout():
     d = _desc(a, b, c, 128, 128, 64)
     d["colsum"] = c.data_ptr()
     assert _hip.lib().pnmn_gemm(d.ctypes.data, 1, _hip.stream_ptr(torch.device("cuda:0"))) == _hip.ESHAPE
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 70), (128, 128, 33), (384, 256, 4 * 32 + 31)])
+def test_interior_tiles_with_a_partial_last_k_tile(ta, tb, M, N, K):
+    """Whole 128 x 128 tiles (the direct-to-LDS loop) followed by a last k tile that is not full (the register loop)."""
+    g = torch.Generator(device="cuda:0").manual_seed(M + 3 * N + 5 * K + ta + 2 * tb)
+    ldk = K + (4 - K % 4) % 4 + 4  # (16-byte aligned rows, wider than K)
+    A = torch.randn((K, M) if ta else (M, ldk), device="cuda:0", generator=g)
+    B = torch.randn((N, ldk) if tb else (K, N), device="cuda:0", generator=g)
+    Av, Bv = (A if ta else A[:, :K]), (B[:, :K] if tb else B)
+    C = torch.full((M, N), float("nan"), device="cuda:0")
+    _run([_desc(Av, Bv, C, M, N, K, flags=ta * _hip.GEMM_A_T + tb * _hip.GEMM_B_T)])
+    _close(C, (Av.double().t() if ta else Av.double()) @ (Bv.double().t() if tb else Bv.double()), K)
+
+
+def test_operands_that_are_not_16_byte_aligned_take_the_register_loader():
+    g = torch.Generator(device="cuda:0").manual_seed(21)
+    M, N, K = 256, 256, 128
+    buf_a = torch.randn(M * K + 1, device="cuda:0", generator=g)
+    buf_b = torch.randn(N * K + 3, device="cuda:0", generator=g)
+    A, B = buf_a[1:].view(M, K), buf_b[3:].view(N, K)  # (4 and 12 bytes off a 16-byte boundary)
+    C = torch.empty(M, N, device="cuda:0")
+    _run([_desc(A, B, C, M, N, K, flags=_hip.GEMM_B_T)])
+    _close(C, A.double() @ B.double().t(), K)
+
+
+@pytest.mark.parametrize("T,rows,split", [(13, 64, 1), (7, 96, 3), (46, 32, 4)])
+def test_shifted_operand_with_interior_tiles(T, rows, split):
+    """dy^T direct to LDS beside the shifted state operand through registers (whole k tiles), then a partial last k tile; the
+    hidden-state rows of example b at t = 0 come from h0[b]."""
+    g = torch.Generator(device="cuda:0").manual_seed(T * rows)
+    H = 256
+    hs = torch.randn(rows, T, H, device="cuda:0", generator=g)
+    h0 = torch.randn(rows, 2 * H, device="cuda:0", generator=g)[:, H:]  # (row stride 512: ld_h0)
+    dg = torch.randn(rows * T, 1024, device="cuda:0", generator=g)
+    for init in (h0, None):
+        first = h0 if init is not None else torch.zeros(rows, H, device="cuda:0")
+        hprev = torch.cat((first.unsqueeze(1), hs[:, :-1]), 1).reshape(rows * T, H)
+        C = torch.empty(1024, H, device="cuda:0")
+        ws = _ws(1024, H, split)
+        _run([_desc(dg, hs.view(rows * T, H), C, 1024, H, rows * T, flags=_hip.GEMM_A_T, split=split, ws=ws, shift_t=T, h0=init)])
+        _close(C, dg.double().t() @ hprev.double(), rows * T)
