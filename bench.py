@@ -397,7 +397,7 @@ def recurrent_kernel_report(dev):
     pmc = pmc_table("recurrent_") or {}
 
     def traffic(*names):
-        hit = [v for k, v in pmc.items() if any(n in k for n in names) and not k.startswith("_")]
+        hit = [v for k, v in pmc.items() if k != "_source" and any(n in k for n in names)]  # (mangled names begin with "_Z")
         return round(sum(hit)) if hit else None
 
     out["lstm_layer"] = {"rows": B, "steps": T, "fwd_ms": round(fwd, 3), "fwd_us_per_step": round(fwd / T * 1e3, 2),
