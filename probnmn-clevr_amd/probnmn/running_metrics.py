@@ -84,6 +84,37 @@ class BLEU:
         self._totals = Counter()
         self._prediction_length = 0
         self._reference_length = 0
+        self._pending = []  # device batches on their way to the host: (pinned predictions, pinned targets, event)
+
+    # Device tensors are counted LATER: the matrices go to page-locked buffers with asynchronous copies, and a batch is
+    # counted once its copy has landed -- when the next batch arrives, or in get_metric().  Counting at once made every
+    # evaluation forward pass wait for its own kernels (a validation loop could queue nothing behind the generator's pass
+    # until it had finished: evaluators.answering_evaluator).  The counts are the same sums in the same order.
+    _RING = 4
+
+    def _drain(self, wait: bool) -> None:
+        while self._pending and (wait or self._pending[0][2].query()):
+            pred, gold, event = self._pending.pop(0)
+            event.synchronize()
+            self._count(pred.numpy().astype(np.int64, copy=False), gold.numpy().astype(np.int64, copy=False))
+
+    def _defer(self, predictions: torch.Tensor, gold_targets: torch.Tensor) -> None:
+        if len(self._pending) >= self._RING:  # (its buffers are the oldest entry's: count that one first)
+            pred, gold, event = self._pending.pop(0)
+            event.synchronize()
+            self._count(pred.numpy().astype(np.int64, copy=False), gold.numpy().astype(np.int64, copy=False))
+        pool = self.__dict__.setdefault("_pinned", {})
+        slot = self.__dict__["_slot"] = (self.__dict__.get("_slot", -1) + 1) % self._RING
+        hosts = []
+        for name, t in (("p", predictions), ("g", gold_targets)):
+            key = (name, slot, tuple(t.shape), t.dtype)
+            if key not in pool:
+                pool[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            pool[key].copy_(t.detach(), non_blocking=True)
+            hosts.append(pool[key])
+        event = torch.cuda.Event()
+        event.record()
+        self._pending.append((hosts[0], hosts[1], event))
 
     def _keys(self, tokens: np.ndarray, n: int) -> np.ndarray:
         """One int64 key per n-gram of every row that holds no excluded index: (row, the n tokens)."""
@@ -103,8 +134,16 @@ class BLEU:
     def __call__(self, predictions: torch.Tensor, gold_targets: torch.Tensor) -> None:
         # (vectorised over the batch: the per-row Python loops of the first version took 35 ms per 256-row validation
         # batch -- nine tenths of evaluate_answer_accuracy)
-        pred = predictions.detach().cpu().numpy().astype(np.int64, copy=False)
-        gold = gold_targets.detach().cpu().numpy().astype(np.int64, copy=False)
+        if predictions.is_cuda and gold_targets.is_cuda and predictions.dim() == 2 and gold_targets.dim() == 2 \
+                and predictions.size(0) == gold_targets.size(0):
+            self._drain(wait=False)
+            self._defer(predictions, gold_targets)
+            return
+        self._drain(wait=True)  # (counts stay in call order)
+        self._count(predictions.detach().cpu().numpy().astype(np.int64, copy=False),
+                    gold_targets.detach().cpu().numpy().astype(np.int64, copy=False))
+
+    def _count(self, pred: np.ndarray, gold: np.ndarray) -> None:
         if pred.ndim != 2 or gold.ndim != 2 or pred.shape[0] != gold.shape[0]:
             raise ValueError("BLEU takes (batch, length) prediction and target matrices")
         top = int(max(pred.max(initial=0), gold.max(initial=0))) + 1
@@ -117,7 +156,7 @@ class BLEU:
             # (row * base**n overflows int64 from 32 768 rows on: count such a batch in pieces)
             step = (1 << 62) // self._base ** len(self._ngram_weights)
             for lo in range(0, pred.shape[0], step):
-                self(predictions[lo:lo + step], gold_targets[lo:lo + step])
+                self._count(pred[lo:lo + step], gold[lo:lo + step])
             return
         for n in range(1, len(self._ngram_weights) + 1):
             pk, pc = np.unique(self._keys(pred, n), return_counts=True)
@@ -140,6 +179,7 @@ class BLEU:
         return math.exp(1.0 - self._reference_length / self._prediction_length)
 
     def get_metric(self, reset: bool = False):
+        self._drain(wait=True)
         scores = (w * (math.log(self._matches[n] + 1e-13) - math.log(self._totals[n] + 1e-13))
                   for n, w in enumerate(self._ngram_weights, start=1))
         bleu = self._brevity_penalty() * math.exp(sum(scores))

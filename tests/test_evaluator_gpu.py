@@ -85,3 +85,25 @@ def test_phase_evaluators_and_inference():
         for a in out["predictions"].tolist():
             assert records[k]["answer"] == vocab.get_token_from_index(a, "answers")
             k += 1
+
+
+def test_bleu_counts_device_batches_later_and_the_same():
+    """running_metrics.BLEU: device batches are copied out asynchronously and counted when the copy has landed (more batches
+    than its ring of page-locked buffers, a host batch in between, get_metric at the end): the same corpus BLEU as counting
+    every batch at once on the host."""
+    import numpy as np
+    from probnmn.running_metrics import BLEU
+
+    rng = np.random.default_rng(0)
+    dev = torch.device("cuda:0")
+    a, b = BLEU(exclude_indices={0, 2, 3}), BLEU(exclude_indices={0, 2, 3})
+    for k in range(7):
+        pred = torch.from_numpy(rng.integers(0, 9, size=(5 + k % 2, 11)))
+        gold = torch.from_numpy(rng.integers(0, 9, size=(5 + k % 2, 11)))
+        a(pred, gold)
+        if k == 3:
+            b(pred, gold)  # (a host batch between device batches: counted behind the ones before it)
+        else:
+            b(pred.to(dev), gold.to(dev))
+    assert b.get_metric(reset=True)["BLEU"] == a.get_metric(reset=True)["BLEU"]
+    assert b.get_metric()["BLEU"] == a.get_metric()["BLEU"]  # (both empty again)
