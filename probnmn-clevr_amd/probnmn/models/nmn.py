@@ -106,8 +106,100 @@ class _WeightGradOnly(torch.autograd.Function):
         return (dy.t() @ x if ctx.needs_input_grad[0] else None, dy.sum(0) if ctx.needs_input_grad[1] else None, None)
 
 
+# ---- the same layer on this build's GEMM (csrc/gemm.hip) ----------------------------------------------------------------
+# OPT-IN (PNMN_FC_OWN_ROWS=<rows>: from that many rows on; default 0 = never): the three products of the layer on pnmn_gemm --
+# whole 128-row tiles straight into LDS, the forward product split along K so that its 8 x rows/128 output tiles fill the
+# chip (partials added in chunk order: deterministic), the bias added in the epilogue, the bias gradient summed beside the
+# weight gradient (colsum).  Measured at 512 rows (the 1024-question step): forward 503 us, d(input) 499, weight gradient
+# 460 against the library path's 398 / 437 / 418 -- the step 27.60 against 27.13 ms (28.99 / 28.59 on one stream); at 64 rows
+# a 128-row tile is half empty (41 against 88 TFLOP/s).  So the library path above stays the default (DESIGN 4.2 "Round 6").
+OWN_FC_ROWS = int(__import__("os").environ.get("PNMN_FC_OWN_ROWS", "0"))
+_FC_WORKSPACES: dict = {}
+
+
+def _own_gemm(a, b, c, M, N, K, lda, ldb, ldc, ta=False, tb=False, bias=None, colsum=None, split=1):
+    import numpy as np
+    from probnmn import _hip
+
+    lib, dev = _hip.lib(), c.device
+    d = np.zeros(1, _hip.GEMM_DESC)
+    d["a"], d["b"], d["c"] = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    d["lda"], d["ldb"], d["ldc"], d["M"], d["N"], d["K"] = lda, ldb, ldc, M, N, K
+    d["flags"] = (_hip.GEMM_A_T if ta else 0) | (_hip.GEMM_B_T if tb else 0)
+    d["split_k"] = split
+    if bias is not None:
+        d["bias"] = bias.data_ptr()
+    if colsum is not None:
+        d["colsum"] = colsum.data_ptr()
+    if split > 1:
+        need = int(lib.pnmn_gemm_workspace_bytes(M, N, split))
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ws = _FC_WORKSPACES.get(key)
+        if ws is None or ws.numel() < need:  # (one grow-only buffer per device: the products of a step run one after another)
+            ws = _FC_WORKSPACES[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+        d["workspace"] = ws.data_ptr()
+    _hip.check(lib.pnmn_gemm(d.ctypes.data, 1, _hip.stream_ptr(dev)), "pnmn_gemm (fully connected layer)")
+
+
+class _OwnLinear(torch.autograd.Function):
+    """``F.linear`` of the first fully connected layer on pnmn_gemm: y = x W^T + b; backward: d(input) only (the weight
+    gradient is ``_OwnWeightGrad``'s, see ``_WeightGradOnly`` for why the two are separate nodes)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from probnmn import _hip
+
+        ctx.save_for_backward(weight)
+        M, K = x.shape
+        N = weight.size(0)
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        split = int(_hip.lib().pnmn_gemm_split_k(M, N, K, 0))
+        _own_gemm(x, weight, y, M, N, K, K, K, N, tb=True, bias=bias, split=split)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        dy = dy.contiguous()
+        M, N = dy.shape
+        K = weight.size(1)
+        dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
+        _own_gemm(dy, weight, dx, M, K, N, N, K, K)  # dy [M][N] . W [N][K]
+        return dx, None, None
+
+
+class _OwnWeightGrad(torch.autograd.Function):
+    """``_WeightGradOnly`` on pnmn_gemm: dW = dy^T x with db = the column sums of dy from the same pass."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, x):
+        ctx.save_for_backward(x)
+        return x.new_zeros(x.size(0), weight.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, N = dy.shape
+        K = x.size(1)
+        dw = torch.empty(N, K, dtype=dy.dtype, device=dy.device)
+        db = torch.empty(N, dtype=dy.dtype, device=dy.device)
+        _own_gemm(dy, x, dw, N, K, R, N, K, K, ta=True, colsum=db)  # dy^T [N][R] . x [R][K]
+        return dw, db, None
+
+
 def _first_fc(layer: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     K = layer.in_features
+    if (x.is_cuda and x.dim() == 2 and x.is_contiguous() and layer.weight.is_contiguous() and layer.bias is not None
+            and x.dtype == torch.float32 and 0 < OWN_FC_ROWS <= x.size(0) and K % 4 == 0):
+        if torch.is_grad_enabled() and x.requires_grad and layer.weight.requires_grad:
+            from_weights = _OwnWeightGrad.apply(layer.weight, layer.bias, x.detach())
+            return _OwnLinear.apply(x, layer.weight.detach(), layer.bias.detach()) + from_weights
+        if not torch.is_grad_enabled() or not (x.requires_grad or layer.weight.requires_grad or layer.bias.requires_grad):
+            return _OwnLinear.apply(x, layer.weight, layer.bias)
+        # (gradients for some of the three only: the library path below knows every combination)
     if (x.is_cuda and x.dim() == 2 and x.is_contiguous() and layer.weight.is_contiguous() and layer.bias is not None
             and K % _SplitKLinear.SLABS == 0 and K >= 8192):
         if torch.is_grad_enabled() and x.requires_grad and layer.weight.requires_grad:

@@ -364,3 +364,28 @@ def test_conv_splits_give_bit_identical_activations(n, deep, cus):
             assert float((g - grads1[k]).abs().max()) <= 1e-4 * scale, (split, k)
 
 
+
+
+def test_first_fully_connected_layer_on_own_gemm_equals_the_library_path(monkeypatch):
+    """models.nmn._first_fc with PNMN_FC_OWN_ROWS set (opt-in: pnmn_gemm for the 50 176 -> 1024 layer) against the default
+    library path: output, d(input), weight and bias gradients at a row count with a ragged last tile."""
+    import torch.nn as nn
+    from probnmn.models import nmn as M
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    layer = nn.Linear(50176, 1024).to(dev)
+    x = torch.randn(200, 50176, device=dev)
+    dy = torch.randn(200, 1024, device=dev)
+    outs = []
+    for rows in (0, 1):
+        monkeypatch.setattr(M, "OWN_FC_ROWS", rows)
+        layer.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = M._first_fc(layer, xi)
+        y.backward(dy)
+        outs.append((y.detach(), xi.grad, layer.weight.grad.clone(), layer.bias.grad.clone()))
+        with torch.no_grad():
+            assert torch.allclose(M._first_fc(layer, x), y.detach(), rtol=0, atol=1e-5 * float(y.abs().max()))
+    for got, want in zip(outs[1], outs[0]):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
