@@ -128,12 +128,38 @@ def predict_answers(program_generator, nmn, batches: Iterable[Dict[str, torch.Te
     nmn.eval()
     records: List[Dict[str, Any]] = []
     try:
-        for batch in batches:
+        # (as in answering_evaluator: batch i + 1's generator pass is queued before batch i's programs are awaited on the host)
+        pinned: Dict[Any, torch.Tensor] = {}
+
+        def queue(batch, iteration):
             programs = program_generator(batch["question"])["predictions"]
+            if not (programs.is_cuda and batch["image"].is_cuda):
+                return programs, None
+            key = (iteration & 1, tuple(programs.shape), programs.dtype)
+            if key not in pinned:
+                pinned[key] = torch.empty(programs.shape, dtype=programs.dtype, pin_memory=True)
+            pinned[key].copy_(programs, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+            return pinned[key], copied
+
+        def finish(batch, queued):
+            programs, copied = queued
+            if copied is not None:
+                copied.synchronize()
             answers = nmn(batch["image"], programs)["predictions"].cpu().tolist()
             index = batch["question_index"].cpu().tolist() if "question_index" in batch else range(len(records), len(records) + len(answers))
             for qi, a in zip(index, answers):
                 records.append({"question_index": int(qi), "answer": vocabulary.get_token_from_index(int(a), namespace="answers")})
+
+        pending = None
+        for iteration, batch in enumerate(batches):
+            queued = queue(batch, iteration)
+            if pending is not None:
+                finish(*pending)
+            pending = (batch, queued)
+        if pending is not None:
+            finish(*pending)
         return records
     finally:
         program_generator.train(was_training[0])
